@@ -1,0 +1,799 @@
+/*
+ * oracle/h264_enc.c -- TEST INFRASTRUCTURE ONLY (see h264_oracle.h).
+ *
+ * Scalar CPU H.264 encoder: the checker the GPU path is compared against.
+ * It restates, stage by stage, what happens inside the reference's single
+ * external call ISVCEncoder::EncodeFrame
+ * (/root/reference/video_codec/VideoEncoderOpenH264.cpp:344; preset at
+ * :228-296: one spatial layer, one slice per picture (:247), one reference
+ * frame (:290), loop filter on (:295), IDR every uiIntraPeriod (:242)).
+ *
+ * PARITY UNPINNED vs OpenH264 -- the non-normative choices below are this
+ * build's own and are written so that every macroblock decision depends only
+ * on data that is final before the stage starts (so the GPU can run each stage
+ * over all macroblocks at once):
+ *   - I pictures: Intra16x16 (4 modes by SATD) + chroma (4 modes by SATD)
+ *   - P pictures: per MB a zero-motion "all levels quantise to zero" test,
+ *     else full search dx,dy in [-16,15] on SAD + lambda*bits(mv), then half-
+ *     and quarter-pel refinement on SATD + lambda*bits(mv); P_L0_16x16 only;
+ *     P_Skip iff mv == skip predictor and no coefficient survives
+ *   - quantiser: reference-model multipliers, offsets 1/3 (intra), 1/6 (inter)
+ *   - CAVLC, fixed picture QP, deblocking per 8.7 with offsets 0
+ * Normative stages (dequant, inverse transform, interpolation, intra
+ * prediction, deblocking, syntax) follow ITU-T H.264 and are pinned by
+ * tests/ known answers plus the encode->decode round trip.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "h264_oracle.h"
+#include "h264_tables.h"
+
+static inline int clip3(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
+static inline uint8_t clip1(int v) { return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
+
+/* ------------------------------------------------------------ bit writer */
+typedef struct {
+    uint8_t *buf;
+    size_t cap;
+    uint64_t bits; /* total bits written */
+} bitw;
+
+static void bw_put(bitw *b, int n, uint32_t v)
+{
+    for (int i = n - 1; i >= 0; i--) {
+        size_t byte = b->bits >> 3;
+        if (byte >= b->cap) { b->bits++; continue; }
+        if ((v >> i) & 1) b->buf[byte] |= (uint8_t)(0x80 >> (b->bits & 7));
+        b->bits++;
+    }
+}
+static void bw_ue(bitw *b, uint32_t v)
+{
+    uint32_t code;
+    int n = h264o_ue_bits(v, &code);
+    if (n > 32) { bw_put(b, n - 32, 0); bw_put(b, 32, code); }
+    else bw_put(b, n, code);
+}
+static void bw_se(bitw *b, int32_t v)
+{
+    uint32_t code;
+    int n = h264o_se_bits(v, &code);
+    bw_put(b, n, code);
+}
+static void bw_trailing(bitw *b)
+{
+    bw_put(b, 1, 1);
+    while (b->bits & 7) bw_put(b, 1, 0);
+}
+static int se_len(int v)
+{
+    uint32_t c;
+    return h264o_se_bits(v, &c);
+}
+
+/* ------------------------------------------------------------ CAVLC 9.2 */
+static void cavlc_block(bitw *b, const int16_t *lv, int max_coeff, int nC)
+{
+    int level[16], idx[16], tc = 0, t1 = 0;
+    for (int i = max_coeff - 1; i >= 0; i--)
+        if (lv[i]) { level[tc] = lv[i]; idx[tc] = i; tc++; }
+    while (t1 < tc && t1 < 3 && abs(level[t1]) == 1) t1++;
+    if (nC == -1) {
+        bw_put(b, o_chroma_dc_token_len[4 * tc + t1], o_chroma_dc_token_bits[4 * tc + t1]);
+    } else {
+        int tab = nC < 2 ? 0 : nC < 4 ? 1 : nC < 8 ? 2 : 3;
+        bw_put(b, o_coeff_token_len[tab][4 * tc + t1], o_coeff_token_bits[tab][4 * tc + t1]);
+    }
+    if (!tc) return;
+    for (int k = 0; k < t1; k++) bw_put(b, 1, level[k] < 0);
+    int suffix_len = (tc > 10 && t1 < 3) ? 1 : 0;
+    for (int k = t1; k < tc; k++) {
+        int lvl = level[k];
+        int code = lvl > 0 ? 2 * lvl - 2 : -2 * lvl - 1;
+        if (k == t1 && t1 < 3) code -= 2;
+        if (suffix_len == 0) {
+            if (code < 14) {
+                bw_put(b, code + 1, 1);
+            } else if (code < 30) {
+                bw_put(b, 15, 1);
+                bw_put(b, 4, (uint32_t)(code - 14));
+            } else {
+                int c = code - 30, prefix = 15;
+                while (c >= (1 << (prefix - 3))) { c -= 1 << (prefix - 3); prefix++; }
+                /* prefix>15 handled per 9.2.2.1: levelCode += (1<<(prefix-3)) - 4096 */
+                if (prefix > 15) c = code - 30 - ((1 << (prefix - 3)) - 4096);
+                bw_put(b, prefix + 1, 1);
+                bw_put(b, prefix - 3, (uint32_t)c);
+            }
+        } else {
+            if (code < (15 << suffix_len)) {
+                bw_put(b, (code >> suffix_len) + 1, 1);
+                bw_put(b, suffix_len, (uint32_t)(code & ((1 << suffix_len) - 1)));
+            } else {
+                int c = code - (15 << suffix_len), prefix = 15;
+                while (c >= (1 << (prefix - 3))) { c -= 1 << (prefix - 3); prefix++; }
+                if (prefix > 15) c = code - (15 << suffix_len) - ((1 << (prefix - 3)) - 4096);
+                bw_put(b, prefix + 1, 1);
+                bw_put(b, prefix - 3, (uint32_t)c);
+            }
+        }
+        if (suffix_len == 0) suffix_len = 1;
+        if (abs(lvl) > (3 << (suffix_len - 1)) && suffix_len < 6) suffix_len++;
+    }
+    if (tc < max_coeff) {
+        int tz = idx[0] + 1 - tc;
+        if (nC == -1) bw_put(b, o_cdc_total_zeros_len[tc - 1][tz], o_cdc_total_zeros_bits[tc - 1][tz]);
+        else bw_put(b, o_total_zeros_len[tc - 1][tz], o_total_zeros_bits[tc - 1][tz]);
+        int zl = tz;
+        for (int k = 0; k < tc - 1 && zl > 0; k++) {
+            int run = idx[k] - idx[k + 1] - 1;
+            int t = (zl > 7 ? 7 : zl) - 1;
+            bw_put(b, o_run_len[t][run], o_run_bits[t][run]);
+            zl -= run;
+        }
+    }
+}
+
+int h264o_cavlc_block(const int16_t *lv, int max_coeff, int nC, uint8_t *buf)
+{
+    bitw b = {buf, 64, 0};
+    cavlc_block(&b, lv, max_coeff, nC);
+    return (int)b.bits;
+}
+
+/* ------------------------------------------------------------ encoder state */
+struct h264o_enc {
+    h264o_config cfg;
+    int mbw, mbh, cw, ch, level_idc;
+    uint8_t *src[3], *rec[3], *cur[3], *ref[3]; /* coded size; pitch cw / cw/2 */
+    h264o_mbinfo *mb;
+    int16_t *levels;
+    int frame_in_gop, frame_num, idr_id;
+    long frames;
+    uint8_t *rbsp;
+    size_t rbsp_cap;
+    int64_t last_slice_bits;
+};
+
+static int pick_level(int mbs, int fps)
+{
+    for (unsigned i = 0; i < sizeof(o_levels) / sizeof(o_levels[0]); i++)
+        if ((uint32_t)mbs <= o_levels[i].fs && (uint32_t)(mbs * fps) <= o_levels[i].mbps)
+            return o_levels[i].idc;
+    return 52;
+}
+
+h264o_enc *h264o_enc_create(const h264o_config *cfg)
+{
+    if (!cfg || cfg->width < 16 || cfg->height < 16 || cfg->width > 4096 || cfg->height > 4096) return NULL;
+    if ((cfg->width | cfg->height) & 1) return NULL;
+    if (cfg->qp < 10 || cfg->qp > 51) return NULL;
+    h264o_enc *e = (h264o_enc *)calloc(1, sizeof(*e));
+    e->cfg = *cfg;
+    if (e->cfg.gop < 1) e->cfg.gop = 1;
+    e->mbw = (cfg->width + 15) / 16;
+    e->mbh = (cfg->height + 15) / 16;
+    e->cw = e->mbw * 16;
+    e->ch = e->mbh * 16;
+    int lvl = pick_level(e->mbw * e->mbh, cfg->fps > 0 ? cfg->fps : 30);
+    e->level_idc = lvl < 32 ? 32 : lvl; /* the reference asks for LEVEL_3_2 (ref :255) */
+    size_t ysz = (size_t)e->cw * e->ch, csz = ysz / 4;
+    for (int p = 0; p < 3; p++) {
+        size_t sz = p ? csz : ysz;
+        e->src[p] = (uint8_t *)calloc(sz, 1);
+        e->rec[p] = (uint8_t *)calloc(sz, 1);
+        e->cur[p] = (uint8_t *)calloc(sz, 1);
+        e->ref[p] = (uint8_t *)calloc(sz, 1);
+    }
+    e->mb = (h264o_mbinfo *)calloc((size_t)e->mbw * e->mbh, sizeof(h264o_mbinfo));
+    e->levels = (int16_t *)calloc((size_t)e->mbw * e->mbh * H264O_LV_STRIDE, sizeof(int16_t));
+    e->rbsp_cap = ysz * 4 + 65536;
+    e->rbsp = (uint8_t *)malloc(e->rbsp_cap);
+    return e;
+}
+
+void h264o_enc_destroy(h264o_enc *e)
+{
+    if (!e) return;
+    for (int p = 0; p < 3; p++) { free(e->src[p]); free(e->rec[p]); free(e->cur[p]); free(e->ref[p]); }
+    free(e->mb);
+    free(e->levels);
+    free(e->rbsp);
+    free(e);
+}
+
+int h264o_enc_coded_width(const h264o_enc *e) { return e->cw; }
+int h264o_enc_coded_height(const h264o_enc *e) { return e->ch; }
+const uint8_t *h264o_enc_recon(const h264o_enc *e, int p) { return e->ref[p]; }
+const uint8_t *h264o_enc_recon_pre(const h264o_enc *e, int p) { return e->rec[p]; }
+const h264o_mbinfo *h264o_enc_mbinfo(const h264o_enc *e) { return e->mb; }
+const int16_t *h264o_enc_levels(const h264o_enc *e) { return e->levels; }
+int64_t h264o_enc_last_slice_bits(const h264o_enc *e) { return e->last_slice_bits; }
+
+/* ------------------------------------------------------------ headers 7.3.2 */
+static void write_sps(h264o_enc *e, bitw *b)
+{
+    int prof = e->cfg.profile_idc;
+    bw_put(b, 8, (uint32_t)prof);
+    /* constraint_set0..5 + 2 reserved bits */
+    bw_put(b, 8, prof == 66 ? 0xC0 : prof == 77 ? 0x40 : 0x00);
+    bw_put(b, 8, (uint32_t)e->level_idc);
+    bw_ue(b, 0); /* seq_parameter_set_id */
+    if (prof == 100) {
+        bw_ue(b, 1);     /* chroma_format_idc 4:2:0 */
+        bw_ue(b, 0);     /* bit_depth_luma_minus8 */
+        bw_ue(b, 0);     /* bit_depth_chroma_minus8 */
+        bw_put(b, 1, 0); /* qpprime_y_zero_transform_bypass_flag */
+        bw_put(b, 1, 0); /* seq_scaling_matrix_present_flag */
+    }
+    bw_ue(b, 4);     /* log2_max_frame_num_minus4 -> MaxFrameNum 256 */
+    bw_ue(b, 2);     /* pic_order_cnt_type 2: output order == decode order */
+    bw_ue(b, 1);     /* max_num_ref_frames (ref :290 iNumRefFrame = 1) */
+    bw_put(b, 1, 0); /* gaps_in_frame_num_value_allowed_flag */
+    bw_ue(b, (uint32_t)e->mbw - 1);
+    bw_ue(b, (uint32_t)e->mbh - 1);
+    bw_put(b, 1, 1); /* frame_mbs_only_flag */
+    bw_put(b, 1, 1); /* direct_8x8_inference_flag */
+    int cr = (e->cw - e->cfg.width) / 2, cb = (e->ch - e->cfg.height) / 2;
+    if (cr || cb) {
+        bw_put(b, 1, 1);
+        bw_ue(b, 0);
+        bw_ue(b, (uint32_t)cr);
+        bw_ue(b, 0);
+        bw_ue(b, (uint32_t)cb);
+    } else {
+        bw_put(b, 1, 0);
+    }
+    bw_put(b, 1, 0); /* vui_parameters_present_flag */
+    bw_trailing(b);
+}
+
+static void write_pps(h264o_enc *e, bitw *b)
+{
+    bw_ue(b, 0);     /* pic_parameter_set_id */
+    bw_ue(b, 0);     /* seq_parameter_set_id */
+    bw_put(b, 1, 0); /* entropy_coding_mode_flag: CAVLC */
+    bw_put(b, 1, 0); /* bottom_field_pic_order_in_frame_present_flag */
+    bw_ue(b, 0);     /* num_slice_groups_minus1 */
+    bw_ue(b, 0);     /* num_ref_idx_l0_default_active_minus1 */
+    bw_ue(b, 0);     /* num_ref_idx_l1_default_active_minus1 */
+    bw_put(b, 1, 0); /* weighted_pred_flag */
+    bw_put(b, 2, 0); /* weighted_bipred_idc */
+    bw_se(b, 0);     /* pic_init_qp_minus26 */
+    bw_se(b, 0);     /* pic_init_qs_minus26 */
+    bw_se(b, 0);     /* chroma_qp_index_offset */
+    bw_put(b, 1, 1); /* deblocking_filter_control_present_flag */
+    bw_put(b, 1, 0); /* constrained_intra_pred_flag */
+    bw_put(b, 1, 0); /* redundant_pic_cnt_present_flag */
+    if (e->cfg.profile_idc == 100) {
+        bw_put(b, 1, 0); /* transform_8x8_mode_flag */
+        bw_put(b, 1, 0); /* pic_scaling_matrix_present_flag */
+        bw_se(b, 0);     /* second_chroma_qp_index_offset */
+    }
+    bw_trailing(b);
+}
+
+static void write_slice_header(h264o_enc *e, bitw *b, int idr)
+{
+    bw_ue(b, 0);              /* first_mb_in_slice */
+    bw_ue(b, idr ? 7 : 5);    /* slice_type: all slices of the picture I / P */
+    bw_ue(b, 0);              /* pic_parameter_set_id */
+    bw_put(b, 8, (uint32_t)e->frame_num);
+    if (idr) bw_ue(b, (uint32_t)e->idr_id);
+    if (!idr) {
+        bw_put(b, 1, 0); /* num_ref_idx_active_override_flag */
+        bw_put(b, 1, 0); /* ref_pic_list_modification_flag_l0 */
+    }
+    if (idr) {
+        bw_put(b, 1, 0); /* no_output_of_prior_pics_flag */
+        bw_put(b, 1, 0); /* long_term_reference_flag */
+    } else {
+        bw_put(b, 1, 0); /* adaptive_ref_pic_marking_mode_flag */
+    }
+    bw_se(b, e->cfg.qp - 26); /* slice_qp_delta */
+    bw_ue(b, e->cfg.disable_deblock ? 1 : 0);
+    if (!e->cfg.disable_deblock) {
+        bw_se(b, 0); /* slice_alpha_c0_offset_div2 */
+        bw_se(b, 0); /* slice_beta_offset_div2 */
+    }
+}
+
+static size_t emit_nal(uint8_t *out, size_t cap, size_t pos, int ref_idc, int type, const uint8_t *rbsp, size_t n)
+{
+    if (pos + 5 + n + n / 2 + 8 > cap) return (size_t)-1;
+    out[pos++] = 0; out[pos++] = 0; out[pos++] = 0; out[pos++] = 1;
+    out[pos++] = (uint8_t)((ref_idc << 5) | type);
+    pos += h264o_nal_escape(rbsp, n, out + pos);
+    return pos;
+}
+
+/* ------------------------------------------------------------ residual coding */
+static const uint8_t xy2blk[16] = {0, 1, 4, 5, 2, 3, 6, 7, 8, 9, 12, 13, 10, 11, 14, 15};
+
+/* forward transform + quant of one 4x4 of (src - pred); returns nnz over
+ * zig-zag positions [first..15]; writes zig-zag levels and raster dequantised
+ * coefficients (DC left to caller when first==1) */
+static int tq_block(const uint8_t *s, int ss, const uint8_t *p, int ps, int qp, int intra, int first,
+                    int16_t *lvz, int16_t deq[16], int16_t *dc_out)
+{
+    int16_t d[16], w[16], lv[16];
+    for (int y = 0; y < 4; y++)
+        for (int x = 0; x < 4; x++) d[4 * y + x] = (int16_t)(s[y * ss + x] - p[y * ps + x]);
+    h264o_fdct4x4(d, w);
+    if (dc_out) *dc_out = w[0];
+    h264o_quant4x4(w, qp, intra, lv);
+    if (first) lv[0] = 0;
+    h264o_dequant4x4(lv, qp, deq);
+    int nnz = 0;
+    for (int i = 0; i < 16; i++) {
+        lvz[i] = lv[o_zigzag4x4[i]];
+        nnz += lvz[i] != 0;
+    }
+    return nnz;
+}
+
+/* chroma of one MB (both planes): pred in predc[2][64]; writes levels, tc, recon.
+ * returns cbp_chroma 0..2 */
+static int code_chroma(h264o_enc *e, int mx, int my, uint8_t predc[2][64], int intra, int16_t *lv,
+                       uint8_t *tc, int write_recon)
+{
+    int qpc = o_chroma_qp[e->cfg.qp], cs = e->cw / 2;
+    int qbits = 15 + qpc / 6, f = (1 << qbits) / (intra ? 3 : 6);
+    int any_dc = 0, any_ac = 0;
+    int16_t deq[2][4][16];
+    for (int pl = 0; pl < 2; pl++) {
+        const uint8_t *s = e->src[1 + pl] + (8 * my) * cs + 8 * mx;
+        int16_t dc[4];
+        for (int b = 0; b < 4; b++) {
+            int bx = (b & 1) * 4, by = (b >> 1) * 4;
+            int nnz = tq_block(s + by * cs + bx, cs, predc[pl] + by * 8 + bx, 8, qpc, intra, 1,
+                               lv + H264O_LV_CHROMA_AC + (pl * 4 + b) * 16, deq[pl][b], &dc[b]);
+            tc[16 + pl * 4 + b] = (uint8_t)nnz;
+            any_ac |= nnz;
+        }
+        int fd[4] = {dc[0] + dc[1] + dc[2] + dc[3], dc[0] - dc[1] + dc[2] - dc[3],
+                     dc[0] + dc[1] - dc[2] - dc[3], dc[0] - dc[1] - dc[2] + dc[3]};
+        int16_t *ldc = lv + H264O_LV_CHROMA_DC + pl * 4;
+        for (int i = 0; i < 4; i++) {
+            int a = abs(fd[i]);
+            int l = (int)(((int64_t)a * o_quant_mf[qpc % 6][0] + 2 * (int64_t)f) >> (qbits + 1));
+            ldc[i] = (int16_t)(fd[i] < 0 ? -l : l);
+            any_dc |= l;
+        }
+        /* 8.5.11.2 chroma DC scaling */
+        int c0 = ldc[0], c1 = ldc[1], c2 = ldc[2], c3 = ldc[3];
+        int fi[4] = {c0 + c1 + c2 + c3, c0 - c1 + c2 - c3, c0 + c1 - c2 - c3, c0 - c1 - c2 + c3};
+        for (int b = 0; b < 4; b++)
+            deq[pl][b][0] = (int16_t)(((fi[b] * 16 * o_dequant_v[qpc % 6][0]) << (qpc / 6)) >> 5);
+    }
+    int cbp = any_ac ? 2 : any_dc ? 1 : 0;
+    if (cbp < 2)
+        for (int i = 16; i < 24; i++) tc[i] = 0;
+    if (write_recon)
+        for (int pl = 0; pl < 2; pl++) {
+            uint8_t *r = e->rec[1 + pl] + (8 * my) * cs + 8 * mx;
+            for (int y = 0; y < 8; y++) memcpy(r + y * cs, predc[pl] + 8 * y, 8);
+            for (int b = 0; b < 4; b++) h264o_idct4x4_add(deq[pl][b], r + (b >> 1) * 4 * cs + (b & 1) * 4, cs);
+        }
+    return cbp;
+}
+
+/* ------------------------------------------------------------ intra picture */
+static void encode_intra_mb(h264o_enc *e, int mx, int my)
+{
+    int qp = e->cfg.qp, cw = e->cw, cs = cw / 2;
+    h264o_mbinfo *mb = &e->mb[my * e->mbw + mx];
+    int16_t *lv = e->levels + (size_t)(my * e->mbw + mx) * H264O_LV_STRIDE;
+    memset(lv, 0, H264O_LV_STRIDE * sizeof(int16_t));
+    memset(mb, 0, sizeof(*mb));
+    mb->type = H264O_MB_I16;
+    int avail = (mx > 0 ? 1 : 0) | (my > 0 ? 2 : 0) | ((mx > 0 && my > 0) ? 4 : 0);
+    const uint8_t *s = e->src[0] + (16 * my) * cw + 16 * mx;
+    uint8_t *r = e->rec[0] + (16 * my) * cw + 16 * mx;
+    uint8_t pred[256], best_pred[256];
+    int best = -1, best_cost = 0;
+    for (int mode = 0; mode < 4; mode++) {
+        if (mode == 0 && !(avail & 2)) continue;
+        if (mode == 1 && !(avail & 1)) continue;
+        if (mode == 3 && avail != 7) continue;
+        h264o_pred16x16(r, cw, mode, avail, pred);
+        int cost = h264o_satd16x16(s, cw, pred, 16);
+        if (best < 0 || cost < best_cost) { best = mode; best_cost = cost; memcpy(best_pred, pred, 256); }
+    }
+    mb->i16_mode = (uint8_t)best;
+    /* luma: 16 AC blocks + DC Hadamard */
+    int16_t deq[16][16], dcw[16];
+    int any_ac = 0;
+    for (int b = 0; b < 16; b++) {
+        int bx = o_blk_x[b] * 4, by = o_blk_y[b] * 4;
+        int nnz = tq_block(s + by * cw + bx, cw, best_pred + by * 16 + bx, 16, qp, 1, 1,
+                           lv + H264O_LV_LUMA + b * 16, deq[b], &dcw[o_blk_y[b] * 4 + o_blk_x[b]]);
+        mb->tc[b] = (uint8_t)nnz;
+        any_ac |= nnz;
+    }
+    /* forward 4x4 Hadamard of the DC terms (raster by block position), quant at
+     * (qbits+2) with offset 4f: the 1/2 of the reference model folded in */
+    int t[16], yd[16];
+    for (int i = 0; i < 4; i++) {
+        int a = dcw[4 * i], b = dcw[4 * i + 1], c = dcw[4 * i + 2], d = dcw[4 * i + 3];
+        t[4 * i] = a + b + c + d; t[4 * i + 1] = a + b - c - d;
+        t[4 * i + 2] = a - b - c + d; t[4 * i + 3] = a - b + c - d;
+    }
+    for (int j = 0; j < 4; j++) {
+        int a = t[j], b = t[4 + j], c = t[8 + j], d = t[12 + j];
+        yd[j] = a + b + c + d; yd[4 + j] = a + b - c - d;
+        yd[8 + j] = a - b - c + d; yd[12 + j] = a - b + c - d;
+    }
+    int qbits = 15 + qp / 6, f = (1 << qbits) / 3;
+    int16_t ldc[16];
+    for (int i = 0; i < 16; i++) {
+        int64_t a = yd[i] < 0 ? -yd[i] : yd[i];
+        int l = (int)((a * o_quant_mf[qp % 6][0] + 4 * (int64_t)f) >> (qbits + 2));
+        ldc[i] = (int16_t)(yd[i] < 0 ? -l : l);
+    }
+    for (int i = 0; i < 16; i++) lv[H264O_LV_LUMA_DC + i] = ldc[o_zigzag4x4[i]];
+    /* 8.5.10: inverse Hadamard then scaling */
+    int fi[16];
+    for (int i = 0; i < 4; i++) {
+        int a = ldc[4 * i], b = ldc[4 * i + 1], c = ldc[4 * i + 2], d = ldc[4 * i + 3];
+        t[4 * i] = a + b + c + d; t[4 * i + 1] = a + b - c - d;
+        t[4 * i + 2] = a - b - c + d; t[4 * i + 3] = a - b + c - d;
+    }
+    for (int j = 0; j < 4; j++) {
+        int a = t[j], b = t[4 + j], c = t[8 + j], d = t[12 + j];
+        fi[j] = a + b + c + d; fi[4 + j] = a + b - c - d;
+        fi[8 + j] = a - b - c + d; fi[12 + j] = a - b + c - d;
+    }
+    int ls = 16 * o_dequant_v[qp % 6][0];
+    for (int i = 0; i < 16; i++) {
+        int dc = qp >= 36 ? (fi[i] * ls) << (qp / 6 - 6) : (fi[i] * ls + (1 << (5 - qp / 6))) >> (6 - qp / 6);
+        deq[xy2blk[i]][0] = (int16_t)dc;
+    }
+    if (!any_ac)
+        for (int b = 0; b < 16; b++) mb->tc[b] = 0;
+    for (int y = 0; y < 16; y++) memcpy(r + y * cw, best_pred + 16 * y, 16);
+    for (int b = 0; b < 16; b++) h264o_idct4x4_add(deq[b], r + o_blk_y[b] * 4 * cw + o_blk_x[b] * 4, cw);
+    /* chroma mode by SATD over both planes */
+    uint8_t predc[2][64], bestc[2][64];
+    int cbest = -1, ccost = 0;
+    for (int mode = 0; mode < 4; mode++) {
+        if (mode == 1 && !(avail & 1)) continue;
+        if (mode == 2 && !(avail & 2)) continue;
+        if (mode == 3 && avail != 7) continue;
+        int cost = 0;
+        for (int pl = 0; pl < 2; pl++) {
+            h264o_pred_chroma8x8(e->rec[1 + pl] + (8 * my) * cs + 8 * mx, cs, mode, avail, predc[pl]);
+            cost += h264o_satd8x8(e->src[1 + pl] + (8 * my) * cs + 8 * mx, cs, predc[pl], 8);
+        }
+        if (cbest < 0 || cost < ccost) { cbest = mode; ccost = cost; memcpy(bestc, predc, sizeof(predc)); }
+    }
+    mb->chroma_mode = (uint8_t)cbest;
+    int cbpc = code_chroma(e, mx, my, bestc, 1, lv, mb->tc, 1);
+    mb->cbp = (uint8_t)((any_ac ? 15 : 0) | (cbpc << 4));
+}
+
+/* ------------------------------------------------------------ motion search */
+typedef struct { int16_t x, y; } mv_t;
+
+static inline int refpx(const uint8_t *ref, int stride, int w, int h, int x, int y)
+{
+    return ref[clip3(0, h - 1, y) * stride + clip3(0, w - 1, x)];
+}
+
+/* does the zero-motion residual of this MB quantise to nothing? */
+static int zero_mv_all_zero(h264o_enc *e, int mx, int my)
+{
+    int qp = e->cfg.qp, cw = e->cw, cs = cw / 2, qpc = o_chroma_qp[qp];
+    int16_t lvz[16], deq[16];
+    for (int b = 0; b < 16; b++) {
+        int off = (16 * my + o_blk_y[b] * 4) * cw + 16 * mx + o_blk_x[b] * 4;
+        if (tq_block(e->src[0] + off, cw, e->ref[0] + off, cw, qp, 0, 0, lvz, deq, NULL)) return 0;
+    }
+    int qbits = 15 + qpc / 6, f = (1 << qbits) / 6;
+    for (int pl = 0; pl < 2; pl++) {
+        int16_t dc[4];
+        for (int b = 0; b < 4; b++) {
+            int off = (8 * my + (b >> 1) * 4) * cs + 8 * mx + (b & 1) * 4;
+            if (tq_block(e->src[1 + pl] + off, cs, e->ref[1 + pl] + off, cs, qpc, 0, 1, lvz, deq, &dc[b])) return 0;
+        }
+        int fd[4] = {dc[0] + dc[1] + dc[2] + dc[3], dc[0] - dc[1] + dc[2] - dc[3],
+                     dc[0] + dc[1] - dc[2] - dc[3], dc[0] - dc[1] - dc[2] + dc[3]};
+        for (int i = 0; i < 4; i++)
+            if ((((int64_t)abs(fd[i]) * o_quant_mf[qpc % 6][0] + 2 * (int64_t)f) >> (qbits + 1)) != 0) return 0;
+    }
+    return 1;
+}
+
+static mv_t motion_search(h264o_enc *e, int mx, int my)
+{
+    int cw = e->cw, ch = e->ch, lambda = o_lambda[e->cfg.qp];
+    const uint8_t *s = e->src[0] + (16 * my) * cw + 16 * mx;
+    int bx = 16 * mx, by = 16 * my;
+    /* clamped 54x54 window: integer range [-16,15] + 16 + 3-tap apron each side */
+    enum { R = 16, AP = 4, WS = 16 + 2 * R + 2 * AP };
+    static __thread uint8_t win[WS * WS];
+    for (int y = 0; y < WS; y++)
+        for (int x = 0; x < WS; x++) win[y * WS + x] = (uint8_t)refpx(e->ref[0], cw, cw, ch, bx - R - AP + x, by - R - AP + y);
+    uint32_t best_key = 0xFFFFFFFFu;
+    for (int dy = -R; dy < R; dy++)
+        for (int dx = -R; dx < R; dx++) {
+            int sad = h264o_sad16x16(s, cw, win + (dy + R + AP) * WS + dx + R + AP, WS);
+            uint32_t cost = (uint32_t)(sad + lambda * (se_len(4 * dx) + se_len(4 * dy)));
+            uint32_t key = (cost << 10) | (uint32_t)(((dy + R) << 5) | (dx + R));
+            if (key < best_key) best_key = key;
+        }
+    int idx = best_key & 1023, ix = (idx & 31) - R, iy = (idx >> 5) - R;
+    /* half-sample planes on an 18x18 grid with origin (ix-1, iy-1) */
+    enum { GS = 18 };
+    uint8_t G[GS][GS], B[GS][GS], H[GS][GS], J[GS][GS];
+    int b1[GS + 5][GS];
+    const uint8_t *o = win + (iy + R + AP - 1) * WS + ix + R + AP - 1; /* grid (0,0) */
+#define WP(x, y) o[(y) * WS + (x)]
+    for (int y = -2; y < GS + 3; y++)
+        for (int x = 0; x < GS; x++)
+            b1[y + 2][x] = WP(x - 2, y) - 5 * WP(x - 1, y) + 20 * WP(x, y) + 20 * WP(x + 1, y) - 5 * WP(x + 2, y) + WP(x + 3, y);
+    for (int y = 0; y < GS; y++)
+        for (int x = 0; x < GS; x++) {
+            G[y][x] = WP(x, y);
+            B[y][x] = clip1((b1[y + 2][x] + 16) >> 5);
+            H[y][x] = clip1((WP(x, y - 2) - 5 * WP(x, y - 1) + 20 * WP(x, y) + 20 * WP(x, y + 1) - 5 * WP(x, y + 2) + WP(x, y + 3) + 16) >> 5);
+            J[y][x] = clip1((b1[y][x] - 5 * b1[y + 1][x] + 20 * b1[y + 2][x] + 20 * b1[y + 3][x] - 5 * b1[y + 4][x] + b1[y + 5][x] + 512) >> 10);
+        }
+#undef WP
+    int cx = 4 * ix, cy = 4 * iy; /* best so far, quarter units */
+    int best_cost = 0;
+    uint8_t pred[256];
+    static const int8_t nb[8][2] = {{-1, -1}, {0, -1}, {1, -1}, {-1, 0}, {1, 0}, {-1, 1}, {0, 1}, {1, 1}};
+    for (int pass = 0; pass < 2; pass++) {
+        int step = pass == 0 ? 2 : 1, bcx = cx, bcy = cy;
+        for (int k = (pass == 0 ? -1 : 0); k < 8; k++) {
+            int qx = k < 0 ? cx : cx + step * nb[k][0], qy = k < 0 ? cy : cy + step * nb[k][1];
+            int ox = qx - 4 * ix, oy = qy - 4 * iy; /* -3..3 relative to integer best */
+            int gx = 1 + (ox >> 2), gy = 1 + (oy >> 2), fx = ox & 3, fy = oy & 3;
+            for (int y = 0; y < 16; y++)
+                for (int x = 0; x < 16; x++) {
+                    int X = gx + x, Y = gy + y, v;
+                    if (fy == 0) v = fx == 0 ? G[Y][X] : fx == 2 ? B[Y][X] : fx == 1 ? (G[Y][X] + B[Y][X] + 1) >> 1 : (G[Y][X + 1] + B[Y][X] + 1) >> 1;
+                    else if (fx == 0) v = fy == 2 ? H[Y][X] : fy == 1 ? (G[Y][X] + H[Y][X] + 1) >> 1 : (G[Y + 1][X] + H[Y][X] + 1) >> 1;
+                    else if (fx == 2 && fy == 2) v = J[Y][X];
+                    else if (fx == 2) v = ((fy == 1 ? B[Y][X] : B[Y + 1][X]) + J[Y][X] + 1) >> 1;
+                    else if (fy == 2) v = ((fx == 1 ? H[Y][X] : H[Y][X + 1]) + J[Y][X] + 1) >> 1;
+                    else v = ((fy == 1 ? B[Y][X] : B[Y + 1][X]) + (fx == 1 ? H[Y][X] : H[Y][X + 1]) + 1) >> 1;
+                    pred[16 * y + x] = (uint8_t)v;
+                }
+            int cost = h264o_satd16x16(s, cw, pred, 16) + lambda * (se_len(qx) + se_len(qy));
+            if (k < 0 || cost < best_cost) { best_cost = cost; bcx = qx; bcy = qy; }
+        }
+        cx = bcx;
+        cy = bcy;
+    }
+    mv_t r = {(int16_t)cx, (int16_t)cy};
+    return r;
+}
+
+/* 8.4.1.3 median prediction for a 16x16 partition, single reference */
+static void neighbour(const h264o_enc *e, int mx, int my, int *avail, int *ref, mv_t *mv)
+{
+    *avail = mx >= 0 && my >= 0 && mx < e->mbw;
+    *ref = -1;
+    mv->x = mv->y = 0;
+    if (!*avail) return;
+    const h264o_mbinfo *m = &e->mb[my * e->mbw + mx];
+    if (m->type != H264O_MB_I16) { *ref = 0; mv->x = m->mvx; mv->y = m->mvy; }
+}
+static int med3(int a, int b, int c) { return a > b ? (b > c ? b : (a > c ? c : a)) : (a > c ? a : (b > c ? c : b)); }
+
+static mv_t predict_mv(const h264o_enc *e, int mx, int my, mv_t *skip_mv)
+{
+    int aA, aB, aC, rA, rB, rC;
+    mv_t A, B, C;
+    neighbour(e, mx - 1, my, &aA, &rA, &A);
+    neighbour(e, mx, my - 1, &aB, &rB, &B);
+    neighbour(e, mx + 1, my - 1, &aC, &rC, &C);
+    if (!aC) neighbour(e, mx - 1, my - 1, &aC, &rC, &C);
+    if (!aB && !aC && aA) { B = A; C = A; rB = rA; rC = rA; }
+    mv_t p;
+    int n = (rA == 0) + (rB == 0) + (rC == 0);
+    if (n == 1) p = rA == 0 ? A : rB == 0 ? B : C;
+    else { p.x = (int16_t)med3(A.x, B.x, C.x); p.y = (int16_t)med3(A.y, B.y, C.y); }
+    if (skip_mv) {
+        int uA, uB, t;
+        mv_t tA, tB;
+        neighbour(e, mx - 1, my, &uA, &t, &tA);
+        int refA = t;
+        neighbour(e, mx, my - 1, &uB, &t, &tB);
+        int refB = t;
+        if (!uA || !uB || (refA == 0 && tA.x == 0 && tA.y == 0) || (refB == 0 && tB.x == 0 && tB.y == 0)) skip_mv->x = skip_mv->y = 0;
+        else *skip_mv = p;
+    }
+    return p;
+}
+
+static void encode_inter_mb(h264o_enc *e, int mx, int my)
+{
+    int qp = e->cfg.qp, cw = e->cw, cs = cw / 2, ch = e->ch;
+    h264o_mbinfo *mb = &e->mb[my * e->mbw + mx];
+    int16_t *lv = e->levels + (size_t)(my * e->mbw + mx) * H264O_LV_STRIDE;
+    memset(lv, 0, H264O_LV_STRIDE * sizeof(int16_t));
+    uint8_t pred[256], predc[2][64];
+    h264o_mc_luma(e->ref[0], cw, cw, ch, 16 * mx, 16 * my, mb->mvx, mb->mvy, 16, 16, pred, 16);
+    for (int pl = 0; pl < 2; pl++)
+        h264o_mc_chroma(e->ref[1 + pl], cs, cs, ch / 2, 8 * mx, 8 * my, mb->mvx, mb->mvy, 8, 8, predc[pl], 8);
+    const uint8_t *s = e->src[0] + (16 * my) * cw + 16 * mx;
+    uint8_t *r = e->rec[0] + (16 * my) * cw + 16 * mx;
+    int cbp = 0;
+    for (int y = 0; y < 16; y++) memcpy(r + y * cw, pred + 16 * y, 16);
+    for (int b = 0; b < 16; b++) {
+        int bx = o_blk_x[b] * 4, by = o_blk_y[b] * 4;
+        int16_t deq[16];
+        int nnz = tq_block(s + by * cw + bx, cw, pred + by * 16 + bx, 16, qp, 0, 0, lv + H264O_LV_LUMA + b * 16, deq, NULL);
+        mb->tc[b] = (uint8_t)nnz;
+        if (nnz) {
+            cbp |= 1 << (b >> 2);
+            h264o_idct4x4_add(deq, r + by * cw + bx, cw);
+        }
+    }
+    int cbpc = code_chroma(e, mx, my, predc, 0, lv, mb->tc, 1);
+    mb->cbp = (uint8_t)(cbp | (cbpc << 4));
+    mv_t skip;
+    predict_mv(e, mx, my, &skip);
+    mb->type = (mb->cbp == 0 && skip.x == mb->mvx && skip.y == mb->mvy) ? H264O_MB_PSKIP : H264O_MB_P16;
+    mb->i16_mode = mb->chroma_mode = 0;
+}
+
+/* ------------------------------------------------------------ slice data 7.3.4/7.3.5 */
+static int nc_luma(const h264o_enc *e, int mx, int my, int b)
+{
+    int x = o_blk_x[b], y = o_blk_y[b], nA = -1, nB = -1;
+    const h264o_mbinfo *m = &e->mb[my * e->mbw + mx];
+    if (x > 0) nA = m->tc[xy2blk[4 * y + x - 1]];
+    else if (mx > 0) nA = (m - 1)->tc[xy2blk[4 * y + 3]];
+    if (y > 0) nB = m->tc[xy2blk[4 * (y - 1) + x]];
+    else if (my > 0) nB = (m - e->mbw)->tc[xy2blk[12 + x]];
+    if (nA >= 0 && nB >= 0) return (nA + nB + 1) >> 1;
+    return nA >= 0 ? nA : nB >= 0 ? nB : 0;
+}
+static int nc_chroma(const h264o_enc *e, int mx, int my, int pl, int b)
+{
+    int x = b & 1, y = b >> 1, nA = -1, nB = -1, base = 16 + pl * 4;
+    const h264o_mbinfo *m = &e->mb[my * e->mbw + mx];
+    if (x > 0) nA = m->tc[base + 2 * y];
+    else if (mx > 0) nA = (m - 1)->tc[base + 2 * y + 1];
+    if (y > 0) nB = m->tc[base + x];
+    else if (my > 0) nB = (m - e->mbw)->tc[base + 2 + x];
+    if (nA >= 0 && nB >= 0) return (nA + nB + 1) >> 1;
+    return nA >= 0 ? nA : nB >= 0 ? nB : 0;
+}
+
+static void write_mb(h264o_enc *e, bitw *b, int mx, int my, int p_slice)
+{
+    const h264o_mbinfo *mb = &e->mb[my * e->mbw + mx];
+    const int16_t *lv = e->levels + (size_t)(my * e->mbw + mx) * H264O_LV_STRIDE;
+    int cbpl = mb->cbp & 15, cbpc = mb->cbp >> 4;
+    if (mb->type == H264O_MB_I16) {
+        int t = 1 + mb->i16_mode + 4 * cbpc + (cbpl ? 12 : 0);
+        bw_ue(b, (uint32_t)(p_slice ? 5 + t : t));
+        bw_ue(b, mb->chroma_mode);
+        bw_se(b, 0); /* mb_qp_delta */
+        cavlc_block(b, lv + H264O_LV_LUMA_DC, 16, nc_luma(e, mx, my, 0));
+    } else {
+        bw_ue(b, 0); /* P_L0_16x16 */
+        mv_t p = predict_mv(e, mx, my, NULL);
+        bw_se(b, mb->mvx - p.x);
+        bw_se(b, mb->mvy - p.y);
+        int code = 0;
+        while (o_cbp_code2inter[code] != mb->cbp) code++;
+        bw_ue(b, (uint32_t)code);
+        if (mb->cbp) bw_se(b, 0); /* mb_qp_delta */
+    }
+    for (int b8 = 0; b8 < 4; b8++)
+        if (cbpl & (1 << b8))
+            for (int k = 0; k < 4; k++) {
+                int blk = 4 * b8 + k;
+                if (mb->type == H264O_MB_I16) cavlc_block(b, lv + H264O_LV_LUMA + blk * 16 + 1, 15, nc_luma(e, mx, my, blk));
+                else cavlc_block(b, lv + H264O_LV_LUMA + blk * 16, 16, nc_luma(e, mx, my, blk));
+            }
+    if (cbpc) {
+        cavlc_block(b, lv + H264O_LV_CHROMA_DC, 4, -1);
+        cavlc_block(b, lv + H264O_LV_CHROMA_DC + 4, 4, -1);
+    }
+    if (cbpc == 2)
+        for (int pl = 0; pl < 2; pl++)
+            for (int k = 0; k < 4; k++)
+                cavlc_block(b, lv + H264O_LV_CHROMA_AC + (pl * 4 + k) * 16 + 1, 15, nc_chroma(e, mx, my, pl, k));
+}
+
+/* ------------------------------------------------------------ picture driver */
+static void load_source(h264o_enc *e, const uint8_t *y, int ys, const uint8_t *u, int us, const uint8_t *v, int vs)
+{
+    const uint8_t *in[3] = {y, u, v};
+    int st[3] = {ys, us, vs};
+    for (int p = 0; p < 3; p++) {
+        int w = p ? e->cfg.width / 2 : e->cfg.width, h = p ? e->cfg.height / 2 : e->cfg.height;
+        int cw = p ? e->cw / 2 : e->cw, ch = p ? e->ch / 2 : e->ch;
+        for (int r = 0; r < ch; r++) {
+            const uint8_t *srow = in[p] + (size_t)(r < h ? r : h - 1) * st[p];
+            uint8_t *d = e->src[p] + (size_t)r * cw;
+            memcpy(d, srow, (size_t)w);
+            for (int c = w; c < cw; c++) d[c] = srow[w - 1];
+        }
+    }
+}
+
+int64_t h264o_enc_encode(h264o_enc *e, const uint8_t *y, int ys, const uint8_t *u, int us,
+                         const uint8_t *v, int vs, int force_idr, uint8_t *out, size_t out_cap, int *is_idr)
+{
+    if (!e || !y || !u || !v || !out) return -1;
+    load_source(e, y, ys, u, us, v, vs);
+    int idr = force_idr || e->frames == 0 || e->frame_in_gop >= e->cfg.gop;
+    if (idr) { e->frame_in_gop = 0; e->frame_num = 0; }
+    if (is_idr) *is_idr = idr;
+    size_t pos = 0;
+    bitw b;
+    if (idr) {
+        memset(e->rbsp, 0, 256);
+        b = (bitw){e->rbsp, e->rbsp_cap, 0};
+        write_sps(e, &b);
+        pos = emit_nal(out, out_cap, pos, 3, 7, e->rbsp, (size_t)(b.bits >> 3));
+        if (pos == (size_t)-1) return -2;
+        memset(e->rbsp, 0, 256);
+        b = (bitw){e->rbsp, e->rbsp_cap, 0};
+        write_pps(e, &b);
+        pos = emit_nal(out, out_cap, pos, 3, 8, e->rbsp, (size_t)(b.bits >> 3));
+        if (pos == (size_t)-1) return -2;
+    }
+    /* stage 1: decisions + reconstruction (pre-deblock) */
+    if (idr) {
+        for (int my = 0; my < e->mbh; my++)
+            for (int mx = 0; mx < e->mbw; mx++) encode_intra_mb(e, mx, my);
+    } else {
+        for (int my = 0; my < e->mbh; my++)
+            for (int mx = 0; mx < e->mbw; mx++) {
+                h264o_mbinfo *mb = &e->mb[my * e->mbw + mx];
+                memset(mb, 0, sizeof(*mb));
+                mb->type = H264O_MB_P16;
+                if (!zero_mv_all_zero(e, mx, my)) {
+                    mv_t m = motion_search(e, mx, my);
+                    mb->mvx = m.x;
+                    mb->mvy = m.y;
+                }
+            }
+        for (int my = 0; my < e->mbh; my++)
+            for (int mx = 0; mx < e->mbw; mx++) encode_inter_mb(e, mx, my);
+    }
+    /* stage 2: entropy coding */
+    memset(e->rbsp, 0, e->rbsp_cap);
+    b = (bitw){e->rbsp, e->rbsp_cap, 0};
+    write_slice_header(e, &b, idr);
+    uint64_t hdr_bits = b.bits;
+    int skip_run = 0;
+    for (int my = 0; my < e->mbh; my++)
+        for (int mx = 0; mx < e->mbw; mx++) {
+            const h264o_mbinfo *mb = &e->mb[my * e->mbw + mx];
+            if (!idr) {
+                if (mb->type == H264O_MB_PSKIP) { skip_run++; continue; }
+                bw_ue(&b, (uint32_t)skip_run);
+                skip_run = 0;
+            }
+            write_mb(e, &b, mx, my, !idr);
+        }
+    if (skip_run) bw_ue(&b, (uint32_t)skip_run);
+    e->last_slice_bits = (int64_t)(b.bits - hdr_bits);
+    bw_trailing(&b);
+    if ((b.bits >> 3) > e->rbsp_cap) return -3;
+    pos = emit_nal(out, out_cap, pos, idr ? 3 : 2, idr ? 5 : 1, e->rbsp, (size_t)(b.bits >> 3));
+    if (pos == (size_t)-1) return -2;
+    /* stage 3: in-loop filter into the next reference */
+    size_t ysz = (size_t)e->cw * e->ch;
+    memcpy(e->cur[0], e->rec[0], ysz);
+    memcpy(e->cur[1], e->rec[1], ysz / 4);
+    memcpy(e->cur[2], e->rec[2], ysz / 4);
+    if (!e->cfg.disable_deblock) h264o_deblock_picture(e->cur[0], e->cur[1], e->cur[2], e->cw, e->ch, e->mb, e->cfg.qp);
+    for (int p = 0; p < 3; p++) { uint8_t *t = e->ref[p]; e->ref[p] = e->cur[p]; e->cur[p] = t; }
+    if (idr) e->idr_id = (e->idr_id + 1) & 0xFFFF;
+    e->frame_num = (e->frame_num + 1) & 255;
+    e->frame_in_gop++;
+    e->frames++;
+    return (int64_t)pos;
+}

@@ -1,0 +1,129 @@
+/*
+ * oracle/h264_oracle.h -- TEST INFRASTRUCTURE ONLY.
+ *
+ * CPU restatement ("oracle") of the H.264 encode hot path that the reference
+ * delegates to ISVCEncoder::EncodeFrame
+ * (/root/reference/video_codec/VideoEncoderOpenH264.cpp:344), plus a test-side
+ * decoder used for encode->decode round trips.
+ *
+ * PARITY UNPINNED vs OpenH264: the reference ships no codec source, no
+ * libopenh264.so, no tests and no golden vectors.
+ * What pins this oracle instead: (i) known answers from ITU-T H.264 held in
+ * tests/, (ii) encoder reconstruction == decoder output byte for byte, which
+ * ties every normative stage to the standard.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load
+ * this library.  The product (media_amd/) never does.
+ */
+#ifndef ORACLE_H264_ORACLE_H
+#define ORACLE_H264_ORACLE_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Layout of one macroblock's quantised levels (int16), shared with the GPU
+ * path's debug dump so the two can be compared array-for-array. */
+enum {
+    H264O_LV_LUMA_DC = 0,     /* 16: Intra16x16 DC levels, zig-zag order            */
+    H264O_LV_LUMA = 16,       /* 16 blocks (blkIdx order) x 16 levels, zig-zag      */
+    H264O_LV_CHROMA_DC = 272, /* Cb 4, Cr 4 (raster 2x2 order = chroma DC scan)     */
+    H264O_LV_CHROMA_AC = 280, /* Cb blk0..3, Cr blk0..3, x16 zig-zag (idx0 unused)  */
+    H264O_LV_STRIDE = 416     /* int16 per macroblock (832 B)                       */
+};
+
+enum { H264O_MB_I16 = 0, H264O_MB_P16 = 1, H264O_MB_PSKIP = 2 };
+
+typedef struct {
+    int32_t width, height;  /* display size, even, 16..4096                          */
+    int32_t fps;            /* 30 or 60 (level selection only)                       */
+    int32_t qp;             /* fixed frame QP, 10..51                                */
+    int32_t gop;            /* IDR period in frames (uiIntraPeriod, ref :242)        */
+    int32_t profile_idc;    /* 66 baseline, 77 main (CAVLC), 100 high (no 8x8)       */
+    int32_t disable_deblock;/* 0: in-loop filter on (ref :295 iLoopFilterDisableIdc) */
+} h264o_config;
+
+typedef struct h264o_enc h264o_enc;
+typedef struct h264o_dec h264o_dec;
+
+/* per-macroblock side information exposed for stage-by-stage parity checks */
+typedef struct {
+    int16_t mvx, mvy;      /* quarter-pel motion vector (0 for intra)              */
+    uint8_t type;          /* H264O_MB_*                                            */
+    uint8_t i16_mode;      /* Intra16x16PredMode 0..3                               */
+    uint8_t chroma_mode;   /* intra_chroma_pred_mode 0..3                           */
+    uint8_t cbp;           /* coded_block_pattern (luma | chroma<<4)                */
+    uint8_t tc[24];        /* TotalCoeff per 4x4: 16 luma (blkIdx), 4 Cb, 4 Cr      */
+} h264o_mbinfo;            /* 32 bytes                                              */
+
+h264o_enc *h264o_enc_create(const h264o_config *cfg);
+void h264o_enc_destroy(h264o_enc *e);
+/* Encode one I420 picture.  Returns bytes written (Annex B, 4-byte start codes;
+ * SPS+PPS precede every IDR) or <0 on error.  *is_idr receives 1 for IDR. */
+int64_t h264o_enc_encode(h264o_enc *e, const uint8_t *y, int ys, const uint8_t *u, int us,
+                         const uint8_t *v, int vs, int force_idr, uint8_t *out, size_t out_cap,
+                         int *is_idr);
+/* Accessors valid until the next encode call.  Planes are coded size
+ * (multiples of 16), pitch == coded width (chroma: half). */
+int h264o_enc_coded_width(const h264o_enc *e);
+int h264o_enc_coded_height(const h264o_enc *e);
+const uint8_t *h264o_enc_recon(const h264o_enc *e, int plane);       /* deblocked */
+const uint8_t *h264o_enc_recon_pre(const h264o_enc *e, int plane);   /* before loop filter */
+const h264o_mbinfo *h264o_enc_mbinfo(const h264o_enc *e);
+const int16_t *h264o_enc_levels(const h264o_enc *e);
+/* bits of slice_data() of the last slice, before trailing bits (for tests) */
+int64_t h264o_enc_last_slice_bits(const h264o_enc *e);
+
+/* ---- stand-alone stage functions (kernel-level parity, known-answer tests) ---- */
+void h264o_fdct4x4(const int16_t in[16], int16_t out[16]);
+void h264o_idct4x4_add(const int16_t coef[16], uint8_t *dst, int stride);
+/* quantise one 4x4 of forward-transform output (raster); intra selects the
+ * rounding offset; returns levels in raster order */
+void h264o_quant4x4(const int16_t w[16], int qp, int intra, int16_t lv[16]);
+void h264o_dequant4x4(const int16_t lv[16], int qp, int16_t out[16]);
+/* luma quarter-pel and chroma eighth-pel motion compensation (8.4.2.2) on a
+ * w x h plane with edge clamping */
+void h264o_mc_luma(const uint8_t *ref, int stride, int w, int h, int x, int y, int mvx, int mvy,
+                   int bw, int bh, uint8_t *dst, int dstride);
+/* spec-literal one-sample evaluation of 8.4.2.2.1 (cross-check of the block form) */
+int h264o_luma_sample_ref(const uint8_t *ref, int stride, int w, int h, int x, int y, int mvx, int mvy);
+void h264o_mc_chroma(const uint8_t *ref, int stride, int w, int h, int x, int y, int mvx,
+                     int mvy, int bw, int bh, uint8_t *dst, int dstride);
+int h264o_sad16x16(const uint8_t *a, int as, const uint8_t *b, int bs);
+int h264o_satd16x16(const uint8_t *a, int as, const uint8_t *b, int bs);
+int h264o_satd8x8(const uint8_t *a, int as, const uint8_t *b, int bs);
+/* intra predictors; avail bit0 = left, bit1 = top, bit2 = top-left */
+void h264o_pred16x16(const uint8_t *rec, int stride, int mode, int avail, uint8_t pred[256]);
+void h264o_pred_chroma8x8(const uint8_t *rec, int stride, int mode, int avail, uint8_t pred[64]);
+/* deblock a whole picture in place given per-MB info (8.7) */
+void h264o_deblock_picture(uint8_t *y, uint8_t *u, uint8_t *v, int cw, int ch,
+                           const h264o_mbinfo *mbs, int qp);
+/* Exp-Golomb / CAVLC helpers for known-answer tests */
+int h264o_ue_bits(uint32_t v, uint32_t *code); /* returns length, *code = bit pattern */
+int h264o_se_bits(int32_t v, uint32_t *code);
+/* writes one residual block with CAVLC; returns number of bits appended to buf
+ * (MSB first, buf must be zeroed, cap >= 64 bytes) */
+int h264o_cavlc_block(const int16_t *lv, int max_coeff, int nC, uint8_t *buf);
+size_t h264o_nal_escape(const uint8_t *rbsp, size_t n, uint8_t *out);
+
+/* ---- decoder ---- */
+h264o_dec *h264o_dec_create(void);
+void h264o_dec_destroy(h264o_dec *d);
+/* Feed one access unit (any number of Annex B NALs).  Returns 1 when a picture
+ * was completed, 0 for parameter sets only, <0 on a syntax/feature error. */
+int h264o_dec_decode(h264o_dec *d, const uint8_t *data, size_t len);
+int h264o_dec_width(const h264o_dec *d);         /* cropped */
+int h264o_dec_height(const h264o_dec *d);
+int h264o_dec_coded_width(const h264o_dec *d);
+int h264o_dec_coded_height(const h264o_dec *d);
+const uint8_t *h264o_dec_plane(const h264o_dec *d, int plane); /* coded size, pitch = coded w */
+const char *h264o_dec_error(const h264o_dec *d);
+int h264o_dec_last_slice_type(const h264o_dec *d); /* 0 P, 2 I */
+int h264o_dec_last_nal_type(const h264o_dec *d);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
