@@ -1,0 +1,149 @@
+/*
+ * include/mi355x_h264.h -- the drop-in boundary: a plain C ABI over the
+ * hand-written HIP (gfx950) H.264 encode path.  No C++ or torch types cross it.
+ *
+ * Each entry point replaces one use of the OpenH264 vtable that the
+ * reference's adapter makes (paths relative to /root/reference):
+ *
+ *   mi355x_h264_create      <- WelsCreateSVCEncoder + ISVCEncoder::InitializeExt
+ *                              + SetOption(ENCODER_OPTION_DATAFORMAT)
+ *                              video_codec/VideoEncoderOpenH264.cpp:142, :257, :262
+ *                              (decl vendor/openh264/codec_api.h:286, :545)
+ *   mi355x_h264_encode      <- ISVCEncoder::EncodeFrame
+ *                              video_codec/VideoEncoderOpenH264.cpp:344
+ *                              (decl vendor/openh264/codec_api.h:309); the
+ *                              SSourcePicture plane/stride triple of :354-365
+ *                              becomes the y/u/v + stride arguments, and the
+ *                              SFrameBSInfo consumption of :349-350 becomes
+ *                              (*out, *out_len)
+ *   mi355x_h264_force_idr   <- ISVCEncoder::ForceIntraFrame(true)
+ *                              video_codec/VideoEncoderOpenH264.cpp:408
+ *                              (decl vendor/openh264/codec_api.h:323)
+ *   mi355x_h264_destroy     <- ISVCEncoder::Uninitialize + WelsDestroySVCEncoder
+ *                              video_codec/VideoEncoderOpenH264.cpp:382-383
+ *
+ * The *_device / *_batch entry points are this build's additions for callers
+ * whose frames are already resident in HBM (bench.py, multi-stream sharding);
+ * the mi355x_h264_debug_* ones expose intermediate device buffers so tests can
+ * compare every stage against the CPU oracle.
+ *
+ * Ownership mirrors the reference: input is caller-owned and
+ * only read during the call; the output bitstream lives in encoder-owned
+ * (pinned host) memory and stays valid until the next encode / destroy on the
+ * same handle.  All functions return 0 on success or a negative MI355X_H264_E_*.
+ * Nothing here falls back to a CPU encoder: if no HIP device is usable,
+ * mi355x_h264_create fails with MI355X_H264_E_NODEVICE.
+ */
+#ifndef MI355X_H264_H
+#define MI355X_H264_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI355X_H264_ABI_VERSION 1
+
+enum {
+    MI355X_H264_OK = 0,
+    MI355X_H264_E_ARG = -1,      /* bad argument / unsupported configuration        */
+    MI355X_H264_E_NODEVICE = -2, /* no usable HIP device (never a silent CPU path)  */
+    MI355X_H264_E_HIP = -3,      /* a HIP runtime call failed (see last_error)      */
+    MI355X_H264_E_NOMEM = -4,
+    MI355X_H264_E_OVERFLOW = -5, /* bitstream exceeded the output buffer            */
+    MI355X_H264_E_INTERNAL = -6
+};
+
+enum { MI355X_H264_FRAME_IDR = 1, MI355X_H264_FRAME_P = 3 }; /* EVideoFrameType values, codec_def.h:70,72 */
+
+enum { MI355X_H264_RC_FIXED_QP = 0, MI355X_H264_RC_BITRATE = 1 };
+
+typedef struct mi355x_h264_config {
+    uint32_t struct_size;    /* sizeof(mi355x_h264_config), for ABI growth          */
+    int32_t width, height;   /* iPicWidth/iPicHeight (ref :235-236); even, 16..4096 */
+    int32_t fps;             /* fMaxFrameRate (ref :241): 30 or 60                  */
+    int32_t bitrate;         /* iTargetBitrate (ref :239), used when rc_mode == 1   */
+    int32_t gop;             /* uiIntraPeriod (ref :242)                            */
+    int32_t profile_idc;     /* uiProfileIdc (ref :248-254): 66, 77 or 100          */
+    int32_t rc_mode;         /* MI355X_H264_RC_*; the reference preset is BITRATE   */
+    int32_t qp;              /* picture QP for FIXED_QP (10..51); initial QP else   */
+    int32_t device;          /* HIP device ordinal                                  */
+    int32_t disable_deblock; /* iLoopFilterDisableIdc (ref :295), 0 = filter on     */
+    int32_t reserved[5];
+} mi355x_h264_config;
+
+typedef struct mi355x_h264_encoder mi355x_h264_encoder;
+
+int mi355x_h264_abi_version(void);
+void mi355x_h264_default_config(mi355x_h264_config *cfg);
+int mi355x_h264_create(const mi355x_h264_config *cfg, mi355x_h264_encoder **out);
+void mi355x_h264_destroy(mi355x_h264_encoder *enc);
+
+/* Encode one I420 picture given as host pointers.  *out receives an Annex-B
+ * access unit (SPS+PPS+IDR slice, or one P slice) in encoder-owned memory. */
+int mi355x_h264_encode(mi355x_h264_encoder *enc, const uint8_t *y, int y_stride, const uint8_t *u,
+                       int u_stride, const uint8_t *v, int v_stride, uint8_t **out, uint32_t *out_len,
+                       int *frame_type);
+
+/* Same, with the picture already in device memory as one tightly packed I420
+ * buffer (Y, then U, then V; width*height*3/2 bytes). */
+int mi355x_h264_encode_device(mi355x_h264_encoder *enc, const void *d_i420, uint8_t **out,
+                              uint32_t *out_len, int *frame_type);
+
+/* Encode `count` device-resident pictures back to back; picture i starts at
+ * d_frames + i*frame_stride_bytes.  Access units are appended to host_out
+ * (capacity out_cap); sizes[i] receives the byte length of picture i.  The
+ * host-side finishing of picture i overlaps the GPU work of picture i+1. */
+int mi355x_h264_encode_batch_device(mi355x_h264_encoder *enc, const void *d_frames,
+                                    size_t frame_stride_bytes, int count, uint8_t *host_out,
+                                    size_t out_cap, uint32_t *sizes, size_t *total_len);
+
+int mi355x_h264_force_idr(mi355x_h264_encoder *enc);
+/* picture QP (10..51) for the pictures that follow; the hook the rate controller
+ * of the host class drives (RC_BITRATE_MODE, ref :274) */
+int mi355x_h264_set_qp(mi355x_h264_encoder *enc, int qp);
+const char *mi355x_h264_last_error(const mi355x_h264_encoder *enc);
+
+/* coded picture geometry (multiples of 16) */
+int mi355x_h264_coded_width(const mi355x_h264_encoder *enc);
+int mi355x_h264_coded_height(const mi355x_h264_encoder *enc);
+
+/* ---- test / measurement hooks ---- */
+enum {
+    MI355X_H264_DBG_RECON_Y = 0,   /* deblocked reconstruction = next reference, coded size */
+    MI355X_H264_DBG_RECON_U = 1,
+    MI355X_H264_DBG_RECON_V = 2,
+    MI355X_H264_DBG_MBINFO = 3,    /* 32 B per macroblock, layout of h264 mbinfo below      */
+    MI355X_H264_DBG_LEVELS = 4,    /* 416 int16 per macroblock                              */
+    MI355X_H264_DBG_PRE_Y = 5,     /* reconstruction before the loop filter (needs          */
+    MI355X_H264_DBG_PRE_U = 6,     /*  mi355x_h264_debug_keep_pre(enc, 1))                  */
+    MI355X_H264_DBG_PRE_V = 7
+};
+int mi355x_h264_debug_keep_pre(mi355x_h264_encoder *enc, int on);
+/* copies the named device buffer of the last encoded picture to dst; returns bytes or <0 */
+int64_t mi355x_h264_debug_read(mi355x_h264_encoder *enc, int what, void *dst, size_t cap);
+
+/* per-kernel device time accumulated since the last reset, measured with HIP
+ * events on the encoder's own stream */
+enum {
+    MI355X_H264_K_ME = 0,       /* motion search (SAD integer + SATD sub-pel)      */
+    MI355X_H264_K_PMB = 1,      /* MC + fDCT + quant + dequant + iDCT + recon      */
+    MI355X_H264_K_INTRA = 2,    /* Intra16x16 wavefront                            */
+    MI355X_H264_K_CAVLC = 3,    /* entropy coding + packing                        */
+    MI355X_H264_K_DEBLOCK = 4,  /* loop filter wavefront                           */
+    MI355X_H264_K_COUNT = 5
+};
+typedef struct mi355x_h264_stats {
+    double ms[MI355X_H264_K_COUNT];       /* summed device milliseconds           */
+    uint64_t launches[MI355X_H264_K_COUNT];
+    uint64_t mbs[MI355X_H264_K_COUNT];    /* macroblocks processed by that kernel */
+    uint64_t frames;
+} mi355x_h264_stats;
+int mi355x_h264_stats_enable(mi355x_h264_encoder *enc, int on);
+int mi355x_h264_stats_read(mi355x_h264_encoder *enc, mi355x_h264_stats *out, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,170 @@
+"""ctypes binding of the C ABI in include/mi355x_h264.h (media_amd/lib/libmi355x_h264.so).
+
+This is plumbing for tests and bench.py; the product's host side is the C++
+VideoEncoderMI355X class in media_amd/host/.  There is no fallback: if the HIP
+library is missing or no device is usable, loading / creating raises.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmi355x_h264.so")
+
+LV_STRIDE = 416
+MBINFO_DTYPE = np.dtype([("mvx", "<i2"), ("mvy", "<i2"), ("type", "u1"), ("i16_mode", "u1"),
+                         ("chroma_mode", "u1"), ("cbp", "u1"), ("tc", "u1", (24,))])
+FRAME_IDR, FRAME_P = 1, 3
+DBG_RECON_Y, DBG_RECON_U, DBG_RECON_V, DBG_MBINFO, DBG_LEVELS, DBG_PRE_Y, DBG_PRE_U, DBG_PRE_V = range(8)
+K_NAMES = ["me", "pmb", "intra", "cavlc", "deblock"]
+
+EXPORTS = [
+    "mi355x_h264_abi_version", "mi355x_h264_default_config", "mi355x_h264_create", "mi355x_h264_destroy",
+    "mi355x_h264_encode", "mi355x_h264_encode_device", "mi355x_h264_encode_batch_device",
+    "mi355x_h264_force_idr", "mi355x_h264_last_error", "mi355x_h264_coded_width", "mi355x_h264_coded_height",
+    "mi355x_h264_debug_keep_pre", "mi355x_h264_debug_read", "mi355x_h264_stats_enable", "mi355x_h264_stats_read",
+    "mi355x_h264_set_qp",
+]
+
+
+class Config(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("width", C.c_int32), ("height", C.c_int32), ("fps", C.c_int32),
+                ("bitrate", C.c_int32), ("gop", C.c_int32), ("profile_idc", C.c_int32), ("rc_mode", C.c_int32),
+                ("qp", C.c_int32), ("device", C.c_int32), ("disable_deblock", C.c_int32),
+                ("reserved", C.c_int32 * 5)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("ms", C.c_double * 5), ("launches", C.c_uint64 * 5), ("mbs", C.c_uint64 * 5),
+                ("frames", C.c_uint64)]
+
+
+_lib = None
+
+
+def lib():
+    """load the HIP library; raises OSError when it has not been built"""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise OSError("HIP extension missing: %s (run __graft_entry__.build())" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        vp = C.c_void_p
+        L.mi355x_h264_default_config.argtypes = [C.POINTER(Config)]
+        L.mi355x_h264_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
+        L.mi355x_h264_destroy.argtypes = [vp]
+        L.mi355x_h264_destroy.restype = None
+        L.mi355x_h264_encode.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp, C.c_int, C.POINTER(vp),
+                                         C.POINTER(C.c_uint32), C.POINTER(C.c_int)]
+        L.mi355x_h264_encode_device.argtypes = [vp, vp, C.POINTER(vp), C.POINTER(C.c_uint32), C.POINTER(C.c_int)]
+        L.mi355x_h264_encode_batch_device.argtypes = [vp, vp, C.c_size_t, C.c_int, vp, C.c_size_t, vp,
+                                                      C.POINTER(C.c_size_t)]
+        L.mi355x_h264_force_idr.argtypes = [vp]
+        L.mi355x_h264_set_qp.argtypes = [vp, C.c_int]
+        L.mi355x_h264_last_error.argtypes = [vp]
+        L.mi355x_h264_last_error.restype = C.c_char_p
+        L.mi355x_h264_coded_width.argtypes = [vp]
+        L.mi355x_h264_coded_height.argtypes = [vp]
+        L.mi355x_h264_debug_keep_pre.argtypes = [vp, C.c_int]
+        L.mi355x_h264_debug_read.argtypes = [vp, C.c_int, vp, C.c_size_t]
+        L.mi355x_h264_debug_read.restype = C.c_int64
+        L.mi355x_h264_stats_enable.argtypes = [vp, C.c_int]
+        L.mi355x_h264_stats_read.argtypes = [vp, C.POINTER(Stats), C.c_int]
+        _lib = L
+    return _lib
+
+
+class EncoderError(RuntimeError):
+    pass
+
+
+class Encoder:
+    """thin object wrapper; argument meaning follows mi355x_h264_config"""
+
+    def __init__(self, width, height, qp=26, gop=30, fps=30, profile_idc=66, device=0, disable_deblock=0,
+                 bitrate=5000000, rc_mode=0):
+        L = lib()
+        cfg = Config()
+        L.mi355x_h264_default_config(C.byref(cfg))
+        cfg.width, cfg.height, cfg.qp, cfg.gop, cfg.fps = width, height, qp, gop, fps
+        cfg.profile_idc, cfg.device, cfg.disable_deblock = profile_idc, device, disable_deblock
+        cfg.bitrate, cfg.rc_mode = bitrate, rc_mode
+        self.h = C.c_void_p()
+        rc = L.mi355x_h264_create(C.byref(cfg), C.byref(self.h))
+        if rc != 0:
+            self.h = None
+            raise EncoderError("mi355x_h264_create failed: %d" % rc)
+        self.width, self.height = width, height
+        self.cw, self.ch = L.mi355x_h264_coded_width(self.h), L.mi355x_h264_coded_height(self.h)
+        self.nmb = (self.cw // 16) * (self.ch // 16)
+
+    def _check(self, rc):
+        if rc != 0:
+            raise EncoderError("rc=%d: %s" % (rc, lib().mi355x_h264_last_error(self.h).decode()))
+
+    def encode(self, i420):
+        """host I420 (numpy uint8, width*height*3/2) -> (bytes, frame_type)"""
+        w, h = self.width, self.height
+        f = np.ascontiguousarray(i420, dtype=np.uint8)
+        base = f.ctypes.data
+        out, n, ft = C.c_void_p(), C.c_uint32(), C.c_int()
+        self._check(lib().mi355x_h264_encode(self.h, base, w, base + w * h, w // 2, base + w * h * 5 // 4, w // 2,
+                                             C.byref(out), C.byref(n), C.byref(ft)))
+        return C.string_at(out.value, n.value), ft.value
+
+    def encode_device(self, dev_ptr):
+        out, n, ft = C.c_void_p(), C.c_uint32(), C.c_int()
+        self._check(lib().mi355x_h264_encode_device(self.h, C.c_void_p(dev_ptr), C.byref(out), C.byref(n), C.byref(ft)))
+        return C.string_at(out.value, n.value), ft.value
+
+    def encode_batch_device(self, dev_ptr, stride, count, out_buf, sizes):
+        """out_buf: numpy uint8 host buffer; sizes: numpy uint32[count]; returns total bytes"""
+        tot = C.c_size_t()
+        self._check(lib().mi355x_h264_encode_batch_device(self.h, C.c_void_p(dev_ptr), stride, count,
+                                                          out_buf.ctypes.data, out_buf.size, sizes.ctypes.data,
+                                                          C.byref(tot)))
+        return tot.value
+
+    def force_idr(self):
+        self._check(lib().mi355x_h264_force_idr(self.h))
+
+    def set_qp(self, qp):
+        self._check(lib().mi355x_h264_set_qp(self.h, qp))
+
+    def keep_pre(self, on=True):
+        self._check(lib().mi355x_h264_debug_keep_pre(self.h, int(on)))
+
+    def debug_read(self, what):
+        ysz = self.cw * self.ch
+        if what in (DBG_RECON_Y, DBG_PRE_Y):
+            a = np.empty((self.ch, self.cw), np.uint8)
+        elif what in (DBG_RECON_U, DBG_RECON_V, DBG_PRE_U, DBG_PRE_V):
+            a = np.empty((self.ch // 2, self.cw // 2), np.uint8)
+        elif what == DBG_MBINFO:
+            a = np.empty(self.nmb, MBINFO_DTYPE)
+        else:
+            a = np.empty((self.nmb, LV_STRIDE), np.int16)
+        n = lib().mi355x_h264_debug_read(self.h, what, a.ctypes.data, a.nbytes)
+        if n != a.nbytes:
+            raise EncoderError("debug_read(%d) -> %d" % (what, n))
+        return a
+
+    def stats_enable(self, on=True):
+        self._check(lib().mi355x_h264_stats_enable(self.h, int(on)))
+
+    def stats(self, reset=True):
+        s = Stats()
+        self._check(lib().mi355x_h264_stats_read(self.h, C.byref(s), int(reset)))
+        return {"frames": s.frames,
+                "kernels": {K_NAMES[i]: {"ms": s.ms[i], "launches": s.launches[i], "mbs": s.mbs[i]} for i in range(5)}}
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().mi355x_h264_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,256 @@
+// media_amd/csrc/dev_common.h -- shared device-side definitions of the MI355X
+// (gfx950) H.264 encode path.  Wave = 64 lanes everywhere; every kernel in this
+// directory launches 64-thread workgroups (one wavefront per macroblock) unless
+// it says otherwise.
+//
+// What is restated here is the interior of ISVCEncoder::EncodeFrame, which the
+// reference reaches at /root/reference/video_codec/VideoEncoderOpenH264.cpp:344
+// (SURVEY.md 8a rows a6.1-a6.5).  Tables are ITU-T H.264 constants.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace h264 {
+
+enum { MB_I16 = 0, MB_P16 = 1, MB_PSKIP = 2 };
+enum { LV_LUMA_DC = 0, LV_LUMA = 16, LV_CHROMA_DC = 272, LV_CHROMA_AC = 280, LV_STRIDE = 416 };
+
+// 32 bytes; identical to the debug layout documented in include/mi355x_h264.h
+struct MbInfo {
+    int16_t mvx, mvy;
+    uint8_t type, i16_mode, chroma_mode, cbp;
+    uint8_t tc[24];  // TotalCoeff: 16 luma (blkIdx order), 4 Cb, 4 Cr
+};
+static_assert(sizeof(MbInfo) == 32, "MbInfo layout");
+
+// forward quantiser constants for one QP (host-prepared)
+struct Quant {
+    int qbits;          // 15 + qp/6
+    int f_intra, f_inter;
+    int mf[3];          // multiplier per position class
+    int dq[3];          // dequant v[class] << (qp/6)
+    int thr_inter[3];   // smallest |w| whose inter-rounded level is non-zero
+    int thr_dc_inter;   // same for the chroma DC path (2x2 Hadamard output)
+    int qp;
+};
+
+struct FrameParams {
+    const uint8_t* src;  // tight I420 picture in HBM: Y (w*h), U, V
+    int w, h;            // display size
+    int cw, ch, mbw, mbh;
+    uint8_t* rec[3];        // current picture reconstruction (pitch cw, cw/2, cw/2)
+    const uint8_t* ref[3];  // previous deblocked picture
+    MbInfo* mb;
+    int16_t* levels;     // LV_STRIDE int16 per macroblock
+    int16_t* mvd;        // 2 int16 per macroblock (mv - predictor)
+    Quant qy, qc;        // luma / chroma quantisers
+    int lambda;
+};
+
+__device__ __forceinline__ int clip3(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
+__device__ __forceinline__ int clip255(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
+__device__ __forceinline__ int iabs(int v) { return v < 0 ? -v : v; }
+
+// position class of raster index i in a 4x4 block: 0 (even,even) 1 (odd,odd) 2 otherwise
+__device__ __forceinline__ int pos_class(int i)
+{
+    const int x = i & 1, y = (i >> 2) & 1;
+    return (x & y) ? 1 : ((x | y) ? 2 : 0);
+}
+
+// 6.4.3: blkIdx <-> 4x4 raster position
+__device__ __forceinline__ int blk_x(int b) { return (b & 1) | ((b >> 1) & 2); }
+__device__ __forceinline__ int blk_y(int b) { return ((b >> 1) & 1) | ((b >> 2) & 2); }
+__device__ __forceinline__ int xy2blk(int x, int y) { return (x & 1) | ((y & 1) << 1) | ((x & 2) << 1) | ((y & 2) << 2); }
+
+__constant__ const uint8_t c_zigzag[16] = {0, 1, 4, 8, 5, 2, 3, 6, 9, 12, 13, 10, 7, 11, 14, 15};
+// raster position -> zig-zag index
+__constant__ const uint8_t c_zigzag_inv[16] = {0, 1, 5, 6, 2, 4, 7, 12, 3, 8, 11, 13, 9, 10, 14, 15};
+
+// length in bits of se(v)
+__device__ __forceinline__ int se_len(int v)
+{
+    if (v == 0) return 1;
+    const unsigned k1 = v > 0 ? 2u * (unsigned)v : 2u * (unsigned)(-v) + 1u;  // codeNum + 1
+    return 2 * (31 - __clz((int)k1)) + 1;
+}
+
+// forward 4x4 core transform, in place on 16 ints (raster)
+__device__ __forceinline__ void fdct4x4(int d[16])
+{
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int a = d[4 * i], b = d[4 * i + 1], c = d[4 * i + 2], e = d[4 * i + 3];
+        const int s0 = a + e, s1 = b + c, d0 = a - e, d1 = b - c;
+        d[4 * i] = s0 + s1; d[4 * i + 1] = 2 * d0 + d1; d[4 * i + 2] = s0 - s1; d[4 * i + 3] = d0 - 2 * d1;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int a = d[j], b = d[4 + j], c = d[8 + j], e = d[12 + j];
+        const int s0 = a + e, s1 = b + c, d0 = a - e, d1 = b - c;
+        d[j] = s0 + s1; d[4 + j] = 2 * d0 + d1; d[8 + j] = s0 - s1; d[12 + j] = d0 - 2 * d1;
+    }
+}
+
+// 8.5.12.2 inverse transform; in: scaled coefficients, out: residual (rounded >>6)
+__device__ __forceinline__ void idct4x4(int d[16])
+{
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int d0 = d[4 * i], d1 = d[4 * i + 1], d2 = d[4 * i + 2], d3 = d[4 * i + 3];
+        const int e0 = d0 + d2, e1 = d0 - d2, e2 = (d1 >> 1) - d3, e3 = d1 + (d3 >> 1);
+        d[4 * i] = e0 + e3; d[4 * i + 1] = e1 + e2; d[4 * i + 2] = e1 - e2; d[4 * i + 3] = e0 - e3;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int f0 = d[j], f1 = d[4 + j], f2 = d[8 + j], f3 = d[12 + j];
+        const int g0 = f0 + f2, g1 = f0 - f2, g2 = (f1 >> 1) - f3, g3 = f1 + (f3 >> 1);
+        d[j] = (g0 + g3 + 32) >> 6; d[4 + j] = (g1 + g2 + 32) >> 6;
+        d[8 + j] = (g1 - g2 + 32) >> 6; d[12 + j] = (g0 - g3 + 32) >> 6;
+    }
+}
+
+// sum |H4 D H4^T| of 16 differences (no normalisation)
+__device__ __forceinline__ int hadamard_abs(int d[16])
+{
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int s0 = d[4 * i] + d[4 * i + 3], s1 = d[4 * i + 1] + d[4 * i + 2];
+        const int d0 = d[4 * i] - d[4 * i + 3], d1 = d[4 * i + 1] - d[4 * i + 2];
+        d[4 * i] = s0 + s1; d[4 * i + 1] = d0 + d1; d[4 * i + 2] = s0 - s1; d[4 * i + 3] = d0 - d1;
+    }
+    int s = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int s0 = d[j] + d[12 + j], s1 = d[4 + j] + d[8 + j];
+        const int d0 = d[j] - d[12 + j], d1 = d[4 + j] - d[8 + j];
+        s += iabs(s0 + s1) + iabs(d0 + d1) + iabs(s0 - s1) + iabs(d0 - d1);
+    }
+    return s;
+}
+
+// symmetric 4x4 Hadamard (rows 1111 / 11-1-1 / 1-1-11 / 1-11-1), in place
+__device__ __forceinline__ void hadamard4x4(int d[16])
+{
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int a = d[4 * i], b = d[4 * i + 1], c = d[4 * i + 2], e = d[4 * i + 3];
+        d[4 * i] = a + b + c + e; d[4 * i + 1] = a + b - c - e; d[4 * i + 2] = a - b - c + e; d[4 * i + 3] = a - b + c - e;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int a = d[j], b = d[4 + j], c = d[8 + j], e = d[12 + j];
+        d[j] = a + b + c + e; d[4 + j] = a + b - c - e; d[8 + j] = a - b - c + e; d[12 + j] = a - b + c - e;
+    }
+}
+
+__device__ __forceinline__ int quant1(int w, int mf, int f, int qbits)
+{
+    const int a = iabs(w);
+    const int l = (int)(((unsigned)a * (unsigned)mf + (unsigned)f) >> qbits);
+    return w < 0 ? -l : l;
+}
+
+// wave-wide reductions over 64 lanes
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned t = (unsigned)__shfl_xor((int)v, o);
+        v = t < v ? t : v;
+    }
+    return v;
+}
+// sum across aligned groups of `width` lanes (power of two <= 64)
+template <int WIDTH>
+__device__ __forceinline__ int group_sum(int v)
+{
+#pragma unroll
+    for (int o = WIDTH / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// clamped fetch of one source sample (the coded picture extends the display
+// picture by replicating its last column / row)
+__device__ __forceinline__ int src_px(const uint8_t* plane, int pw, int ph, int x, int y)
+{
+    return plane[(size_t)(y < ph ? y : ph - 1) * pw + (x < pw ? x : pw - 1)];
+}
+
+// Load the source macroblock (mx,my) into LDS: y[256] (pitch 16), c[128] (Cb 8x8 then Cr 8x8).
+__device__ __forceinline__ void load_src_mb(const FrameParams& P, int mx, int my, uint8_t* sy, uint8_t* sc, int lane)
+{
+    const uint8_t* Y = P.src;
+    const uint8_t* U = Y + (size_t)P.w * P.h;
+    const uint8_t* V = U + (size_t)(P.w / 2) * (P.h / 2);
+    {
+        const int row = lane >> 2, xs = (lane & 3) * 4;
+        const int gy = 16 * my + row, gx = 16 * mx + xs;
+        const int yy = gy < P.h ? gy : P.h - 1;
+        const uint8_t* p = Y + (size_t)yy * P.w + gx;
+        uint32_t v;
+        if (gx + 3 < P.w && (((uintptr_t)p) & 3) == 0) v = *(const uint32_t*)p;
+        else {
+            v = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) v |= (uint32_t)src_px(Y, P.w, P.h, gx + k, gy) << (8 * k);
+        }
+        *(uint32_t*)(sy + row * 16 + xs) = v;
+    }
+    if (lane < 32) {
+        const int pl = lane >> 4, row = (lane >> 1) & 7, xs = (lane & 1) * 4;
+        const uint8_t* C = pl ? V : U;
+        const int pw = P.w / 2, ph = P.h / 2;
+        const int gy = 8 * my + row, gx = 8 * mx + xs;
+        const int yy = gy < ph ? gy : ph - 1;
+        const uint8_t* p = C + (size_t)yy * pw + gx;
+        uint32_t v;
+        if (gx + 3 < pw && (((uintptr_t)p) & 3) == 0) v = *(const uint32_t*)p;
+        else {
+            v = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) v |= (uint32_t)src_px(C, pw, ph, gx + k, gy) << (8 * k);
+        }
+        *(uint32_t*)(sc + pl * 64 + row * 8 + xs) = v;
+    }
+}
+
+// 8.4.1.3 motion vector prediction for a 16x16 partition with one reference
+// frame.  All macroblocks of the picture already carry their final vectors, so
+// any neighbour inside the picture is "available" (single slice).
+struct Mv { int x, y; };
+__device__ __forceinline__ void nb_mv(const FrameParams& P, int mx, int my, int& avail, int& ref, Mv& mv)
+{
+    avail = (mx >= 0 && my >= 0 && mx < P.mbw) ? 1 : 0;
+    ref = -1; mv.x = 0; mv.y = 0;
+    if (avail) {
+        const MbInfo* m = P.mb + (size_t)my * P.mbw + mx;
+        if (m->type != MB_I16) { ref = 0; mv.x = m->mvx; mv.y = m->mvy; }
+    }
+}
+__device__ __forceinline__ int med3(int a, int b, int c)
+{
+    const int mn = min(a, min(b, c)), mxv = max(a, max(b, c));
+    return a + b + c - mn - mxv;
+}
+// returns predictor; skip receives the P_Skip vector.  Neighbour `type` fields of a
+// P picture are never MB_I16 in this build, but the general rule is kept.
+__device__ __forceinline__ Mv predict_mv(const FrameParams& P, int mx, int my, Mv& skip)
+{
+    int aA, aB, aC, rA, rB, rC;
+    Mv A, B, C;
+    nb_mv(P, mx - 1, my, aA, rA, A);
+    nb_mv(P, mx, my - 1, aB, rB, B);
+    nb_mv(P, mx + 1, my - 1, aC, rC, C);
+    if (!aC) nb_mv(P, mx - 1, my - 1, aC, rC, C);
+    const bool zero_skip = !aA || !aB || (rA == 0 && A.x == 0 && A.y == 0) || (rB == 0 && B.x == 0 && B.y == 0);
+    if (!aB && !aC && aA) { B = A; C = A; rB = rA; rC = rA; }
+    Mv p;
+    const int n = (rA == 0) + (rB == 0) + (rC == 0);
+    if (n == 1) p = rA == 0 ? A : (rB == 0 ? B : C);
+    else { p.x = med3(A.x, B.x, C.x); p.y = med3(A.y, B.y, C.y); }
+    if (zero_skip) { skip.x = 0; skip.y = 0; } else skip = p;
+    return p;
+}
+
+}  // namespace h264

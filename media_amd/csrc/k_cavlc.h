@@ -1,0 +1,408 @@
+// media_amd/csrc/k_cavlc.h -- CAVLC entropy coding on the device (H.264 7.3.5, 9.2).
+//
+// SURVEY.md 8a row a6.5 (inside ISVCEncoder::EncodeFrame,
+// /root/reference/video_codec/VideoEncoderOpenH264.cpp:344).
+//
+// Every syntax element of a macroblock depends only on data that is final once
+// the reconstruction kernels have run (levels, TotalCoeff of neighbours, motion
+// vector differences, skip flags), so the slice is coded in three launches:
+//   k_cavlc<false>  one lane per (macroblock, block slot): bit LENGTH of each slot
+//   k_bit_scan      exclusive prefix sum of macroblock lengths -> bit offsets,
+//                   slice header, trailing mb_skip_run and rbsp stop bit
+//   k_cavlc<true>   same traversal, now writing bits at their final position
+//   k_pack          device bit buffer -> pinned host access unit, counting the
+//                   byte patterns that need emulation prevention (7.4.1)
+#pragma once
+#include "dev_common.h"
+
+namespace h264 {
+
+// ---- Table 9-5 .. 9-10 (ITU-T H.264) ----
+__constant__ const uint8_t c_ct_len[4][68] = {
+    {1,  0,  0,  0,  6,  2,  0,  0,  8,  6,  3,  0,  9,  8,  7,  5,  10, 9,  8,  6,  11, 10, 9,
+     7,  13, 11, 10, 8,  13, 13, 11, 9,  13, 13, 13, 10, 14, 14, 13, 11, 14, 14, 14, 13, 15, 15,
+     14, 14, 15, 15, 15, 14, 16, 15, 15, 15, 16, 16, 16, 15, 16, 16, 16, 16, 16, 16, 16, 16},
+    {2,  0,  0,  0,  6,  2,  0,  0,  6,  5,  3,  0,  7,  6,  6,  4,  8,  6,  6,  4,  8,  7,  7,
+     5,  9,  8,  8,  6,  11, 9,  9,  6,  11, 11, 11, 7,  12, 11, 11, 9,  12, 12, 12, 11, 12, 12,
+     12, 11, 13, 13, 13, 12, 13, 13, 13, 13, 13, 14, 13, 13, 14, 14, 14, 13, 14, 14, 14, 14},
+    {4,  0,  0,  0,  6,  4,  0,  0,  6,  5,  4,  0,  6,  5,  5,  4,  7,  5,  5,  4,  7,  5,  5,
+     4,  7,  6,  6,  4,  7,  6,  6,  4,  8,  7,  7,  5,  8,  8,  7,  6,  9,  8,  8,  7,  9,  9,
+     8,  8,  9,  9,  9,  8,  10, 9,  9,  9,  10, 10, 10, 10, 10, 10, 10, 10, 10, 10, 10, 10},
+    {6, 0, 0, 0, 6, 6, 0, 0, 6, 6, 6, 0, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6,
+     6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6}};
+__constant__ const uint8_t c_ct_bits[4][68] = {
+    {1,  0,  0,  0,  5,  1,  0,  0,  7,  4,  1,  0,  7,  6,  5,  3,  7,  6,  5,  3,  7,  6,  5,
+     4,  15, 6,  5,  4,  11, 14, 5,  4,  8,  10, 13, 4,  15, 14, 9,  4,  11, 10, 13, 12, 15, 14,
+     9,  12, 11, 10, 13, 8,  15, 1,  9,  12, 11, 14, 13, 8,  7,  10, 9,  12, 4,  6,  5,  8},
+    {3,  0,  0,  0,  11, 2,  0,  0,  7,  7,  3,  0,  7,  10, 9,  5,  7,  6,  5,  4,  4,  6,  5,
+     6,  7,  6,  5,  8,  15, 6,  5,  4,  11, 14, 13, 4,  15, 10, 9,  4,  11, 14, 13, 12, 8,  10,
+     9,  8,  15, 14, 13, 12, 11, 10, 9,  12, 7,  11, 6,  8,  9,  8,  10, 1,  7,  6,  5,  4},
+    {15, 0,  0,  0,  15, 14, 0,  0,  11, 15, 13, 0,  8,  12, 14, 12, 15, 10, 11, 11, 11, 8,  9,
+     10, 9,  14, 13, 9,  8,  10, 9,  8,  15, 14, 13, 13, 11, 14, 10, 12, 15, 10, 13, 12, 11, 14,
+     9,  12, 8,  10, 13, 8,  13, 7,  9,  12, 9,  12, 11, 10, 5,  8,  7,  6,  1,  4,  3,  2},
+    {3,  0,  0,  0,  0,  1,  0,  0,  4,  5,  6,  0,  8,  9,  10, 11, 12, 13, 14, 15, 16, 17, 18,
+     19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35, 36, 37, 38, 39, 40, 41,
+     42, 43, 44, 45, 46, 47, 48, 49, 50, 51, 52, 53, 54, 55, 56, 57, 58, 59, 60, 61, 62, 63}};
+__constant__ const uint8_t c_cdc_len[20] = {2, 0, 0, 0, 6, 1, 0, 0, 6, 6, 3, 0, 6, 7, 7, 6, 6, 8, 8, 7};
+__constant__ const uint8_t c_cdc_bits[20] = {1, 0, 0, 0, 7, 1, 0, 0, 4, 6, 1, 0, 3, 3, 2, 5, 2, 3, 2, 0};
+__constant__ const uint8_t c_tz_len[15][16] = {
+    {1, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 9}, {3, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 6, 6, 6, 6},
+    {4, 3, 3, 3, 4, 4, 3, 3, 4, 5, 5, 6, 5, 6},       {5, 3, 4, 4, 3, 3, 3, 4, 3, 4, 5, 5, 5},
+    {4, 4, 4, 3, 3, 3, 3, 3, 4, 5, 4, 5},             {6, 5, 3, 3, 3, 3, 3, 3, 4, 3, 6},
+    {6, 5, 3, 3, 3, 2, 3, 4, 3, 6},                   {6, 4, 5, 3, 2, 2, 3, 3, 6},
+    {6, 6, 4, 2, 2, 3, 2, 5},                         {5, 5, 3, 2, 2, 2, 4},
+    {4, 4, 3, 3, 1, 3},                               {4, 4, 2, 1, 3},
+    {3, 3, 1, 2},                                     {2, 2, 1},
+    {1, 1}};
+__constant__ const uint8_t c_tz_bits[15][16] = {
+    {1, 3, 2, 3, 2, 3, 2, 3, 2, 3, 2, 3, 2, 3, 2, 1}, {7, 6, 5, 4, 3, 5, 4, 3, 2, 3, 2, 3, 2, 1, 0},
+    {5, 7, 6, 5, 4, 3, 4, 3, 2, 3, 2, 1, 1, 0},       {3, 7, 5, 4, 6, 5, 4, 3, 3, 2, 2, 1, 0},
+    {5, 4, 3, 7, 6, 5, 4, 3, 2, 1, 1, 0},             {1, 1, 7, 6, 5, 4, 3, 2, 1, 1, 0},
+    {1, 1, 5, 4, 3, 3, 2, 1, 1, 0},                   {1, 1, 1, 3, 3, 2, 2, 1, 0},
+    {1, 0, 1, 3, 2, 1, 1, 1},                         {1, 0, 1, 3, 2, 1, 1},
+    {0, 1, 1, 2, 1, 3},                               {0, 1, 1, 1, 1},
+    {0, 1, 1, 1},                                     {0, 1, 1},
+    {0, 1}};
+__constant__ const uint8_t c_ctz_len[3][4] = {{1, 2, 3, 3}, {1, 2, 2, 0}, {1, 1, 0, 0}};
+__constant__ const uint8_t c_ctz_bits[3][4] = {{1, 1, 1, 0}, {1, 1, 0, 0}, {1, 0, 0, 0}};
+__constant__ const uint8_t c_run_len[7][16] = {{1, 1},
+                                               {1, 2, 2},
+                                               {2, 2, 2, 2},
+                                               {2, 2, 2, 3, 3},
+                                               {2, 2, 3, 3, 3, 3},
+                                               {2, 3, 3, 3, 3, 3, 3},
+                                               {3, 3, 3, 3, 3, 3, 3, 4, 5, 6, 7, 8, 9, 10, 11}};
+__constant__ const uint8_t c_run_bits[7][16] = {{1, 0},
+                                                {1, 1, 0},
+                                                {3, 2, 1, 0},
+                                                {3, 2, 1, 1, 0},
+                                                {3, 2, 3, 2, 1, 0},
+                                                {3, 0, 1, 3, 2, 5, 4},
+                                                {7, 6, 5, 4, 3, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1}};
+// Table 9-4, inverted for the encoder: coded_block_pattern -> codeNum (inter)
+__constant__ const uint8_t c_cbp2code_inter[48] = {
+    0,  2,  3,  7,  4,  8,  17, 13, 5,  18, 9,  14, 10, 15, 16, 11, 1,  32, 33, 36, 34, 37, 44, 40,
+    35, 45, 38, 41, 39, 42, 43, 19, 6,  24, 25, 20, 26, 21, 46, 28, 27, 47, 22, 29, 23, 30, 31, 12};
+
+// ---- bit sinks ----
+struct BitCount {
+    unsigned n;
+    __device__ __forceinline__ void init(unsigned) { n = 0; }
+    __device__ __forceinline__ void put(int len, unsigned) { n += (unsigned)len; }
+    __device__ __forceinline__ void flush() {}
+};
+struct BitWrite {
+    uint32_t* buf;
+    unsigned word, nb;
+    unsigned long long acc;  // pending bits, left aligned
+    __device__ __forceinline__ void init(unsigned pos) { word = pos >> 5; nb = pos & 31; acc = 0; }
+    __device__ __forceinline__ void put(int len, unsigned v)
+    {
+        if (len <= 0) return;
+        acc |= (unsigned long long)v << (64 - nb - len);
+        nb += (unsigned)len;
+        if (nb >= 32) {
+            const unsigned w = (unsigned)(acc >> 32);
+            if (w) atomicOr(buf + word, __builtin_bswap32(w));
+            acc <<= 32; nb -= 32; word++;
+        }
+    }
+    __device__ __forceinline__ void flush()
+    {
+        const unsigned w = (unsigned)(acc >> 32);
+        if (nb && w) atomicOr(buf + word, __builtin_bswap32(w));
+        nb = 0; acc = 0;
+    }
+};
+
+template <class S>
+__device__ __forceinline__ void put_ue(S& s, unsigned v)
+{
+    const unsigned x = v + 1;
+    const int n = 31 - __clz((int)x);  // floor(log2 x), x < 2^31
+    if (2 * n + 1 > 32) { s.put(2 * n + 1 - 32, 0); s.put(32, x); }
+    else s.put(2 * n + 1, x);
+}
+template <class S>
+__device__ __forceinline__ void put_se(S& s, int v)
+{
+    put_ue(s, v > 0 ? (unsigned)(2 * v - 1) : (unsigned)(-2 * v));
+}
+
+// 9.2.2.1 level_prefix / level_suffix for one levelCode
+template <class S>
+__device__ __forceinline__ void put_level(S& s, int code, int suffix_len)
+{
+    if (suffix_len == 0) {
+        if (code < 14) { s.put(code + 1, 1); return; }
+        if (code < 30) { s.put(15, 1); s.put(4, (unsigned)(code - 14)); return; }
+        int c = code - 30, prefix = 15;
+        while (c >= (1 << (prefix - 3))) { c -= 1 << (prefix - 3); prefix++; }
+        s.put(prefix + 1, 1);
+        s.put(prefix - 3, (unsigned)c);
+        return;
+    }
+    if (code < (15 << suffix_len)) {
+        s.put((code >> suffix_len) + 1, 1);
+        s.put(suffix_len, (unsigned)(code & ((1 << suffix_len) - 1)));
+        return;
+    }
+    int c = code - (15 << suffix_len), prefix = 15;
+    while (c >= (1 << (prefix - 3))) { c -= 1 << (prefix - 3); prefix++; }
+    s.put(prefix + 1, 1);
+    s.put(prefix - 3, (unsigned)c);
+}
+
+// residual_block_cavlc(): lv points at scan position 0 of this block's list
+template <class S>
+__device__ __forceinline__ void cavlc_block(S& s, const int16_t* lv, int maxc, int nC)
+{
+    unsigned nzm = 0, one = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const int v = i < maxc ? (int)lv[i] : 0;
+        nzm |= (unsigned)(v != 0) << i;
+        one |= (unsigned)(v == 1 || v == -1) << i;
+    }
+    const int tc = __popc(nzm);
+    int t1 = 0;
+    {
+        unsigned m = nzm;
+        while (m && t1 < 3) {
+            const int i = 31 - __clz((int)m);
+            if (!((one >> i) & 1)) break;
+            t1++; m &= ~(1u << i);
+        }
+    }
+    if (nC == -1) s.put(c_cdc_len[4 * tc + t1], c_cdc_bits[4 * tc + t1]);
+    else {
+        const int tab = nC < 2 ? 0 : nC < 4 ? 1 : nC < 8 ? 2 : 3;
+        s.put(c_ct_len[tab][4 * tc + t1], c_ct_bits[tab][4 * tc + t1]);
+    }
+    if (!tc) return;
+    unsigned m = nzm;
+    for (int k = 0; k < t1; k++) {
+        const int i = 31 - __clz((int)m);
+        s.put(1, lv[i] < 0 ? 1u : 0u);
+        m &= ~(1u << i);
+    }
+    int suffix_len = (tc > 10 && t1 < 3) ? 1 : 0;
+    bool first = true;
+    while (m) {
+        const int i = 31 - __clz((int)m);
+        m &= ~(1u << i);
+        const int lvl = lv[i];
+        int code = lvl > 0 ? 2 * lvl - 2 : -2 * lvl - 1;
+        if (first && t1 < 3) code -= 2;
+        first = false;
+        put_level(s, code, suffix_len);
+        if (suffix_len == 0) suffix_len = 1;
+        if (iabs(lvl) > (3 << (suffix_len - 1)) && suffix_len < 6) suffix_len++;
+    }
+    const int top = 31 - __clz((int)nzm);
+    if (tc < maxc) {
+        const int tz = top + 1 - tc;
+        if (nC == -1) s.put(c_ctz_len[tc - 1][tz], c_ctz_bits[tc - 1][tz]);
+        else s.put(c_tz_len[tc - 1][tz], c_tz_bits[tc - 1][tz]);
+        int zl = tz;
+        m = nzm;
+        int hi = top;
+        m &= ~(1u << hi);
+        while (m && zl > 0) {
+            const int lo = 31 - __clz((int)m);
+            m &= ~(1u << lo);
+            const int run = hi - lo - 1;
+            const int t = (zl > 7 ? 7 : zl) - 1;
+            s.put(c_run_len[t][run], c_run_bits[t][run]);
+            zl -= run;
+            hi = lo;
+        }
+    }
+}
+
+// nC of a luma 4x4 block (bx4,by4 in 0..3) / chroma block (2x2 grid), 9.2.1
+__device__ __forceinline__ int nc_luma(const MbInfo* m, int mx, int my, int mbw, int x, int y)
+{
+    int nA = -1, nB = -1;
+    if (x > 0) nA = m->tc[xy2blk(x - 1, y)];
+    else if (mx > 0) nA = (m - 1)->tc[xy2blk(3, y)];
+    if (y > 0) nB = m->tc[xy2blk(x, y - 1)];
+    else if (my > 0) nB = (m - mbw)->tc[xy2blk(x, 3)];
+    if (nA >= 0 && nB >= 0) return (nA + nB + 1) >> 1;
+    return nA >= 0 ? nA : (nB >= 0 ? nB : 0);
+}
+__device__ __forceinline__ int nc_chroma(const MbInfo* m, int mx, int my, int mbw, int pl, int x, int y)
+{
+    const int base = 16 + pl * 4;
+    int nA = -1, nB = -1;
+    if (x > 0) nA = m->tc[base + 2 * y];
+    else if (mx > 0) nA = (m - 1)->tc[base + 2 * y + 1];
+    if (y > 0) nB = m->tc[base + x];
+    else if (my > 0) nB = (m - mbw)->tc[base + 2 + x];
+    if (nA >= 0 && nB >= 0) return (nA + nB + 1) >> 1;
+    return nA >= 0 ? nA : (nB >= 0 ? nB : 0);
+}
+
+struct CavlcParams {
+    const MbInfo* mb;
+    const int16_t* levels;
+    const int16_t* mvd;
+    int mbw, nmb, p_slice;
+    uint16_t* slotbits;   // 32 per macroblock
+    uint32_t* mbbits;     // per macroblock, then (after the scan) bit offsets
+    uint32_t* bitbuf;     // zeroed slice payload buffer
+};
+
+// slot: 0 header, 1 Intra16x16 DC, 2..17 luma blkIdx 0..15, 18/19 chroma DC, 20..27 chroma AC
+template <class S>
+__device__ __forceinline__ void code_slot(S& s, const CavlcParams& C, int mbi, int slot)
+{
+    const MbInfo* m = C.mb + mbi;
+    if (m->type == MB_PSKIP) return;
+    const int mx = mbi % C.mbw, my = mbi / C.mbw;
+    const int16_t* lv = C.levels + (size_t)mbi * LV_STRIDE;
+    const int cbpl = m->cbp & 15, cbpc = m->cbp >> 4;
+    const bool i16 = m->type == MB_I16;
+    if (slot == 0) {
+        if (C.p_slice) {
+            unsigned run = 0;
+            for (int j = mbi - 1; j >= 0 && C.mb[j].type == MB_PSKIP; j--) run++;
+            put_ue(s, run);
+        }
+        if (i16) {
+            const unsigned t = 1u + m->i16_mode + 4u * (unsigned)cbpc + (cbpl ? 12u : 0u);
+            put_ue(s, C.p_slice ? 5u + t : t);
+            put_ue(s, m->chroma_mode);
+            put_se(s, 0);
+        } else {
+            put_ue(s, 0);
+            put_se(s, C.mvd[2 * mbi]);
+            put_se(s, C.mvd[2 * mbi + 1]);
+            put_ue(s, c_cbp2code_inter[m->cbp]);
+            if (m->cbp) put_se(s, 0);
+        }
+    } else if (slot == 1) {
+        if (i16) cavlc_block(s, lv + LV_LUMA_DC, 16, nc_luma(m, mx, my, C.mbw, 0, 0));
+    } else if (slot < 18) {
+        const int b = slot - 2;
+        if (cbpl & (1 << (b >> 2))) {
+            const int nC = nc_luma(m, mx, my, C.mbw, blk_x(b), blk_y(b));
+            if (i16) cavlc_block(s, lv + LV_LUMA + b * 16 + 1, 15, nC);
+            else cavlc_block(s, lv + LV_LUMA + b * 16, 16, nC);
+        }
+    } else if (slot < 20) {
+        if (cbpc) cavlc_block(s, lv + LV_CHROMA_DC + (slot - 18) * 4, 4, -1);
+    } else if (slot < 28) {
+        const int k = slot - 20, pl = k >> 2, b = k & 3;
+        if (cbpc == 2) cavlc_block(s, lv + LV_CHROMA_AC + k * 16 + 1, 15, nc_chroma(m, mx, my, C.mbw, pl, b & 1, b >> 1));
+    }
+}
+
+template <bool WRITE>
+__global__ __launch_bounds__(64) void k_cavlc(CavlcParams C)
+{
+    const int lane = threadIdx.x, slot = lane & 31;
+    const int mbi = blockIdx.x * 2 + (lane >> 5);
+    const bool live = mbi < C.nmb;
+    if (!WRITE) {
+        BitCount s;
+        s.init(0);
+        if (live) code_slot(s, C, mbi, slot);
+        if (live) C.slotbits[(size_t)mbi * 32 + slot] = (uint16_t)s.n;
+        const int tot = group_sum<32>((int)s.n);
+        if (live && slot == 0) C.mbbits[mbi] = (uint32_t)tot;
+    } else {
+        // exclusive prefix over the 32 slots of this macroblock
+        unsigned n = live ? C.slotbits[(size_t)mbi * 32 + slot] : 0, incl = n;
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) {
+            const unsigned t = (unsigned)__shfl_up((int)incl, o, 32);
+            if (slot >= o) incl += t;
+        }
+        if (live && n) {
+            BitWrite s;
+            s.buf = C.bitbuf;
+            s.init(C.mbbits[mbi] + incl - n);
+            code_slot(s, C, mbi, slot);
+            s.flush();
+        }
+    }
+}
+
+struct SliceInfo {       // lives in pinned host memory, written by the device
+    uint32_t total_bits; // slice_data + header + trailing bits
+    uint32_t total_bytes;
+    uint32_t epb_count;  // positions needing an emulation prevention byte
+    uint32_t error;
+};
+
+// one workgroup of 1024: exclusive scan of mbbits (in place -> offsets), header, tail
+__global__ __launch_bounds__(1024) void k_bit_scan(CavlcParams C, unsigned long long hdr_bits, int hdr_len, SliceInfo* info)
+{
+    __shared__ unsigned s_part[1024];
+    const int t = threadIdx.x;
+    const int per = (C.nmb + 1023) / 1024;
+    const int b0 = t * per, b1 = min(C.nmb, b0 + per);
+    unsigned sum = 0;
+    for (int i = b0; i < b1; i++) sum += C.mbbits[i];
+    s_part[t] = sum;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const unsigned v = t >= o ? s_part[t - o] : 0;
+        __syncthreads();
+        s_part[t] += v;
+        __syncthreads();
+    }
+    unsigned run = (unsigned)hdr_len + s_part[t] - sum;
+    for (int i = b0; i < b1; i++) {
+        const unsigned n = C.mbbits[i];
+        C.mbbits[i] = run;
+        run += n;
+    }
+    if (t == 0) {
+        BitWrite s;
+        s.buf = C.bitbuf;
+        s.init(0);
+        if (hdr_len > 32) { s.put(hdr_len - 32, (unsigned)(hdr_bits >> 32)); s.put(32, (unsigned)hdr_bits); }
+        else s.put(hdr_len, (unsigned)hdr_bits);
+        s.flush();
+        unsigned total = (unsigned)hdr_len + s_part[1023];
+        s.init(total);
+        BitCount c;
+        c.init(0);
+        if (C.p_slice) {
+            unsigned skips = 0;
+            for (int j = C.nmb - 1; j >= 0 && C.mb[j].type == MB_PSKIP; j--) skips++;
+            if (skips) { put_ue(s, skips); put_ue(c, skips); }
+        }
+        s.put(1, 1);  // rbsp_stop_one_bit
+        s.flush();
+        total += c.n + 1;
+        info->total_bits = total;
+        info->total_bytes = (total + 7) >> 3;
+        info->epb_count = 0;
+        info->error = 0;
+    }
+}
+
+// copy payload to the pinned access unit and count emulation-prevention sites
+__global__ __launch_bounds__(256) void k_pack(const uint8_t* bitbuf, uint8_t* dst, SliceInfo* info)
+{
+    const unsigned nbytes = info->total_bytes;
+    unsigned cnt = 0;
+    for (unsigned i = (blockIdx.x * blockDim.x + threadIdx.x) * 16u; i < nbytes; i += gridDim.x * blockDim.x * 16u) {
+        const uint4 v = *(const uint4*)(bitbuf + i);  // buffer is padded and zeroed past the end
+        *(uint4*)(dst + i) = v;
+        const uint32_t nxt = *(const uint32_t*)(bitbuf + i + 16);
+        const uint32_t w[5] = {v.x, v.y, v.z, v.w, nxt};
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const unsigned b0 = (w[k >> 2] >> (8 * (k & 3))) & 255, b1 = (w[(k + 1) >> 2] >> (8 * ((k + 1) & 3))) & 255,
+                           b2 = (w[(k + 2) >> 2] >> (8 * ((k + 2) & 3))) & 255;
+            if (i + k + 2 < nbytes && b0 == 0 && b1 == 0 && b2 <= 3) cnt++;
+        }
+    }
+    if (cnt) atomicAdd(&info->epb_count, cnt);
+}
+
+}  // namespace h264

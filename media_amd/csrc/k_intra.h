@@ -1,0 +1,263 @@
+// media_amd/csrc/k_intra.h -- IDR pictures: Intra16x16 + chroma intra, one
+// wavefront per macroblock, launched one anti-diagonal (mx + my == s) at a time
+// because prediction needs the left / top / top-left reconstruction (8.3.3, 8.3.4).
+// Kernel boundaries carry the dependency, so no in-kernel hand-off is needed.
+//
+// SURVEY.md 8a row a6 / a6.2 (inside ISVCEncoder::EncodeFrame,
+// /root/reference/video_codec/VideoEncoderOpenH264.cpp:344).
+#pragma once
+#include "dev_common.h"
+#include "k_pmb.h"
+
+namespace h264 {
+
+// Intra16x16 predictor sample (8.3.3); top[0..16] holds p[-1..15,-1], left[y] = p[-1,y]
+struct I16Params { int dc, a, b, c; };
+__device__ __forceinline__ I16Params i16_params(const uint8_t* top, const uint8_t* left, int avail)
+{
+    I16Params q;
+    int st = 0, sl = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) { st += top[1 + i]; sl += left[i]; }
+    const bool t = avail & 2, l = avail & 1;
+    q.dc = (t && l) ? (st + sl + 16) >> 5 : t ? (st + 8) >> 4 : l ? (sl + 8) >> 4 : 128;
+    int H = 0, V = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        H += (i + 1) * ((int)top[1 + 8 + i] - (int)top[1 + 6 - i]);
+        V += (i + 1) * ((int)left[8 + i] - (i == 7 ? (int)top[0] : (int)left[6 - i]));
+    }
+    q.a = 16 * ((int)left[15] + (int)top[16]);
+    q.b = (5 * H + 32) >> 6;
+    q.c = (5 * V + 32) >> 6;
+    return q;
+}
+__device__ __forceinline__ int i16_px(int mode, int x, int y, const uint8_t* top, const uint8_t* left, const I16Params& q)
+{
+    return mode == 0 ? top[1 + x] : mode == 1 ? left[y] : mode == 2 ? q.dc : clip255((q.a + q.b * (x - 7) + q.c * (y - 7) + 16) >> 5);
+}
+
+// chroma 8x8 predictor (8.3.4): 0 DC, 1 horizontal, 2 vertical, 3 plane
+struct C8Params { int dc[4], a, b, c; };
+__device__ __forceinline__ C8Params c8_params(const uint8_t* top, const uint8_t* left, int avail)
+{
+    C8Params q;
+    const bool t = avail & 2, l = avail & 1;
+    int st[2] = {0, 0}, sl[2] = {0, 0};
+#pragma unroll
+    for (int i = 0; i < 4; i++) { st[0] += top[1 + i]; st[1] += top[5 + i]; sl[0] += left[i]; sl[1] += left[4 + i]; }
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+        const int bx = b & 1, byy = b >> 1;
+        int dc;
+        if (bx == byy) dc = (t && l) ? (st[bx] + sl[byy] + 4) >> 3 : t ? (st[bx] + 2) >> 2 : l ? (sl[byy] + 2) >> 2 : 128;
+        else if (bx == 1) dc = t ? (st[1] + 2) >> 2 : l ? (sl[0] + 2) >> 2 : 128;
+        else dc = l ? (sl[1] + 2) >> 2 : t ? (st[0] + 2) >> 2 : 128;
+        q.dc[b] = dc;
+    }
+    int H = 0, V = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        H += (i + 1) * ((int)top[1 + 4 + i] - (int)top[1 + 2 - i]);
+        V += (i + 1) * ((int)left[4 + i] - (i == 3 ? (int)top[0] : (int)left[2 - i]));
+    }
+    q.a = 16 * ((int)left[7] + (int)top[8]);
+    q.b = (34 * H + 32) >> 6;
+    q.c = (34 * V + 32) >> 6;
+    return q;
+}
+__device__ __forceinline__ int c8_px(int mode, int x, int y, const uint8_t* top, const uint8_t* left, const C8Params& q)
+{
+    return mode == 0 ? q.dc[(y >> 2) * 2 + (x >> 2)] : mode == 1 ? left[y] : mode == 2 ? top[1 + x]
+                                                                                       : clip255((q.a + q.b * (x - 3) + q.c * (y - 3) + 16) >> 5);
+}
+
+__global__ __launch_bounds__(64) void k_intra_diag(FrameParams P, int s)
+{
+    const int lane = threadIdx.x;
+    const int ymin = max(0, s - P.mbw + 1);
+    const int my = ymin + blockIdx.x, mx = s - my;
+    if (my >= P.mbh || mx < 0 || mx >= P.mbw) return;
+    const int mbi = my * P.mbw + mx, bx = 16 * mx, by = 16 * my, cs = P.cw / 2;
+    const int avail = (mx > 0 ? 1 : 0) | (my > 0 ? 2 : 0) | ((mx > 0 && my > 0) ? 4 : 0);
+
+    __shared__ __attribute__((aligned(16))) uint8_t s_src[256];
+    __shared__ __attribute__((aligned(16))) uint8_t s_srcc[128];
+    __shared__ uint8_t s_top[20], s_left[16];        // luma neighbours; s_top[0] = top-left
+    __shared__ uint8_t s_ctop[2][12], s_cleft[2][8];
+    __shared__ __attribute__((aligned(16))) uint8_t s_py[256];
+    __shared__ __attribute__((aligned(16))) uint8_t s_pc[128];
+    __shared__ __attribute__((aligned(16))) int16_t s_lv[LV_STRIDE];
+    __shared__ int s_dc[16];
+
+    load_src_mb(P, mx, my, s_src, s_srcc, lane);
+    for (int i = lane; i < LV_STRIDE / 2; i += 64) ((uint32_t*)s_lv)[i] = 0;
+    {
+        const uint8_t* R = P.rec[0];
+        if (lane < 17) s_top[lane] = (my > 0 && (lane > 0 || mx > 0)) ? R[(size_t)(by - 1) * P.cw + bx - 1 + lane] : 0;
+        else if (lane < 33) s_left[lane - 17] = mx > 0 ? R[(size_t)(by + lane - 17) * P.cw + bx - 1] : 0;
+        else if (lane < 33 + 18) {
+            const int k = lane - 33, pl = k / 9, i = k % 9;
+            s_ctop[pl][i] = (my > 0 && (i > 0 || mx > 0)) ? P.rec[1 + pl][(size_t)(8 * my - 1) * cs + 8 * mx - 1 + i] : 0;
+        }
+        if (lane < 16) {
+            const int pl = lane >> 3, i = lane & 7;
+            s_cleft[pl][i] = mx > 0 ? P.rec[1 + pl][(size_t)(8 * my + i) * cs + 8 * mx - 1] : 0;
+        }
+    }
+    __syncthreads();
+
+    // ---- luma mode decision: lane = (mode, 4x4 block), SATD per mode ----
+    const I16Params ip = i16_params(s_top, s_left, avail);
+    int best_mode;
+    {
+        const int mode = lane >> 4, blk = lane & 15, x0 = (blk & 3) * 4, y0 = (blk >> 2) * 4;
+        int d[16];
+#pragma unroll
+        for (int y = 0; y < 4; y++)
+#pragma unroll
+            for (int x = 0; x < 4; x++)
+                d[4 * y + x] = (int)s_src[(y0 + y) * 16 + x0 + x] - i16_px(mode, x0 + x, y0 + y, s_top, s_left, ip);
+        int sum = group_sum<16>(hadamard_abs(d)) >> 1;
+        const bool ok = mode == 0 ? (avail & 2) : mode == 1 ? (avail & 1) : mode == 2 ? true : avail == 7;
+        unsigned key = ok ? (((unsigned)sum << 2) | (unsigned)mode) : 0xFFFFFFFFu;
+        best_mode = (int)(wave_min_u32(key) & 3);
+    }
+    {
+        const int y = lane >> 2, xs = (lane & 3) * 4;
+        uint32_t o = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) o |= (uint32_t)i16_px(best_mode, xs + k, y, s_top, s_left, ip) << (8 * k);
+        *(uint32_t*)(s_py + y * 16 + xs) = o;
+    }
+    // ---- chroma mode decision: lane<32 = (mode, plane, block) ----
+    int best_cmode;
+    C8Params cp[2] = {c8_params(s_ctop[0], s_cleft[0], avail), c8_params(s_ctop[1], s_cleft[1], avail)};
+    {
+        const int mode = (lane >> 3) & 3, pl = (lane >> 2) & 1, blk = lane & 3, x0 = (blk & 1) * 4, y0 = (blk >> 1) * 4;
+        int d[16];
+#pragma unroll
+        for (int y = 0; y < 4; y++)
+#pragma unroll
+            for (int x = 0; x < 4; x++)
+                d[4 * y + x] = (int)s_srcc[pl * 64 + (y0 + y) * 8 + x0 + x] -
+                               c8_px(mode, x0 + x, y0 + y, s_ctop[pl], s_cleft[pl], pl ? cp[1] : cp[0]);
+        // per-plane SATD is (sum over 4 blocks) >> 1; cost = Cb + Cr
+        int sp = group_sum<4>(hadamard_abs(d)) >> 1;
+        int sum = sp + __shfl_xor(sp, 4);
+        const bool ok = mode == 0 ? true : mode == 1 ? (avail & 1) : mode == 2 ? (avail & 2) : avail == 7;
+        unsigned key = (ok && lane < 32) ? (((unsigned)sum << 2) | (unsigned)mode) : 0xFFFFFFFFu;
+        best_cmode = (int)(wave_min_u32(key) & 3);
+    }
+    if (lane < 32) {
+        const int pl = lane >> 4, y = (lane >> 1) & 7, xs = (lane & 1) * 4;
+        uint32_t o = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) o |= (uint32_t)c8_px(best_cmode, xs + k, y, s_ctop[pl], s_cleft[pl], pl ? cp[1] : cp[0]) << (8 * k);
+        *(uint32_t*)(s_pc + pl * 64 + y * 8 + xs) = o;
+    }
+    __syncthreads();
+
+    // ---- transform / quant: lanes 0..15 luma AC (+DC via Hadamard), 16..23 chroma ----
+    int nnz = 0, dcw = 0;
+    int d[16];
+    const bool is_luma = lane < 16, is_chroma = lane >= 16 && lane < 24;
+    const int cpl = (lane - 16) >> 2, cb = lane & 3;
+    if (is_luma) {
+        const int x = blk_x(lane) * 4, y = blk_y(lane) * 4;
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) d[4 * r + c] = (int)s_src[(y + r) * 16 + x + c] - (int)s_py[(y + r) * 16 + x + c];
+        nnz = tq4x4(d, P.qy, P.qy.f_intra, 1, s_lv + LV_LUMA + lane * 16, &dcw, 0, false);
+        s_dc[blk_y(lane) * 4 + blk_x(lane)] = dcw;
+    } else if (is_chroma) {
+        const int x = (cb & 1) * 4, y = (cb >> 1) * 4;
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+                d[4 * r + c] = (int)s_srcc[cpl * 64 + (y + r) * 8 + x + c] - (int)s_pc[cpl * 64 + (y + r) * 8 + x + c];
+        nnz = tq4x4(d, P.qc, P.qc.f_intra, 1, s_lv + LV_CHROMA_AC + (cpl * 4 + cb) * 16, &dcw, 0, false);
+    }
+    __syncthreads();
+    {   // luma DC: forward Hadamard, quantise at qbits+2, inverse Hadamard, 8.5.10 scaling
+        int h[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) h[i] = s_dc[i];
+        hadamard4x4(h);
+        const int qb = P.qy.qbits;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const unsigned a = (unsigned)iabs(h[i]);
+            const int l = (int)((a * (unsigned)P.qy.mf[0] + 4u * (unsigned)P.qy.f_intra) >> (qb + 2));
+            h[i] = h[i] < 0 ? -l : l;
+        }
+        if (lane == 0)
+#pragma unroll
+            for (int i = 0; i < 16; i++) s_lv[LV_LUMA_DC + c_zigzag_inv[i]] = (int16_t)h[i];
+        hadamard4x4(h);
+        if (is_luma) {
+            const int fi = h[blk_y(lane) * 4 + blk_x(lane)];
+            const int qp = P.qy.qp, ls = 16 * (P.qy.dq[0] >> (qp / 6));
+            d[0] = qp >= 36 ? (fi * ls) << (qp / 6 - 6) : (fi * ls + (1 << (5 - qp / 6))) >> (6 - qp / 6);
+        }
+    }
+    {   // chroma DC
+        const int base = 16 + ((lane - 16) & 4);
+        const int w4[4] = {__shfl(dcw, base), __shfl(dcw, base + 1), __shfl(dcw, base + 2), __shfl(dcw, base + 3)};
+        int lv[4], deq[4];
+        chroma_dc(w4, P.qc, P.qc.f_intra, lv, deq);
+        if (is_chroma) {
+            d[0] = deq[cb];
+            if (cb == 0)
+#pragma unroll
+                for (int i = 0; i < 4; i++) s_lv[LV_CHROMA_DC + cpl * 4 + i] = (int16_t)lv[i];
+            dcw = (lv[0] | lv[1] | lv[2] | lv[3]) != 0;
+        }
+    }
+    const unsigned long long nzmask = __ballot(nnz != 0);
+    const unsigned long long dcmask = __ballot(is_chroma && dcw);
+    const int cbp_luma = (nzmask & 0xFFFF) ? 15 : 0;
+    const int cbp_chroma = ((nzmask >> 16) & 255) ? 2 : (dcmask ? 1 : 0);
+    if (is_luma || is_chroma) {
+        idct4x4(d);
+        uint8_t* dst;
+        const uint8_t* pp;
+        int dp, ppitch;
+        if (is_luma) {
+            const int x = blk_x(lane) * 4, y = blk_y(lane) * 4;
+            dst = P.rec[0] + (size_t)(by + y) * P.cw + bx + x; dp = P.cw;
+            pp = s_py + y * 16 + x; ppitch = 16;
+        } else {
+            const int x = (cb & 1) * 4, y = (cb >> 1) * 4;
+            dst = P.rec[1 + cpl] + (size_t)(8 * my + y) * cs + 8 * mx + x; dp = cs;
+            pp = s_pc + cpl * 64 + y * 8 + x; ppitch = 8;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const uint32_t p = *(const uint32_t*)(pp + r * ppitch);
+            uint32_t o = 0;
+#pragma unroll
+            for (int c = 0; c < 4; c++) o |= (uint32_t)clip255((int)((p >> (8 * c)) & 255) + d[4 * r + c]) << (8 * c);
+            *(uint32_t*)(dst + (size_t)r * dp) = o;
+        }
+    }
+    __syncthreads();
+    MbInfo* m = P.mb + mbi;
+    const int tcv = (lane < 16 ? cbp_luma != 0 : cbp_chroma == 2) ? nnz : 0;
+    if (lane < 24) m->tc[lane] = (uint8_t)tcv;
+    if (lane == 0) {
+        m->mvx = 0; m->mvy = 0; m->type = MB_I16;
+        m->i16_mode = (uint8_t)best_mode; m->chroma_mode = (uint8_t)best_cmode;
+        m->cbp = (uint8_t)(cbp_luma | (cbp_chroma << 4));
+        P.mvd[2 * mbi] = 0; P.mvd[2 * mbi + 1] = 0;
+    }
+    {
+        uint4* g = (uint4*)(P.levels + (size_t)mbi * LV_STRIDE);
+        const uint4* sl = (const uint4*)s_lv;
+        if (lane < LV_STRIDE * 2 / 16) g[lane] = sl[lane];
+    }
+}
+
+}  // namespace h264

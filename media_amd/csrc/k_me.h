@@ -1,0 +1,259 @@
+// media_amd/csrc/k_me.h -- motion search, one wavefront per macroblock.
+//
+// SURVEY.md 8a row a6.1 (the SAD/SATD block-matching part of
+// ISVCEncoder::EncodeFrame, /root/reference/video_codec/VideoEncoderOpenH264.cpp:344).
+//
+// Per macroblock, entirely out of LDS after one coalesced window load:
+//   1. zero-motion test: does (src - ref) quantise to nothing?  -> mv = 0, done
+//   2. full search dx,dy in [-16,15]: lane = (dx, half of dy range); each lane
+//      keeps 16 SAD accumulators (v_sad_u8, four pixels per instruction) and
+//      walks 31 window rows, every row feeding up to 16 candidates
+//   3. half- then quarter-pel refinement on SATD over half-sample planes built
+//      once in LDS (18x18 grid of G/b/h/j, 8.4.2.2.1)
+// Decisions use only the previous picture and this macroblock's source, so the
+// kernel is one launch over all macroblocks.
+#pragma once
+#include "dev_common.h"
+
+namespace h264 {
+
+enum { ME_R = 16, ME_AP = 4, ME_WS = 16 + 2 * ME_R + 2 * ME_AP, ME_WDW = ME_WS / 4, ME_GS = 18 };
+
+// two-tap description of every quarter-sample position: pred = (T0 + T1 + 1) >> 1
+// with Tk read from plane pk at grid offset (dxk, dyk); planes 0 G, 1 b, 2 h, 3 j
+__device__ __forceinline__ void qpel_taps(int fx, int fy, int& o0, int& o1)
+{
+    const int PL = ME_GS * ME_GS;
+    const int G = 0, B = PL, H = 2 * PL, J = 3 * PL, R = 1, D = ME_GS;
+    switch (fy * 4 + fx) {
+        case 0: o0 = G; o1 = G; break;
+        case 1: o0 = G; o1 = B; break;
+        case 2: o0 = B; o1 = B; break;
+        case 3: o0 = G + R; o1 = B; break;
+        case 4: o0 = G; o1 = H; break;
+        case 5: o0 = B; o1 = H; break;
+        case 6: o0 = B; o1 = J; break;
+        case 7: o0 = B; o1 = H + R; break;
+        case 8: o0 = H; o1 = H; break;
+        case 9: o0 = H; o1 = J; break;
+        case 10: o0 = J; o1 = J; break;
+        case 11: o0 = H + R; o1 = J; break;
+        case 12: o0 = G + D; o1 = H; break;
+        case 13: o0 = B + D; o1 = H; break;
+        case 14: o0 = B + D; o1 = J; break;
+        default: o0 = B + D; o1 = H + R; break;
+    }
+}
+
+__global__ __launch_bounds__(64, 4) void k_me(FrameParams P)
+{
+    const int lane = threadIdx.x;
+    const int mbi = blockIdx.x, mx = mbi % P.mbw, my = mbi / P.mbw;
+    const int bx = 16 * mx, by = 16 * my;
+
+    __shared__ __attribute__((aligned(16))) uint32_t s_win[ME_WS * ME_WDW];  // 56 x 56 bytes
+    __shared__ __attribute__((aligned(16))) uint8_t s_src[256];
+    __shared__ __attribute__((aligned(16))) uint8_t s_srcc[128];
+    __shared__ __attribute__((aligned(16))) uint8_t s_refc[128];
+    __shared__ int16_t s_b1[(ME_GS + 5) * ME_GS];
+    __shared__ uint8_t s_pl[4 * ME_GS * ME_GS];
+
+    load_src_mb(P, mx, my, s_src, s_srcc, lane);
+    // reference window, clamped at the picture edge (unrestricted motion vectors)
+    for (int i = lane; i < ME_WS * ME_WDW; i += 64) {
+        const int row = i / ME_WDW, dw = i - row * ME_WDW;
+        const int gy = clip3(0, P.ch - 1, by - ME_R - ME_AP + row);
+        const int gx = bx - ME_R - ME_AP + dw * 4;
+        const uint8_t* rp = P.ref[0] + (size_t)gy * P.cw;
+        uint32_t v;
+        if (gx >= 0 && gx + 3 < P.cw) v = *(const uint32_t*)(rp + gx);
+        else {
+            v = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) v |= (uint32_t)rp[clip3(0, P.cw - 1, gx + k)] << (8 * k);
+        }
+        s_win[i] = v;
+    }
+    if (lane < 32) {  // co-located chroma
+        const int pl = lane >> 4, row = (lane >> 1) & 7, xs = (lane & 1) * 4;
+        *(uint32_t*)(s_refc + pl * 64 + row * 8 + xs) =
+            *(const uint32_t*)(P.ref[1 + pl] + (size_t)(8 * my + row) * (P.cw / 2) + 8 * mx + xs);
+    }
+    __syncthreads();
+    const uint8_t* winb = (const uint8_t*)s_win;
+
+    // ---- 1. zero-motion test (lanes 0..15 luma blocks, 16..23 chroma blocks) ----
+    {
+        int nz = 0, dc = 0;
+        if (lane < 24) {
+            int d[16];
+            const uint8_t *s, *r;
+            int sp, rp;
+            if (lane < 16) {
+                const int x = blk_x(lane) * 4, y = blk_y(lane) * 4;
+                s = s_src + y * 16 + x; sp = 16;
+                r = winb + (ME_R + ME_AP + y) * ME_WS + ME_R + ME_AP + x; rp = ME_WS;
+            } else {
+                const int pl = (lane - 16) >> 2, b = lane & 3;
+                s = s_srcc + pl * 64 + (b >> 1) * 32 + (b & 1) * 4; sp = 8;
+                r = s_refc + pl * 64 + (b >> 1) * 32 + (b & 1) * 4; rp = 8;
+            }
+#pragma unroll
+            for (int y = 0; y < 4; y++)
+#pragma unroll
+                for (int x = 0; x < 4; x++) d[4 * y + x] = (int)s[y * sp + x] - (int)r[y * rp + x];
+            fdct4x4(d);
+            const Quant& q = lane < 16 ? P.qy : P.qc;
+#pragma unroll
+            for (int i = (0); i < 16; i++) {
+                if (i == 0 && lane >= 16) continue;
+                nz |= iabs(d[i]) >= q.thr_inter[pos_class(i)];
+            }
+            dc = d[0];
+        }
+        // chroma DC: 2x2 Hadamard across the four block lanes of each plane
+        const int base = 16 + ((lane - 16) & 4);
+        const int d0 = __shfl(dc, base), d1 = __shfl(dc, base + 1), d2 = __shfl(dc, base + 2), d3 = __shfl(dc, base + 3);
+        if (lane >= 16 && lane < 24) {
+            const int t = P.qc.thr_dc_inter;
+            nz |= iabs(d0 + d1 + d2 + d3) >= t || iabs(d0 - d1 + d2 - d3) >= t || iabs(d0 + d1 - d2 - d3) >= t ||
+                  iabs(d0 - d1 - d2 + d3) >= t;
+        }
+        if (__ballot(nz) == 0ull) {
+            if (lane == 0) {
+                MbInfo* m = P.mb + mbi;
+                m->mvx = 0; m->mvy = 0; m->type = MB_P16;
+            }
+            return;
+        }
+    }
+
+    // ---- 2. integer full search ----
+    unsigned best;
+    {
+        const int dxi = lane & 31, half = lane >> 5;
+        const int col = dxi + ME_AP, cdw = col >> 2, sh = col & 3;
+        uint32_t srow[16][4];
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const uint4 v = *(const uint4*)(s_src + 16 * j);
+            srow[j][0] = v.x; srow[j][1] = v.y; srow[j][2] = v.z; srow[j][3] = v.w;
+        }
+        uint32_t acc[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) acc[k] = 0;
+        const uint32_t* wbase = s_win + (ME_AP + half * 16) * ME_WDW + cdw;
+#pragma unroll
+        for (int r = 0; r < 31; r++) {
+            const uint32_t* wr = wbase + r * ME_WDW;
+            const uint32_t w0 = wr[0], w1 = wr[1], w2 = wr[2], w3 = wr[3], w4 = wr[4];
+            const uint32_t a0 = __builtin_amdgcn_alignbyte(w1, w0, sh), a1 = __builtin_amdgcn_alignbyte(w2, w1, sh);
+            const uint32_t a2 = __builtin_amdgcn_alignbyte(w3, w2, sh), a3 = __builtin_amdgcn_alignbyte(w4, w3, sh);
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const int j = r - k;
+                if (j >= 0 && j < 16) {
+                    uint32_t a = acc[k];
+                    a = __builtin_amdgcn_sad_u8(a0, srow[j][0], a);
+                    a = __builtin_amdgcn_sad_u8(a1, srow[j][1], a);
+                    a = __builtin_amdgcn_sad_u8(a2, srow[j][2], a);
+                    a = __builtin_amdgcn_sad_u8(a3, srow[j][3], a);
+                    acc[k] = a;
+                }
+            }
+        }
+        const int dx = dxi - ME_R;
+        const int rx = se_len(4 * dx);
+        best = 0xFFFFFFFFu;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int dy = half * 16 + k - ME_R;
+            const unsigned cost = acc[k] + (unsigned)(P.lambda * (rx + se_len(4 * dy)));
+            const unsigned key = (cost << 10) | (unsigned)(((dy + ME_R) << 5) | dxi);
+            best = key < best ? key : best;
+        }
+        best = wave_min_u32(best);
+    }
+    const int ix = (int)(best & 31) - ME_R, iy = (int)((best >> 5) & 31) - ME_R;
+
+    // ---- 3. half-sample planes on an 18x18 grid, origin (ix-1, iy-1) ----
+    const uint8_t* o = winb + (iy + ME_R + ME_AP - 1) * ME_WS + ix + ME_R + ME_AP - 1;
+    for (int i = lane; i < (ME_GS + 5) * ME_GS; i += 64) {
+        const int y = i / ME_GS - 2, x = i % ME_GS;
+        const uint8_t* p = o + y * ME_WS + x;
+        s_b1[i] = (int16_t)(p[-2] - 5 * p[-1] + 20 * p[0] + 20 * p[1] - 5 * p[2] + p[3]);
+    }
+    __syncthreads();
+    for (int i = lane; i < ME_GS * ME_GS; i += 64) {
+        const int y = i / ME_GS, x = i % ME_GS;
+        const uint8_t* p = o + y * ME_WS + x;
+        s_pl[i] = p[0];
+        s_pl[ME_GS * ME_GS + i] = (uint8_t)clip255((s_b1[(y + 2) * ME_GS + x] + 16) >> 5);
+        s_pl[2 * ME_GS * ME_GS + i] = (uint8_t)clip255(
+            (p[-2 * ME_WS] - 5 * p[-ME_WS] + 20 * p[0] + 20 * p[ME_WS] - 5 * p[2 * ME_WS] + p[3 * ME_WS] + 16) >> 5);
+        const int16_t* q = s_b1 + y * ME_GS + x;
+        s_pl[3 * ME_GS * ME_GS + i] = (uint8_t)clip255(
+            (q[0] - 5 * q[ME_GS] + 20 * q[2 * ME_GS] + 20 * q[3 * ME_GS] - 5 * q[4 * ME_GS] + q[5 * ME_GS] + 512) >> 10);
+    }
+    __syncthreads();
+
+    // ---- 4. sub-pel refinement: 4 candidates per round, 16 lanes (4x4 blocks) each ----
+    const int grp = lane >> 4, blk = lane & 15, b4x = (blk & 3) * 4, b4y = (blk >> 2) * 4;
+    int sd[16];
+#pragma unroll
+    for (int y = 0; y < 4; y++) {
+        const uint32_t v = *(const uint32_t*)(s_src + (b4y + y) * 16 + b4x);
+#pragma unroll
+        for (int x = 0; x < 4; x++) sd[4 * y + x] = (int)((v >> (8 * x)) & 255);
+    }
+    int cx = 4 * ix, cy = 4 * iy;
+    unsigned best_cost = 0;
+#pragma unroll 1
+    for (int pass = 0; pass < 2; pass++) {
+        const int step = pass == 0 ? 2 : 1;
+        const int ncand = pass == 0 ? 9 : 8;
+        unsigned bestk = pass == 0 ? 0xFFFFFFFFu : (best_cost << 4);
+#pragma unroll 1
+        for (int c0 = 0; c0 < ncand; c0 += 4) {
+            const int c = c0 + grp;                     // candidate index in this pass
+            const int ord = c < ncand ? (pass == 0 ? c : c + 1) : 0;  // 0 = centre (also for idle groups)
+            const int n = ord - 1;                      // neighbour 0..7
+            // neighbour order (-1,-1)(0,-1)(1,-1)(-1,0)(1,0)(-1,1)(0,1)(1,1)
+            const int nn = n >= 4 ? n + 1 : n;
+            const int ddx = ord == 0 ? 0 : (nn % 3) - 1, ddy = ord == 0 ? 0 : (nn / 3) - 1;
+            const int qx = cx + step * ddx, qy = cy + step * ddy;
+            const int ox = qx - 4 * ix, oy = qy - 4 * iy;
+            const int gx = 1 + (ox >> 2), gy = 1 + (oy >> 2);
+            int t0, t1;
+            qpel_taps(ox & 3, oy & 3, t0, t1);
+            int d[16];
+            const int gb = (gy + b4y) * ME_GS + gx + b4x;
+#pragma unroll
+            for (int y = 0; y < 4; y++)
+#pragma unroll
+                for (int x = 0; x < 4; x++) {
+                    const int g = gb + y * ME_GS + x;
+                    d[4 * y + x] = sd[4 * y + x] - (((int)s_pl[t0 + g] + (int)s_pl[t1 + g] + 1) >> 1);
+                }
+            int s = hadamard_abs(d);
+            s = group_sum<16>(s);
+            const unsigned cost = (unsigned)(s >> 1) + (unsigned)(P.lambda * (se_len(qx) + se_len(qy)));
+            unsigned key = c < ncand ? ((cost << 4) | (unsigned)ord) : 0xFFFFFFFFu;
+            key = wave_min_u32(key);
+            bestk = key < bestk ? key : bestk;
+        }
+        const int ord = (int)(bestk & 15);
+        best_cost = bestk >> 4;
+        if (ord) {
+            const int n = ord - 1, nn = n >= 4 ? n + 1 : n;
+            cx += step * ((nn % 3) - 1);
+            cy += step * ((nn / 3) - 1);
+        }
+    }
+    if (lane == 0) {
+        MbInfo* m = P.mb + mbi;
+        m->mvx = (int16_t)cx; m->mvy = (int16_t)cy; m->type = MB_P16;
+    }
+}
+
+}  // namespace h264

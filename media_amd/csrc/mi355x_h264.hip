@@ -1,0 +1,627 @@
+// media_amd/csrc/mi355x_h264.hip -- C ABI of include/mi355x_h264.h: device
+// memory, stream, launches and the host-side framing (SPS/PPS/slice header,
+// NAL wrapping, emulation prevention) around the HIP kernels in this directory.
+//
+// This file stands where the reference's adapter calls into libopenh264.so
+// (/root/reference/video_codec/VideoEncoderOpenH264.cpp:142, :257, :344, :382,
+// :408).  There is no CPU encode path here: without a HIP device create() fails.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/mi355x_h264.h"
+#include "dev_common.h"
+#include "k_cavlc.h"
+#include "k_deblock.h"
+#include "k_intra.h"
+#include "k_me.h"
+#include "k_pmb.h"
+
+using namespace h264;
+
+namespace {
+
+// ---- host tables (ITU-T H.264 Table 8-15, A-1; quantiser of the reference model) ----
+const uint8_t h_chroma_qp[52] = {0,  1,  2,  3,  4,  5,  6,  7,  8,  9,  10, 11, 12, 13, 14, 15, 16, 17,
+                                 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 29, 30, 31, 32, 32, 33,
+                                 34, 34, 35, 35, 36, 36, 37, 37, 37, 38, 38, 38, 39, 39, 39, 39};
+const uint8_t h_dequant_v[6][3] = {{10, 16, 13}, {11, 18, 14}, {13, 20, 16}, {14, 23, 18}, {16, 25, 20}, {18, 29, 23}};
+const uint16_t h_quant_mf[6][3] = {{13107, 5243, 8066}, {11916, 4660, 7490}, {10082, 4194, 6554},
+                                   {9362, 3647, 5825},  {8192, 3355, 5243},  {7282, 2893, 4559}};
+const uint8_t h_lambda[52] = {1,  1,  1,  1,  1,  1,  1,  1,  1,  1,  1,  1,  1,  1,  1,  1,  2,  2,
+                              2,  2,  3,  3,  3,  4,  4,  4,  5,  6,  6,  7,  8,  9,  10, 11, 13, 14,
+                              16, 18, 20, 23, 25, 29, 32, 36, 40, 45, 51, 57, 64, 72, 81, 91};
+const struct { uint8_t idc; uint32_t mbps, fs; } h_levels[] = {
+    {10, 1485, 99},     {11, 3000, 396},     {12, 6000, 396},     {13, 11880, 396},   {20, 11880, 396},  {21, 19800, 792},
+    {22, 20250, 1620},  {30, 40500, 1620},   {31, 108000, 3600},  {32, 216000, 5120}, {40, 245760, 8192}, {41, 245760, 8192},
+    {42, 522240, 8704}, {50, 589824, 22080}, {51, 983040, 36864}, {52, 2073600, 36864}};
+const uint8_t h_alpha[52] = {0,  0,  0,  0,  0,  0,  0,  0,  0,  0,  0,  0,  0,   0,   0,   0,   4,   4,
+                             5,  6,  7,  8,  9,  10, 12, 13, 15, 17, 20, 22, 25,  28,  32,  36,  40,  45,
+                             50, 56, 63, 71, 80, 90, 101, 113, 127, 144, 162, 182, 203, 226, 255, 255};
+const uint8_t h_beta[52] = {0,  0,  0,  0,  0,  0,  0,  0,  0,  0,  0,  0,  0,  0,  0,  0,  2,  2,
+                            2,  3,  3,  3,  3,  4,  4,  4,  6,  6,  7,  7,  8,  8,  9,  9,  10, 10,
+                            11, 11, 12, 12, 13, 13, 14, 14, 15, 15, 16, 16, 17, 17, 18, 18};
+const uint8_t h_tc0[52][3] = {
+    {0, 0, 0},   {0, 0, 0},   {0, 0, 0},    {0, 0, 0},    {0, 0, 0},    {0, 0, 0},   {0, 0, 0},   {0, 0, 0},  {0, 0, 0},
+    {0, 0, 0},   {0, 0, 0},   {0, 0, 0},    {0, 0, 0},    {0, 0, 0},    {0, 0, 0},   {0, 0, 0},   {0, 0, 0},  {0, 0, 1},
+    {0, 0, 1},   {0, 0, 1},   {0, 0, 1},    {0, 1, 1},    {0, 1, 1},    {1, 1, 1},   {1, 1, 1},   {1, 1, 1},  {1, 1, 1},
+    {1, 1, 2},   {1, 1, 2},   {1, 1, 2},    {1, 1, 2},    {1, 2, 3},    {1, 2, 3},   {2, 2, 3},   {2, 2, 4},  {2, 3, 4},
+    {2, 3, 4},   {3, 3, 5},   {3, 4, 6},    {3, 4, 6},    {4, 5, 7},    {4, 5, 8},   {4, 6, 9},   {5, 7, 10}, {6, 8, 11},
+    {6, 8, 13},  {7, 10, 14}, {8, 11, 16},  {9, 12, 18},  {10, 13, 20}, {11, 15, 23}, {13, 17, 25}};
+
+// ---- host bit writer for parameter sets and slice headers ----
+struct HostBits {
+    std::vector<uint8_t> bytes;
+    uint64_t nbits = 0;
+    void put(int n, uint32_t v)
+    {
+        for (int i = n - 1; i >= 0; i--) {
+            if ((nbits >> 3) >= bytes.size()) bytes.push_back(0);
+            if ((v >> i) & 1) bytes[nbits >> 3] |= (uint8_t)(0x80 >> (nbits & 7));
+            nbits++;
+        }
+    }
+    void ue(uint32_t v)
+    {
+        uint32_t x = v + 1;
+        int n = 0;
+        while ((x >> n) > 1) n++;
+        put(n, 0);
+        put(n + 1, x);
+    }
+    void se(int32_t v) { ue(v > 0 ? (uint32_t)(2 * v - 1) : (uint32_t)(-2 * v)); }
+    void trailing()
+    {
+        put(1, 1);
+        while (nbits & 7) put(1, 0);
+    }
+};
+
+size_t nal_escape(const uint8_t* rbsp, size_t n, uint8_t* out)
+{
+    size_t o = 0;
+    int zeros = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (zeros == 2 && rbsp[i] <= 3) { out[o++] = 3; zeros = 0; }
+        out[o++] = rbsp[i];
+        zeros = rbsp[i] == 0 ? zeros + 1 : 0;
+    }
+    return o;
+}
+
+void append_nal(std::vector<uint8_t>& au, int ref_idc, int type, const HostBits& b)
+{
+    const uint8_t sc[5] = {0, 0, 0, 1, (uint8_t)((ref_idc << 5) | type)};
+    au.insert(au.end(), sc, sc + 5);
+    std::vector<uint8_t> esc(b.bytes.size() * 3 / 2 + 4);
+    const size_t n = nal_escape(b.bytes.data(), b.bytes.size(), esc.data());
+    au.insert(au.end(), esc.begin(), esc.begin() + n);
+}
+
+void fill_quant(Quant& q, int qp)
+{
+    q.qp = qp;
+    q.qbits = 15 + qp / 6;
+    q.f_intra = (1 << q.qbits) / 3;
+    q.f_inter = (1 << q.qbits) / 6;
+    for (int c = 0; c < 3; c++) {
+        q.mf[c] = h_quant_mf[qp % 6][c];
+        q.dq[c] = h_dequant_v[qp % 6][c] << (qp / 6);
+        q.thr_inter[c] = (int)((((int64_t)1 << q.qbits) - q.f_inter + q.mf[c] - 1) / q.mf[c]);
+    }
+    q.thr_dc_inter = (int)((((int64_t)1 << (q.qbits + 1)) - 2 * (int64_t)q.f_inter + q.mf[0] - 1) / q.mf[0]);
+}
+
+constexpr int NSLOT = 3;          // access-unit slots in flight
+constexpr int MAX_EV = 64;
+
+struct Slot {
+    uint32_t* d_bitbuf = nullptr;   // device slice payload (zeroed before use)
+    SliceInfo* d_info = nullptr;
+    SliceInfo* h_info = nullptr;    // pinned
+    uint8_t* h_au = nullptr;        // pinned access unit buffer
+    size_t used_bytes = 0;          // payload bytes of the last use (for re-zeroing)
+    size_t payload_off = 0;         // offset of the slice payload inside h_au
+    size_t au_start = 0;            // offset of the first byte of the access unit
+    int nal_hdr = 0;
+    bool idr = false;
+    bool busy = false;
+    hipEvent_t done = nullptr;
+    // stats events of this frame: pairs (start, stop, kernel id, launches, mbs)
+    struct Ev { hipEvent_t a, b; int k; uint32_t launches, mbs; };
+    std::vector<Ev> evs;
+};
+
+}  // namespace
+
+struct mi355x_h264_encoder {
+    mi355x_h264_config cfg{};
+    int mbw = 0, mbh = 0, cw = 0, ch = 0, nmb = 0, level_idc = 0;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    uint8_t* d_planes[2][3] = {{nullptr}};  // ping-pong: [cur][plane]
+    uint8_t* d_pre[3] = {nullptr};           // copy of the reconstruction before the loop filter (debug)
+    int cur = 0;                             // index written by the picture being encoded
+    MbInfo* d_mb = nullptr;
+    int16_t* d_levels = nullptr;
+    int16_t* d_mvd = nullptr;
+    uint16_t* d_slotbits = nullptr;
+    uint32_t* d_mbbits = nullptr;
+    uint8_t* d_stage = nullptr;              // device copy of a host-supplied picture
+    uint8_t* h_stage = nullptr;              // pinned staging for strided host input
+    size_t frame_bytes = 0, bitbuf_cap = 0, au_cap = 0;
+    Slot slots[NSLOT];
+    int next_slot = 0;
+    std::vector<uint8_t> sps_pps;            // Annex-B SPS + PPS NALs
+    std::vector<uint8_t> esc_buf;            // slow path: escaped access unit
+    long frames = 0;
+    int frame_in_gop = 0, frame_num = 0, idr_id = 0, force_idr = 0;
+    int qp = 26;
+    bool keep_pre = false, stats_on = false;
+    std::vector<hipEvent_t> ev_pool;
+    mi355x_h264_stats stats{};
+    char err[256] = {0};
+};
+
+namespace {
+
+int fail(mi355x_h264_encoder* e, int code, const char* fmt, ...)
+{
+    if (e) {
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(e->err, sizeof(e->err), fmt, ap);
+        va_end(ap);
+    }
+    return code;
+}
+
+#define HIPCHK(e, call)                                                                              \
+    do {                                                                                             \
+        hipError_t _r = (call);                                                                      \
+        if (_r != hipSuccess) return fail((e), MI355X_H264_E_HIP, "%s: %s", #call, hipGetErrorString(_r)); \
+    } while (0)
+
+void build_parameter_sets(mi355x_h264_encoder* e)
+{
+    const int prof = e->cfg.profile_idc;
+    HostBits s;
+    s.put(8, (uint32_t)prof);
+    s.put(8, prof == 66 ? 0xC0 : prof == 77 ? 0x40 : 0x00);
+    s.put(8, (uint32_t)e->level_idc);
+    s.ue(0);
+    if (prof == 100) { s.ue(1); s.ue(0); s.ue(0); s.put(1, 0); s.put(1, 0); }
+    s.ue(4);      // log2_max_frame_num_minus4
+    s.ue(2);      // pic_order_cnt_type
+    s.ue(1);      // max_num_ref_frames (ref :290)
+    s.put(1, 0);  // gaps_in_frame_num_value_allowed_flag
+    s.ue((uint32_t)e->mbw - 1);
+    s.ue((uint32_t)e->mbh - 1);
+    s.put(1, 1);  // frame_mbs_only_flag
+    s.put(1, 1);  // direct_8x8_inference_flag
+    const int cr = (e->cw - e->cfg.width) / 2, cb = (e->ch - e->cfg.height) / 2;
+    if (cr || cb) { s.put(1, 1); s.ue(0); s.ue((uint32_t)cr); s.ue(0); s.ue((uint32_t)cb); }
+    else s.put(1, 0);
+    s.put(1, 0);  // vui_parameters_present_flag
+    s.trailing();
+    HostBits p;
+    p.ue(0); p.ue(0);
+    p.put(1, 0);  // CAVLC
+    p.put(1, 0);
+    p.ue(0); p.ue(0); p.ue(0);
+    p.put(1, 0); p.put(2, 0);
+    p.se(0); p.se(0); p.se(0);
+    p.put(1, 1);  // deblocking_filter_control_present_flag
+    p.put(1, 0); p.put(1, 0);
+    if (prof == 100) { p.put(1, 0); p.put(1, 0); p.se(0); }
+    p.trailing();
+    e->sps_pps.clear();
+    append_nal(e->sps_pps, 3, 7, s);
+    append_nal(e->sps_pps, 3, 8, p);
+}
+
+// slice_header() of 7.3.3 for this build's fixed choices; returns bit count (< 64)
+int build_slice_header(const mi355x_h264_encoder* e, bool idr, uint64_t* bits)
+{
+    HostBits h;
+    h.ue(0);
+    h.ue(idr ? 7 : 5);
+    h.ue(0);
+    h.put(8, (uint32_t)e->frame_num);
+    if (idr) h.ue((uint32_t)e->idr_id);
+    if (!idr) { h.put(1, 0); h.put(1, 0); }
+    if (idr) { h.put(1, 0); h.put(1, 0); } else h.put(1, 0);
+    h.se(e->qp - 26);
+    h.ue(e->cfg.disable_deblock ? 1 : 0);
+    if (!e->cfg.disable_deblock) { h.se(0); h.se(0); }
+    uint64_t v = 0;
+    for (uint64_t i = 0; i < h.nbits; i++) v = (v << 1) | ((h.bytes[i >> 3] >> (7 - (i & 7))) & 1);
+    *bits = v;
+    return (int)h.nbits;
+}
+
+hipEvent_t get_event(mi355x_h264_encoder* e)
+{
+    if (!e->ev_pool.empty()) { hipEvent_t ev = e->ev_pool.back(); e->ev_pool.pop_back(); return ev; }
+    hipEvent_t ev = nullptr;
+    if (hipEventCreate(&ev) != hipSuccess) return nullptr;
+    return ev;
+}
+
+struct StatScope {
+    mi355x_h264_encoder* e; Slot* s; int k; uint32_t launches, mbs; hipEvent_t a = nullptr, b = nullptr;
+    StatScope(mi355x_h264_encoder* e_, Slot* s_, int k_, uint32_t l, uint32_t m) : e(e_), s(s_), k(k_), launches(l), mbs(m)
+    {
+        if (e->stats_on) { a = get_event(e); b = get_event(e); if (a) (void)hipEventRecord(a, e->stream); }
+    }
+    ~StatScope()
+    {
+        if (e->stats_on && a && b) { (void)hipEventRecord(b, e->stream); s->evs.push_back({a, b, k, launches, mbs}); }
+    }
+};
+
+// enqueue everything for one picture whose I420 samples are at d_src
+int submit(mi355x_h264_encoder* e, const uint8_t* d_src, int slot_idx)
+{
+    Slot& S = e->slots[slot_idx];
+    const bool idr = e->force_idr || e->frames == 0 || e->frame_in_gop >= e->cfg.gop;
+    if (idr) { e->frame_in_gop = 0; e->frame_num = 0; }
+    e->force_idr = 0;
+    const int cur = e->cur, prev = cur ^ 1;
+    FrameParams P{};
+    P.src = d_src; P.w = e->cfg.width; P.h = e->cfg.height;
+    P.cw = e->cw; P.ch = e->ch; P.mbw = e->mbw; P.mbh = e->mbh;
+    for (int p = 0; p < 3; p++) { P.rec[p] = e->d_planes[cur][p]; P.ref[p] = e->d_planes[prev][p]; }
+    P.mb = e->d_mb; P.levels = e->d_levels; P.mvd = e->d_mvd;
+    fill_quant(P.qy, e->qp);
+    fill_quant(P.qc, h_chroma_qp[e->qp]);
+    P.lambda = h_lambda[e->qp];
+    hipStream_t st = e->stream;
+
+    // re-zero the part of the payload buffer the previous use dirtied
+    if (S.used_bytes) HIPCHK(e, hipMemsetAsync(S.d_bitbuf, 0, std::min(e->bitbuf_cap, S.used_bytes + 64), st));
+    S.used_bytes = 0;
+
+    if (idr) {
+        StatScope sc(e, &S, MI355X_H264_K_INTRA, (uint32_t)(e->mbw + e->mbh - 1), (uint32_t)e->nmb);
+        for (int s = 0; s < e->mbw + e->mbh - 1; s++) {
+            const int ymin = std::max(0, s - e->mbw + 1), ymax = std::min(e->mbh - 1, s);
+            hipLaunchKernelGGL(k_intra_diag, dim3(ymax - ymin + 1), dim3(64), 0, st, P, s);
+        }
+    } else {
+        { StatScope sc(e, &S, MI355X_H264_K_ME, 1, (uint32_t)e->nmb);
+          hipLaunchKernelGGL(k_me, dim3(e->nmb), dim3(64), 0, st, P); }
+        { StatScope sc(e, &S, MI355X_H264_K_PMB, 1, (uint32_t)e->nmb);
+          hipLaunchKernelGGL(k_pmb, dim3(e->nmb), dim3(64), 0, st, P); }
+    }
+    // entropy coding
+    uint64_t hdr = 0;
+    const int hdr_len = build_slice_header(e, idr, &hdr);
+    {
+        StatScope sc(e, &S, MI355X_H264_K_CAVLC, 4, (uint32_t)e->nmb);
+        CavlcParams C{};
+        C.mb = e->d_mb; C.levels = e->d_levels; C.mvd = e->d_mvd; C.mbw = e->mbw; C.nmb = e->nmb; C.p_slice = idr ? 0 : 1;
+        C.slotbits = e->d_slotbits; C.mbbits = e->d_mbbits; C.bitbuf = S.d_bitbuf;
+        const int grid = (e->nmb + 1) / 2;
+        hipLaunchKernelGGL(k_cavlc<false>, dim3(grid), dim3(64), 0, st, C);
+        hipLaunchKernelGGL(k_bit_scan, dim3(1), dim3(1024), 0, st, C, (unsigned long long)hdr, hdr_len, S.d_info);
+        hipLaunchKernelGGL(k_cavlc<true>, dim3(grid), dim3(64), 0, st, C);
+        // access unit layout in the pinned buffer: [pad][SPS PPS (IDR only)][00 00 00 01 hdr][payload...]
+        const size_t pre = (idr ? e->sps_pps.size() : 0) + 5;
+        const size_t pad = (16 - (pre & 15)) & 15;
+        S.au_start = pad;
+        S.payload_off = pad + pre;
+        S.idr = idr;
+        S.nal_hdr = idr ? ((3 << 5) | 5) : ((2 << 5) | 1);
+        hipLaunchKernelGGL(k_pack, dim3(64), dim3(256), 0, st, (const uint8_t*)S.d_bitbuf, S.h_au + S.payload_off, S.d_info);
+        HIPCHK(e, hipMemcpyAsync(S.h_info, S.d_info, sizeof(SliceInfo), hipMemcpyDeviceToHost, st));
+    }
+    if (e->keep_pre)
+        for (int p = 0; p < 3; p++)
+            HIPCHK(e, hipMemcpyAsync(e->d_pre[p], e->d_planes[cur][p], (size_t)e->cw * e->ch / (p ? 4 : 1), hipMemcpyDeviceToDevice, st));
+    if (!e->cfg.disable_deblock) {
+        const int steps = e->mbw + 2 * (e->mbh - 1);
+        StatScope sc(e, &S, MI355X_H264_K_DEBLOCK, (uint32_t)steps, (uint32_t)e->nmb);
+        DbParams D{};
+        for (int p = 0; p < 3; p++) D.pl[p] = e->d_planes[cur][p];
+        D.mb = e->d_mb; D.cw = e->cw; D.ch = e->ch; D.mbw = e->mbw; D.mbh = e->mbh;
+        const int qp = e->qp, qpc = h_chroma_qp[qp];
+        D.alpha_y = h_alpha[qp]; D.beta_y = h_beta[qp]; D.alpha_c = h_alpha[qpc]; D.beta_c = h_beta[qpc];
+        for (int i = 0; i < 3; i++) { D.tc0_y[i] = h_tc0[qp][i]; D.tc0_c[i] = h_tc0[qpc][i]; }
+        for (int s = 0; s < steps; s++) {
+            const int ymin = std::max(0, (s - (e->mbw - 1) + 1) >> 1), ymax = std::min(e->mbh - 1, s >> 1);
+            if (ymax < ymin) continue;
+            hipLaunchKernelGGL(k_deblock_diag, dim3(ymax - ymin + 1), dim3(64), 0, st, D, s);
+        }
+    }
+    HIPCHK(e, hipEventRecord(S.done, st));
+    HIPCHK(e, hipGetLastError());
+    S.busy = true;
+    // bookkeeping for the next picture
+    e->cur ^= 1;
+    if (idr) e->idr_id = (e->idr_id + 1) & 0xFF;
+    e->frame_num = (e->frame_num + 1) & 255;
+    e->frame_in_gop++;
+    e->frames++;
+    return MI355X_H264_OK;
+}
+
+// wait for a slot and finish its access unit on the host
+int collect(mi355x_h264_encoder* e, int slot_idx, uint8_t** out, uint32_t* out_len, int* frame_type)
+{
+    Slot& S = e->slots[slot_idx];
+    if (!S.busy) return fail(e, MI355X_H264_E_INTERNAL, "collect on an idle slot");
+    HIPCHK(e, hipEventSynchronize(S.done));
+    S.busy = false;
+    for (auto& ev : S.evs) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, ev.a, ev.b) == hipSuccess) {
+            e->stats.ms[ev.k] += ms; e->stats.launches[ev.k] += ev.launches; e->stats.mbs[ev.k] += ev.mbs;
+        }
+        e->ev_pool.push_back(ev.a); e->ev_pool.push_back(ev.b);
+    }
+    S.evs.clear();
+    e->stats.frames++;
+    const SliceInfo info = *S.h_info;
+    S.used_bytes = info.total_bytes;
+    if (info.error) return fail(e, MI355X_H264_E_INTERNAL, "device reported error %u", info.error);
+    if ((size_t)info.total_bytes + 64 > e->bitbuf_cap) return fail(e, MI355X_H264_E_OVERFLOW, "slice of %u bytes exceeds buffer", info.total_bytes);
+    uint8_t* au = S.h_au + S.au_start;
+    size_t pos = 0;
+    if (S.idr) { memcpy(au, e->sps_pps.data(), e->sps_pps.size()); pos = e->sps_pps.size(); }
+    au[pos++] = 0; au[pos++] = 0; au[pos++] = 0; au[pos++] = 1; au[pos++] = (uint8_t)S.nal_hdr;
+    if (info.epb_count == 0) {
+        *out = au;
+        *out_len = (uint32_t)(pos + info.total_bytes);
+    } else {  // rare: some 00 00 0x pattern needs an emulation prevention byte
+        e->esc_buf.resize(pos + (size_t)info.total_bytes * 3 / 2 + 16);
+        memcpy(e->esc_buf.data(), au, pos);
+        const size_t n = nal_escape(S.h_au + S.payload_off, info.total_bytes, e->esc_buf.data() + pos);
+        *out = e->esc_buf.data();
+        *out_len = (uint32_t)(pos + n);
+    }
+    if (frame_type) *frame_type = S.idr ? MI355X_H264_FRAME_IDR : MI355X_H264_FRAME_P;
+    return MI355X_H264_OK;
+}
+
+int pick_level(int mbs, int fps)
+{
+    for (const auto& l : h_levels)
+        if ((uint32_t)mbs <= l.fs && (uint32_t)(mbs * fps) <= l.mbps) return l.idc;
+    return 52;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mi355x_h264_abi_version(void) { return MI355X_H264_ABI_VERSION; }
+
+void mi355x_h264_default_config(mi355x_h264_config* c)
+{
+    if (!c) return;
+    memset(c, 0, sizeof(*c));
+    c->struct_size = sizeof(*c);
+    c->width = 720; c->height = 1280;  // reference defaults, VideoEncoderOpenH264.h:13-24
+    c->fps = 30; c->bitrate = 5000000; c->gop = 30; c->profile_idc = 66;
+    c->rc_mode = MI355X_H264_RC_FIXED_QP; c->qp = 26; c->device = 0; c->disable_deblock = 0;
+}
+
+int mi355x_h264_create(const mi355x_h264_config* cfg, mi355x_h264_encoder** out)
+{
+    if (!cfg || !out || cfg->struct_size != sizeof(mi355x_h264_config)) return MI355X_H264_E_ARG;
+    *out = nullptr;
+    if (cfg->width < 16 || cfg->height < 16 || cfg->width > 4096 || cfg->height > 4096 || ((cfg->width | cfg->height) & 1))
+        return MI355X_H264_E_ARG;
+    if (cfg->qp < 10 || cfg->qp > 51 || cfg->gop < 1) return MI355X_H264_E_ARG;
+    if (cfg->profile_idc != 66 && cfg->profile_idc != 77 && cfg->profile_idc != 100) return MI355X_H264_E_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev) return MI355X_H264_E_NODEVICE;
+    mi355x_h264_encoder* e = new (std::nothrow) mi355x_h264_encoder();
+    if (!e) return MI355X_H264_E_NOMEM;
+    e->cfg = *cfg;
+    e->device = cfg->device;
+    e->qp = cfg->qp;
+    e->mbw = (cfg->width + 15) / 16; e->mbh = (cfg->height + 15) / 16;
+    e->cw = e->mbw * 16; e->ch = e->mbh * 16; e->nmb = e->mbw * e->mbh;
+    e->level_idc = std::max(32, pick_level(e->nmb, cfg->fps > 0 ? cfg->fps : 30));
+    build_parameter_sets(e);
+#define CK(call)                                                              \
+    do {                                                                      \
+        hipError_t _r = (call);                                               \
+        if (_r != hipSuccess) {                                               \
+            fprintf(stderr, "mi355x_h264_create: %s: %s\n", #call, hipGetErrorString(_r)); \
+            mi355x_h264_destroy(e);                                           \
+            return _r == hipErrorOutOfMemory ? MI355X_H264_E_NOMEM : MI355X_H264_E_HIP; \
+        }                                                                     \
+    } while (0)
+    CK(hipSetDevice(e->device));
+    CK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    const size_t ysz = (size_t)e->cw * e->ch;
+    for (int b = 0; b < 2; b++)
+        for (int p = 0; p < 3; p++) {
+            CK(hipMalloc((void**)&e->d_planes[b][p], (p ? ysz / 4 : ysz) + 256));
+            CK(hipMemset(e->d_planes[b][p], 0, (p ? ysz / 4 : ysz) + 256));
+        }
+    for (int p = 0; p < 3; p++) CK(hipMalloc((void**)&e->d_pre[p], (p ? ysz / 4 : ysz) + 256));
+    CK(hipMalloc((void**)&e->d_mb, (size_t)e->nmb * sizeof(MbInfo)));
+    CK(hipMemset(e->d_mb, 0, (size_t)e->nmb * sizeof(MbInfo)));
+    CK(hipMalloc((void**)&e->d_levels, (size_t)e->nmb * LV_STRIDE * sizeof(int16_t)));
+    CK(hipMalloc((void**)&e->d_mvd, (size_t)e->nmb * 2 * sizeof(int16_t)));
+    CK(hipMalloc((void**)&e->d_slotbits, (size_t)e->nmb * 32 * sizeof(uint16_t)));
+    CK(hipMalloc((void**)&e->d_mbbits, (size_t)e->nmb * sizeof(uint32_t)));
+    e->frame_bytes = (size_t)cfg->width * cfg->height * 3 / 2;
+    CK(hipMalloc((void**)&e->d_stage, e->frame_bytes + 256));
+    CK(hipHostMalloc((void**)&e->h_stage, e->frame_bytes + 256, hipHostMallocDefault));
+    e->bitbuf_cap = ysz * 2 + (1 << 16);
+    e->au_cap = e->bitbuf_cap + e->sps_pps.size() + 64;
+    for (auto& S : e->slots) {
+        CK(hipMalloc((void**)&S.d_bitbuf, e->bitbuf_cap + 256));
+        CK(hipMemset(S.d_bitbuf, 0, e->bitbuf_cap + 256));
+        CK(hipMalloc((void**)&S.d_info, sizeof(SliceInfo)));
+        CK(hipHostMalloc((void**)&S.h_info, sizeof(SliceInfo), hipHostMallocDefault));
+        CK(hipHostMalloc((void**)&S.h_au, e->au_cap + 256, hipHostMallocDefault));
+        CK(hipEventCreateWithFlags(&S.done, hipEventDisableTiming));
+    }
+    CK(hipDeviceSynchronize());
+#undef CK
+    *out = e;
+    return MI355X_H264_OK;
+}
+
+void mi355x_h264_destroy(mi355x_h264_encoder* e)
+{
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    for (int b = 0; b < 2; b++)
+        for (int p = 0; p < 3; p++) (void)hipFree(e->d_planes[b][p]);
+    for (int p = 0; p < 3; p++) (void)hipFree(e->d_pre[p]);
+    (void)hipFree(e->d_mb); (void)hipFree(e->d_levels); (void)hipFree(e->d_mvd);
+    (void)hipFree(e->d_slotbits); (void)hipFree(e->d_mbbits); (void)hipFree(e->d_stage);
+    if (e->h_stage) (void)hipHostFree(e->h_stage);
+    for (auto& S : e->slots) {
+        (void)hipFree(S.d_bitbuf); (void)hipFree(S.d_info);
+        if (S.h_info) (void)hipHostFree(S.h_info);
+        if (S.h_au) (void)hipHostFree(S.h_au);
+        if (S.done) (void)hipEventDestroy(S.done);
+        for (auto& ev : S.evs) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
+    }
+    for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+int mi355x_h264_encode_device(mi355x_h264_encoder* e, const void* d_i420, uint8_t** out, uint32_t* out_len, int* frame_type)
+{
+    if (!e || !d_i420 || !out || !out_len) return fail(e, MI355X_H264_E_ARG, "null argument");
+    HIPCHK(e, hipSetDevice(e->device));
+    const int slot = e->next_slot;
+    e->next_slot = (e->next_slot + 1) % NSLOT;
+    int rc = submit(e, (const uint8_t*)d_i420, slot);
+    if (rc) return rc;
+    return collect(e, slot, out, out_len, frame_type);
+}
+
+int mi355x_h264_encode(mi355x_h264_encoder* e, const uint8_t* y, int ys, const uint8_t* u, int us, const uint8_t* v, int vs,
+                       uint8_t** out, uint32_t* out_len, int* frame_type)
+{
+    if (!e || !y || !u || !v || !out || !out_len) return fail(e, MI355X_H264_E_ARG, "null argument");
+    const int w = e->cfg.width, h = e->cfg.height;
+    if (ys < w || us < w / 2 || vs < w / 2) return fail(e, MI355X_H264_E_ARG, "stride smaller than width");
+    HIPCHK(e, hipSetDevice(e->device));
+    // the previous picture's use of the staging buffers has completed (encode is synchronous)
+    uint8_t* d = e->h_stage;
+    for (int r = 0; r < h; r++) memcpy(d + (size_t)r * w, y + (size_t)r * ys, (size_t)w);
+    d += (size_t)w * h;
+    for (int r = 0; r < h / 2; r++) memcpy(d + (size_t)r * (w / 2), u + (size_t)r * us, (size_t)(w / 2));
+    d += (size_t)(w / 2) * (h / 2);
+    for (int r = 0; r < h / 2; r++) memcpy(d + (size_t)r * (w / 2), v + (size_t)r * vs, (size_t)(w / 2));
+    HIPCHK(e, hipMemcpyAsync(e->d_stage, e->h_stage, e->frame_bytes, hipMemcpyHostToDevice, e->stream));
+    return mi355x_h264_encode_device(e, e->d_stage, out, out_len, frame_type);
+}
+
+int mi355x_h264_encode_batch_device(mi355x_h264_encoder* e, const void* d_frames, size_t stride, int count, uint8_t* host_out,
+                                    size_t out_cap, uint32_t* sizes, size_t* total_len)
+{
+    if (!e || !d_frames || !host_out || !sizes || count < 0) return fail(e, MI355X_H264_E_ARG, "null argument");
+    HIPCHK(e, hipSetDevice(e->device));
+    size_t pos = 0;
+    int pending[NSLOT], npend = 0, head = 0;
+    auto drain_one = [&]() -> int {
+        uint8_t* p = nullptr; uint32_t n = 0;
+        const int slot = pending[head % NSLOT];
+        int rc = collect(e, slot, &p, &n, nullptr);
+        if (rc) return rc;
+        const int idx = head;
+        head++; npend--;
+        if (pos + n > out_cap) return fail(e, MI355X_H264_E_OVERFLOW, "batch output buffer too small");
+        memcpy(host_out + pos, p, n);
+        sizes[idx] = n;
+        pos += n;
+        return 0;
+    };
+    for (int i = 0; i < count; i++) {
+        if (npend == NSLOT - 1) { int rc = drain_one(); if (rc) return rc; }
+        const int slot = e->next_slot;
+        e->next_slot = (e->next_slot + 1) % NSLOT;
+        pending[i % NSLOT] = slot;
+        int rc = submit(e, (const uint8_t*)d_frames + (size_t)i * stride, slot);
+        if (rc) return rc;
+        npend++;
+    }
+    while (npend) { int rc = drain_one(); if (rc) return rc; }
+    if (total_len) *total_len = pos;
+    return MI355X_H264_OK;
+}
+
+int mi355x_h264_force_idr(mi355x_h264_encoder* e)
+{
+    if (!e) return MI355X_H264_E_ARG;
+    e->force_idr = 1;
+    return MI355X_H264_OK;
+}
+
+int mi355x_h264_set_qp(mi355x_h264_encoder* e, int qp)
+{
+    if (!e || qp < 10 || qp > 51) return MI355X_H264_E_ARG;
+    e->qp = qp;
+    return MI355X_H264_OK;
+}
+
+const char* mi355x_h264_last_error(const mi355x_h264_encoder* e) { return e ? e->err : "null encoder"; }
+int mi355x_h264_coded_width(const mi355x_h264_encoder* e) { return e ? e->cw : 0; }
+int mi355x_h264_coded_height(const mi355x_h264_encoder* e) { return e ? e->ch : 0; }
+
+int mi355x_h264_debug_keep_pre(mi355x_h264_encoder* e, int on)
+{
+    if (!e) return MI355X_H264_E_ARG;
+    e->keep_pre = on != 0;
+    return MI355X_H264_OK;
+}
+
+int64_t mi355x_h264_debug_read(mi355x_h264_encoder* e, int what, void* dst, size_t cap)
+{
+    if (!e || !dst) return MI355X_H264_E_ARG;
+    if (hipSetDevice(e->device) != hipSuccess) return MI355X_H264_E_HIP;
+    const void* src = nullptr;
+    size_t n = 0;
+    const size_t ysz = (size_t)e->cw * e->ch;
+    const int last = e->cur ^ 1;  // picture finished by the last encode
+    switch (what) {
+        case MI355X_H264_DBG_RECON_Y: case MI355X_H264_DBG_RECON_U: case MI355X_H264_DBG_RECON_V:
+            src = e->d_planes[last][what]; n = what ? ysz / 4 : ysz; break;
+        case MI355X_H264_DBG_PRE_Y: case MI355X_H264_DBG_PRE_U: case MI355X_H264_DBG_PRE_V:
+            src = e->d_pre[what - MI355X_H264_DBG_PRE_Y]; n = what != MI355X_H264_DBG_PRE_Y ? ysz / 4 : ysz; break;
+        case MI355X_H264_DBG_MBINFO: src = e->d_mb; n = (size_t)e->nmb * sizeof(MbInfo); break;
+        case MI355X_H264_DBG_LEVELS: src = e->d_levels; n = (size_t)e->nmb * LV_STRIDE * 2; break;
+        default: return MI355X_H264_E_ARG;
+    }
+    if (cap < n) return MI355X_H264_E_ARG;
+    if (hipStreamSynchronize(e->stream) != hipSuccess) return MI355X_H264_E_HIP;
+    if (hipMemcpy(dst, src, n, hipMemcpyDeviceToHost) != hipSuccess) return MI355X_H264_E_HIP;
+    return (int64_t)n;
+}
+
+int mi355x_h264_stats_enable(mi355x_h264_encoder* e, int on)
+{
+    if (!e) return MI355X_H264_E_ARG;
+    e->stats_on = on != 0;
+    return MI355X_H264_OK;
+}
+
+int mi355x_h264_stats_read(mi355x_h264_encoder* e, mi355x_h264_stats* out, int reset)
+{
+    if (!e || !out) return MI355X_H264_E_ARG;
+    *out = e->stats;
+    if (reset) memset(&e->stats, 0, sizeof(e->stats));
+    return MI355X_H264_OK;
+}
+
+}  // extern "C"

@@ -203,6 +203,12 @@ void h264o_enc_destroy(h264o_enc *e)
     free(e);
 }
 
+int h264o_enc_set_qp(h264o_enc *e, int qp)
+{
+    if (!e || qp < 10 || qp > 51) return -1;
+    e->cfg.qp = qp;
+    return 0;
+}
 int h264o_enc_coded_width(const h264o_enc *e) { return e->cw; }
 int h264o_enc_coded_height(const h264o_enc *e) { return e->ch; }
 const uint8_t *h264o_enc_recon(const h264o_enc *e, int p) { return e->ref[p]; }
@@ -791,7 +797,7 @@ int64_t h264o_enc_encode(h264o_enc *e, const uint8_t *y, int ys, const uint8_t *
     memcpy(e->cur[2], e->rec[2], ysz / 4);
     if (!e->cfg.disable_deblock) h264o_deblock_picture(e->cur[0], e->cur[1], e->cur[2], e->cw, e->ch, e->mb, e->cfg.qp);
     for (int p = 0; p < 3; p++) { uint8_t *t = e->ref[p]; e->ref[p] = e->cur[p]; e->cur[p] = t; }
-    if (idr) e->idr_id = (e->idr_id + 1) & 0xFFFF;
+    if (idr) e->idr_id = (e->idr_id + 1) & 0xFF;
     e->frame_num = (e->frame_num + 1) & 255;
     e->frame_in_gop++;
     e->frames++;

@@ -65,6 +65,8 @@ void h264o_enc_destroy(h264o_enc *e);
 int64_t h264o_enc_encode(h264o_enc *e, const uint8_t *y, int ys, const uint8_t *u, int us,
                          const uint8_t *v, int vs, int force_idr, uint8_t *out, size_t out_cap,
                          int *is_idr);
+/* picture QP for the pictures that follow (mirrors mi355x_h264_set_qp) */
+int h264o_enc_set_qp(h264o_enc *e, int qp);
 /* Accessors valid until the next encode call.  Planes are coded size
  * (multiples of 16), pitch == coded width (chroma: half). */
 int h264o_enc_coded_width(const h264o_enc *e);

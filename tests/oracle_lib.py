@@ -52,6 +52,7 @@ def lib():
         L.h264o_enc_mbinfo.argtypes = [vp]
         L.h264o_enc_levels.restype = vp
         L.h264o_enc_levels.argtypes = [vp]
+        L.h264o_enc_set_qp.argtypes = [vp, C.c_int]
         L.h264o_enc_last_slice_bits.restype = C.c_int64
         L.h264o_enc_last_slice_bits.argtypes = [vp]
         L.h264o_dec_create.restype = vp
@@ -132,6 +133,10 @@ class OracleEncoder:
         n = (self.cw // 16) * (self.ch // 16)
         addr = lib().h264o_enc_levels(self.h)
         return np.ctypeslib.as_array(C.cast(addr, C.POINTER(C.c_int16)), shape=(n, LV_STRIDE)).copy()
+
+    def set_qp(self, qp):
+        if lib().h264o_enc_set_qp(self.h, qp) != 0:
+            raise ValueError("bad qp")
 
     def slice_bits(self):
         return lib().h264o_enc_last_slice_bits(self.h)
