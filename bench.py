@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""bench.py -- encoded frames/s of the MI355X H.264 path on BASELINE.json configs[1]:
+1080p30 I420 synthetic (S1 pan+noise), baseline profile, fixed QP 26, one stream per GPU.
+
+A "step" is one pass of the hot path over one batch: a 30-picture GOP (1 IDR + 29 P,
+the reference's default uiIntraPeriod, VideoEncoderOpenH264.h:18) whose pictures are
+already resident in HBM.  N GPUs = N independent streams, one process per GPU, no
+data-path collective (weak scaling); torch.distributed is used only for the barrier
+and the max-over-ranks clock.
+
+Prints ONE JSON line (rank 0) carrying `roofline` for the MC+DCT kernel (k_pmb) and
+`cpu_baseline` (the CPU oracle timed on this box's host cores, rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WIDTH, HEIGHT, QP, GOP = 1920, 1080, 26, 30
+FRAMES_PER_STEP = GOP
+# algorithmic HBM bytes per macroblock of the MC+DCT kernel:
+# source 384 + reference 384 in; reconstruction 384 + levels 768 + side info 32 out
+PMB_BYTES_PER_MB = 384 + 384 + 384 + 768 + 32
+HBM_PEAK_GBS = 8000.0
+
+
+def cpu_baseline(frames, cores, per_thread_frames):
+    """time the CPU oracle (kind 'port') on host cores: `cores` independent encoder
+    instances, each encoding the first `per_thread_frames` pictures of the workload"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_lib import OracleEncoder
+    encs = [OracleEncoder(WIDTH, HEIGHT, qp=QP, gop=GOP) for _ in range(cores)]
+
+    def work(e):
+        for i in range(per_thread_frames):
+            e.encode(frames[i % len(frames)])
+
+    ths = [threading.Thread(target=work, args=(e,)) for e in encs]
+    t0 = time.perf_counter()
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    dt = time.perf_counter() - t0
+    # single-core figure from one more instance
+    e1 = OracleEncoder(WIDTH, HEIGHT, qp=QP, gop=GOP)
+    t1 = time.perf_counter()
+    n1 = min(per_thread_frames, 6)
+    for i in range(n1):
+        e1.encode(frames[i])
+    d1 = time.perf_counter() - t1
+    return cores * per_thread_frames / dt, n1 / d1
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=8, help="pictures per CPU-baseline thread")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    from media_amd import capi, synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    # synthetic workload, resident in HBM before any timing
+    frames = synth.sequence("s1", WIDTH, HEIGHT, FRAMES_PER_STEP)
+    fbytes = WIDTH * HEIGHT * 3 // 2
+    stride = (fbytes + 255) // 256 * 256
+    host = np.zeros((FRAMES_PER_STEP, stride), np.uint8)
+    for i, f in enumerate(frames):
+        host[i, :fbytes] = f
+    dev = torch.from_numpy(host).to("cuda:%d" % local_rank)
+    torch.cuda.synchronize()
+
+    enc = capi.Encoder(WIDTH, HEIGHT, qp=QP, gop=GOP, device=local_rank)
+    out = np.zeros(FRAMES_PER_STEP * fbytes // 2, np.uint8)
+    sizes = np.zeros(FRAMES_PER_STEP, np.uint32)
+
+    def step():
+        enc.force_idr()  # every step is one closed GOP
+        return enc.encode_batch_device(dev.data_ptr(), stride, FRAMES_PER_STEP, out, sizes)
+
+    for _ in range(args.warmup):
+        step()
+    enc.stats_enable(True)
+    enc.stats(reset=True)
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    nbytes = 0
+    for _ in range(args.steps):
+        nbytes = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda:%d" % local_rank)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    st = enc.stats(reset=True)
+    enc.close()
+
+    if rank == 0:
+        total_frames = world * args.steps * FRAMES_PER_STEP
+        fps = total_frames / dt
+        k = st["kernels"]
+        nmb = (WIDTH // 16) * ((HEIGHT + 15) // 16)
+        pmb = k["pmb"]
+        pmb_ms = pmb["ms"] / max(1, pmb["launches"])
+        achieved = PMB_BYTES_PER_MB * nmb / (pmb_ms * 1e-3) / 1e9 if pmb_ms > 0 else 0.0
+        per_kernel = {}
+        for name, v in k.items():
+            if v["launches"]:
+                per_kernel[name] = {"ms_per_picture": round(v["ms"] * nmb / max(1, v["mbs"]), 4),
+                                    "launches_per_picture": round(v["launches"] * nmb / max(1, v["mbs"]), 1)}
+        res = {
+            "metric": "encoded fps @1080p I420 baseline-profile, 1/2/4/8 MI355X vs OpenH264 CPU",
+            "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "1080p30 I420 synthetic S1 pan+noise, baseline profile, fixed QP 26, "
+                                   "GOP 30 (1 IDR + 29 P per step), single slice, 1 ref, deblock on, CAVLC; "
+                                   "one stream per GPU, pictures resident in HBM",
+                       "width": WIDTH, "height": HEIGHT, "qp": QP, "gop": GOP, "frames_per_step": FRAMES_PER_STEP,
+                       "streams": world, "bytes_per_gop": int(nbytes), "parity": "bit-exact vs CPU oracle "
+                       "(oracle unpinned vs OpenH264: no libopenh264 available)"},
+            "roofline": {"kernel": "k_pmb (MC + fDCT + quant + dequant + iDCT + recon)", "bound": "hbm",
+                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "bytes_per_launch": PMB_BYTES_PER_MB * nmb, "avg_launch_ms": round(pmb_ms, 5)},
+            "kernels": per_kernel,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cores = min(16, os.cpu_count() or 1)
+            agg, single = cpu_baseline(frames, cores, args.cpu_frames)
+            res["cpu_baseline"] = {"value": round(agg, 2), "unit": "frames/s", "cores": cores, "kind": "port",
+                                   "sample": "%d independent CPU-oracle encoder instances (one per core), each "
+                                             "encoding the first %d pictures (1 IDR + %d P) of the same 1080p "
+                                             "S1 workload" % (cores, args.cpu_frames, args.cpu_frames - 1),
+                                   "single_core_fps": round(single, 2),
+                                   "note": "own scalar CPU restatement (full-search algorithm), not OpenH264"}
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
