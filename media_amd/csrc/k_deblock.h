@@ -179,4 +179,231 @@ __global__ __launch_bounds__(64) void k_deblock_diag(DbParams D, int s)
     }
 }
 
+// ===========================================================================
+// Persistent form: ONE launch, one wavefront per macroblock row.  Row r walks its
+// macroblocks left to right; macroblock mx needs the bottom four luma / two chroma
+// sample rows of macroblock (mx, r-1), which row r-1 PUBLISHES once it has
+// finished macroblock mx+1 (whose left-edge filter is the last thing that touches
+// them).  That is exactly the 8.7 raster-order dependency (left, top, top-right).
+//
+// Hand-off (cdna_hip_programming.md Guideline 16, form R2 "the data is the flag"):
+// 24 granules per macroblock, each ONE aligned 8-byte agent-scope relaxed atomic
+// store of {tag = picture serial, 4 samples}; the consumer re-reads its granules
+// with agent-scope atomic loads (L1-bypassing) until every tag matches.  No fence,
+// no separate flag, no drain.  Each sample of the picture has exactly one writer:
+// a row stores rows 0..11 of its macroblocks (0..5 chroma), the row below stores
+// rows 12..15 (6..7) after its own top-edge filter; the last row stores all 16.
+// Everything a macroblock needs from HBM (its samples, MbInfo, granules) is
+// requested one macroblock ahead, so an iteration is LDS/VALU work only.
+// Every spin is bounded; a timeout sets *err and the grid still drains.
+// ===========================================================================
+typedef unsigned long long u64;
+#define AT_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define AT_STORE(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+
+struct DbRowParams {
+    DbParams d;
+    u64* handoff;        // [mbh][mbw][24] granules: 16 luma dwords (rows 12..15), 8 chroma dwords (rows 6..7 of Cb, Cr)
+    const uint32_t* bs;  // [nmb][8]: boundary strengths, word dir*4+edge, byte = segment along the edge
+    unsigned* err;
+    unsigned serial;     // changes every picture, never 0
+};
+
+// boundary strengths of every macroblock edge, fully parallel (8.7.2.1): lane = (dir, edge, segment)
+__global__ __launch_bounds__(64) void k_bs(const MbInfo* mb, uint8_t* bs, int mbw, int nmb)
+{
+    const int lane = threadIdx.x, mbi = blockIdx.x * 2 + (lane >> 5), l = lane & 31;
+    if (mbi >= nmb) return;
+    const int mx = mbi % mbw, my = mbi / mbw;
+    const MbInfo* q = mb + mbi;
+    const int dir = l >> 4, e = (l >> 2) & 3, k = l & 3;
+    int bS = 0;
+    if (dir == 0) {
+        if (!(e == 0 && mx == 0)) {
+            const MbInfo* p = e == 0 ? q - 1 : q;
+            bS = edge_bs(p, e == 0 ? xy2blk(3, k) : xy2blk(e - 1, k), q, xy2blk(e, k), e == 0);
+        }
+    } else {
+        if (!(e == 0 && my == 0)) {
+            const MbInfo* p = e == 0 ? q - mbw : q;
+            bS = edge_bs(p, e == 0 ? xy2blk(k, 3) : xy2blk(k, e - 1), q, xy2blk(k, e), e == 0);
+        }
+    }
+    bs[(size_t)mbi * 32 + l] = (uint8_t)bS;
+}
+
+// One edge, one line of samples held in registers, branch-free so that luma and
+// chroma lines share one instruction stream (8.7.2.3 / 8.7.2.4).  chroma lanes
+// never touch p1/q1 and use tc = tc0 + 1.  BS4 compiles the intra (bS = 4) form in.
+template <bool BS4>
+__device__ __forceinline__ void filt_uni(const int p3, int& p2, int& p1, int& p0, int& q0, int& q1, int& q2, const int q3,
+                                         int bS, bool chroma, int alpha, int beta, int t1, int t2, int t3)
+{
+    const int tc0 = bS == 1 ? t1 : (bS == 2 ? t2 : t3);
+    const bool f = bS != 0 && iabs(p0 - q0) < alpha && iabs(p1 - p0) < beta && iabs(q1 - q0) < beta;
+    const bool ap = !chroma && iabs(p2 - p0) < beta, aq = !chroma && iabs(q2 - q0) < beta;
+    const int tc = tc0 + (chroma ? 1 : (int)ap + (int)aq);
+    const int d = clip3(-tc, tc, (((q0 - p0) << 2) + (p1 - q1) + 4) >> 3);
+    const int avg = (p0 + q0 + 1) >> 1;
+    int np0 = clip255(p0 + d), nq0 = clip255(q0 - d);
+    int np1 = ap ? p1 + clip3(-tc0, tc0, (p2 + avg - (p1 << 1)) >> 1) : p1;
+    int nq1 = aq ? q1 + clip3(-tc0, tc0, (q2 + avg - (q1 << 1)) >> 1) : q1;
+    int np2 = p2, nq2 = q2;
+    if (BS4) {
+        const bool s4 = bS == 4;
+        const bool strong = iabs(p0 - q0) < ((alpha >> 2) + 2);
+        const bool sp = ap && strong, sq = aq && strong;
+        const int wp0 = sp ? (p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3 : (2 * p1 + p0 + q1 + 2) >> 2;
+        const int wq0 = sq ? (p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3 : (2 * q1 + q0 + p1 + 2) >> 2;
+        const int wp1 = sp ? (p2 + p1 + p0 + q0 + 2) >> 2 : p1, wq1 = sq ? (p0 + q0 + q1 + q2 + 2) >> 2 : q1;
+        const int wp2 = sp ? (2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3 : p2, wq2 = sq ? (2 * q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3 : q2;
+        np0 = s4 ? wp0 : np0; nq0 = s4 ? wq0 : nq0; np1 = s4 ? wp1 : np1; nq1 = s4 ? wq1 : nq1; np2 = s4 ? wp2 : np2; nq2 = s4 ? wq2 : nq2;
+    }
+    p0 = f ? np0 : p0; q0 = f ? nq0 : q0; p1 = f ? np1 : p1; q1 = f ? nq1 : q1;
+    if (BS4) { p2 = f ? np2 : p2; q2 = f ? nq2 : q2; }
+}
+
+enum { DR_LP = 40, DR_CP = 24 };  // LDS pitches; luma tile cols -16..15 (+4 pad), rows -4..15; chroma cols -8..7, rows -4..15
+
+template <bool BS4>
+__global__ __launch_bounds__(64) void k_deblock_rows(DbRowParams R)
+{
+    const DbParams& D = R.d;
+    const int lane = threadIdx.x, my = blockIdx.x, cs = D.cw / 2;
+    const bool last_row = my == D.mbh - 1;
+    __shared__ __attribute__((aligned(16))) uint8_t s_y[20 * DR_LP];     // [row+4][col+16]
+    __shared__ __attribute__((aligned(16))) uint8_t s_c[2][20 * DR_CP];  // [row+4][col+8] (rows 8.. unused padding)
+#define SY(r, c) s_y[((r) + 4) * DR_LP + (c) + 16]
+#define SC(pl, r, c) s_c[pl][((r) + 4) * DR_CP + (c) + 8]
+    bool timed_out = false;
+    const int yr = lane >> 2, yc4 = (lane & 3) * 4;                                   // luma dword owned by this lane
+    const int cpl_l = (lane >> 4) & 1, cr_l = (lane >> 1) & 7, cc4 = (lane & 1) * 4;  // chroma dword (lanes < 32)
+    // granule k (lane < 24): 0..15 luma row 12 + k/4, dword k%4; 16..23 chroma plane (k-16)/4, row 6 + ((k-16)/2)%2, dword (k-16)%2
+    const int gk = lane;
+    // filter lanes: 0..15 luma lines, 16..31 chroma lines (plane, line)
+    const bool isC = lane >= 16;
+    const int fpl = (lane >> 3) & 1, fln = isC ? (lane & 7) : lane;
+    const int seg8 = 8 * (isC ? (fln >> 1) : (fln >> 2));
+    const int al = isC ? D.alpha_c : D.alpha_y, be = isC ? D.beta_c : D.beta_y;
+    const int t1 = isC ? D.tc0_c[0] : D.tc0_y[0], t2 = isC ? D.tc0_c[1] : D.tc0_y[1], t3 = isC ? D.tc0_c[2] : D.tc0_y[2];
+    uint8_t* vrow = isC ? &SC(fpl, fln, -4) : &SY(fln, -4);                 // V phase: this lane's line, 4-byte aligned
+    uint8_t* hcol = isC ? &SC(fpl, -4, fln) : &SY(-4, fln);                 // H phase: top of this lane's column
+    const int hstride = isC ? DR_CP : DR_LP;
+
+    // prefetch registers for the macroblock about to be processed
+    uint32_t pf_y = 0, pf_c = 0;
+    uint4 pf_b0 = {0, 0, 0, 0}, pf_b1 = pf_b0;
+    u64 pf_g = 0;
+    auto prefetch = [&](int mx) {
+        pf_y = *(const uint32_t*)(D.pl[0] + (size_t)(16 * my + yr) * D.cw + 16 * mx + yc4);
+        if (lane < 32) pf_c = *(const uint32_t*)(D.pl[1 + cpl_l] + (size_t)(8 * my + cr_l) * cs + 8 * mx + cc4);
+        const uint4* b = (const uint4*)(R.bs + ((size_t)my * D.mbw + mx) * 8);
+        pf_b0 = b[0]; pf_b1 = b[1];
+        if (my > 0 && lane < 24) pf_g = AT_LOAD(R.handoff + ((size_t)(my - 1) * D.mbw + mx) * 24 + gk);
+    };
+    prefetch(0);
+
+    for (int mx = 0; mx <= D.mbw; mx++) {
+        const bool have_cur = mx < D.mbw;
+        if (have_cur) {
+            const uint32_t cur_y = pf_y, cur_c = pf_c;
+            const uint4 b0 = pf_b0, b1 = pf_b1;
+            u64 g = pf_g;
+            if (mx + 1 < D.mbw) prefetch(mx + 1);
+            // 1. previous macroblock moves to the left half of the tile
+            if (mx > 0) {
+                *(uint32_t*)&SY(yr, yc4 - 16) = *(const uint32_t*)&SY(yr, yc4);
+                if (lane < 32) *(uint32_t*)&SC(cpl_l, cr_l, cc4 - 8) = *(const uint32_t*)&SC(cpl_l, cr_l, cc4);
+            }
+            __syncthreads();
+            // 2. current macroblock into LDS
+            *(uint32_t*)&SY(yr, yc4) = cur_y;
+            if (lane < 32) *(uint32_t*)&SC(cpl_l, cr_l, cc4) = cur_c;
+            // 3. top apron: wait until every granule carries this picture's tag
+            if (my > 0) {
+                unsigned spins = 0;
+                while (!timed_out) {
+                    const bool bad = lane < 24 && (unsigned)(g >> 32) != R.serial;
+                    if (__ballot(bad) == 0ull) break;
+                    if (++spins > (1u << 20)) { timed_out = true; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                    if (lane < 24) g = AT_LOAD(R.handoff + ((size_t)(my - 1) * D.mbw + mx) * 24 + gk);
+                }
+                if (lane < 16) *(uint32_t*)&SY(-4 + (gk >> 2), (gk & 3) * 4) = (uint32_t)g;
+                else if (lane < 24) *(uint32_t*)&SC((gk - 16) >> 2, -2 + (((gk - 16) >> 1) & 1), ((gk - 16) & 1) * 4) = (uint32_t)g;
+            }
+            __syncthreads();
+            const bool any_v = (b0.x | b0.y | b0.z | b0.w) != 0, any_h = (b1.x | b1.y | b1.z | b1.w) != 0;
+            // 4. vertical edges: lane = one line of samples, four edges in registers.
+            //    chroma lines take part in steps 0 and 1 (chroma edges 0 and 4 <-> luma edges 0 and 8)
+            if (any_v && lane < 32) {
+                int px[20];
+#pragma unroll
+                for (int w = 0; w < 5; w++) {
+                    const uint32_t v = *(const uint32_t*)(vrow + 4 * w);
+#pragma unroll
+                    for (int b = 0; b < 4; b++) px[4 * w + b] = (int)((v >> (8 * b)) & 255);
+                }
+                const int e0 = (int)(((isC ? b0.x : b0.x) >> seg8) & 255), e1 = (int)(((isC ? b0.z : b0.y) >> seg8) & 255);
+                const int e2 = isC ? 0 : (int)((b0.z >> seg8) & 255), e3 = isC ? 0 : (int)((b0.w >> seg8) & 255);
+                filt_uni<BS4>(px[0], px[1], px[2], px[3], px[4], px[5], px[6], px[7], e0, isC, al, be, t1, t2, t3);
+                filt_uni<BS4>(px[4], px[5], px[6], px[7], px[8], px[9], px[10], px[11], e1, isC, al, be, t1, t2, t3);
+                filt_uni<BS4>(px[8], px[9], px[10], px[11], px[12], px[13], px[14], px[15], e2, isC, al, be, t1, t2, t3);
+                filt_uni<BS4>(px[12], px[13], px[14], px[15], px[16], px[17], px[18], px[19], e3, isC, al, be, t1, t2, t3);
+#pragma unroll
+                for (int w = 0; w < 5; w++)
+                    if (w < 3 || !isC)
+                        *(uint32_t*)(vrow + 4 * w) = (uint32_t)px[4 * w] | ((uint32_t)px[4 * w + 1] << 8) | ((uint32_t)px[4 * w + 2] << 16) | ((uint32_t)px[4 * w + 3] << 24);
+            }
+            __syncthreads();
+            // 5. horizontal edges: lane = one column of samples (rows -4..15; chroma uses rows -4..7 of its tile)
+            if (any_h && lane < 32) {
+                int px[20];
+#pragma unroll
+                for (int r = 0; r < 20; r++) px[r] = hcol[r * hstride];
+                const int e0 = (int)((b1.x >> seg8) & 255), e1 = (int)(((isC ? b1.z : b1.y) >> seg8) & 255);
+                const int e2 = isC ? 0 : (int)((b1.z >> seg8) & 255), e3 = isC ? 0 : (int)((b1.w >> seg8) & 255);
+                filt_uni<BS4>(px[0], px[1], px[2], px[3], px[4], px[5], px[6], px[7], e0, isC, al, be, t1, t2, t3);
+                filt_uni<BS4>(px[4], px[5], px[6], px[7], px[8], px[9], px[10], px[11], e1, isC, al, be, t1, t2, t3);
+                filt_uni<BS4>(px[8], px[9], px[10], px[11], px[12], px[13], px[14], px[15], e2, isC, al, be, t1, t2, t3);
+                filt_uni<BS4>(px[12], px[13], px[14], px[15], px[16], px[17], px[18], px[19], e3, isC, al, be, t1, t2, t3);
+                // samples an edge can change: p2..q2 around rows 0,4,8,12 -> rows -3..14; chroma: p0,q0 around rows 0,4
+#pragma unroll
+                for (int r = 1; r < 19; r++) {
+                    const bool both = r == 3 || r == 4 || r == 7 || r == 8;
+                    if (both || !isC) hcol[r * hstride] = (uint8_t)px[r];
+                }
+            }
+            __syncthreads();
+            // 6. the top apron (rows 12..15 / 6..7 of the macroblock above) is final: store it
+            if (my > 0) {
+                if (lane < 16) *(uint32_t*)(D.pl[0] + (size_t)(16 * my - 4 + (gk >> 2)) * D.cw + 16 * mx + (gk & 3) * 4) = *(const uint32_t*)&SY(-4 + (gk >> 2), (gk & 3) * 4);
+                else if (lane < 24) {
+                    const int k = gk - 16, pl = k >> 2, r = (k >> 1) & 1, c4 = (k & 1) * 4;
+                    *(uint32_t*)(D.pl[1 + pl] + (size_t)(8 * my - 2 + r) * cs + 8 * mx + c4) = *(const uint32_t*)&SC(pl, -2 + r, c4);
+                }
+            }
+        }
+        // 7. the previous macroblock is final with respect to this row: store / publish it
+        if (mx > 0) {
+            const int pmx = mx - 1;
+            const int co = have_cur ? -16 : 0, cco = have_cur ? -8 : 0;  // after the last macroblock there was no shift
+            const int nrow = last_row ? 16 : 12, ncrow = last_row ? 8 : 6;
+            if (yr < nrow) *(uint32_t*)(D.pl[0] + (size_t)(16 * my + yr) * D.cw + 16 * pmx + yc4) = *(const uint32_t*)&SY(yr, co + yc4);
+            if (lane < 32 && cr_l < ncrow)
+                *(uint32_t*)(D.pl[1 + cpl_l] + (size_t)(8 * my + cr_l) * cs + 8 * pmx + cc4) = *(const uint32_t*)&SC(cpl_l, cr_l, cco + cc4);
+            if (!last_row && lane < 24) {
+                uint32_t v;
+                if (lane < 16) v = *(const uint32_t*)&SY(12 + (gk >> 2), co + (gk & 3) * 4);
+                else v = *(const uint32_t*)&SC((gk - 16) >> 2, 6 + (((gk - 16) >> 1) & 1), cco + ((gk - 16) & 1) * 4);
+                AT_STORE(R.handoff + ((size_t)my * D.mbw + pmx) * 24 + gk, ((u64)R.serial << 32) | v);
+            }
+        }
+        __syncthreads();
+    }
+    if (timed_out && lane == 0) atomicOr(R.err, 1u);
+#undef SY
+#undef SC
+}
+
 }  // namespace h264

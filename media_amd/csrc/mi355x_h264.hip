@@ -125,6 +125,7 @@ struct Slot {
     uint32_t* d_bitbuf = nullptr;   // device slice payload (zeroed before use)
     SliceInfo* d_info = nullptr;
     SliceInfo* h_info = nullptr;    // pinned
+    unsigned* h_err = nullptr;      // pinned copy of the wavefront kernels' timeout flag
     uint8_t* h_au = nullptr;        // pinned access unit buffer
     size_t used_bytes = 0;          // payload bytes of the last use (for re-zeroing)
     size_t payload_off = 0;         // offset of the slice payload inside h_au
@@ -153,6 +154,12 @@ struct mi355x_h264_encoder {
     int16_t* d_mvd = nullptr;
     uint16_t* d_slotbits = nullptr;
     uint32_t* d_mbbits = nullptr;
+    unsigned long long* d_handoff = nullptr; // row-to-row hand-off of the wavefront kernels
+    unsigned* d_progress = nullptr;          // [2][mbh]: deblock rows, intra rows
+    unsigned* d_err = nullptr;
+    uint32_t* d_bs = nullptr;                // boundary strengths, 32 B per macroblock
+    unsigned serial = 0;
+    bool diag_mode = false;                  // debug: one launch per wavefront step instead
     uint8_t* d_stage = nullptr;              // device copy of a host-supplied picture
     uint8_t* h_stage = nullptr;              // pinned staging for strided host input
     size_t frame_bytes = 0, bitbuf_cap = 0, au_cap = 0;
@@ -334,12 +341,24 @@ int submit(mi355x_h264_encoder* e, const uint8_t* d_src, int slot_idx)
         const int qp = e->qp, qpc = h_chroma_qp[qp];
         D.alpha_y = h_alpha[qp]; D.beta_y = h_beta[qp]; D.alpha_c = h_alpha[qpc]; D.beta_c = h_beta[qpc];
         for (int i = 0; i < 3; i++) { D.tc0_y[i] = h_tc0[qp][i]; D.tc0_c[i] = h_tc0[qpc][i]; }
-        for (int s = 0; s < steps; s++) {
-            const int ymin = std::max(0, (s - (e->mbw - 1) + 1) >> 1), ymax = std::min(e->mbh - 1, s >> 1);
-            if (ymax < ymin) continue;
-            hipLaunchKernelGGL(k_deblock_diag, dim3(ymax - ymin + 1), dim3(64), 0, st, D, s);
+        if (e->diag_mode) {
+            for (int s = 0; s < steps; s++) {
+                const int ymin = std::max(0, (s - (e->mbw - 1) + 1) >> 1), ymax = std::min(e->mbh - 1, s >> 1);
+                if (ymax < ymin) continue;
+                hipLaunchKernelGGL(k_deblock_diag, dim3(ymax - ymin + 1), dim3(64), 0, st, D, s);
+            }
+        } else {
+            DbRowParams R{};
+            R.d = D; R.handoff = e->d_handoff; R.err = e->d_err;
+            e->serial = e->serial == 0xFFFFFFFFu ? 1 : e->serial + 1;
+            R.serial = e->serial;
+            R.bs = e->d_bs;
+            hipLaunchKernelGGL(k_bs, dim3((e->nmb + 1) / 2), dim3(64), 0, st, (const MbInfo*)e->d_mb, (uint8_t*)e->d_bs, e->mbw, e->nmb);
+            if (idr) hipLaunchKernelGGL(k_deblock_rows<true>, dim3(e->mbh), dim3(64), 0, st, R);
+            else hipLaunchKernelGGL(k_deblock_rows<false>, dim3(e->mbh), dim3(64), 0, st, R);
         }
     }
+    HIPCHK(e, hipMemcpyAsync(S.h_err, e->d_err, sizeof(unsigned), hipMemcpyDeviceToHost, st));
     HIPCHK(e, hipEventRecord(S.done, st));
     HIPCHK(e, hipGetLastError());
     S.busy = true;
@@ -369,6 +388,7 @@ int collect(mi355x_h264_encoder* e, int slot_idx, uint8_t** out, uint32_t* out_l
     S.evs.clear();
     e->stats.frames++;
     const SliceInfo info = *S.h_info;
+    if (*S.h_err) return fail(e, MI355X_H264_E_INTERNAL, "wavefront kernel hand-off timed out (flag %u)", *S.h_err);
     S.used_bytes = info.total_bytes;
     if (info.error) return fail(e, MI355X_H264_E_INTERNAL, "device reported error %u", info.error);
     if ((size_t)info.total_bytes + 64 > e->bitbuf_cap) return fail(e, MI355X_H264_E_OVERFLOW, "slice of %u bytes exceeds buffer", info.total_bytes);
@@ -456,6 +476,14 @@ int mi355x_h264_create(const mi355x_h264_config* cfg, mi355x_h264_encoder** out)
     CK(hipMalloc((void**)&e->d_mvd, (size_t)e->nmb * 2 * sizeof(int16_t)));
     CK(hipMalloc((void**)&e->d_slotbits, (size_t)e->nmb * 32 * sizeof(uint16_t)));
     CK(hipMalloc((void**)&e->d_mbbits, (size_t)e->nmb * sizeof(uint32_t)));
+    CK(hipMalloc((void**)&e->d_handoff, (size_t)e->nmb * 24 * sizeof(unsigned long long)));
+    CK(hipMemset(e->d_handoff, 0, (size_t)e->nmb * 24 * sizeof(unsigned long long)));
+    CK(hipMalloc((void**)&e->d_progress, (size_t)2 * e->mbh * sizeof(unsigned)));
+    CK(hipMemset(e->d_progress, 0, (size_t)2 * e->mbh * sizeof(unsigned)));
+    CK(hipMalloc((void**)&e->d_err, sizeof(unsigned)));
+    CK(hipMalloc((void**)&e->d_bs, (size_t)e->nmb * 32));
+    CK(hipMemset(e->d_err, 0, sizeof(unsigned)));
+    e->diag_mode = getenv("MI355X_H264_DIAG") != nullptr;
     e->frame_bytes = (size_t)cfg->width * cfg->height * 3 / 2;
     CK(hipMalloc((void**)&e->d_stage, e->frame_bytes + 256));
     CK(hipHostMalloc((void**)&e->h_stage, e->frame_bytes + 256, hipHostMallocDefault));
@@ -466,6 +494,8 @@ int mi355x_h264_create(const mi355x_h264_config* cfg, mi355x_h264_encoder** out)
         CK(hipMemset(S.d_bitbuf, 0, e->bitbuf_cap + 256));
         CK(hipMalloc((void**)&S.d_info, sizeof(SliceInfo)));
         CK(hipHostMalloc((void**)&S.h_info, sizeof(SliceInfo), hipHostMallocDefault));
+        CK(hipHostMalloc((void**)&S.h_err, sizeof(unsigned), hipHostMallocDefault));
+        *S.h_err = 0;
         CK(hipHostMalloc((void**)&S.h_au, e->au_cap + 256, hipHostMallocDefault));
         CK(hipEventCreateWithFlags(&S.done, hipEventDisableTiming));
     }
@@ -485,10 +515,12 @@ void mi355x_h264_destroy(mi355x_h264_encoder* e)
     for (int p = 0; p < 3; p++) (void)hipFree(e->d_pre[p]);
     (void)hipFree(e->d_mb); (void)hipFree(e->d_levels); (void)hipFree(e->d_mvd);
     (void)hipFree(e->d_slotbits); (void)hipFree(e->d_mbbits); (void)hipFree(e->d_stage);
+    (void)hipFree(e->d_handoff); (void)hipFree(e->d_progress); (void)hipFree(e->d_err); (void)hipFree(e->d_bs);
     if (e->h_stage) (void)hipHostFree(e->h_stage);
     for (auto& S : e->slots) {
         (void)hipFree(S.d_bitbuf); (void)hipFree(S.d_info);
         if (S.h_info) (void)hipHostFree(S.h_info);
+        if (S.h_err) (void)hipHostFree(S.h_err);
         if (S.h_au) (void)hipHostFree(S.h_au);
         if (S.done) (void)hipEventDestroy(S.done);
         for (auto& ev : S.evs) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
