@@ -63,6 +63,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gops-in-flight", type=int, default=int(os.environ.get("BENCH_GOPS_IN_FLIGHT", "1")),
+                    help="closed GOPs of the stream encoded concurrently per GPU (each on its own HIP stream)")
     ap.add_argument("--cpu-frames", type=int, default=8, help="pictures per CPU-baseline thread")
     args = ap.parse_args()
 
@@ -94,18 +96,34 @@ def main():
     dev = torch.from_numpy(host).to("cuda:%d" % local_rank)
     torch.cuda.synchronize()
 
-    enc = capi.Encoder(WIDTH, HEIGHT, qp=QP, gop=GOP, device=local_rank)
-    out = np.zeros(FRAMES_PER_STEP * fbytes // 2, np.uint8)
-    sizes = np.zeros(FRAMES_PER_STEP, np.uint32)
+    G = max(1, args.gops_in_flight)
+    encs = [capi.Encoder(WIDTH, HEIGHT, qp=QP, gop=GOP, device=local_rank) for _ in range(G)]
+    enc = encs[0]
+    outs = [np.zeros(FRAMES_PER_STEP * fbytes // 2, np.uint8) for _ in range(G)]
+    sizes = [np.zeros(FRAMES_PER_STEP, np.uint32) for _ in range(G)]
+    results = [0] * G
+
+    def one_gop(i):
+        encs[i].force_idr()  # every GOP is closed: IDR + 29 P
+        results[i] = encs[i].encode_batch_device(dev.data_ptr(), stride, FRAMES_PER_STEP, outs[i], sizes[i])
 
     def step():
-        enc.force_idr()  # every step is one closed GOP
-        return enc.encode_batch_device(dev.data_ptr(), stride, FRAMES_PER_STEP, out, sizes)
+        # one step = G closed GOPs of the stream, encoded concurrently (G host threads, G HIP streams)
+        if G == 1:
+            one_gop(0)
+        else:
+            ths = [threading.Thread(target=one_gop, args=(i,)) for i in range(G)]
+            for t in ths:
+                t.start()
+            for t in ths:
+                t.join()
+        return results[0]
 
     for _ in range(args.warmup):
         step()
-    enc.stats_enable(True)
-    enc.stats(reset=True)
+    for e_ in encs:
+        e_.stats_enable(not os.environ.get("BENCH_NO_STATS"))
+        e_.stats(reset=True)
 
     def fence():
         torch.cuda.synchronize()
@@ -125,10 +143,11 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     st = enc.stats(reset=True)
-    enc.close()
+    for e_ in encs:
+        e_.close()
 
     if rank == 0:
-        total_frames = world * args.steps * FRAMES_PER_STEP
+        total_frames = world * args.steps * FRAMES_PER_STEP * G
         fps = total_frames / dt
         k = st["kernels"]
         nmb = (WIDTH // 16) * ((HEIGHT + 15) // 16)
@@ -148,7 +167,7 @@ def main():
             "config": {"workload": "1080p30 I420 synthetic S1 pan+noise, baseline profile, fixed QP 26, "
                                    "GOP 30 (1 IDR + 29 P per step), single slice, 1 ref, deblock on, CAVLC; "
                                    "one stream per GPU, pictures resident in HBM",
-                       "width": WIDTH, "height": HEIGHT, "qp": QP, "gop": GOP, "frames_per_step": FRAMES_PER_STEP,
+                       "width": WIDTH, "height": HEIGHT, "qp": QP, "gop": GOP, "frames_per_step": FRAMES_PER_STEP * G, "gops_in_flight": G,
                        "streams": world, "bytes_per_gop": int(nbytes), "parity": "bit-exact vs CPU oracle "
                        "(oracle unpinned vs OpenH264: no libopenh264 available)"},
             "roofline": {"kernel": "k_pmb (MC + fDCT + quant + dequant + iDCT + recon)", "bound": "hbm",

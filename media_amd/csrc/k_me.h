@@ -133,48 +133,59 @@ __global__ __launch_bounds__(64, 4) void k_me(FrameParams P)
     {
         const int dxi = lane & 31, half = lane >> 5;
         const int col = dxi + ME_AP, cdw = col >> 2, sh = col & 3;
+        // the source macroblock is wave-uniform: keep its 64 dwords in SGPRs (v_sad_u8 takes one scalar operand)
         uint32_t srow[16][4];
 #pragma unroll
         for (int j = 0; j < 16; j++) {
             const uint4 v = *(const uint4*)(s_src + 16 * j);
-            srow[j][0] = v.x; srow[j][1] = v.y; srow[j][2] = v.z; srow[j][3] = v.w;
-        }
-        uint32_t acc[16];
-#pragma unroll
-        for (int k = 0; k < 16; k++) acc[k] = 0;
-        const uint32_t* wbase = s_win + (ME_AP + half * 16) * ME_WDW + cdw;
-#pragma unroll
-        for (int r = 0; r < 31; r++) {
-            const uint32_t* wr = wbase + r * ME_WDW;
-            const uint32_t w0 = wr[0], w1 = wr[1], w2 = wr[2], w3 = wr[3], w4 = wr[4];
-            const uint32_t a0 = __builtin_amdgcn_alignbyte(w1, w0, sh), a1 = __builtin_amdgcn_alignbyte(w2, w1, sh);
-            const uint32_t a2 = __builtin_amdgcn_alignbyte(w3, w2, sh), a3 = __builtin_amdgcn_alignbyte(w4, w3, sh);
-#pragma unroll
-            for (int k = 0; k < 16; k++) {
-                const int j = r - k;
-                if (j >= 0 && j < 16) {
-                    uint32_t a = acc[k];
-                    a = __builtin_amdgcn_sad_u8(a0, srow[j][0], a);
-                    a = __builtin_amdgcn_sad_u8(a1, srow[j][1], a);
-                    a = __builtin_amdgcn_sad_u8(a2, srow[j][2], a);
-                    a = __builtin_amdgcn_sad_u8(a3, srow[j][3], a);
-                    acc[k] = a;
-                }
-            }
+            srow[j][0] = __builtin_amdgcn_readfirstlane(v.x); srow[j][1] = __builtin_amdgcn_readfirstlane(v.y);
+            srow[j][2] = __builtin_amdgcn_readfirstlane(v.z); srow[j][3] = __builtin_amdgcn_readfirstlane(v.w);
         }
         const int dx = dxi - ME_R;
         const int rx = se_len(4 * dx);
         best = 0xFFFFFFFFu;
+        // four dy candidates at a time: 19 window rows feed 4 accumulators; rows stream through
+        // registers (compiler memory barriers keep the LDS reads next to their use, so VGPR use stays small)
+#pragma unroll 1
+        for (int g = 0; g < 4; g++) {
+            const uint32_t* wb = s_win + (ME_AP + half * 16 + 4 * g) * ME_WDW + cdw;
+            uint32_t acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const int dy = half * 16 + k - ME_R;
-            const unsigned cost = acc[k] + (unsigned)(P.lambda * (rx + se_len(4 * dy)));
-            const unsigned key = (cost << 10) | (unsigned)(((dy + ME_R) << 5) | dxi);
-            best = key < best ? key : best;
+            for (int r = 0; r < 19; r++) {
+                const uint32_t* wr = wb + r * ME_WDW;
+                const uint32_t w0 = wr[0], w1 = wr[1], w2 = wr[2], w3 = wr[3], w4 = wr[4];
+                const uint32_t a0 = __builtin_amdgcn_alignbyte(w1, w0, sh), a1 = __builtin_amdgcn_alignbyte(w2, w1, sh);
+                const uint32_t a2 = __builtin_amdgcn_alignbyte(w3, w2, sh), a3 = __builtin_amdgcn_alignbyte(w4, w3, sh);
+#define ME_SAD4(ACC, J)                                                   \
+    do {                                                                  \
+        ACC = __builtin_amdgcn_sad_u8(a0, srow[J][0], ACC);              \
+        ACC = __builtin_amdgcn_sad_u8(a1, srow[J][1], ACC);              \
+        ACC = __builtin_amdgcn_sad_u8(a2, srow[J][2], ACC);              \
+        ACC = __builtin_amdgcn_sad_u8(a3, srow[J][3], ACC);              \
+    } while (0)
+                if (r >= 0 && r < 16) ME_SAD4(acc0, r);
+                if (r >= 1 && r < 17) ME_SAD4(acc1, r - 1);
+                if (r >= 2 && r < 18) ME_SAD4(acc2, r - 2);
+                if (r >= 3 && r < 19) ME_SAD4(acc3, r - 3);
+#undef ME_SAD4
+                asm volatile("" ::: "memory");
+            }
+            const uint32_t accs[4] = {acc0, acc1, acc2, acc3};
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) {
+                const int dy = half * 16 + 4 * g + kk - ME_R;
+                const unsigned cost = accs[kk] + (unsigned)(P.lambda * (rx + se_len(4 * dy)));
+                const unsigned key = (cost << 10) | (unsigned)(((dy + ME_R) << 5) | dxi);
+                best = key < best ? key : best;
+            }
         }
         best = wave_min_u32(best);
     }
     const int ix = (int)(best & 31) - ME_R, iy = (int)((best >> 5) & 31) - ME_R;
+#ifdef ME_TIMING_NO_SUBPEL
+    if (lane == 0) { MbInfo* m = P.mb + mbi; m->mvx = (int16_t)(4 * ix); m->mvy = (int16_t)(4 * iy); m->type = MB_P16; }
+    return;
+#endif
 
     // ---- 3. half-sample planes on an 18x18 grid, origin (ix-1, iy-1) ----
     const uint8_t* o = winb + (iy + ME_R + ME_AP - 1) * ME_WS + ix + ME_R + ME_AP - 1;
