@@ -103,6 +103,10 @@ int mi355x_h264_force_idr(mi355x_h264_encoder *enc);
 /* picture QP (10..51) for the pictures that follow; the hook the rate controller
  * of the host class drives (RC_BITRATE_MODE, ref :274) */
 int mi355x_h264_set_qp(mi355x_h264_encoder *enc, int qp);
+/* idr_pic_id of the next IDR picture and its increment per IDR (mod 256).  With closed GOPs
+ * sharded over several encoder instances / GPUs (instance i of G: next = i, step = G) the
+ * concatenated output equals the serial stream byte for byte. */
+int mi355x_h264_set_idr_pic_id(mi355x_h264_encoder *enc, int next, int step);
 const char *mi355x_h264_last_error(const mi355x_h264_encoder *enc);
 
 /* coded picture geometry (multiples of 16) */

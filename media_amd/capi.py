@@ -23,7 +23,7 @@ EXPORTS = [
     "mi355x_h264_encode", "mi355x_h264_encode_device", "mi355x_h264_encode_batch_device",
     "mi355x_h264_force_idr", "mi355x_h264_last_error", "mi355x_h264_coded_width", "mi355x_h264_coded_height",
     "mi355x_h264_debug_keep_pre", "mi355x_h264_debug_read", "mi355x_h264_stats_enable", "mi355x_h264_stats_read",
-    "mi355x_h264_set_qp",
+    "mi355x_h264_set_qp", "mi355x_h264_set_idr_pic_id",
 ]
 
 
@@ -61,6 +61,7 @@ def lib():
                                                       C.POINTER(C.c_size_t)]
         L.mi355x_h264_force_idr.argtypes = [vp]
         L.mi355x_h264_set_qp.argtypes = [vp, C.c_int]
+        L.mi355x_h264_set_idr_pic_id.argtypes = [vp, C.c_int, C.c_int]
         L.mi355x_h264_last_error.argtypes = [vp]
         L.mi355x_h264_last_error.restype = C.c_char_p
         L.mi355x_h264_coded_width.argtypes = [vp]
@@ -130,6 +131,9 @@ class Encoder:
 
     def set_qp(self, qp):
         self._check(lib().mi355x_h264_set_qp(self.h, qp))
+
+    def set_idr_pic_id(self, nxt, step=1):
+        self._check(lib().mi355x_h264_set_idr_pic_id(self.h, nxt, step))
 
     def keep_pre(self, on=True):
         self._check(lib().mi355x_h264_debug_keep_pre(self.h, int(on)))

@@ -168,7 +168,7 @@ struct mi355x_h264_encoder {
     std::vector<uint8_t> sps_pps;            // Annex-B SPS + PPS NALs
     std::vector<uint8_t> esc_buf;            // slow path: escaped access unit
     long frames = 0;
-    int frame_in_gop = 0, frame_num = 0, idr_id = 0, force_idr = 0;
+    int frame_in_gop = 0, frame_num = 0, idr_id = 0, idr_step = 1, force_idr = 0;
     int qp = 26;
     bool keep_pre = false, stats_on = false;
     std::vector<hipEvent_t> ev_pool;
@@ -364,7 +364,7 @@ int submit(mi355x_h264_encoder* e, const uint8_t* d_src, int slot_idx)
     S.busy = true;
     // bookkeeping for the next picture
     e->cur ^= 1;
-    if (idr) e->idr_id = (e->idr_id + 1) & 0xFF;
+    if (idr) e->idr_id = (e->idr_id + e->idr_step) & 0xFF;
     e->frame_num = (e->frame_num + 1) & 255;
     e->frame_in_gop++;
     e->frames++;
@@ -604,6 +604,14 @@ int mi355x_h264_set_qp(mi355x_h264_encoder* e, int qp)
 {
     if (!e || qp < 10 || qp > 51) return MI355X_H264_E_ARG;
     e->qp = qp;
+    return MI355X_H264_OK;
+}
+
+int mi355x_h264_set_idr_pic_id(mi355x_h264_encoder* e, int next, int step)
+{
+    if (!e) return MI355X_H264_E_ARG;
+    e->idr_id = next & 0xFF;
+    e->idr_step = step;
     return MI355X_H264_OK;
 }
 

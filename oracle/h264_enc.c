@@ -149,7 +149,7 @@ struct h264o_enc {
     uint8_t *src[3], *rec[3], *cur[3], *ref[3]; /* coded size; pitch cw / cw/2 */
     h264o_mbinfo *mb;
     int16_t *levels;
-    int frame_in_gop, frame_num, idr_id;
+    int frame_in_gop, frame_num, idr_id, idr_step;
     long frames;
     uint8_t *rbsp;
     size_t rbsp_cap;
@@ -171,6 +171,7 @@ h264o_enc *h264o_enc_create(const h264o_config *cfg)
     if (cfg->qp < 10 || cfg->qp > 51) return NULL;
     h264o_enc *e = (h264o_enc *)calloc(1, sizeof(*e));
     e->cfg = *cfg;
+    e->idr_step = 1;
     if (e->cfg.gop < 1) e->cfg.gop = 1;
     e->mbw = (cfg->width + 15) / 16;
     e->mbh = (cfg->height + 15) / 16;
@@ -207,6 +208,13 @@ int h264o_enc_set_qp(h264o_enc *e, int qp)
 {
     if (!e || qp < 10 || qp > 51) return -1;
     e->cfg.qp = qp;
+    return 0;
+}
+int h264o_enc_set_idr_id(h264o_enc *e, int next, int step)
+{
+    if (!e) return -1;
+    e->idr_id = next & 0xFF;
+    e->idr_step = step;
     return 0;
 }
 int h264o_enc_coded_width(const h264o_enc *e) { return e->cw; }
@@ -797,7 +805,7 @@ int64_t h264o_enc_encode(h264o_enc *e, const uint8_t *y, int ys, const uint8_t *
     memcpy(e->cur[2], e->rec[2], ysz / 4);
     if (!e->cfg.disable_deblock) h264o_deblock_picture(e->cur[0], e->cur[1], e->cur[2], e->cw, e->ch, e->mb, e->cfg.qp);
     for (int p = 0; p < 3; p++) { uint8_t *t = e->ref[p]; e->ref[p] = e->cur[p]; e->cur[p] = t; }
-    if (idr) e->idr_id = (e->idr_id + 1) & 0xFF;
+    if (idr) e->idr_id = (e->idr_id + e->idr_step) & 0xFF;
     e->frame_num = (e->frame_num + 1) & 255;
     e->frame_in_gop++;
     e->frames++;

@@ -67,6 +67,9 @@ int64_t h264o_enc_encode(h264o_enc *e, const uint8_t *y, int ys, const uint8_t *
                          int *is_idr);
 /* picture QP for the pictures that follow (mirrors mi355x_h264_set_qp) */
 int h264o_enc_set_qp(h264o_enc *e, int qp);
+/* idr_pic_id of the next IDR and its increment per IDR (mod 256): lets closed GOPs of one
+ * stream be encoded by different instances and still concatenate to the serial stream */
+int h264o_enc_set_idr_id(h264o_enc *e, int next, int step);
 /* Accessors valid until the next encode call.  Planes are coded size
  * (multiples of 16), pitch == coded width (chroma: half). */
 int h264o_enc_coded_width(const h264o_enc *e);

@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/oracle_vectors.json from the CPU oracle on seeded synthetic
+inputs (media_amd/synth.py).  The reference holds no golden vectors of its own
+ and its arithmetic (libopenh264.so) is absent here, so these
+vectors pin GPU == oracle and guard the oracle against regressions; they are NOT outputs
+of the reference.  Run:  python tests/golden/make_golden.py
+"""
+import hashlib
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from media_amd import synth  # noqa: E402
+from oracle_lib import OracleEncoder  # noqa: E402
+
+CASES = [
+    # name, width, height, kind, qp, gop, frames, profile_idc
+    ("qcif_s1_qp26", 176, 144, "s1", 26, 30, 6, 66),
+    ("qvga_s1_gop4", 320, 240, "s1", 26, 4, 6, 66),
+    ("tiny_s2_static", 64, 48, "s2", 26, 30, 4, 66),
+    ("odd_s3_random_qp30", 200, 120, "s3", 30, 30, 3, 66),
+    ("crop_130x98_s1", 130, 98, "s1", 28, 30, 4, 66),
+    ("min_16x16_s1", 16, 16, "s1", 26, 30, 3, 66),
+    ("qcif_s1_qp12", 176, 144, "s1", 12, 30, 3, 66),
+    ("qcif_s1_qp48", 176, 144, "s1", 48, 30, 3, 66),
+    ("qcif_s1_main", 176, 144, "s1", 26, 30, 3, 77),
+    ("qcif_s1_high", 176, 144, "s1", 26, 30, 3, 100),
+    ("portrait_720x1280_s1", 720, 1280, "s1", 26, 30, 3, 66),
+]
+
+
+def run_case(name, w, h, kind, qp, gop, n, prof):
+    enc = OracleEncoder(w, h, qp=qp, gop=gop, profile_idc=prof)
+    frames = []
+    for f in synth.sequence(kind, w, h, n):
+        bs, idr = enc.encode(f)
+        rec = hashlib.sha256(b"".join(enc.recon(p).tobytes() for p in range(3))).hexdigest()
+        frames.append({"idr": bool(idr), "bytes": len(bs), "sha256": hashlib.sha256(bs).hexdigest(), "recon_sha256": rec})
+    enc.close()
+    return {"name": name, "width": w, "height": h, "kind": kind, "qp": qp, "gop": gop, "profile_idc": prof, "frames": frames}
+
+
+if __name__ == "__main__":
+    out = {"generator": "tests/golden/make_golden.py", "source": "CPU oracle (oracle/), not the reference",
+           "cases": [run_case(*c) for c in CASES]}
+    with open(os.path.join(HERE, "oracle_vectors.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print("wrote", len(out["cases"]), "cases")

@@ -53,6 +53,7 @@ def lib():
         L.h264o_enc_levels.restype = vp
         L.h264o_enc_levels.argtypes = [vp]
         L.h264o_enc_set_qp.argtypes = [vp, C.c_int]
+        L.h264o_enc_set_idr_id.argtypes = [vp, C.c_int, C.c_int]
         L.h264o_enc_last_slice_bits.restype = C.c_int64
         L.h264o_enc_last_slice_bits.argtypes = [vp]
         L.h264o_dec_create.restype = vp
@@ -137,6 +138,9 @@ class OracleEncoder:
     def set_qp(self, qp):
         if lib().h264o_enc_set_qp(self.h, qp) != 0:
             raise ValueError("bad qp")
+
+    def set_idr_id(self, nxt, step=1):
+        lib().h264o_enc_set_idr_id(self.h, nxt, step)
 
     def slice_bits(self):
         return lib().h264o_enc_last_slice_bits(self.h)

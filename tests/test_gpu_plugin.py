@@ -1,0 +1,87 @@
+"""GPU tests of the drop-in boundary: the C++ VideoEncoder plugin surface
+(CreateVideoEncoder -> VideoEncoderMI355X), driven like the reference's caller would
+(SURVEY.md 8b, Appendix A, D), with the CPU oracle replaying the same QP sequence."""
+import numpy as np
+import pytest
+from media_amd import synth
+from media_amd import videocodec as vc
+from oracle_lib import OracleEncoder, OracleDecoder
+
+pytestmark = pytest.mark.gpu
+
+
+def _new(width, height, **kw):
+    vc.set_video_mode(width, height, **kw)
+    e = vc.VideoEncoder()
+    assert e.rc_create == vc.SUCCESS
+    assert e.init() == vc.SUCCESS and e.start() == vc.SUCCESS
+    return e
+
+
+def test_fixed_qp_sequence_matches_oracle_and_ownership():
+    w, h = 320, 240
+    e = _new(w, h, qp=26, gop=30)
+    orc = OracleEncoder(w, h, qp=26, gop=30)
+    frames = synth.sequence("s1", w, h, 4)
+    for f in frames:
+        rc, bs = e.encode(f)
+        assert rc == vc.SUCCESS and bs == orc.encode(f)[0]
+    # size guard: inputSize < w*h*3/2 -> ENCODE_FAIL, larger is fine (VideoEncoderOpenH264.cpp:307)
+    assert e.encode(frames[0], size=w * h)[0] == vc.ENCODE_FAIL
+    big = np.concatenate([frames[0], np.zeros(64, np.uint8)])
+    assert e.encode(big)[0] == vc.SUCCESS
+    assert e.stop() == vc.SUCCESS
+    e.destroy()
+    e.destroy()
+    assert e.delete() == vc.SUCCESS
+
+
+def test_keyframe_and_param_adjust_handshake():
+    w, h = 176, 144
+    e = _new(w, h, qp=28, gop=300)
+    frames = synth.sequence("s1", w, h, 6)
+    kinds = []
+    for i, f in enumerate(frames):
+        if i == 2:
+            vc.prop_set("persist.vmi.video.encode.keyframe", "1")
+        if i == 4:   # live re-config: new GOP size -> full reset -> next output starts with SPS/PPS + IDR
+            vc.prop_set("persist.vmi.video.encode.gopsize", "60")
+            vc.prop_set("persist.vmi.video.encode.param_adjusting", "1")
+        rc, bs = e.encode(f)
+        assert rc == vc.SUCCESS
+        kinds.append(bs[4] & 31)
+        assert vc.prop_get("persist.vmi.video.encode.keyframe") == "0"
+        assert vc.prop_get("persist.vmi.video.encode.param_adjusting") == "0"
+    assert kinds == [7, 1, 7, 1, 7, 1]
+    # anything but "0"/"1" is reset to "0" with a warning (:320-323)
+    vc.prop_set("persist.vmi.video.encode.param_adjusting", "banana")
+    assert e.encode(frames[0])[0] == vc.SUCCESS
+    assert vc.prop_get("persist.vmi.video.encode.param_adjusting") == "0"
+    assert e.reset() == vc.SUCCESS
+    rc, bs = e.encode(frames[1])
+    assert rc == vc.SUCCESS and (bs[4] & 31) == 7
+    e.delete()
+
+
+def test_bitrate_mode_tracks_target_and_replays_on_oracle():
+    """reference preset: RC_BITRATE_MODE (VideoEncoderOpenH264.cpp:274).  The controller is host
+    logic; the oracle replays its QP decisions and must produce the same stream."""
+    w, h, fps, bitrate = 640, 368, 30, 1000000
+    e = _new(w, h, fps=fps, bitrate=bitrate, gop=30, qp=None)
+    orc = OracleEncoder(w, h, qp=30, gop=30)
+    dec = OracleDecoder()
+    total, qps = 0, []
+    frames = synth.sequence("s1", w, h, 60)
+    for f in frames:
+        rc, bs = e.encode(f)
+        assert rc == vc.SUCCESS
+        qp = e.last_qp()
+        qps.append(qp)
+        orc.set_qp(qp)
+        assert bs == orc.encode(f)[0]
+        assert dec.decode(bs) == 1
+        total += len(bs)
+    achieved = total * 8 * fps / len(frames)
+    assert 0.6 * bitrate < achieved < 1.5 * bitrate, (achieved, qps)
+    assert min(qps) >= 12 and max(qps) <= 48
+    e.delete()

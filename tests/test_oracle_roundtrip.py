@@ -1,0 +1,73 @@
+"""Oracle pinning, part 2: decode(encode(yuv)) must reproduce the encoder's
+reconstruction byte for byte (ties dequant, inverse transform, interpolation, intra
+prediction, deblocking and the CAVLC syntax to ITU-T H.264 through an independently
+written parser), and the committed golden vectors must still match.  CPU only."""
+import hashlib
+import json
+import os
+import numpy as np
+import pytest
+from media_amd import synth
+from oracle_lib import OracleEncoder, OracleDecoder
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "oracle_vectors.json")))
+
+
+@pytest.mark.parametrize("case", GOLD["cases"], ids=[c["name"] for c in GOLD["cases"]])
+def test_golden_and_roundtrip(case):
+    w, h = case["width"], case["height"]
+    enc = OracleEncoder(w, h, qp=case["qp"], gop=case["gop"], profile_idc=case["profile_idc"])
+    dec = OracleDecoder()
+    for i, (f, g) in enumerate(zip(synth.sequence(case["kind"], w, h, len(case["frames"])), case["frames"])):
+        bs, idr = enc.encode(f)
+        assert idr == g["idr"] and len(bs) == g["bytes"], "frame %d" % i
+        assert hashlib.sha256(bs).hexdigest() == g["sha256"], "frame %d bitstream" % i
+        rec = b"".join(enc.recon(p).tobytes() for p in range(3))
+        assert hashlib.sha256(rec).hexdigest() == g["recon_sha256"], "frame %d reconstruction" % i
+        assert dec.decode(bs) == 1
+        assert dec.size == (w, h)
+        for p in range(3):
+            assert np.array_equal(dec.plane(p), enc.recon(p)), "frame %d plane %d: decoder != encoder" % (i, p)
+        # the stream is a legal Annex-B access unit: 4-byte start codes, SPS+PPS before every IDR
+        assert bs[:4] == b"\x00\x00\x00\x01"
+        assert (bs[4] & 31) == (7 if idr else 1)
+
+
+def test_quality_and_skip_behaviour():
+    w, h = 320, 240
+    enc = OracleEncoder(w, h, qp=26)
+    for i, f in enumerate(synth.sequence("s1", w, h, 4)):
+        enc.encode(f)
+        y = f[: w * h].reshape(h, w)
+        assert synth.psnr(y, enc.recon(0)[:h, :w]) > 36.0
+    # static content: after the IDR everything collapses to P_Skip and a few bytes per picture
+    enc = OracleEncoder(w, h, qp=26)
+    sizes = []
+    for f in synth.sequence("s2", w, h, 5):
+        bs, _ = enc.encode(f)
+        sizes.append(len(bs))
+    mb = enc.mbinfo()
+    assert (mb["type"] == 2).all() and sizes[-1] < 16
+
+
+def test_forced_idr_and_qp_change():
+    w, h = 176, 144
+    enc = OracleEncoder(w, h, qp=30, gop=100)
+    dec = OracleDecoder()
+    fr = synth.sequence("s1", w, h, 5)
+    kinds = []
+    for i, f in enumerate(fr):
+        if i == 3:
+            enc.set_qp(36)
+        bs, idr = enc.encode(f, force_idr=(i == 2))
+        kinds.append(idr)
+        assert dec.decode(bs) == 1
+        for p in range(3):
+            assert np.array_equal(dec.plane(p), enc.recon(p))
+    assert kinds == [True, False, True, False, False]
+
+
+def test_decoder_rejects_garbage():
+    dec = OracleDecoder()
+    with pytest.raises(RuntimeError):
+        dec.decode(b"\x00\x00\x00\x01\x65\x88\x84\x00\x10")  # slice before parameter sets
