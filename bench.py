@@ -2,11 +2,13 @@
 """bench.py -- encoded frames/s of the MI355X H.264 path on BASELINE.json configs[1]:
 1080p30 I420 synthetic (S1 pan+noise), baseline profile, fixed QP 26, one stream per GPU.
 
-A "step" is one pass of the hot path over one batch: a 30-picture GOP (1 IDR + 29 P,
-the reference's default uiIntraPeriod, VideoEncoderOpenH264.h:18) whose pictures are
-already resident in HBM.  N GPUs = N independent streams, one process per GPU, no
-data-path collective (weak scaling); torch.distributed is used only for the barrier
-and the max-over-ranks clock.
+A "step" is one pass of the hot path over one batch: G closed 30-picture GOPs (1 IDR +
+29 P each, the reference's default uiIntraPeriod, VideoEncoderOpenH264.h:18) of the
+stream, encoded concurrently (G = --gops-in-flight encoder instances / HIP streams;
+closed GOPs are independent under fixed QP and concatenate to the serial stream), with
+all pictures already resident in HBM.  N GPUs = N independent streams, one process per
+GPU, no data-path collective (weak scaling); torch.distributed is used only for the
+barrier and the max-over-ranks clock.  G = 1 is measured too (single_gop_in_flight_fps).
 
 Prints ONE JSON line (rank 0) carrying `roofline` for the MC+DCT kernel (k_pmb) and
 `cpu_baseline` (the CPU oracle timed on this box's host cores, rank 0, N=1 only).
@@ -20,6 +22,10 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# HIP maps streams onto this many hardware queues; the default (4) would serialise the
+# concurrently encoded GOPs.  Must be set before the HIP runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 WIDTH, HEIGHT, QP, GOP = 1920, 1080, 26, 30
 FRAMES_PER_STEP = GOP
@@ -63,7 +69,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--gops-in-flight", type=int, default=int(os.environ.get("BENCH_GOPS_IN_FLIGHT", "1")),
+    ap.add_argument("--gops-in-flight", type=int, default=int(os.environ.get("BENCH_GOPS_IN_FLIGHT", "16")),
                     help="closed GOPs of the stream encoded concurrently per GPU (each on its own HIP stream)")
     ap.add_argument("--cpu-frames", type=int, default=8, help="pictures per CPU-baseline thread")
     args = ap.parse_args()
@@ -143,6 +149,16 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     st = enc.stats(reset=True)
+    # latency mode for reference: one GOP in flight, kernels alone on the GPU (also gives the
+    # MC+DCT kernel's duration without other streams' kernels sharing the chip)
+    fence()
+    t1 = time.perf_counter()
+    lat_steps = 2
+    for _ in range(lat_steps):
+        one_gop(0)
+    fence()
+    lat_dt = time.perf_counter() - t1
+    st1 = enc.stats(reset=True)
     for e_ in encs:
         e_.close()
 
@@ -175,7 +191,15 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                          "bytes_per_launch": PMB_BYTES_PER_MB * nmb, "avg_launch_ms": round(pmb_ms, 5)},
             "kernels": per_kernel,
+            "single_gop_in_flight_fps": round(lat_steps * FRAMES_PER_STEP / lat_dt, 2),
         }
+        p1 = st1["kernels"]["pmb"]
+        if p1["launches"]:
+            ms1 = p1["ms"] / p1["launches"]
+            a1 = PMB_BYTES_PER_MB * nmb / (ms1 * 1e-3) / 1e9
+            res["roofline_isolated"] = {"kernel": "k_pmb, one GOP in flight (no other kernels on the chip)",
+                                        "achieved": round(a1, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                        "frac": round(a1 / HBM_PEAK_GBS, 4), "avg_launch_ms": round(ms1, 5)}
         if world == 1 and not args.no_cpu_baseline:
             cores = min(16, os.cpu_count() or 1)
             agg, single = cpu_baseline(frames, cores, args.cpu_frames)
