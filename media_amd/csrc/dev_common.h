@@ -215,6 +215,16 @@ __device__ __forceinline__ void load_src_mb(const FrameParams& P, int mx, int my
     }
 }
 
+// XCD-aware block -> macroblock map.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and
+// b+8 share an L2), so block b works on macroblock (b % 8) * (n/8) + b/8: each XCD's L2 then sees one
+// contiguous band of macroblock rows and overlapping reference windows hit in L2 instead of being
+// fetched once per XCD.  Placement only affects speed, never results.
+__device__ __forceinline__ int xcd_mb_index(int b, int n)
+{
+    const int n8 = n >> 3;
+    return b < 8 * n8 ? (b & 7) * n8 + (b >> 3) : b;
+}
+
 // 8.4.1.3 motion vector prediction for a 16x16 partition with one reference
 // frame.  All macroblocks of the picture already carry their final vectors, so
 // any neighbour inside the picture is "available" (single slice).

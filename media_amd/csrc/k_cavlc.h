@@ -251,7 +251,23 @@ struct CavlcParams {
     uint16_t* slotbits;   // 32 per macroblock
     uint32_t* mbbits;     // per macroblock, then (after the scan) bit offsets
     uint32_t* bitbuf;     // zeroed slice payload buffer
+    uint8_t* bs;          // boundary strengths for the loop filter, 32 B per macroblock (written by the count pass)
 };
+
+// 8.7.2.1 boundary strength of one 4-sample edge segment; l = (dir, edge, segment) within the macroblock.
+// Computed here because this pass already walks (macroblock, 32 lanes) over final MbInfo.
+__device__ __forceinline__ int mb_edge_strength(const MbInfo* q, int mx, int my, int mbw, int l)
+{
+    const int dir = l >> 4, e = (l >> 2) & 3, k = l & 3;
+    if (e == 0 && (dir == 0 ? mx == 0 : my == 0)) return 0;
+    const MbInfo* p = e == 0 ? (dir == 0 ? q - 1 : q - mbw) : q;
+    const int bq = dir == 0 ? xy2blk(e, k) : xy2blk(k, e);
+    const int bp = dir == 0 ? (e == 0 ? xy2blk(3, k) : xy2blk(e - 1, k)) : (e == 0 ? xy2blk(k, 3) : xy2blk(k, e - 1));
+    if (p->type == MB_I16 || q->type == MB_I16) return e == 0 ? 4 : 3;
+    if (p->tc[bp] || q->tc[bq]) return 2;
+    if (iabs(p->mvx - q->mvx) >= 4 || iabs(p->mvy - q->mvy) >= 4) return 1;
+    return 0;
+}
 
 // slot: 0 header, 1 Intra16x16 DC, 2..17 luma blkIdx 0..15, 18/19 chroma DC, 20..27 chroma AC
 template <class S>
@@ -309,6 +325,7 @@ __global__ __launch_bounds__(64) void k_cavlc(CavlcParams C)
         s.init(0);
         if (live) code_slot(s, C, mbi, slot);
         if (live) C.slotbits[(size_t)mbi * 32 + slot] = (uint16_t)s.n;
+        if (live && C.bs) C.bs[(size_t)mbi * 32 + slot] = (uint8_t)mb_edge_strength(C.mb + mbi, mbi % C.mbw, mbi / C.mbw, C.mbw, slot);
         const int tot = group_sum<32>((int)s.n);
         if (live && slot == 0) C.mbbits[mbi] = (uint32_t)tot;
     } else {
@@ -385,12 +402,16 @@ __global__ __launch_bounds__(1024) void k_bit_scan(CavlcParams C, unsigned long 
     }
 }
 
-// copy payload to the pinned access unit and count emulation-prevention sites
-__global__ __launch_bounds__(256) void k_pack(const uint8_t* bitbuf, uint8_t* dst, SliceInfo* info)
+// Copy the payload to the pinned access unit, count emulation-prevention sites, publish SliceInfo to
+// pinned host memory and leave the device bit buffer zeroed for its next use (one workgroup).
+__global__ __launch_bounds__(1024) void k_pack(uint8_t* bitbuf, uint8_t* dst, const SliceInfo* info, SliceInfo* host_info)
 {
+    __shared__ unsigned s_cnt;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
     const unsigned nbytes = info->total_bytes;
     unsigned cnt = 0;
-    for (unsigned i = (blockIdx.x * blockDim.x + threadIdx.x) * 16u; i < nbytes; i += gridDim.x * blockDim.x * 16u) {
+    for (unsigned i = threadIdx.x * 16u; i < nbytes; i += blockDim.x * 16u) {
         const uint4 v = *(const uint4*)(bitbuf + i);  // buffer is padded and zeroed past the end
         *(uint4*)(dst + i) = v;
         const uint32_t nxt = *(const uint32_t*)(bitbuf + i + 16);
@@ -402,7 +423,14 @@ __global__ __launch_bounds__(256) void k_pack(const uint8_t* bitbuf, uint8_t* ds
             if (i + k + 2 < nbytes && b0 == 0 && b1 == 0 && b2 <= 3) cnt++;
         }
     }
-    if (cnt) atomicAdd(&info->epb_count, cnt);
+    if (cnt) atomicAdd(&s_cnt, cnt);
+    __syncthreads();   // every thread has read its own chunk and its look-ahead word
+    for (unsigned i = threadIdx.x * 16u; i < nbytes + 16u; i += blockDim.x * 16u) *(uint4*)(bitbuf + i) = make_uint4(0, 0, 0, 0);
+    if (threadIdx.x == 0) {
+        SliceInfo o = *info;
+        o.epb_count = s_cnt;
+        *host_info = o;
+    }
 }
 
 }  // namespace h264

@@ -204,33 +204,10 @@ typedef unsigned long long u64;
 struct DbRowParams {
     DbParams d;
     u64* handoff;        // [mbh][mbw][24] granules: 16 luma dwords (rows 12..15), 8 chroma dwords (rows 6..7 of Cb, Cr)
-    const uint32_t* bs;  // [nmb][8]: boundary strengths, word dir*4+edge, byte = segment along the edge
+    const uint32_t* bs;  // [nmb][8]: boundary strengths (k_cavlc count pass), word dir*4+edge, byte = segment along the edge
     unsigned* err;
     unsigned serial;     // changes every picture, never 0
 };
-
-// boundary strengths of every macroblock edge, fully parallel (8.7.2.1): lane = (dir, edge, segment)
-__global__ __launch_bounds__(64) void k_bs(const MbInfo* mb, uint8_t* bs, int mbw, int nmb)
-{
-    const int lane = threadIdx.x, mbi = blockIdx.x * 2 + (lane >> 5), l = lane & 31;
-    if (mbi >= nmb) return;
-    const int mx = mbi % mbw, my = mbi / mbw;
-    const MbInfo* q = mb + mbi;
-    const int dir = l >> 4, e = (l >> 2) & 3, k = l & 3;
-    int bS = 0;
-    if (dir == 0) {
-        if (!(e == 0 && mx == 0)) {
-            const MbInfo* p = e == 0 ? q - 1 : q;
-            bS = edge_bs(p, e == 0 ? xy2blk(3, k) : xy2blk(e - 1, k), q, xy2blk(e, k), e == 0);
-        }
-    } else {
-        if (!(e == 0 && my == 0)) {
-            const MbInfo* p = e == 0 ? q - mbw : q;
-            bS = edge_bs(p, e == 0 ? xy2blk(k, 3) : xy2blk(k, e - 1), q, xy2blk(k, e), e == 0);
-        }
-    }
-    bs[(size_t)mbi * 32 + l] = (uint8_t)bS;
-}
 
 // One edge, one line of samples held in registers, branch-free so that luma and
 // chroma lines share one instruction stream (8.7.2.3 / 8.7.2.4).  chroma lanes
@@ -401,7 +378,7 @@ __global__ __launch_bounds__(64) void k_deblock_rows(DbRowParams R)
         }
         __syncthreads();
     }
-    if (timed_out && lane == 0) atomicOr(R.err, 1u);
+    if (timed_out && lane == 0) *R.err = 1u;  // pinned host word, read after the picture's event
 #undef SY
 #undef SC
 }

@@ -48,7 +48,7 @@ __device__ __forceinline__ void qpel_taps(int fx, int fy, int& o0, int& o1)
 __global__ __launch_bounds__(64, 4) void k_me(FrameParams P)
 {
     const int lane = threadIdx.x;
-    const int mbi = blockIdx.x, mx = mbi % P.mbw, my = mbi / P.mbw;
+    const int mbi = xcd_mb_index(blockIdx.x, P.mbw * P.mbh), mx = mbi % P.mbw, my = mbi / P.mbw;
     const int bx = 16 * mx, by = 16 * my;
 
     __shared__ __attribute__((aligned(16))) uint32_t s_win[ME_WS * ME_WDW];  // 56 x 56 bytes
@@ -59,20 +59,30 @@ __global__ __launch_bounds__(64, 4) void k_me(FrameParams P)
     __shared__ uint8_t s_pl[4 * ME_GS * ME_GS];
 
     load_src_mb(P, mx, my, s_src, s_srcc, lane);
-    // reference window, clamped at the picture edge (unrestricted motion vectors)
-    for (int i = lane; i < ME_WS * ME_WDW; i += 64) {
-        const int row = i / ME_WDW, dw = i - row * ME_WDW;
-        const int gy = clip3(0, P.ch - 1, by - ME_R - ME_AP + row);
-        const int gx = bx - ME_R - ME_AP + dw * 4;
-        const uint8_t* rp = P.ref[0] + (size_t)gy * P.cw;
-        uint32_t v;
-        if (gx >= 0 && gx + 3 < P.cw) v = *(const uint32_t*)(rp + gx);
-        else {
-            v = 0;
+    // reference window, clamped at the picture edge (unrestricted motion vectors).  All 13 requests of a
+    // lane are issued before the first is consumed (one HBM/L2 latency instead of thirteen).
+    {
+        const bool interior = bx - ME_R - ME_AP >= 0 && bx + 16 + ME_R + ME_AP <= P.cw;
+        uint32_t v[13];
 #pragma unroll
-            for (int k = 0; k < 4; k++) v |= (uint32_t)rp[clip3(0, P.cw - 1, gx + k)] << (8 * k);
+        for (int t = 0; t < 13; t++) {
+            const int i = lane + 64 * t;
+            const int row = i / ME_WDW, dw = i - row * ME_WDW;
+            const int gy = clip3(0, P.ch - 1, by - ME_R - ME_AP + row);
+            const int gx = bx - ME_R - ME_AP + dw * 4;
+            const uint8_t* rp = P.ref[0] + (size_t)gy * P.cw;
+            v[t] = 0;
+            if (i < ME_WS * ME_WDW) {
+                if (interior) v[t] = *(const uint32_t*)(rp + gx);
+                else {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) v[t] |= (uint32_t)rp[clip3(0, P.cw - 1, gx + k)] << (8 * k);
+                }
+            }
         }
-        s_win[i] = v;
+#pragma unroll
+        for (int t = 0; t < 13; t++)
+            if (lane + 64 * t < ME_WS * ME_WDW) s_win[lane + 64 * t] = v[t];
     }
     if (lane < 32) {  // co-located chroma
         const int pl = lane >> 4, row = (lane >> 1) & 7, xs = (lane & 1) * 4;
@@ -128,6 +138,10 @@ __global__ __launch_bounds__(64, 4) void k_me(FrameParams P)
         }
     }
 
+#ifdef ME_TIMING_NO_SEARCH
+    if (lane == 0) { MbInfo* m = P.mb + mbi; m->mvx = 0; m->mvy = 0; m->type = MB_P16; }
+    return;
+#endif
     // ---- 2. integer full search ----
     unsigned best;
     {

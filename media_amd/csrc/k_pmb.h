@@ -57,13 +57,13 @@ __device__ __forceinline__ void chroma_dc(const int dcw[4], const Quant& q, int 
 __global__ __launch_bounds__(64) void k_pmb(FrameParams P)
 {
     const int lane = threadIdx.x;
-    const int mbi = blockIdx.x, mx = mbi % P.mbw, my = mbi / P.mbw;
+    const int mbi = xcd_mb_index(blockIdx.x, P.mbw * P.mbh), mx = mbi % P.mbw, my = mbi / P.mbw;
     const int bx = 16 * mx, by = 16 * my, cs = P.cw / 2;
 
     __shared__ __attribute__((aligned(16))) uint8_t s_src[256];
     __shared__ __attribute__((aligned(16))) uint8_t s_srcc[128];
-    __shared__ __attribute__((aligned(16))) uint8_t s_w[21 * 24];       // luma window, pitch 24
-    __shared__ __attribute__((aligned(16))) uint8_t s_cw[2][9 * 12];    // chroma windows, pitch 12
+    __shared__ __attribute__((aligned(16))) uint8_t s_w[21 * 28 + 4];   // luma window, pitch 28 (7 aligned dwords per row)
+    __shared__ __attribute__((aligned(16))) uint8_t s_cw[2][9 * 12 + 4];  // chroma windows, pitch 12 (3 aligned dwords per row)
     __shared__ int16_t s_b1[21 * 16];
     __shared__ __attribute__((aligned(16))) uint8_t s_py[256];
     __shared__ __attribute__((aligned(16))) uint8_t s_pc[128];
@@ -76,17 +76,45 @@ __global__ __launch_bounds__(64) void k_pmb(FrameParams P)
 
     load_src_mb(P, mx, my, s_src, s_srcc, lane);
     for (int i = lane; i < LV_STRIDE / 2; i += 64) ((uint32_t*)s_lv)[i] = 0;
-    {   // luma window: 21x21 samples from (bx + ix - 2, by + iy - 2), clamped
-        const int x0 = bx + (mvx >> 2) - 2, y0 = by + (mvy >> 2) - 2;
-        for (int i = lane; i < 21 * 21; i += 64) {
-            const int r = i / 21, c = i - r * 21;
-            s_w[r * 24 + c] = P.ref[0][(size_t)clip3(0, P.ch - 1, y0 + r) * P.cw + clip3(0, P.cw - 1, x0 + c)];
+    // luma window: 21x21 samples from (bx + ix - 2, by + iy - 2), clamped at the picture edge.
+    // Interior macroblocks fetch it as aligned dwords (7 per row) with all requests in flight together;
+    // wxo is the column of the first wanted sample inside the 28-byte LDS row.
+    const int x0 = bx + (mvx >> 2) - 2, y0 = by + (mvy >> 2) - 2;
+    const int xa = x0 & ~3, wxo = x0 - xa;
+    const int cx0 = 8 * mx + (mvx >> 3), cy0 = 8 * my + (mvy >> 3);
+    const int cxa = cx0 & ~3, cxo = cx0 - cxa;
+    {
+        const bool interior = xa >= 0 && xa + 28 <= P.cw && y0 >= 0 && y0 + 21 <= P.ch;
+        if (interior) {
+            uint32_t v[3];
+#pragma unroll
+            for (int t = 0; t < 3; t++) {
+                const int i = lane + 64 * t, r = i / 7, c = i - r * 7;
+                v[t] = i < 147 ? *(const uint32_t*)(P.ref[0] + (size_t)(y0 + r) * P.cw + xa + 4 * c) : 0;
+            }
+#pragma unroll
+            for (int t = 0; t < 3; t++) {
+                const int i = lane + 64 * t, r = i / 7, c = i - r * 7;
+                if (i < 147) *(uint32_t*)(s_w + r * 28 + 4 * c) = v[t];
+            }
+        } else {
+            for (int i = lane; i < 21 * 21; i += 64) {
+                const int r = i / 21, c = i - r * 21;
+                s_w[r * 28 + wxo + c] = P.ref[0][(size_t)clip3(0, P.ch - 1, y0 + r) * P.cw + clip3(0, P.cw - 1, x0 + c)];
+            }
         }
-        const int cx0 = 8 * mx + (mvx >> 3), cy0 = 8 * my + (mvy >> 3);
-        for (int i = lane; i < 2 * 81; i += 64) {
-            const int pl = i / 81, k = i - pl * 81, r = k / 9, c = k - r * 9;
-            s_cw[pl][r * 12 + c] =
-                P.ref[1 + pl][(size_t)clip3(0, P.ch / 2 - 1, cy0 + r) * cs + clip3(0, cs - 1, cx0 + c)];
+        const bool cinterior = cxa >= 0 && cxa + 12 <= cs && cy0 >= 0 && cy0 + 9 <= P.ch / 2;
+        if (cinterior) {
+            if (lane < 54) {   // 2 planes x 9 rows x 3 dwords
+                const int pl = lane / 27, k = lane - pl * 27, r = k / 3, c = k - r * 3;
+                *(uint32_t*)(s_cw[pl] + r * 12 + 4 * c) = *(const uint32_t*)(P.ref[1 + pl] + (size_t)(cy0 + r) * cs + cxa + 4 * c);
+            }
+        } else {
+            for (int i = lane; i < 2 * 81; i += 64) {
+                const int pl = i / 81, k = i - pl * 81, r = k / 9, c = k - r * 9;
+                s_cw[pl][r * 12 + cxo + c] =
+                    P.ref[1 + pl][(size_t)clip3(0, P.ch / 2 - 1, cy0 + r) * cs + clip3(0, cs - 1, cx0 + c)];
+            }
         }
     }
     __syncthreads();
@@ -94,7 +122,7 @@ __global__ __launch_bounds__(64) void k_pmb(FrameParams P)
     if (fx) {
         for (int i = lane; i < 21 * 16; i += 64) {
             const int r = i >> 4, c = i & 15;
-            const uint8_t* p = s_w + r * 24 + c;  // p[2] is sample (c, r-2)
+            const uint8_t* p = s_w + r * 28 + wxo + c;  // p[2] is sample (c, r-2)
             s_b1[i] = (int16_t)(p[0] - 5 * p[1] + 20 * p[2] + 20 * p[3] - 5 * p[4] + p[5]);
         }
         __syncthreads();
@@ -105,8 +133,8 @@ __global__ __launch_bounds__(64) void k_pmb(FrameParams P)
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const int x = xs + k;
-            const uint8_t* g = s_w + (y + 2) * 24 + x + 2;  // integer sample G(x,y)
-#define HV(px) clip255(((px)[-48] - 5 * (px)[-24] + 20 * (px)[0] + 20 * (px)[24] - 5 * (px)[48] + (px)[72] + 16) >> 5)
+            const uint8_t* g = s_w + (y + 2) * 28 + wxo + x + 2;  // integer sample G(x,y)
+#define HV(px) clip255(((px)[-56] - 5 * (px)[-28] + 20 * (px)[0] + 20 * (px)[28] - 5 * (px)[56] + (px)[84] + 16) >> 5)
 #define BH(xx, yy) clip255((s_b1[((yy) + 2) * 16 + (xx)] + 16) >> 5)
 #define JC(xx, yy) clip255((s_b1[(yy) * 16 + (xx)] - 5 * s_b1[((yy) + 1) * 16 + (xx)] + 20 * s_b1[((yy) + 2) * 16 + (xx)] + \
                             20 * s_b1[((yy) + 3) * 16 + (xx)] - 5 * s_b1[((yy) + 4) * 16 + (xx)] + s_b1[((yy) + 5) * 16 + (xx)] + 512) >> 10)
@@ -119,7 +147,7 @@ __global__ __launch_bounds__(64) void k_pmb(FrameParams P)
                 }
             } else if (fx == 0) {
                 const int h = HV(g);
-                v = fy == 2 ? h : (fy == 1 ? (g[0] + h + 1) >> 1 : (g[24] + h + 1) >> 1);
+                v = fy == 2 ? h : (fy == 1 ? (g[0] + h + 1) >> 1 : (g[28] + h + 1) >> 1);
             } else if (fx == 2 && fy == 2) {
                 v = JC(x, y);
             } else if (fx == 2) {
@@ -145,7 +173,7 @@ __global__ __launch_bounds__(64) void k_pmb(FrameParams P)
         uint32_t out = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const uint8_t* p = s_cw[pl] + y * 12 + xs + k;
+            const uint8_t* p = s_cw[pl] + y * 12 + cxo + xs + k;
             const int v = ((8 - dx) * (8 - dy) * p[0] + dx * (8 - dy) * p[1] + (8 - dx) * dy * p[12] + dx * dy * p[13] + 32) >> 6;
             out |= (uint32_t)v << (8 * k);
         }

@@ -291,9 +291,7 @@ int submit(mi355x_h264_encoder* e, const uint8_t* d_src, int slot_idx)
     P.lambda = h_lambda[e->qp];
     hipStream_t st = e->stream;
 
-    // re-zero the part of the payload buffer the previous use dirtied
-    if (S.used_bytes) HIPCHK(e, hipMemsetAsync(S.d_bitbuf, 0, std::min(e->bitbuf_cap, S.used_bytes + 64), st));
-    S.used_bytes = 0;
+    // (the payload buffer of this slot was left zeroed by the k_pack of its previous use)
 
     if (idr) {
         StatScope sc(e, &S, MI355X_H264_K_INTRA, (uint32_t)(e->mbw + e->mbh - 1), (uint32_t)e->nmb);
@@ -315,6 +313,7 @@ int submit(mi355x_h264_encoder* e, const uint8_t* d_src, int slot_idx)
         CavlcParams C{};
         C.mb = e->d_mb; C.levels = e->d_levels; C.mvd = e->d_mvd; C.mbw = e->mbw; C.nmb = e->nmb; C.p_slice = idr ? 0 : 1;
         C.slotbits = e->d_slotbits; C.mbbits = e->d_mbbits; C.bitbuf = S.d_bitbuf;
+        C.bs = (!e->cfg.disable_deblock && !e->diag_mode) ? (uint8_t*)e->d_bs : nullptr;
         const int grid = (e->nmb + 1) / 2;
         hipLaunchKernelGGL(k_cavlc<false>, dim3(grid), dim3(64), 0, st, C);
         hipLaunchKernelGGL(k_bit_scan, dim3(1), dim3(1024), 0, st, C, (unsigned long long)hdr, hdr_len, S.d_info);
@@ -326,8 +325,7 @@ int submit(mi355x_h264_encoder* e, const uint8_t* d_src, int slot_idx)
         S.payload_off = pad + pre;
         S.idr = idr;
         S.nal_hdr = idr ? ((3 << 5) | 5) : ((2 << 5) | 1);
-        hipLaunchKernelGGL(k_pack, dim3(64), dim3(256), 0, st, (const uint8_t*)S.d_bitbuf, S.h_au + S.payload_off, S.d_info);
-        HIPCHK(e, hipMemcpyAsync(S.h_info, S.d_info, sizeof(SliceInfo), hipMemcpyDeviceToHost, st));
+        hipLaunchKernelGGL(k_pack, dim3(1), dim3(1024), 0, st, (uint8_t*)S.d_bitbuf, S.h_au + S.payload_off, (const SliceInfo*)S.d_info, S.h_info);
     }
     if (e->keep_pre)
         for (int p = 0; p < 3; p++)
@@ -349,16 +347,14 @@ int submit(mi355x_h264_encoder* e, const uint8_t* d_src, int slot_idx)
             }
         } else {
             DbRowParams R{};
-            R.d = D; R.handoff = e->d_handoff; R.err = e->d_err;
+            R.d = D; R.handoff = e->d_handoff; R.err = S.h_err;
             e->serial = e->serial == 0xFFFFFFFFu ? 1 : e->serial + 1;
             R.serial = e->serial;
             R.bs = e->d_bs;
-            hipLaunchKernelGGL(k_bs, dim3((e->nmb + 1) / 2), dim3(64), 0, st, (const MbInfo*)e->d_mb, (uint8_t*)e->d_bs, e->mbw, e->nmb);
             if (idr) hipLaunchKernelGGL(k_deblock_rows<true>, dim3(e->mbh), dim3(64), 0, st, R);
             else hipLaunchKernelGGL(k_deblock_rows<false>, dim3(e->mbh), dim3(64), 0, st, R);
         }
     }
-    HIPCHK(e, hipMemcpyAsync(S.h_err, e->d_err, sizeof(unsigned), hipMemcpyDeviceToHost, st));
     HIPCHK(e, hipEventRecord(S.done, st));
     HIPCHK(e, hipGetLastError());
     S.busy = true;
