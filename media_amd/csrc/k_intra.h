@@ -72,43 +72,31 @@ __device__ __forceinline__ int c8_px(int mode, int x, int y, const uint8_t* top,
                                                                                        : clip255((q.a + q.b * (x - 3) + q.c * (y - 3) + 16) >> 5);
 }
 
-__global__ __launch_bounds__(64) void k_intra_diag(FrameParams P, int s)
+// LDS working set of one intra macroblock
+struct IntraLds {
+    __attribute__((aligned(16))) uint8_t src[256];
+    __attribute__((aligned(16))) uint8_t srcc[128];
+    __attribute__((aligned(16))) uint8_t py[256];
+    __attribute__((aligned(16))) uint8_t pc[128];
+    __attribute__((aligned(16))) uint8_t rec_y[256];   // reconstruction of this macroblock (pitch 16)
+    __attribute__((aligned(16))) uint8_t rec_c[128];   // Cb 8x8, Cr 8x8 (pitch 8)
+    __attribute__((aligned(16))) int16_t lv[LV_STRIDE];
+    int dc[16];
+    uint8_t top[20], left[16];        // luma neighbours; top[0] = top-left
+    uint8_t ctop[2][12], cleft[2][8];
+};
+
+// Mode decision, transform, quantisation and reconstruction of one Intra16x16 macroblock whose source and
+// neighbour samples are already in S (and visible to the whole wave).  Writes recon (global + S.rec_*),
+// levels, MbInfo, mvd.
+__device__ __forceinline__ void intra_mb_core(const FrameParams& P, int mx, int my, IntraLds& S, int lane)
 {
-    const int lane = threadIdx.x;
-    const int ymin = max(0, s - P.mbw + 1);
-    const int my = ymin + blockIdx.x, mx = s - my;
-    if (my >= P.mbh || mx < 0 || mx >= P.mbw) return;
     const int mbi = my * P.mbw + mx, bx = 16 * mx, by = 16 * my, cs = P.cw / 2;
     const int avail = (mx > 0 ? 1 : 0) | (my > 0 ? 2 : 0) | ((mx > 0 && my > 0) ? 4 : 0);
-
-    __shared__ __attribute__((aligned(16))) uint8_t s_src[256];
-    __shared__ __attribute__((aligned(16))) uint8_t s_srcc[128];
-    __shared__ uint8_t s_top[20], s_left[16];        // luma neighbours; s_top[0] = top-left
-    __shared__ uint8_t s_ctop[2][12], s_cleft[2][8];
-    __shared__ __attribute__((aligned(16))) uint8_t s_py[256];
-    __shared__ __attribute__((aligned(16))) uint8_t s_pc[128];
-    __shared__ __attribute__((aligned(16))) int16_t s_lv[LV_STRIDE];
-    __shared__ int s_dc[16];
-
-    load_src_mb(P, mx, my, s_src, s_srcc, lane);
-    for (int i = lane; i < LV_STRIDE / 2; i += 64) ((uint32_t*)s_lv)[i] = 0;
-    {
-        const uint8_t* R = P.rec[0];
-        if (lane < 17) s_top[lane] = (my > 0 && (lane > 0 || mx > 0)) ? R[(size_t)(by - 1) * P.cw + bx - 1 + lane] : 0;
-        else if (lane < 33) s_left[lane - 17] = mx > 0 ? R[(size_t)(by + lane - 17) * P.cw + bx - 1] : 0;
-        else if (lane < 33 + 18) {
-            const int k = lane - 33, pl = k / 9, i = k % 9;
-            s_ctop[pl][i] = (my > 0 && (i > 0 || mx > 0)) ? P.rec[1 + pl][(size_t)(8 * my - 1) * cs + 8 * mx - 1 + i] : 0;
-        }
-        if (lane < 16) {
-            const int pl = lane >> 3, i = lane & 7;
-            s_cleft[pl][i] = mx > 0 ? P.rec[1 + pl][(size_t)(8 * my + i) * cs + 8 * mx - 1] : 0;
-        }
-    }
-    __syncthreads();
+    for (int i = lane; i < LV_STRIDE / 2; i += 64) ((uint32_t*)S.lv)[i] = 0;
 
     // ---- luma mode decision: lane = (mode, 4x4 block), SATD per mode ----
-    const I16Params ip = i16_params(s_top, s_left, avail);
+    const I16Params ip = i16_params(S.top, S.left, avail);
     int best_mode;
     {
         const int mode = lane >> 4, blk = lane & 15, x0 = (blk & 3) * 4, y0 = (blk >> 2) * 4;
@@ -117,7 +105,7 @@ __global__ __launch_bounds__(64) void k_intra_diag(FrameParams P, int s)
         for (int y = 0; y < 4; y++)
 #pragma unroll
             for (int x = 0; x < 4; x++)
-                d[4 * y + x] = (int)s_src[(y0 + y) * 16 + x0 + x] - i16_px(mode, x0 + x, y0 + y, s_top, s_left, ip);
+                d[4 * y + x] = (int)S.src[(y0 + y) * 16 + x0 + x] - i16_px(mode, x0 + x, y0 + y, S.top, S.left, ip);
         int sum = group_sum<16>(hadamard_abs(d)) >> 1;
         const bool ok = mode == 0 ? (avail & 2) : mode == 1 ? (avail & 1) : mode == 2 ? true : avail == 7;
         unsigned key = ok ? (((unsigned)sum << 2) | (unsigned)mode) : 0xFFFFFFFFu;
@@ -127,12 +115,12 @@ __global__ __launch_bounds__(64) void k_intra_diag(FrameParams P, int s)
         const int y = lane >> 2, xs = (lane & 3) * 4;
         uint32_t o = 0;
 #pragma unroll
-        for (int k = 0; k < 4; k++) o |= (uint32_t)i16_px(best_mode, xs + k, y, s_top, s_left, ip) << (8 * k);
-        *(uint32_t*)(s_py + y * 16 + xs) = o;
+        for (int k = 0; k < 4; k++) o |= (uint32_t)i16_px(best_mode, xs + k, y, S.top, S.left, ip) << (8 * k);
+        *(uint32_t*)(S.py + y * 16 + xs) = o;
     }
     // ---- chroma mode decision: lane<32 = (mode, plane, block) ----
     int best_cmode;
-    C8Params cp[2] = {c8_params(s_ctop[0], s_cleft[0], avail), c8_params(s_ctop[1], s_cleft[1], avail)};
+    C8Params cp[2] = {c8_params(S.ctop[0], S.cleft[0], avail), c8_params(S.ctop[1], S.cleft[1], avail)};
     {
         const int mode = (lane >> 3) & 3, pl = (lane >> 2) & 1, blk = lane & 3, x0 = (blk & 1) * 4, y0 = (blk >> 1) * 4;
         int d[16];
@@ -140,8 +128,8 @@ __global__ __launch_bounds__(64) void k_intra_diag(FrameParams P, int s)
         for (int y = 0; y < 4; y++)
 #pragma unroll
             for (int x = 0; x < 4; x++)
-                d[4 * y + x] = (int)s_srcc[pl * 64 + (y0 + y) * 8 + x0 + x] -
-                               c8_px(mode, x0 + x, y0 + y, s_ctop[pl], s_cleft[pl], pl ? cp[1] : cp[0]);
+                d[4 * y + x] = (int)S.srcc[pl * 64 + (y0 + y) * 8 + x0 + x] -
+                               c8_px(mode, x0 + x, y0 + y, S.ctop[pl], S.cleft[pl], pl ? cp[1] : cp[0]);
         // per-plane SATD is (sum over 4 blocks) >> 1; cost = Cb + Cr
         int sp = group_sum<4>(hadamard_abs(d)) >> 1;
         int sum = sp + __shfl_xor(sp, 4);
@@ -153,8 +141,8 @@ __global__ __launch_bounds__(64) void k_intra_diag(FrameParams P, int s)
         const int pl = lane >> 4, y = (lane >> 1) & 7, xs = (lane & 1) * 4;
         uint32_t o = 0;
 #pragma unroll
-        for (int k = 0; k < 4; k++) o |= (uint32_t)c8_px(best_cmode, xs + k, y, s_ctop[pl], s_cleft[pl], pl ? cp[1] : cp[0]) << (8 * k);
-        *(uint32_t*)(s_pc + pl * 64 + y * 8 + xs) = o;
+        for (int k = 0; k < 4; k++) o |= (uint32_t)c8_px(best_cmode, xs + k, y, S.ctop[pl], S.cleft[pl], pl ? cp[1] : cp[0]) << (8 * k);
+        *(uint32_t*)(S.pc + pl * 64 + y * 8 + xs) = o;
     }
     __syncthreads();
 
@@ -168,23 +156,23 @@ __global__ __launch_bounds__(64) void k_intra_diag(FrameParams P, int s)
 #pragma unroll
         for (int r = 0; r < 4; r++)
 #pragma unroll
-            for (int c = 0; c < 4; c++) d[4 * r + c] = (int)s_src[(y + r) * 16 + x + c] - (int)s_py[(y + r) * 16 + x + c];
-        nnz = tq4x4(d, P.qy, P.qy.f_intra, 1, s_lv + LV_LUMA + lane * 16, &dcw, 0, false);
-        s_dc[blk_y(lane) * 4 + blk_x(lane)] = dcw;
+            for (int c = 0; c < 4; c++) d[4 * r + c] = (int)S.src[(y + r) * 16 + x + c] - (int)S.py[(y + r) * 16 + x + c];
+        nnz = tq4x4(d, P.qy, P.qy.f_intra, 1, S.lv + LV_LUMA + lane * 16, &dcw, 0, false);
+        S.dc[blk_y(lane) * 4 + blk_x(lane)] = dcw;
     } else if (is_chroma) {
         const int x = (cb & 1) * 4, y = (cb >> 1) * 4;
 #pragma unroll
         for (int r = 0; r < 4; r++)
 #pragma unroll
             for (int c = 0; c < 4; c++)
-                d[4 * r + c] = (int)s_srcc[cpl * 64 + (y + r) * 8 + x + c] - (int)s_pc[cpl * 64 + (y + r) * 8 + x + c];
-        nnz = tq4x4(d, P.qc, P.qc.f_intra, 1, s_lv + LV_CHROMA_AC + (cpl * 4 + cb) * 16, &dcw, 0, false);
+                d[4 * r + c] = (int)S.srcc[cpl * 64 + (y + r) * 8 + x + c] - (int)S.pc[cpl * 64 + (y + r) * 8 + x + c];
+        nnz = tq4x4(d, P.qc, P.qc.f_intra, 1, S.lv + LV_CHROMA_AC + (cpl * 4 + cb) * 16, &dcw, 0, false);
     }
     __syncthreads();
     {   // luma DC: forward Hadamard, quantise at qbits+2, inverse Hadamard, 8.5.10 scaling
         int h[16];
 #pragma unroll
-        for (int i = 0; i < 16; i++) h[i] = s_dc[i];
+        for (int i = 0; i < 16; i++) h[i] = S.dc[i];
         hadamard4x4(h);
         const int qb = P.qy.qbits;
 #pragma unroll
@@ -195,7 +183,7 @@ __global__ __launch_bounds__(64) void k_intra_diag(FrameParams P, int s)
         }
         if (lane == 0)
 #pragma unroll
-            for (int i = 0; i < 16; i++) s_lv[LV_LUMA_DC + c_zigzag_inv[i]] = (int16_t)h[i];
+            for (int i = 0; i < 16; i++) S.lv[LV_LUMA_DC + c_zigzag_inv[i]] = (int16_t)h[i];
         hadamard4x4(h);
         if (is_luma) {
             const int fi = h[blk_y(lane) * 4 + blk_x(lane)];
@@ -212,7 +200,7 @@ __global__ __launch_bounds__(64) void k_intra_diag(FrameParams P, int s)
             d[0] = deq[cb];
             if (cb == 0)
 #pragma unroll
-                for (int i = 0; i < 4; i++) s_lv[LV_CHROMA_DC + cpl * 4 + i] = (int16_t)lv[i];
+                for (int i = 0; i < 4; i++) S.lv[LV_CHROMA_DC + cpl * 4 + i] = (int16_t)lv[i];
             dcw = (lv[0] | lv[1] | lv[2] | lv[3]) != 0;
         }
     }
@@ -222,17 +210,17 @@ __global__ __launch_bounds__(64) void k_intra_diag(FrameParams P, int s)
     const int cbp_chroma = ((nzmask >> 16) & 255) ? 2 : (dcmask ? 1 : 0);
     if (is_luma || is_chroma) {
         idct4x4(d);
-        uint8_t* dst;
+        uint8_t *dst, *ldst;
         const uint8_t* pp;
         int dp, ppitch;
         if (is_luma) {
             const int x = blk_x(lane) * 4, y = blk_y(lane) * 4;
             dst = P.rec[0] + (size_t)(by + y) * P.cw + bx + x; dp = P.cw;
-            pp = s_py + y * 16 + x; ppitch = 16;
+            pp = S.py + y * 16 + x; ppitch = 16; ldst = S.rec_y + y * 16 + x;
         } else {
             const int x = (cb & 1) * 4, y = (cb >> 1) * 4;
             dst = P.rec[1 + cpl] + (size_t)(8 * my + y) * cs + 8 * mx + x; dp = cs;
-            pp = s_pc + cpl * 64 + y * 8 + x; ppitch = 8;
+            pp = S.pc + cpl * 64 + y * 8 + x; ppitch = 8; ldst = S.rec_c + cpl * 64 + y * 8 + x;
         }
 #pragma unroll
         for (int r = 0; r < 4; r++) {
@@ -241,6 +229,7 @@ __global__ __launch_bounds__(64) void k_intra_diag(FrameParams P, int s)
 #pragma unroll
             for (int c = 0; c < 4; c++) o |= (uint32_t)clip255((int)((p >> (8 * c)) & 255) + d[4 * r + c]) << (8 * c);
             *(uint32_t*)(dst + (size_t)r * dp) = o;
+            *(uint32_t*)(ldst + r * ppitch) = o;
         }
     }
     __syncthreads();
@@ -255,9 +244,139 @@ __global__ __launch_bounds__(64) void k_intra_diag(FrameParams P, int s)
     }
     {
         uint4* g = (uint4*)(P.levels + (size_t)mbi * LV_STRIDE);
-        const uint4* sl = (const uint4*)s_lv;
+        const uint4* sl = (const uint4*)S.lv;
         if (lane < LV_STRIDE * 2 / 16) g[lane] = sl[lane];
     }
+}
+
+// one anti-diagonal per launch (kept as the simple reference form; MI355X_H264_DIAG=1 selects it)
+__global__ __launch_bounds__(64) void k_intra_diag(FrameParams P, int s)
+{
+    const int lane = threadIdx.x;
+    const int ymin = max(0, s - P.mbw + 1);
+    const int my = ymin + blockIdx.x, mx = s - my;
+    if (my >= P.mbh || mx < 0 || mx >= P.mbw) return;
+    const int bx = 16 * mx, by = 16 * my, cs = P.cw / 2;
+    __shared__ IntraLds S;
+    load_src_mb(P, mx, my, S.src, S.srcc, lane);
+    {
+        const uint8_t* R = P.rec[0];
+        if (lane < 17) S.top[lane] = (my > 0 && (lane > 0 || mx > 0)) ? R[(size_t)(by - 1) * P.cw + bx - 1 + lane] : 0;
+        else if (lane < 33) S.left[lane - 17] = mx > 0 ? R[(size_t)(by + lane - 17) * P.cw + bx - 1] : 0;
+        else if (lane < 33 + 18) {
+            const int k = lane - 33, pl = k / 9, i = k % 9;
+            S.ctop[pl][i] = (my > 0 && (i > 0 || mx > 0)) ? P.rec[1 + pl][(size_t)(8 * my - 1) * cs + 8 * mx - 1 + i] : 0;
+        }
+        if (lane < 16) {
+            const int pl = lane >> 3, i = lane & 7;
+            S.cleft[pl][i] = mx > 0 ? P.rec[1 + pl][(size_t)(8 * my + i) * cs + 8 * mx - 1] : 0;
+        }
+    }
+    __syncthreads();
+    intra_mb_core(P, mx, my, S, lane);
+}
+
+// ===========================================================================
+// Persistent form: ONE launch, one wavefront per macroblock row.  Intra16x16 / chroma
+// prediction of macroblock (mx, r) needs the bottom sample row of (mx, r-1) (and of
+// (mx-1, r-1) for the corner), the left column comes from this row's previous
+// macroblock (kept in LDS).  Row r-1 publishes the bottom row of each macroblock as
+// 8 granules {tag = picture serial, 4 samples} (16 luma + 8 Cb + 8 Cr samples), the
+// same fence-free hand-off as the deblocking wavefront (k_deblock.h).  The source of
+// the next macroblock is requested one iteration ahead.
+// ===========================================================================
+struct IntraRowParams {
+    FrameParams p;
+    unsigned long long* handoff;  // [mbh][mbw][8]
+    unsigned* err;                // pinned host word
+    unsigned serial;
+};
+
+__global__ __launch_bounds__(64) void k_intra_rows(IntraRowParams R)
+{
+    const FrameParams& P = R.p;
+    const int lane = threadIdx.x, my = blockIdx.x;
+    __shared__ IntraLds S;
+    bool timed_out = false;
+    const uint8_t* Y = P.src;
+    const uint8_t* U = Y + (size_t)P.w * P.h;
+    const uint8_t* V = U + (size_t)(P.w / 2) * (P.h / 2);
+    // source fetch of one macroblock into registers (same clamping as load_src_mb)
+    uint32_t pf_y = 0, pf_c = 0;
+    unsigned long long pf_g = 0;
+    auto prefetch = [&](int mx) {
+        {
+            const int row = lane >> 2, xs = (lane & 3) * 4;
+            const int gy = 16 * my + row, gx = 16 * mx + xs;
+            const uint8_t* p = Y + (size_t)(gy < P.h ? gy : P.h - 1) * P.w + gx;
+            if (gx + 3 < P.w && (((uintptr_t)p) & 3) == 0) pf_y = *(const uint32_t*)p;
+            else {
+                pf_y = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) pf_y |= (uint32_t)src_px(Y, P.w, P.h, gx + k, gy) << (8 * k);
+            }
+        }
+        if (lane < 32) {
+            const int pl = lane >> 4, row = (lane >> 1) & 7, xs = (lane & 1) * 4;
+            const uint8_t* Cp = pl ? V : U;
+            const int pw = P.w / 2, ph = P.h / 2;
+            const int gy = 8 * my + row, gx = 8 * mx + xs;
+            const uint8_t* p = Cp + (size_t)(gy < ph ? gy : ph - 1) * pw + gx;
+            if (gx + 3 < pw && (((uintptr_t)p) & 3) == 0) pf_c = *(const uint32_t*)p;
+            else {
+                pf_c = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) pf_c |= (uint32_t)src_px(Cp, pw, ph, gx + k, gy) << (8 * k);
+            }
+        }
+        if (my > 0 && lane < 8) pf_g = __hip_atomic_load(R.handoff + ((size_t)(my - 1) * P.mbw + mx) * 8 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    prefetch(0);
+    for (int mx = 0; mx < P.mbw; mx++) {
+        const uint32_t cur_y = pf_y, cur_c = pf_c;
+        unsigned long long g = pf_g;
+        if (mx + 1 < P.mbw) prefetch(mx + 1);
+        // left neighbours = last column of the previous reconstruction; corner = last sample of the previous top row
+        if (mx > 0) {
+            if (lane < 16) S.left[lane] = S.rec_y[lane * 16 + 15];
+            else if (lane < 32) S.cleft[(lane >> 3) & 1][lane & 7] = S.rec_c[((lane >> 3) & 1) * 64 + (lane & 7) * 8 + 7];
+            else if (lane == 32) S.top[0] = S.top[16];
+            else if (lane == 33) S.ctop[0][0] = S.ctop[0][8];
+            else if (lane == 34) S.ctop[1][0] = S.ctop[1][8];
+        }
+        *(uint32_t*)(S.src + (lane >> 2) * 16 + (lane & 3) * 4) = cur_y;
+        if (lane < 32) *(uint32_t*)(S.srcc + (lane >> 4) * 64 + ((lane >> 1) & 7) * 8 + (lane & 1) * 4) = cur_c;
+        __syncthreads();   // corner moved before the top row is overwritten
+        if (my > 0) {
+            unsigned spins = 0;
+            while (!timed_out) {
+                const bool bad = lane < 8 && (unsigned)(g >> 32) != R.serial;
+                if (__ballot(bad) == 0ull) break;
+                if (++spins > (1u << 20)) { timed_out = true; break; }
+                __builtin_amdgcn_s_sleep(1);
+                if (lane < 8) g = __hip_atomic_load(R.handoff + ((size_t)(my - 1) * P.mbw + mx) * 8 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            // granules 0..3 luma samples 0..15 -> top[1..16]; 4,5 Cb -> ctop[0][1..8]; 6,7 Cr -> ctop[1][1..8]
+            if (lane < 8) {
+                const uint32_t v = (uint32_t)g;
+                uint8_t* dst = lane < 4 ? S.top + 1 + 4 * lane : S.ctop[(lane - 4) >> 1] + 1 + 4 * (lane & 1);
+#pragma unroll
+                for (int k = 0; k < 4; k++) dst[k] = (uint8_t)(v >> (8 * k));
+            }
+        }
+        __syncthreads();
+        intra_mb_core(P, mx, my, S, lane);
+        // publish this macroblock's bottom sample row for the row below
+        if (my + 1 < P.mbh && lane < 8) {
+            uint32_t v;
+            if (lane < 4) v = *(const uint32_t*)(S.rec_y + 15 * 16 + 4 * lane);
+            else v = *(const uint32_t*)(S.rec_c + ((lane - 4) >> 1) * 64 + 7 * 8 + 4 * (lane & 1));
+            __hip_atomic_store(R.handoff + ((size_t)my * P.mbw + mx) * 8 + lane, ((unsigned long long)R.serial << 32) | v,
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+    }
+    if (timed_out && lane == 0) *R.err = 2u;
 }
 
 }  // namespace h264

@@ -294,10 +294,18 @@ int submit(mi355x_h264_encoder* e, const uint8_t* d_src, int slot_idx)
     // (the payload buffer of this slot was left zeroed by the k_pack of its previous use)
 
     if (idr) {
-        StatScope sc(e, &S, MI355X_H264_K_INTRA, (uint32_t)(e->mbw + e->mbh - 1), (uint32_t)e->nmb);
-        for (int s = 0; s < e->mbw + e->mbh - 1; s++) {
-            const int ymin = std::max(0, s - e->mbw + 1), ymax = std::min(e->mbh - 1, s);
-            hipLaunchKernelGGL(k_intra_diag, dim3(ymax - ymin + 1), dim3(64), 0, st, P, s);
+        StatScope sc(e, &S, MI355X_H264_K_INTRA, (uint32_t)(e->diag_mode ? e->mbw + e->mbh - 1 : 1), (uint32_t)e->nmb);
+        if (e->diag_mode) {
+            for (int s = 0; s < e->mbw + e->mbh - 1; s++) {
+                const int ymin = std::max(0, s - e->mbw + 1), ymax = std::min(e->mbh - 1, s);
+                hipLaunchKernelGGL(k_intra_diag, dim3(ymax - ymin + 1), dim3(64), 0, st, P, s);
+            }
+        } else {
+            IntraRowParams R{};
+            R.p = P; R.handoff = e->d_handoff; R.err = S.h_err;
+            e->serial = e->serial == 0xFFFFFFFFu ? 1 : e->serial + 1;
+            R.serial = e->serial;
+            hipLaunchKernelGGL(k_intra_rows, dim3(e->mbh), dim3(64), 0, st, R);
         }
     } else {
         { StatScope sc(e, &S, MI355X_H264_K_ME, 1, (uint32_t)e->nmb);
@@ -332,7 +340,7 @@ int submit(mi355x_h264_encoder* e, const uint8_t* d_src, int slot_idx)
             HIPCHK(e, hipMemcpyAsync(e->d_pre[p], e->d_planes[cur][p], (size_t)e->cw * e->ch / (p ? 4 : 1), hipMemcpyDeviceToDevice, st));
     if (!e->cfg.disable_deblock) {
         const int steps = e->mbw + 2 * (e->mbh - 1);
-        StatScope sc(e, &S, MI355X_H264_K_DEBLOCK, (uint32_t)steps, (uint32_t)e->nmb);
+        StatScope sc(e, &S, MI355X_H264_K_DEBLOCK, (uint32_t)(e->diag_mode ? steps : 1), (uint32_t)e->nmb);
         DbParams D{};
         for (int p = 0; p < 3; p++) D.pl[p] = e->d_planes[cur][p];
         D.mb = e->d_mb; D.cw = e->cw; D.ch = e->ch; D.mbw = e->mbw; D.mbh = e->mbh;
