@@ -91,6 +91,15 @@ int mi355x_h264_encode(mi355x_h264_encoder *enc, const uint8_t *y, int y_stride,
 int mi355x_h264_encode_device(mi355x_h264_encoder *enc, const void *d_i420, uint8_t **out,
                               uint32_t *out_len, int *frame_type);
 
+/* NV12 ingest (BASELINE.json configs[2]): Y plane followed by one interleaved
+ * UV plane.  OpenH264 itself only takes I420 (ref :256,:262); here a de-interleave kernel runs
+ * in front of the encoder so the host never touches the samples.  uv_stride in bytes. */
+int mi355x_h264_encode_nv12(mi355x_h264_encoder *enc, const uint8_t *y, int y_stride, const uint8_t *uv,
+                            int uv_stride, uint8_t **out, uint32_t *out_len, int *frame_type);
+/* tightly packed NV12 in device memory: Y (width*height) then UV (width*height/2) */
+int mi355x_h264_encode_nv12_device(mi355x_h264_encoder *enc, const void *d_nv12, uint8_t **out,
+                                   uint32_t *out_len, int *frame_type);
+
 /* Encode `count` device-resident pictures back to back; picture i starts at
  * d_frames + i*frame_stride_bytes.  Access units are appended to host_out
  * (capacity out_cap); sizes[i] receives the byte length of picture i.  The

@@ -23,7 +23,7 @@ EXPORTS = [
     "mi355x_h264_encode", "mi355x_h264_encode_device", "mi355x_h264_encode_batch_device",
     "mi355x_h264_force_idr", "mi355x_h264_last_error", "mi355x_h264_coded_width", "mi355x_h264_coded_height",
     "mi355x_h264_debug_keep_pre", "mi355x_h264_debug_read", "mi355x_h264_stats_enable", "mi355x_h264_stats_read",
-    "mi355x_h264_set_qp", "mi355x_h264_set_idr_pic_id",
+    "mi355x_h264_set_qp", "mi355x_h264_set_idr_pic_id", "mi355x_h264_encode_nv12", "mi355x_h264_encode_nv12_device",
 ]
 
 
@@ -57,6 +57,8 @@ def lib():
         L.mi355x_h264_encode.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp, C.c_int, C.POINTER(vp),
                                          C.POINTER(C.c_uint32), C.POINTER(C.c_int)]
         L.mi355x_h264_encode_device.argtypes = [vp, vp, C.POINTER(vp), C.POINTER(C.c_uint32), C.POINTER(C.c_int)]
+        L.mi355x_h264_encode_nv12.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_uint32), C.POINTER(C.c_int)]
+        L.mi355x_h264_encode_nv12_device.argtypes = [vp, vp, C.POINTER(vp), C.POINTER(C.c_uint32), C.POINTER(C.c_int)]
         L.mi355x_h264_encode_batch_device.argtypes = [vp, vp, C.c_size_t, C.c_int, vp, C.c_size_t, vp,
                                                       C.POINTER(C.c_size_t)]
         L.mi355x_h264_force_idr.argtypes = [vp]
@@ -111,6 +113,15 @@ class Encoder:
         out, n, ft = C.c_void_p(), C.c_uint32(), C.c_int()
         self._check(lib().mi355x_h264_encode(self.h, base, w, base + w * h, w // 2, base + w * h * 5 // 4, w // 2,
                                              C.byref(out), C.byref(n), C.byref(ft)))
+        return C.string_at(out.value, n.value), ft.value
+
+    def encode_nv12(self, nv12):
+        """host NV12 (Y plane then interleaved UV) -> (bytes, frame_type)"""
+        w, h = self.width, self.height
+        f = np.ascontiguousarray(nv12, dtype=np.uint8)
+        out, n, ft = C.c_void_p(), C.c_uint32(), C.c_int()
+        self._check(lib().mi355x_h264_encode_nv12(self.h, f.ctypes.data, w, f.ctypes.data + w * h, w,
+                                                  C.byref(out), C.byref(n), C.byref(ft)))
         return C.string_at(out.value, n.value), ft.value
 
     def encode_device(self, dev_ptr):

@@ -27,6 +27,23 @@ using namespace h264;
 
 namespace {
 
+// NV12 -> I420: de-interleave the UV plane (8 bytes = 4 chroma sample pairs per thread); Y is copied as is
+__global__ __launch_bounds__(256) void k_nv12_to_i420(const uint8_t* nv12, uint8_t* i420, int w, int h)
+{
+    const size_t ysz = (size_t)w * h, csz = ysz / 4;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // index of a 4-pair group (or a 16-byte Y chunk)
+    for (size_t k = i; k * 16 < ysz; k += (size_t)gridDim.x * blockDim.x) {
+        if (k * 16 + 16 <= ysz && ((ysz | (uintptr_t)nv12 | (uintptr_t)i420) & 15) == 0) *(uint4*)(i420 + k * 16) = *(const uint4*)(nv12 + k * 16);
+        else for (size_t b = k * 16; b < ysz && b < k * 16 + 16; b++) i420[b] = nv12[b];
+    }
+    const uint8_t* uv = nv12 + ysz;
+    uint8_t* u = i420 + ysz;
+    uint8_t* v = u + csz;
+    for (size_t k = i; k * 4 < csz; k += (size_t)gridDim.x * blockDim.x) {
+        for (size_t c = k * 4; c < csz && c < k * 4 + 4; c++) { u[c] = uv[2 * c]; v[c] = uv[2 * c + 1]; }
+    }
+}
+
 // ---- host tables (ITU-T H.264 Table 8-15, A-1; quantiser of the reference model) ----
 const uint8_t h_chroma_qp[52] = {0,  1,  2,  3,  4,  5,  6,  7,  8,  9,  10, 11, 12, 13, 14, 15, 16, 17,
                                  18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 29, 30, 31, 32, 32, 33,
@@ -161,6 +178,7 @@ struct mi355x_h264_encoder {
     unsigned serial = 0;
     bool diag_mode = false;                  // debug: one launch per wavefront step instead
     uint8_t* d_stage = nullptr;              // device copy of a host-supplied picture
+    uint8_t* d_stage2 = nullptr;             // device copy of a host-supplied NV12 picture
     uint8_t* h_stage = nullptr;              // pinned staging for strided host input
     size_t frame_bytes = 0, bitbuf_cap = 0, au_cap = 0;
     Slot slots[NSLOT];
@@ -490,6 +508,7 @@ int mi355x_h264_create(const mi355x_h264_config* cfg, mi355x_h264_encoder** out)
     e->diag_mode = getenv("MI355X_H264_DIAG") != nullptr;
     e->frame_bytes = (size_t)cfg->width * cfg->height * 3 / 2;
     CK(hipMalloc((void**)&e->d_stage, e->frame_bytes + 256));
+    CK(hipMalloc((void**)&e->d_stage2, e->frame_bytes + 256));
     CK(hipHostMalloc((void**)&e->h_stage, e->frame_bytes + 256, hipHostMallocDefault));
     e->bitbuf_cap = ysz * 2 + (1 << 16);
     e->au_cap = e->bitbuf_cap + e->sps_pps.size() + 64;
@@ -518,7 +537,7 @@ void mi355x_h264_destroy(mi355x_h264_encoder* e)
         for (int p = 0; p < 3; p++) (void)hipFree(e->d_planes[b][p]);
     for (int p = 0; p < 3; p++) (void)hipFree(e->d_pre[p]);
     (void)hipFree(e->d_mb); (void)hipFree(e->d_levels); (void)hipFree(e->d_mvd);
-    (void)hipFree(e->d_slotbits); (void)hipFree(e->d_mbbits); (void)hipFree(e->d_stage);
+    (void)hipFree(e->d_slotbits); (void)hipFree(e->d_mbbits); (void)hipFree(e->d_stage); (void)hipFree(e->d_stage2);
     (void)hipFree(e->d_handoff); (void)hipFree(e->d_progress); (void)hipFree(e->d_err); (void)hipFree(e->d_bs);
     if (e->h_stage) (void)hipHostFree(e->h_stage);
     for (auto& S : e->slots) {
@@ -561,6 +580,29 @@ int mi355x_h264_encode(mi355x_h264_encoder* e, const uint8_t* y, int ys, const u
     for (int r = 0; r < h / 2; r++) memcpy(d + (size_t)r * (w / 2), v + (size_t)r * vs, (size_t)(w / 2));
     HIPCHK(e, hipMemcpyAsync(e->d_stage, e->h_stage, e->frame_bytes, hipMemcpyHostToDevice, e->stream));
     return mi355x_h264_encode_device(e, e->d_stage, out, out_len, frame_type);
+}
+
+int mi355x_h264_encode_nv12_device(mi355x_h264_encoder* e, const void* d_nv12, uint8_t** out, uint32_t* out_len, int* frame_type)
+{
+    if (!e || !d_nv12 || !out || !out_len) return fail(e, MI355X_H264_E_ARG, "null argument");
+    HIPCHK(e, hipSetDevice(e->device));
+    hipLaunchKernelGGL(k_nv12_to_i420, dim3(512), dim3(256), 0, e->stream, (const uint8_t*)d_nv12, e->d_stage, e->cfg.width, e->cfg.height);
+    return mi355x_h264_encode_device(e, e->d_stage, out, out_len, frame_type);
+}
+
+int mi355x_h264_encode_nv12(mi355x_h264_encoder* e, const uint8_t* y, int ys, const uint8_t* uv, int uvs, uint8_t** out,
+                            uint32_t* out_len, int* frame_type)
+{
+    if (!e || !y || !uv || !out || !out_len) return fail(e, MI355X_H264_E_ARG, "null argument");
+    const int w = e->cfg.width, h = e->cfg.height;
+    if (ys < w || uvs < w) return fail(e, MI355X_H264_E_ARG, "stride smaller than width");
+    HIPCHK(e, hipSetDevice(e->device));
+    uint8_t* d = e->h_stage;
+    for (int r = 0; r < h; r++) memcpy(d + (size_t)r * w, y + (size_t)r * ys, (size_t)w);
+    d += (size_t)w * h;
+    for (int r = 0; r < h / 2; r++) memcpy(d + (size_t)r * w, uv + (size_t)r * uvs, (size_t)w);
+    HIPCHK(e, hipMemcpyAsync(e->d_stage2, e->h_stage, e->frame_bytes, hipMemcpyHostToDevice, e->stream));
+    return mi355x_h264_encode_nv12_device(e, e->d_stage2, out, out_len, frame_type);
 }
 
 int mi355x_h264_encode_batch_device(mi355x_h264_encoder* e, const void* d_frames, size_t stride, int count, uint8_t* host_out,

@@ -70,6 +70,30 @@ def test_forced_idr_qp_change_and_strided_input():
     enc.close()
 
 
+def test_nv12_ingest_main_profile_1080p60():
+    """BASELINE.json configs[2]: 1080p60 NV12, main profile, CABAC off (CAVLC): the de-interleave kernel in
+    front of the encoder must give exactly the I420 result"""
+    w, h = 1920, 1080
+    enc = capi.Encoder(w, h, qp=26, gop=30, fps=60, profile_idc=77)
+    orc = OracleEncoder(w, h, qp=26, gop=30, fps=60, profile_idc=77)
+    for i, f in enumerate(synth.sequence("s1", w, h, 3)):
+        y, u, v = f[: w * h], f[w * h: w * h * 5 // 4], f[w * h * 5 // 4:]
+        nv12 = np.concatenate([y, np.stack([u, v], axis=1).ravel()])
+        bs, _ = enc.encode_nv12(nv12)
+        assert bs == orc.encode(f)[0]
+        if i == 0:
+            assert bs[:8] == bytes([0, 0, 0, 1, 0x67, 77, 0x40, 42])   # main profile, level 4.2 for 1080p60
+    enc.close()
+    # odd geometry through the scalar tail of the kernel
+    w, h = 130, 98
+    enc = capi.Encoder(w, h, qp=28)
+    orc = OracleEncoder(w, h, qp=28)
+    for f in synth.sequence("s1", w, h, 2):
+        y, u, v = f[: w * h], f[w * h: w * h * 5 // 4], f[w * h * 5 // 4:]
+        assert enc.encode_nv12(np.concatenate([y, np.stack([u, v], axis=1).ravel()]))[0] == orc.encode(f)[0]
+    enc.close()
+
+
 def test_no_deblock_variant():
     w, h = 160, 96
     enc = capi.Encoder(w, h, qp=32, disable_deblock=1)
