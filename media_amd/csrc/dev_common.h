@@ -229,32 +229,37 @@ __device__ __forceinline__ int xcd_mb_index(int b, int n)
 // frame.  All macroblocks of the picture already carry their final vectors, so
 // any neighbour inside the picture is "available" (single slice).
 struct Mv { int x, y; };
-__device__ __forceinline__ void nb_mv(const FrameParams& P, int mx, int my, int& avail, int& ref, Mv& mv)
-{
-    avail = (mx >= 0 && my >= 0 && mx < P.mbw) ? 1 : 0;
-    ref = -1; mv.x = 0; mv.y = 0;
-    if (avail) {
-        const MbInfo* m = P.mb + (size_t)my * P.mbw + mx;
-        if (m->type != MB_I16) { ref = 0; mv.x = m->mvx; mv.y = m->mvy; }
-    }
-}
 __device__ __forceinline__ int med3(int a, int b, int c)
 {
     const int mn = min(a, min(b, c)), mxv = max(a, max(b, c));
     return a + b + c - mn - mxv;
 }
-// returns predictor; skip receives the P_Skip vector.  Neighbour `type` fields of a
-// P picture are never MB_I16 in this build, but the general rule is kept.
+// returns predictor; skip receives the P_Skip vector.  The four candidate neighbours (A left, B top,
+// C top-right, D top-left) are fetched with independent 8-byte loads issued together (one memory round
+// trip), availability is applied afterwards.  Neighbour `type` fields of a P picture are never MB_I16 in
+// this build, but the general rule is kept.
 __device__ __forceinline__ Mv predict_mv(const FrameParams& P, int mx, int my, Mv& skip)
 {
-    int aA, aB, aC, rA, rB, rC;
+    const bool avA = mx > 0, avB = my > 0, avC0 = my > 0 && mx + 1 < P.mbw, avD = mx > 0 && my > 0;
+    const MbInfo* base = P.mb + (size_t)my * P.mbw + mx;
+    const uint2 wA = *(const uint2*)(avA ? base - 1 : base);
+    const uint2 wB = *(const uint2*)(avB ? base - P.mbw : base);
+    const uint2 wC = *(const uint2*)(avC0 ? base - P.mbw + 1 : base);
+    const uint2 wD = *(const uint2*)(avD ? base - P.mbw - 1 : base);
+    auto unpack = [](const uint2 w, bool av, int& ref, Mv& mv) {
+        const int type = (int)(w.y & 255);
+        ref = -1; mv.x = 0; mv.y = 0;
+        if (av && type != MB_I16) { ref = 0; mv.x = (int)(int16_t)(w.x & 0xFFFF); mv.y = (int)(int16_t)(w.x >> 16); }
+    };
+    int rA, rB, rC;
     Mv A, B, C;
-    nb_mv(P, mx - 1, my, aA, rA, A);
-    nb_mv(P, mx, my - 1, aB, rB, B);
-    nb_mv(P, mx + 1, my - 1, aC, rC, C);
-    if (!aC) nb_mv(P, mx - 1, my - 1, aC, rC, C);
-    const bool zero_skip = !aA || !aB || (rA == 0 && A.x == 0 && A.y == 0) || (rB == 0 && B.x == 0 && B.y == 0);
-    if (!aB && !aC && aA) { B = A; C = A; rB = rA; rC = rA; }
+    unpack(wA, avA, rA, A);
+    unpack(wB, avB, rB, B);
+    bool aC = avC0;
+    if (avC0) unpack(wC, true, rC, C);
+    else { unpack(wD, avD, rC, C); aC = avD; }
+    const bool zero_skip = !avA || !avB || (rA == 0 && A.x == 0 && A.y == 0) || (rB == 0 && B.x == 0 && B.y == 0);
+    if (!avB && !aC && avA) { B = A; C = A; rB = rA; rC = rA; }
     Mv p;
     const int n = (rA == 0) + (rB == 0) + (rC == 0);
     if (n == 1) p = rA == 0 ? A : (rB == 0 ? B : C);

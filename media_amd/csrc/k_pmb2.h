@@ -1,0 +1,334 @@
+// media_amd/csrc/k_pmb2.h -- inter macroblock coding, second form of k_pmb.h (same results, bit for bit).
+//
+// One wavefront per macroblock with lane = (4x4 block, row): every lane owns FOUR consecutive samples of
+// one row from motion compensation to reconstruction, so nothing per-sample goes through LDS:
+//   - the reference window is fetched as aligned dwords; a lane reads its samples as dwords and realigns
+//     them with v_alignbyte (no byte-wide LDS traffic)
+//   - the 4x4 transforms run as an in-lane row pass plus a column pass over the four lanes of a quad
+//     (DPP quad_perm broadcasts), forward and inverse
+//   - prediction stays in a register until it is added back for the reconstruction
+// Luma uses all 64 lanes (16 blocks x 4 rows), chroma 32 lanes (2 planes x 4 blocks x 4 rows).
+//
+// SURVEY.md 8a rows a6.2 + a6.3 (inside ISVCEncoder::EncodeFrame,
+// /root/reference/video_codec/VideoEncoderOpenH264.cpp:344).  Algorithmic HBM bytes per macroblock:
+// source 384 + reference 384 in; reconstruction 384 + levels 768 + side info 32 out = 1952.
+#pragma once
+#include "dev_common.h"
+#include "k_pmb.h"
+
+namespace h264 {
+
+template <int K>
+__device__ __forceinline__ int quad_bcast(int v)
+{
+    return __builtin_amdgcn_mov_dpp(v, K * 0x55, 0xf, 0xf, false);  // quad_perm:[K,K,K,K]
+}
+// four bytes starting at byte offset o of an LDS byte array (any alignment)
+__device__ __forceinline__ uint32_t lds_ld4(const uint8_t* base, int o)
+{
+    const uint32_t* p = (const uint32_t*)(base + (o & ~3));
+    return __builtin_amdgcn_alignbyte(p[1], p[0], o & 3);
+}
+__device__ __forceinline__ int byte_of(uint32_t v, int k) { return (int)((v >> (8 * k)) & 255); }
+__device__ __forceinline__ uint32_t pack4(int a, int b, int c, int d)
+{
+    return (uint32_t)a | ((uint32_t)b << 8) | ((uint32_t)c << 16) | ((uint32_t)d << 24);
+}
+__device__ __forceinline__ uint32_t avg4(uint32_t a, uint32_t b)  // per-byte (a + b + 1) >> 1
+{
+    return (a | b) - (((a ^ b) >> 1) & 0x7F7F7F7Fu);
+}
+
+// unclipped horizontal 6-tap sums for 4 consecutive outputs; `o` = LDS byte offset of the sample 2 left of output 0
+__device__ __forceinline__ void htap4(const uint8_t* base, int o, int out[4])
+{
+    const uint32_t* p = (const uint32_t*)(base + (o & ~3));
+    const int sh = o & 3;
+    const uint32_t d0 = p[0], d1 = p[1], d2 = p[2], d3 = p[3];
+    const uint32_t a0 = __builtin_amdgcn_alignbyte(d1, d0, sh), a1 = __builtin_amdgcn_alignbyte(d2, d1, sh),
+                   a2 = __builtin_amdgcn_alignbyte(d3, d2, sh);
+    const int b[9] = {byte_of(a0, 0), byte_of(a0, 1), byte_of(a0, 2), byte_of(a0, 3), byte_of(a1, 0),
+                      byte_of(a1, 1), byte_of(a1, 2), byte_of(a1, 3), byte_of(a2, 0)};
+#pragma unroll
+    for (int k = 0; k < 4; k++) out[k] = b[k] + b[k + 5] - 5 * (b[k + 1] + b[k + 4]) + 20 * (b[k + 2] + b[k + 3]);
+}
+// vertical 6-tap for 4 columns: o = LDS offset of the sample 2 rows above output, pitch in bytes
+__device__ __forceinline__ void vtap4(const uint8_t* base, int o, int pitch, int out[4])
+{
+    uint32_t r[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) r[i] = lds_ld4(base, o + i * pitch);
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        out[k] = byte_of(r[0], k) + byte_of(r[5], k) - 5 * (byte_of(r[1], k) + byte_of(r[4], k)) + 20 * (byte_of(r[2], k) + byte_of(r[3], k));
+}
+// hipcc (ROCm 7.2, gfx950) fuses "shift, clamp to 0..255, pack two bytes" into v_ashr_pk_u8_i32 and then
+// ORs further bytes into its result assuming the upper 16 bits are zero; the instruction leaves them
+// unchanged (observed: bytes 2,3 corrupted).  Keeping the clamped values opaque avoids that selection.
+__device__ __forceinline__ int opaque(int v)
+{
+    asm volatile("" : "+v"(v));
+    return v;
+}
+__device__ __forceinline__ uint32_t round5_pack(const int t[4])
+{
+    return pack4(opaque(clip255((t[0] + 16) >> 5)), opaque(clip255((t[1] + 16) >> 5)), opaque(clip255((t[2] + 16) >> 5)),
+                 opaque(clip255((t[3] + 16) >> 5)));
+}
+
+// forward 4x4 core transform of the quad's block: in d[4] = this lane's residual row, out d[4] = row `r` of W
+__device__ __forceinline__ void fdct_quad(int d[4], int r)
+{
+    {
+        const int s0 = d[0] + d[3], s1 = d[1] + d[2], d0 = d[0] - d[3], d1 = d[1] - d[2];
+        d[0] = s0 + s1; d[1] = 2 * d0 + d1; d[2] = s0 - s1; d[3] = d0 - 2 * d1;
+    }
+    const bool odd = r & 1;
+    const int mA = r == 1 ? 2 : 1, mB = r == 0 ? 1 : (r == 1 ? 1 : (r == 2 ? -1 : -2));
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const int t0 = quad_bcast<0>(d[c]), t1 = quad_bcast<1>(d[c]), t2 = quad_bcast<2>(d[c]), t3 = quad_bcast<3>(d[c]);
+        const int A = odd ? t0 - t3 : t0 + t3, B = odd ? t1 - t2 : t1 + t2;
+        d[c] = mA * A + mB * B;  // r0: s0+s1, r1: 2d0+d1, r2: s0-s1, r3: d0-2d1
+    }
+}
+// inverse (8.5.12.2): in d[4] = row r of the scaled coefficients, out d[4] = row r of the residual (rounded)
+__device__ __forceinline__ void idct_quad(int d[4], int r)
+{
+    {
+        const int e0 = d[0] + d[2], e1 = d[0] - d[2], e2 = (d[1] >> 1) - d[3], e3 = d[1] + (d[3] >> 1);
+        d[0] = e0 + e3; d[1] = e1 + e2; d[2] = e1 - e2; d[3] = e0 - e3;
+    }
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const int f0 = quad_bcast<0>(d[c]), f1 = quad_bcast<1>(d[c]), f2 = quad_bcast<2>(d[c]), f3 = quad_bcast<3>(d[c]);
+        const int g0 = f0 + f2, g1 = f0 - f2, g2 = (f1 >> 1) - f3, g3 = f1 + (f3 >> 1);
+        const int v = r == 0 ? g0 + g3 : (r == 1 ? g1 + g2 : (r == 2 ? g1 - g2 : g0 - g3));
+        d[c] = (v + 32) >> 6;
+    }
+}
+
+__constant__ const uint16_t c_zz_row[4] = {0x6510, 0xC742, 0xDB83, 0xFEA9};  // zig-zag index of raster (r, c), nibble c
+
+__global__ __launch_bounds__(64) void k_pmb2(FrameParams P)
+{
+    const int lane = threadIdx.x;
+    const int mbi = xcd_mb_index(blockIdx.x, P.mbw * P.mbh), mx = mbi % P.mbw, my = mbi / P.mbw;
+    const int bx = 16 * mx, by = 16 * my, cs = P.cw / 2;
+
+    __shared__ __attribute__((aligned(16))) uint8_t s_w[21 * 28 + 12];     // luma window, pitch 28
+    __shared__ __attribute__((aligned(16))) uint8_t s_cw[2][9 * 12 + 12];  // chroma windows, pitch 12
+    __shared__ __attribute__((aligned(16))) int16_t s_b1[21 * 16];         // unclipped horizontal sums (centre positions)
+    __shared__ __attribute__((aligned(16))) int16_t s_lv[LV_STRIDE];
+
+    MbInfo* m = P.mb + mbi;
+    const int mvx = m->mvx, mvy = m->mvy;
+    Mv skip;
+    const Mv pred = predict_mv(P, mx, my, skip);
+
+    // lane geometry: luma (blk, r) -> samples (lx..lx+3, ly); chroma lane cl -> plane, block, row
+    const int blk = lane >> 2, r = lane & 3, lx = blk_x(blk) * 4, ly = blk_y(blk) * 4 + r;
+    const int cpl = (lane >> 4) & 1, cblk = (lane >> 2) & 3, cx = (cblk & 1) * 4, cy = (cblk >> 1) * 4 + r;
+
+    // ---- all global requests first: reference windows, source samples ----
+    const int x0 = bx + (mvx >> 2) - 2, y0 = by + (mvy >> 2) - 2;
+    const int xa = x0 & ~3, wxo = x0 - xa;
+    const int cx0 = 8 * mx + (mvx >> 3), cy0 = 8 * my + (mvy >> 3);
+    const int cxa = cx0 & ~3, cxo = cx0 - cxa;
+    const bool interior = xa >= 0 && xa + 28 <= P.cw && y0 >= 0 && y0 + 21 <= P.ch;
+    const bool cinterior = cxa >= 0 && cxa + 12 <= cs && cy0 >= 0 && cy0 + 9 <= P.ch / 2;
+    uint32_t wv[3] = {0, 0, 0}, cwv = 0;
+    if (interior) {
+#pragma unroll
+        for (int t = 0; t < 3; t++) {
+            const int i = lane + 64 * t, rr = i / 7, c = i - rr * 7;
+            if (i < 147) wv[t] = *(const uint32_t*)(P.ref[0] + (size_t)(y0 + rr) * P.cw + xa + 4 * c);
+        }
+    }
+    if (cinterior && lane < 54) {
+        const int pl = lane / 27, k = lane - pl * 27, rr = k / 3, c = k - rr * 3;
+        cwv = *(const uint32_t*)(P.ref[1 + pl] + (size_t)(cy0 + rr) * cs + cxa + 4 * c);
+    }
+    uint32_t src4, csrc4 = 0;
+    {
+        const uint8_t* Y = P.src;
+        const int gy = by + ly, gx = bx + lx;
+        const uint8_t* p = Y + (size_t)(gy < P.h ? gy : P.h - 1) * P.w + gx;
+        if (gx + 3 < P.w && (((uintptr_t)p) & 3) == 0) src4 = *(const uint32_t*)p;
+        else src4 = pack4(src_px(Y, P.w, P.h, gx, gy), src_px(Y, P.w, P.h, gx + 1, gy), src_px(Y, P.w, P.h, gx + 2, gy), src_px(Y, P.w, P.h, gx + 3, gy));
+        if (lane < 32) {
+            const int pw = P.w / 2, ph = P.h / 2;
+            const uint8_t* C = Y + (size_t)P.w * P.h + (cpl ? (size_t)pw * ph : 0);
+            const int cgy = 8 * my + cy, cgx = 8 * mx + cx;
+            const uint8_t* q = C + (size_t)(cgy < ph ? cgy : ph - 1) * pw + cgx;
+            if (cgx + 3 < pw && (((uintptr_t)q) & 3) == 0) csrc4 = *(const uint32_t*)q;
+            else csrc4 = pack4(src_px(C, pw, ph, cgx, cgy), src_px(C, pw, ph, cgx + 1, cgy), src_px(C, pw, ph, cgx + 2, cgy), src_px(C, pw, ph, cgx + 3, cgy));
+        }
+    }
+    if (lane < LV_STRIDE * 2 / 16) ((uint4*)s_lv)[lane] = make_uint4(0, 0, 0, 0);
+    if (interior) {
+#pragma unroll
+        for (int t = 0; t < 3; t++) {
+            const int i = lane + 64 * t, rr = i / 7, c = i - rr * 7;
+            if (i < 147) *(uint32_t*)(s_w + rr * 28 + 4 * c) = wv[t];
+        }
+    } else {
+        for (int i = lane; i < 21 * 21; i += 64) {
+            const int rr = i / 21, c = i - rr * 21;
+            s_w[rr * 28 + wxo + c] = P.ref[0][(size_t)clip3(0, P.ch - 1, y0 + rr) * P.cw + clip3(0, P.cw - 1, x0 + c)];
+        }
+    }
+    if (cinterior) {
+        if (lane < 54) {
+            const int pl = lane / 27, k = lane - pl * 27, rr = k / 3, c = k - rr * 3;
+            *(uint32_t*)(s_cw[pl] + rr * 12 + 4 * c) = cwv;
+        }
+    } else {
+        for (int i = lane; i < 2 * 81; i += 64) {
+            const int pl = i / 81, k = i - pl * 81, rr = k / 9, c = k - rr * 9;
+            s_cw[pl][rr * 12 + cxo + c] = P.ref[1 + pl][(size_t)clip3(0, P.ch / 2 - 1, cy0 + rr) * cs + clip3(0, cs - 1, cx0 + c)];
+        }
+    }
+    __syncthreads();
+
+    // ---- luma prediction (8.4.2.2.1): 4 samples per lane, branches are wave-uniform ----
+    const int fx = mvx & 3, fy = mvy & 3;
+    const bool need_j = (fx == 2 && fy != 0) || (fy == 2 && fx != 0);
+    if (need_j) {  // stage the unclipped horizontal sums of all 21 window rows (84 row segments)
+        for (int i = lane; i < 84; i += 64) {
+            const int rr = i >> 2, seg = (i & 3) * 4;
+            int t[4];
+            htap4(s_w, rr * 28 + wxo + seg, t);
+            *(uint2*)(s_b1 + rr * 16 + seg) = make_uint2((uint32_t)(t[0] & 0xFFFF) | ((uint32_t)t[1] << 16), (uint32_t)(t[2] & 0xFFFF) | ((uint32_t)t[3] << 16));
+        }
+        __syncthreads();
+    }
+    uint32_t pred4;
+    {
+        const int g = (ly + 2) * 28 + wxo + lx + 2;  // LDS offset of integer sample G(lx, ly)
+        uint32_t Gv = 0, Bv = 0, Hv = 0, Jv = 0;
+        const bool use_b = fx != 0 && fy != 2, use_h = fy != 0 && fx != 2;
+        if (fx == 0 || fy == 0) Gv = lds_ld4(s_w, g + (fx == 3 ? 1 : 0) + (fy == 3 ? 28 : 0));
+        if (use_b) { int t[4]; htap4(s_w, g - 2 + (fy == 3 ? 28 : 0), t); Bv = round5_pack(t); }
+        if (use_h) { int t[4]; vtap4(s_w, g - 56 + (fx == 3 ? 1 : 0), 28, t); Hv = round5_pack(t); }
+        if (need_j) {
+            int t[4];
+            const int16_t* q = s_b1 + ly * 16 + lx;  // row (ly-2)+2
+            short4 rw[6];
+#pragma unroll
+            for (int i = 0; i < 6; i++) rw[i] = *(const short4*)(q + i * 16);
+            const int16_t* e0 = (const int16_t*)&rw[0]; const int16_t* e1 = (const int16_t*)&rw[1]; const int16_t* e2 = (const int16_t*)&rw[2];
+            const int16_t* e3 = (const int16_t*)&rw[3]; const int16_t* e4 = (const int16_t*)&rw[4]; const int16_t* e5 = (const int16_t*)&rw[5];
+#pragma unroll
+            for (int k = 0; k < 4; k++) t[k] = opaque(clip255((e0[k] + e5[k] - 5 * (e1[k] + e4[k]) + 20 * (e2[k] + e3[k]) + 512) >> 10));
+            Jv = pack4(t[0], t[1], t[2], t[3]);
+        }
+        if (fx == 0 && fy == 0) pred4 = Gv;
+        else if (fy == 0) pred4 = fx == 2 ? Bv : avg4(Gv, Bv);
+        else if (fx == 0) pred4 = fy == 2 ? Hv : avg4(Gv, Hv);
+        else if (fx == 2 && fy == 2) pred4 = Jv;
+        else if (fx == 2) pred4 = avg4(Bv, Jv);
+        else if (fy == 2) pred4 = avg4(Hv, Jv);
+        else pred4 = avg4(Bv, Hv);
+    }
+
+    // ---- luma: residual -> fdct -> quant -> dequant -> idct -> recon ----
+    int d[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) d[k] = byte_of(src4, k) - byte_of(pred4, k);
+    fdct_quad(d, r);
+    int nz = 0;
+    const int zz = c_zz_row[r];
+    {
+        const Quant& q = P.qy;
+        const int mf0 = (r & 1) ? q.mf[2] : q.mf[0], mf1 = (r & 1) ? q.mf[1] : q.mf[2];
+        const int dq0 = (r & 1) ? q.dq[2] : q.dq[0], dq1 = (r & 1) ? q.dq[1] : q.dq[2];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const int l = quant1(d[c], (c & 1) ? mf1 : mf0, q.f_inter, q.qbits);
+            s_lv[LV_LUMA + blk * 16 + ((zz >> (4 * c)) & 15)] = (int16_t)l;
+            nz += l != 0;
+            d[c] = l * ((c & 1) ? dq1 : dq0);
+        }
+    }
+    nz += __builtin_amdgcn_mov_dpp(nz, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
+    nz += __builtin_amdgcn_mov_dpp(nz, 0x4E, 0xf, 0xf, false);   // quad_perm [2,3,0,1]  -> TotalCoeff of the block in all 4 lanes
+    idct_quad(d, r);
+    if (P.lambda < 0) { d[0] = d[1] = d[2] = d[3] = 0; }   // debug: reconstruction = prediction
+    *(uint32_t*)(P.rec[0] + (size_t)(by + ly) * P.cw + bx + lx) =
+        pack4(clip255(byte_of(pred4, 0) + d[0]), clip255(byte_of(pred4, 1) + d[1]), clip255(byte_of(pred4, 2) + d[2]), clip255(byte_of(pred4, 3) + d[3]));
+    const unsigned long long ymask = __ballot(nz != 0);
+    const int cbp_luma = ((ymask & 0xFFFFull) ? 1 : 0) | (((ymask >> 16) & 0xFFFFull) ? 2 : 0) | (((ymask >> 32) & 0xFFFFull) ? 4 : 0) |
+                         (((ymask >> 48) & 0xFFFFull) ? 8 : 0);
+    if (r == 0) m->tc[blk] = (uint8_t)nz;
+
+    // ---- chroma (lanes 0..31): bilinear MC, same chain with the DC terms through the 2x2 Hadamard ----
+    int cnz = 0, cdc = 0;
+    uint32_t cpred4 = 0;
+    int cd[4] = {0, 0, 0, 0};
+    if (lane < 32) {
+        const int dx = mvx & 7, dy = mvy & 7;
+        const int o = cy * 12 + cxo + cx;
+        const uint32_t A = lds_ld4(s_cw[cpl], o), B = lds_ld4(s_cw[cpl], o + 1), Cc = lds_ld4(s_cw[cpl], o + 12), D = lds_ld4(s_cw[cpl], o + 13);
+        const int w00 = (8 - dx) * (8 - dy), w10 = dx * (8 - dy), w01 = (8 - dx) * dy, w11 = dx * dy;
+        int pv[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) pv[k] = (w00 * byte_of(A, k) + w10 * byte_of(B, k) + w01 * byte_of(Cc, k) + w11 * byte_of(D, k) + 32) >> 6;
+        cpred4 = pack4(pv[0], pv[1], pv[2], pv[3]);
+#pragma unroll
+        for (int k = 0; k < 4; k++) cd[k] = byte_of(csrc4, k) - pv[k];
+    }
+    fdct_quad(cd, r);   // all lanes execute the DPP exchanges; lanes >= 32 carry zeros
+    cdc = cd[0];        // valid in lanes with r == 0
+    {
+        const Quant& q = P.qc;
+        const int mf0 = (r & 1) ? q.mf[2] : q.mf[0], mf1 = (r & 1) ? q.mf[1] : q.mf[2];
+        const int dq0 = (r & 1) ? q.dq[2] : q.dq[0], dq1 = (r & 1) ? q.dq[1] : q.dq[2];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            int l = quant1(cd[c], (c & 1) ? mf1 : mf0, q.f_inter, q.qbits);
+            if (r == 0 && c == 0) l = 0;  // DC goes through the 2x2 Hadamard
+            if (lane < 32) s_lv[LV_CHROMA_AC + (cpl * 4 + cblk) * 16 + ((zz >> (4 * c)) & 15)] = (int16_t)l;
+            cnz += l != 0;
+            cd[c] = l * ((c & 1) ? dq1 : dq0);
+        }
+    }
+    cnz += __builtin_amdgcn_mov_dpp(cnz, 0xB1, 0xf, 0xf, false);
+    cnz += __builtin_amdgcn_mov_dpp(cnz, 0x4E, 0xf, 0xf, false);
+    int any_dc = 0;
+    {   // chroma DC: block DCs sit in lanes pl*16 + blk*4 (r == 0)
+        int dcw[2][4];
+#pragma unroll
+        for (int pl = 0; pl < 2; pl++)
+#pragma unroll
+            for (int b = 0; b < 4; b++) dcw[pl][b] = __builtin_amdgcn_readlane(cdc, pl * 16 + b * 4);
+#pragma unroll
+        for (int pl = 0; pl < 2; pl++) {
+            int lv[4], deq[4];
+            chroma_dc(dcw[pl], P.qc, P.qc.f_inter, lv, deq);
+            any_dc |= lv[0] | lv[1] | lv[2] | lv[3];
+            if (lane == pl)
+#pragma unroll
+                for (int i = 0; i < 4; i++) s_lv[LV_CHROMA_DC + pl * 4 + i] = (int16_t)lv[i];
+            if (lane < 32 && cpl == pl && r == 0) cd[0] = cblk == 0 ? deq[0] : (cblk == 1 ? deq[1] : (cblk == 2 ? deq[2] : deq[3]));
+        }
+    }
+    idct_quad(cd, r);
+    if (lane < 32)
+        *(uint32_t*)(P.rec[1 + cpl] + (size_t)(8 * my + cy) * cs + 8 * mx + cx) =
+            pack4(clip255(byte_of(cpred4, 0) + cd[0]), clip255(byte_of(cpred4, 1) + cd[1]), clip255(byte_of(cpred4, 2) + cd[2]), clip255(byte_of(cpred4, 3) + cd[3]));
+    const unsigned long long cmask = __ballot(lane < 32 && cnz != 0);
+    const int cbp_chroma = cmask ? 2 : (any_dc ? 1 : 0);
+    const int cbp = cbp_luma | (cbp_chroma << 4);
+    if (lane < 32 && r == 0) m->tc[16 + cpl * 4 + cblk] = (uint8_t)(cbp_chroma == 2 ? cnz : 0);
+    if (lane == 0) {
+        m->type = (cbp == 0 && skip.x == mvx && skip.y == mvy) ? MB_PSKIP : MB_P16;
+        m->i16_mode = 0; m->chroma_mode = 0; m->cbp = (uint8_t)cbp;
+        P.mvd[2 * mbi] = (int16_t)(mvx - pred.x);
+        P.mvd[2 * mbi + 1] = (int16_t)(mvy - pred.y);
+    }
+    __syncthreads();
+    if (lane < LV_STRIDE * 2 / 16) ((uint4*)(P.levels + (size_t)mbi * LV_STRIDE))[lane] = ((const uint4*)s_lv)[lane];
+}
+
+}  // namespace h264

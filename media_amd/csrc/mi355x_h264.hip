@@ -22,6 +22,7 @@
 #include "k_intra.h"
 #include "k_me.h"
 #include "k_pmb.h"
+#include "k_pmb2.h"
 
 using namespace h264;
 
@@ -177,6 +178,7 @@ struct mi355x_h264_encoder {
     uint32_t* d_bs = nullptr;                // boundary strengths, 32 B per macroblock
     unsigned serial = 0;
     bool diag_mode = false;                  // debug: one launch per wavefront step instead
+    bool pmb_v1 = false;                     // debug: first form of the MC+DCT kernel (k_pmb.h)
     uint8_t* d_stage = nullptr;              // device copy of a host-supplied picture
     uint8_t* d_stage2 = nullptr;             // device copy of a host-supplied NV12 picture
     uint8_t* h_stage = nullptr;              // pinned staging for strided host input
@@ -329,7 +331,9 @@ int submit(mi355x_h264_encoder* e, const uint8_t* d_src, int slot_idx)
         { StatScope sc(e, &S, MI355X_H264_K_ME, 1, (uint32_t)e->nmb);
           hipLaunchKernelGGL(k_me, dim3(e->nmb), dim3(64), 0, st, P); }
         { StatScope sc(e, &S, MI355X_H264_K_PMB, 1, (uint32_t)e->nmb);
-          hipLaunchKernelGGL(k_pmb, dim3(e->nmb), dim3(64), 0, st, P); }
+          if (getenv("MI355X_H264_DBG_PRED")) P.lambda = -1;
+          if (e->pmb_v1) hipLaunchKernelGGL(k_pmb, dim3(e->nmb), dim3(64), 0, st, P);
+          else hipLaunchKernelGGL(k_pmb2, dim3(e->nmb), dim3(64), 0, st, P); }
     }
     // entropy coding
     uint64_t hdr = 0;
@@ -506,6 +510,7 @@ int mi355x_h264_create(const mi355x_h264_config* cfg, mi355x_h264_encoder** out)
     CK(hipMalloc((void**)&e->d_bs, (size_t)e->nmb * 32));
     CK(hipMemset(e->d_err, 0, sizeof(unsigned)));
     e->diag_mode = getenv("MI355X_H264_DIAG") != nullptr;
+    e->pmb_v1 = getenv("MI355X_H264_PMB_V1") != nullptr;
     e->frame_bytes = (size_t)cfg->width * cfg->height * 3 / 2;
     CK(hipMalloc((void**)&e->d_stage, e->frame_bytes + 256));
     CK(hipMalloc((void**)&e->d_stage2, e->frame_bytes + 256));
