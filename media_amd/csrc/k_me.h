@@ -14,17 +14,18 @@
 // kernel is one launch over all macroblocks.
 #pragma once
 #include "dev_common.h"
+#include "k_pmb2.h"   // lds_ld4 / htap4 / vtap4 / avg4 / round5_pack helpers
 
 namespace h264 {
 
-enum { ME_R = 16, ME_AP = 4, ME_WS = 16 + 2 * ME_R + 2 * ME_AP, ME_WDW = ME_WS / 4, ME_GS = 18 };
+enum { ME_R = 16, ME_AP = 4, ME_WS = 16 + 2 * ME_R + 2 * ME_AP, ME_WDW = ME_WS / 4, ME_GS = 18, ME_GP = 20, ME_PLS = ME_GS * ME_GP };
 
 // two-tap description of every quarter-sample position: pred = (T0 + T1 + 1) >> 1
 // with Tk read from plane pk at grid offset (dxk, dyk); planes 0 G, 1 b, 2 h, 3 j
 __device__ __forceinline__ void qpel_taps(int fx, int fy, int& o0, int& o1)
 {
-    const int PL = ME_GS * ME_GS;
-    const int G = 0, B = PL, H = 2 * PL, J = 3 * PL, R = 1, D = ME_GS;
+    const int PL = ME_PLS;
+    const int G = 0, B = PL, H = 2 * PL, J = 3 * PL, R = 1, D = ME_GP;
     switch (fy * 4 + fx) {
         case 0: o0 = G; o1 = G; break;
         case 1: o0 = G; o1 = B; break;
@@ -55,8 +56,8 @@ __global__ __launch_bounds__(64, 4) void k_me(FrameParams P)
     __shared__ __attribute__((aligned(16))) uint8_t s_src[256];
     __shared__ __attribute__((aligned(16))) uint8_t s_srcc[128];
     __shared__ __attribute__((aligned(16))) uint8_t s_refc[128];
-    __shared__ int16_t s_b1[(ME_GS + 5) * ME_GS];
-    __shared__ uint8_t s_pl[4 * ME_GS * ME_GS];
+    __shared__ __attribute__((aligned(16))) int16_t s_b1[(ME_GS + 5) * ME_GP];   // pitch 20 int16
+    __shared__ __attribute__((aligned(16))) uint8_t s_pl[4 * ME_PLS + 16];        // planes G,b,h,j: 18 rows, pitch 20
 
     load_src_mb(P, mx, my, s_src, s_srcc, lane);
     // reference window, clamped at the picture edge (unrestricted motion vectors).  All 13 requests of a
@@ -201,36 +202,52 @@ __global__ __launch_bounds__(64, 4) void k_me(FrameParams P)
     return;
 #endif
 
-    // ---- 3. half-sample planes on an 18x18 grid, origin (ix-1, iy-1) ----
-    const uint8_t* o = winb + (iy + ME_R + ME_AP - 1) * ME_WS + ix + ME_R + ME_AP - 1;
-    for (int i = lane; i < (ME_GS + 5) * ME_GS; i += 64) {
-        const int y = i / ME_GS - 2, x = i % ME_GS;
-        const uint8_t* p = o + y * ME_WS + x;
-        s_b1[i] = (int16_t)(p[-2] - 5 * p[-1] + 20 * p[0] + 20 * p[1] - 5 * p[2] + p[3]);
+    // ---- 3. half-sample planes on an 18x18 grid, origin (ix-1, iy-1); four samples per lane-task ----
+    const int oo = (iy + ME_R + ME_AP - 1) * ME_WS + ix + ME_R + ME_AP - 1;   // window byte offset of grid (0,0)
+    for (int i = lane; i < (ME_GS + 5) * 5; i += 64) {
+        const int rr = i / 5, seg = (i - rr * 5) * 4;                          // b1 row rr <-> grid row rr - 2
+        int t[4];
+        htap4(winb, oo + (rr - 2) * ME_WS + seg - 2, t);
+        *(uint2*)(s_b1 + rr * ME_GP + seg) = make_uint2((uint32_t)(t[0] & 0xFFFF) | ((uint32_t)t[1] << 16), (uint32_t)(t[2] & 0xFFFF) | ((uint32_t)t[3] << 16));
     }
     __syncthreads();
-    for (int i = lane; i < ME_GS * ME_GS; i += 64) {
-        const int y = i / ME_GS, x = i % ME_GS;
-        const uint8_t* p = o + y * ME_WS + x;
-        s_pl[i] = p[0];
-        s_pl[ME_GS * ME_GS + i] = (uint8_t)clip255((s_b1[(y + 2) * ME_GS + x] + 16) >> 5);
-        s_pl[2 * ME_GS * ME_GS + i] = (uint8_t)clip255(
-            (p[-2 * ME_WS] - 5 * p[-ME_WS] + 20 * p[0] + 20 * p[ME_WS] - 5 * p[2 * ME_WS] + p[3 * ME_WS] + 16) >> 5);
-        const int16_t* q = s_b1 + y * ME_GS + x;
-        s_pl[3 * ME_GS * ME_GS + i] = (uint8_t)clip255(
-            (q[0] - 5 * q[ME_GS] + 20 * q[2 * ME_GS] + 20 * q[3 * ME_GS] - 5 * q[4 * ME_GS] + q[5 * ME_GS] + 512) >> 10);
+    for (int i = lane; i < ME_GS * 5; i += 64) {
+        const int y = i / 5, seg = (i - y * 5) * 4;
+        const uint32_t Gv = lds_ld4(winb, oo + y * ME_WS + seg);
+        int t[4];
+        {
+            const int16_t* q = s_b1 + (y + 2) * ME_GP + seg;
+            const uint2 w = *(const uint2*)q;
+            t[0] = (int)(int16_t)(w.x & 0xFFFF); t[1] = (int)(int16_t)(w.x >> 16); t[2] = (int)(int16_t)(w.y & 0xFFFF); t[3] = (int)(int16_t)(w.y >> 16);
+        }
+        const uint32_t Bv = round5_pack(t);
+        vtap4(winb, oo + (y - 2) * ME_WS + seg, ME_WS, t);
+        const uint32_t Hv = round5_pack(t);
+        {
+            uint2 rw[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) rw[k] = *(const uint2*)(s_b1 + (y + k) * ME_GP + seg);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                int e[6];
+#pragma unroll
+                for (int m = 0; m < 6; m++) e[m] = (int)(int16_t)(((k & 2) ? rw[m].y : rw[m].x) >> ((k & 1) * 16));
+                t[k] = opaque(clip255((e[0] + e[5] - 5 * (e[1] + e[4]) + 20 * (e[2] + e[3]) + 512) >> 10));
+            }
+        }
+        const uint32_t Jv = pack4(t[0], t[1], t[2], t[3]);
+        *(uint32_t*)(s_pl + y * ME_GP + seg) = Gv;
+        *(uint32_t*)(s_pl + ME_PLS + y * ME_GP + seg) = Bv;
+        *(uint32_t*)(s_pl + 2 * ME_PLS + y * ME_GP + seg) = Hv;
+        *(uint32_t*)(s_pl + 3 * ME_PLS + y * ME_GP + seg) = Jv;
     }
     __syncthreads();
 
     // ---- 4. sub-pel refinement: 4 candidates per round, 16 lanes (4x4 blocks) each ----
     const int grp = lane >> 4, blk = lane & 15, b4x = (blk & 3) * 4, b4y = (blk >> 2) * 4;
-    int sd[16];
+    uint32_t sp[4];
 #pragma unroll
-    for (int y = 0; y < 4; y++) {
-        const uint32_t v = *(const uint32_t*)(s_src + (b4y + y) * 16 + b4x);
-#pragma unroll
-        for (int x = 0; x < 4; x++) sd[4 * y + x] = (int)((v >> (8 * x)) & 255);
-    }
+    for (int y = 0; y < 4; y++) sp[y] = *(const uint32_t*)(s_src + (b4y + y) * 16 + b4x);
     int cx = 4 * ix, cy = 4 * iy;
     unsigned best_cost = 0;
 #pragma unroll 1
@@ -252,14 +269,14 @@ __global__ __launch_bounds__(64, 4) void k_me(FrameParams P)
             int t0, t1;
             qpel_taps(ox & 3, oy & 3, t0, t1);
             int d[16];
-            const int gb = (gy + b4y) * ME_GS + gx + b4x;
+            const int gb = (gy + b4y) * ME_GP + gx + b4x;
 #pragma unroll
-            for (int y = 0; y < 4; y++)
+            for (int y = 0; y < 4; y++) {
+                const uint32_t pa = lds_ld4(s_pl, t0 + gb + y * ME_GP), pb = lds_ld4(s_pl, t1 + gb + y * ME_GP);
+                const uint32_t pr = avg4(pa, pb);
 #pragma unroll
-                for (int x = 0; x < 4; x++) {
-                    const int g = gb + y * ME_GS + x;
-                    d[4 * y + x] = sd[4 * y + x] - (((int)s_pl[t0 + g] + (int)s_pl[t1 + g] + 1) >> 1);
-                }
+                for (int x = 0; x < 4; x++) d[4 * y + x] = byte_of(sp[y], x) - byte_of(pr, x);
+            }
             int s = hadamard_abs(d);
             s = group_sum<16>(s);
             const unsigned cost = (unsigned)(s >> 1) + (unsigned)(P.lambda * (se_len(qx) + se_len(qy)));
