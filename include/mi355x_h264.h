@@ -70,7 +70,9 @@ typedef struct mi355x_h264_config {
     int32_t qp;              /* picture QP for FIXED_QP (10..51); initial QP else   */
     int32_t device;          /* HIP device ordinal                                  */
     int32_t disable_deblock; /* iLoopFilterDisableIdc (ref :295), 0 = filter on     */
-    int32_t reserved[5];
+    int32_t batch;           /* closed GOPs (or independent streams) encoded in lockstep by one instance,
+                              * 1..32; > 1 is driven through mi355x_h264_encode_gops_device only      */
+    int32_t reserved[4];
 } mi355x_h264_config;
 
 typedef struct mi355x_h264_encoder mi355x_h264_encoder;
@@ -107,6 +109,16 @@ int mi355x_h264_encode_nv12_device(mi355x_h264_encoder *enc, const void *d_nv12,
 int mi355x_h264_encode_batch_device(mi355x_h264_encoder *enc, const void *d_frames,
                                     size_t frame_stride_bytes, int count, uint8_t *host_out,
                                     size_t out_cap, uint32_t *sizes, size_t *total_len);
+
+/* Lockstep encode of `batch` closed GOPs (config.batch): picture t of GOP g is read from
+ * d_frames + g*gop_stride + t*frame_stride (device memory, tight I420).  Every kernel runs once per
+ * picture index over all GOPs (grid.y = batch), so the launches are `batch` times larger instead of
+ * `batch` times more numerous.  The first picture of every GOP is an IDR; idr_pic_id of GOP g is
+ * next + g*step (set_idr_pic_id), so consecutive GOPs concatenate to the serial stream.  GOP g's access
+ * units are appended at host_out + g*out_cap_per_gop; sizes[g*frames_per_gop + t], gop_bytes[g]. */
+int mi355x_h264_encode_gops_device(mi355x_h264_encoder *enc, const void *d_frames, size_t frame_stride,
+                                   size_t gop_stride, int frames_per_gop, uint8_t *host_out,
+                                   size_t out_cap_per_gop, uint32_t *sizes, size_t *gop_bytes);
 
 int mi355x_h264_force_idr(mi355x_h264_encoder *enc);
 /* picture QP (10..51) for the pictures that follow; the hook the rate controller

@@ -24,6 +24,7 @@ EXPORTS = [
     "mi355x_h264_force_idr", "mi355x_h264_last_error", "mi355x_h264_coded_width", "mi355x_h264_coded_height",
     "mi355x_h264_debug_keep_pre", "mi355x_h264_debug_read", "mi355x_h264_stats_enable", "mi355x_h264_stats_read",
     "mi355x_h264_set_qp", "mi355x_h264_set_idr_pic_id", "mi355x_h264_encode_nv12", "mi355x_h264_encode_nv12_device",
+    "mi355x_h264_encode_gops_device",
 ]
 
 
@@ -31,7 +32,7 @@ class Config(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("width", C.c_int32), ("height", C.c_int32), ("fps", C.c_int32),
                 ("bitrate", C.c_int32), ("gop", C.c_int32), ("profile_idc", C.c_int32), ("rc_mode", C.c_int32),
                 ("qp", C.c_int32), ("device", C.c_int32), ("disable_deblock", C.c_int32),
-                ("reserved", C.c_int32 * 5)]
+                ("batch", C.c_int32), ("reserved", C.c_int32 * 4)]
 
 
 class Stats(C.Structure):
@@ -61,6 +62,7 @@ def lib():
         L.mi355x_h264_encode_nv12_device.argtypes = [vp, vp, C.POINTER(vp), C.POINTER(C.c_uint32), C.POINTER(C.c_int)]
         L.mi355x_h264_encode_batch_device.argtypes = [vp, vp, C.c_size_t, C.c_int, vp, C.c_size_t, vp,
                                                       C.POINTER(C.c_size_t)]
+        L.mi355x_h264_encode_gops_device.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_int, vp, C.c_size_t, vp, vp]
         L.mi355x_h264_force_idr.argtypes = [vp]
         L.mi355x_h264_set_qp.argtypes = [vp, C.c_int]
         L.mi355x_h264_set_idr_pic_id.argtypes = [vp, C.c_int, C.c_int]
@@ -85,13 +87,14 @@ class Encoder:
     """thin object wrapper; argument meaning follows mi355x_h264_config"""
 
     def __init__(self, width, height, qp=26, gop=30, fps=30, profile_idc=66, device=0, disable_deblock=0,
-                 bitrate=5000000, rc_mode=0):
+                 bitrate=5000000, rc_mode=0, batch=1):
         L = lib()
         cfg = Config()
         L.mi355x_h264_default_config(C.byref(cfg))
         cfg.width, cfg.height, cfg.qp, cfg.gop, cfg.fps = width, height, qp, gop, fps
         cfg.profile_idc, cfg.device, cfg.disable_deblock = profile_idc, device, disable_deblock
-        cfg.bitrate, cfg.rc_mode = bitrate, rc_mode
+        cfg.bitrate, cfg.rc_mode, cfg.batch = bitrate, rc_mode, batch
+        self.batch = batch
         self.h = C.c_void_p()
         rc = L.mi355x_h264_create(C.byref(cfg), C.byref(self.h))
         if rc != 0:
@@ -136,6 +139,13 @@ class Encoder:
                                                           out_buf.ctypes.data, out_buf.size, sizes.ctypes.data,
                                                           C.byref(tot)))
         return tot.value
+
+    def encode_gops_device(self, dev_ptr, frame_stride, gop_stride, frames_per_gop, out_buf, out_cap_per_gop, sizes, gop_bytes):
+        """lockstep encode of `batch` closed GOPs; out_buf uint8[batch*out_cap_per_gop], sizes uint32[batch*frames],
+        gop_bytes uint64[batch]"""
+        self._check(lib().mi355x_h264_encode_gops_device(self.h, C.c_void_p(dev_ptr), frame_stride, gop_stride, frames_per_gop,
+                                                         out_buf.ctypes.data, out_cap_per_gop, sizes.ctypes.data,
+                                                         gop_bytes.ctypes.data))
 
     def force_idr(self):
         self._check(lib().mi355x_h264_force_idr(self.h))

@@ -45,7 +45,24 @@ struct FrameParams {
     int16_t* mvd;        // 2 int16 per macroblock (mv - predictor)
     Quant qy, qc;        // luma / chroma quantisers
     int lambda;
+    // lockstep batch (gridDim.y = number of independent closed GOPs / streams encoded together):
+    // element strides between consecutive batch items
+    size_t st_src;       // bytes between the source pictures of two batch items
+    size_t st_y, st_c;   // bytes between reconstruction planes (luma, chroma)
+    int st_mb;           // macroblocks per batch item (MbInfo / levels / mvd arrays)
 };
+
+// the parameter block of batch item g (pointers advanced by g strides)
+__device__ __forceinline__ FrameParams batch_view(FrameParams P, int g)
+{
+    P.src += (size_t)g * P.st_src;
+    P.rec[0] += (size_t)g * P.st_y; P.rec[1] += (size_t)g * P.st_c; P.rec[2] += (size_t)g * P.st_c;
+    P.ref[0] += (size_t)g * P.st_y; P.ref[1] += (size_t)g * P.st_c; P.ref[2] += (size_t)g * P.st_c;
+    P.mb += (size_t)g * P.st_mb;
+    P.levels += (size_t)g * P.st_mb * LV_STRIDE;
+    P.mvd += (size_t)g * P.st_mb * 2;
+    return P;
+}
 
 __device__ __forceinline__ int clip3(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
 __device__ __forceinline__ int clip255(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }

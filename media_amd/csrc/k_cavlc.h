@@ -252,7 +252,17 @@ struct CavlcParams {
     uint32_t* mbbits;     // per macroblock, then (after the scan) bit offsets
     uint32_t* bitbuf;     // zeroed slice payload buffer
     uint8_t* bs;          // boundary strengths for the loop filter, 32 B per macroblock (written by the count pass)
+    int st_mb;            // lockstep batch: macroblocks per batch item (all per-MB arrays)
+    size_t st_bitbuf;     // 32-bit words between the payload buffers of two batch items
 };
+__device__ __forceinline__ CavlcParams batch_view(CavlcParams C, int g)
+{
+    C.mb += (size_t)g * C.st_mb; C.levels += (size_t)g * C.st_mb * LV_STRIDE; C.mvd += (size_t)g * C.st_mb * 2;
+    C.slotbits += (size_t)g * C.st_mb * 32; C.mbbits += (size_t)g * C.st_mb; C.bitbuf += (size_t)g * C.st_bitbuf;
+    if (C.bs) C.bs += (size_t)g * C.st_mb * 32;
+    return C;
+}
+struct HdrBatch { unsigned long long bits[32]; unsigned char len[32]; };  // slice header of every batch item
 
 // 8.7.2.1 boundary strength of one 4-sample edge segment; l = (dir, edge, segment) within the macroblock.
 // Computed here because this pass already walks (macroblock, 32 lanes) over final MbInfo.
@@ -315,8 +325,9 @@ __device__ __forceinline__ void code_slot(S& s, const CavlcParams& C, int mbi, i
 }
 
 template <bool WRITE>
-__global__ __launch_bounds__(64) void k_cavlc(CavlcParams C)
+__global__ __launch_bounds__(64) void k_cavlc(CavlcParams C0)
 {
+    const CavlcParams C = batch_view(C0, blockIdx.y);
     const int lane = threadIdx.x, slot = lane & 31;
     const int mbi = blockIdx.x * 2 + (lane >> 5);
     const bool live = mbi < C.nmb;
@@ -354,8 +365,12 @@ struct SliceInfo {       // lives in pinned host memory, written by the device
 };
 
 // one workgroup of 1024: exclusive scan of mbbits (in place -> offsets), header, tail
-__global__ __launch_bounds__(1024) void k_bit_scan(CavlcParams C, unsigned long long hdr_bits, int hdr_len, SliceInfo* info)
+__global__ __launch_bounds__(1024) void k_bit_scan(CavlcParams C0, HdrBatch H, SliceInfo* info0)
 {
+    const CavlcParams C = batch_view(C0, blockIdx.x);
+    const unsigned long long hdr_bits = H.bits[blockIdx.x];
+    const int hdr_len = H.len[blockIdx.x];
+    SliceInfo* info = info0 + blockIdx.x;
     __shared__ unsigned s_part[1024];
     const int t = threadIdx.x;
     const int per = (C.nmb + 1023) / 1024;
@@ -404,8 +419,13 @@ __global__ __launch_bounds__(1024) void k_bit_scan(CavlcParams C, unsigned long 
 
 // Copy the payload to the pinned access unit, count emulation-prevention sites, publish SliceInfo to
 // pinned host memory and leave the device bit buffer zeroed for its next use (one workgroup).
-__global__ __launch_bounds__(1024) void k_pack(uint8_t* bitbuf, uint8_t* dst, const SliceInfo* info, SliceInfo* host_info)
+__global__ __launch_bounds__(1024) void k_pack(uint8_t* bitbuf0, size_t st_bitbuf_bytes, uint8_t* dst0, size_t st_dst, const SliceInfo* info0,
+                                               SliceInfo* host_info0)
 {
+    uint8_t* bitbuf = bitbuf0 + (size_t)blockIdx.x * st_bitbuf_bytes;
+    uint8_t* dst = dst0 + (size_t)blockIdx.x * st_dst;
+    const SliceInfo* info = info0 + blockIdx.x;
+    SliceInfo* host_info = host_info0 + blockIdx.x;
     __shared__ unsigned s_cnt;
     if (threadIdx.x == 0) s_cnt = 0;
     __syncthreads();

@@ -91,7 +91,7 @@ __device__ __forceinline__ int edge_bs(const MbInfo* p, int bp, const MbInfo* q,
 enum { DB_LP = 24, DB_CP = 12 };  // LDS pitches: luma 20 wide, chroma 10 wide (4 / 2 apron)
 
 __global__ __launch_bounds__(64) void k_deblock_diag(DbParams D, int s)
-{
+{   // (single-item debug form: no batch dimension)
     const int lane = threadIdx.x;
     // macroblocks with mx + 2*my == s
     const int ymin = max(0, (s - (D.mbw - 1) + 1) >> 1);
@@ -207,6 +207,9 @@ struct DbRowParams {
     const uint32_t* bs;  // [nmb][8]: boundary strengths (k_cavlc count pass), word dir*4+edge, byte = segment along the edge
     unsigned* err;
     unsigned serial;     // changes every picture, never 0
+    // lockstep batch strides (gridDim.y items)
+    size_t st_y, st_c, st_handoff;   // bytes, bytes, u64 words
+    int st_mb;
 };
 
 // One edge, one line of samples held in registers, branch-free so that luma and
@@ -245,7 +248,13 @@ enum { DR_LP = 40, DR_CP = 24 };  // LDS pitches; luma tile cols -16..15 (+4 pad
 template <bool BS4>
 __global__ __launch_bounds__(64) void k_deblock_rows(DbRowParams R)
 {
-    const DbParams& D = R.d;
+    DbParams D = R.d;
+    {
+        const size_t g = blockIdx.y;
+        D.pl[0] += g * R.st_y; D.pl[1] += g * R.st_c; D.pl[2] += g * R.st_c; D.mb += g * R.st_mb;
+    }
+    u64* const handoff = R.handoff + (size_t)blockIdx.y * R.st_handoff;
+    const uint32_t* const bsw = R.bs + (size_t)blockIdx.y * R.st_mb * 8;
     const int lane = threadIdx.x, my = blockIdx.x, cs = D.cw / 2;
     const bool last_row = my == D.mbh - 1;
     __shared__ __attribute__((aligned(16))) uint8_t s_y[20 * DR_LP];     // [row+4][col+16]
@@ -274,9 +283,9 @@ __global__ __launch_bounds__(64) void k_deblock_rows(DbRowParams R)
     auto prefetch = [&](int mx) {
         pf_y = *(const uint32_t*)(D.pl[0] + (size_t)(16 * my + yr) * D.cw + 16 * mx + yc4);
         if (lane < 32) pf_c = *(const uint32_t*)(D.pl[1 + cpl_l] + (size_t)(8 * my + cr_l) * cs + 8 * mx + cc4);
-        const uint4* b = (const uint4*)(R.bs + ((size_t)my * D.mbw + mx) * 8);
+        const uint4* b = (const uint4*)(bsw + ((size_t)my * D.mbw + mx) * 8);
         pf_b0 = b[0]; pf_b1 = b[1];
-        if (my > 0 && lane < 24) pf_g = AT_LOAD(R.handoff + ((size_t)(my - 1) * D.mbw + mx) * 24 + gk);
+        if (my > 0 && lane < 24) pf_g = AT_LOAD(handoff + ((size_t)(my - 1) * D.mbw + mx) * 24 + gk);
     };
     prefetch(0);
 
@@ -304,7 +313,7 @@ __global__ __launch_bounds__(64) void k_deblock_rows(DbRowParams R)
                     if (__ballot(bad) == 0ull) break;
                     if (++spins > (1u << 20)) { timed_out = true; break; }
                     __builtin_amdgcn_s_sleep(1);
-                    if (lane < 24) g = AT_LOAD(R.handoff + ((size_t)(my - 1) * D.mbw + mx) * 24 + gk);
+                    if (lane < 24) g = AT_LOAD(handoff + ((size_t)(my - 1) * D.mbw + mx) * 24 + gk);
                 }
                 if (lane < 16) *(uint32_t*)&SY(-4 + (gk >> 2), (gk & 3) * 4) = (uint32_t)g;
                 else if (lane < 24) *(uint32_t*)&SC((gk - 16) >> 2, -2 + (((gk - 16) >> 1) & 1), ((gk - 16) & 1) * 4) = (uint32_t)g;
@@ -373,7 +382,7 @@ __global__ __launch_bounds__(64) void k_deblock_rows(DbRowParams R)
                 uint32_t v;
                 if (lane < 16) v = *(const uint32_t*)&SY(12 + (gk >> 2), co + (gk & 3) * 4);
                 else v = *(const uint32_t*)&SC((gk - 16) >> 2, 6 + (((gk - 16) >> 1) & 1), cco + ((gk - 16) & 1) * 4);
-                AT_STORE(R.handoff + ((size_t)my * D.mbw + pmx) * 24 + gk, ((u64)R.serial << 32) | v);
+                AT_STORE(handoff + ((size_t)my * D.mbw + pmx) * 24 + gk, ((u64)R.serial << 32) | v);
             }
         }
         __syncthreads();

@@ -250,8 +250,9 @@ __device__ __forceinline__ void intra_mb_core(const FrameParams& P, int mx, int 
 }
 
 // one anti-diagonal per launch (kept as the simple reference form; MI355X_H264_DIAG=1 selects it)
-__global__ __launch_bounds__(64) void k_intra_diag(FrameParams P, int s)
+__global__ __launch_bounds__(64) void k_intra_diag(FrameParams P0, int s)
 {
+    const FrameParams P = batch_view(P0, blockIdx.y);
     const int lane = threadIdx.x;
     const int ymin = max(0, s - P.mbw + 1);
     const int my = ymin + blockIdx.x, mx = s - my;
@@ -287,14 +288,16 @@ __global__ __launch_bounds__(64) void k_intra_diag(FrameParams P, int s)
 // ===========================================================================
 struct IntraRowParams {
     FrameParams p;
-    unsigned long long* handoff;  // [mbh][mbw][8]
+    unsigned long long* handoff;  // [batch][mbh][mbw][8]
+    size_t st_handoff;            // u64 words between batch items
     unsigned* err;                // pinned host word
     unsigned serial;
 };
 
 __global__ __launch_bounds__(64) void k_intra_rows(IntraRowParams R)
 {
-    const FrameParams& P = R.p;
+    const FrameParams P = batch_view(R.p, blockIdx.y);
+    unsigned long long* const handoff = R.handoff + (size_t)blockIdx.y * R.st_handoff;
     const int lane = threadIdx.x, my = blockIdx.x;
     __shared__ IntraLds S;
     bool timed_out = false;
@@ -329,7 +332,7 @@ __global__ __launch_bounds__(64) void k_intra_rows(IntraRowParams R)
                 for (int k = 0; k < 4; k++) pf_c |= (uint32_t)src_px(Cp, pw, ph, gx + k, gy) << (8 * k);
             }
         }
-        if (my > 0 && lane < 8) pf_g = __hip_atomic_load(R.handoff + ((size_t)(my - 1) * P.mbw + mx) * 8 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (my > 0 && lane < 8) pf_g = __hip_atomic_load(handoff + ((size_t)(my - 1) * P.mbw + mx) * 8 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
     prefetch(0);
     for (int mx = 0; mx < P.mbw; mx++) {
@@ -354,7 +357,7 @@ __global__ __launch_bounds__(64) void k_intra_rows(IntraRowParams R)
                 if (__ballot(bad) == 0ull) break;
                 if (++spins > (1u << 20)) { timed_out = true; break; }
                 __builtin_amdgcn_s_sleep(1);
-                if (lane < 8) g = __hip_atomic_load(R.handoff + ((size_t)(my - 1) * P.mbw + mx) * 8 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane < 8) g = __hip_atomic_load(handoff + ((size_t)(my - 1) * P.mbw + mx) * 8 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             // granules 0..3 luma samples 0..15 -> top[1..16]; 4,5 Cb -> ctop[0][1..8]; 6,7 Cr -> ctop[1][1..8]
             if (lane < 8) {
@@ -371,7 +374,7 @@ __global__ __launch_bounds__(64) void k_intra_rows(IntraRowParams R)
             uint32_t v;
             if (lane < 4) v = *(const uint32_t*)(S.rec_y + 15 * 16 + 4 * lane);
             else v = *(const uint32_t*)(S.rec_c + ((lane - 4) >> 1) * 64 + 7 * 8 + 4 * (lane & 1));
-            __hip_atomic_store(R.handoff + ((size_t)my * P.mbw + mx) * 8 + lane, ((unsigned long long)R.serial << 32) | v,
+            __hip_atomic_store(handoff + ((size_t)my * P.mbw + mx) * 8 + lane, ((unsigned long long)R.serial << 32) | v,
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();

@@ -46,8 +46,9 @@ __device__ __forceinline__ void qpel_taps(int fx, int fy, int& o0, int& o1)
     }
 }
 
-__global__ __launch_bounds__(64, 4) void k_me(FrameParams P)
+__global__ __launch_bounds__(64, 4) void k_me(FrameParams P0)
 {
+    const FrameParams P = batch_view(P0, blockIdx.y);
     const int lane = threadIdx.x;
     const int mbi = xcd_mb_index(blockIdx.x, P.mbw * P.mbh), mx = mbi % P.mbw, my = mbi / P.mbw;
     const int bx = 16 * mx, by = 16 * my;

@@ -54,8 +54,9 @@ __device__ __forceinline__ void chroma_dc(const int dcw[4], const Quant& q, int 
     for (int i = 0; i < 4; i++) deq[i] = (fi[i] * 16 * q.dq[0]) >> 5;
 }
 
-__global__ __launch_bounds__(64) void k_pmb(FrameParams P)
+__global__ __launch_bounds__(64) void k_pmb(FrameParams P0)
 {
+    const FrameParams P = batch_view(P0, blockIdx.y);
     const int lane = threadIdx.x;
     const int mbi = xcd_mb_index(blockIdx.x, P.mbw * P.mbh), mx = mbi % P.mbw, my = mbi / P.mbw;
     const int bx = 16 * mx, by = 16 * my, cs = P.cw / 2;

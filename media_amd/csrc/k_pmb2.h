@@ -110,8 +110,9 @@ __device__ __forceinline__ void idct_quad(int d[4], int r)
 
 __constant__ const uint16_t c_zz_row[4] = {0x6510, 0xC742, 0xDB83, 0xFEA9};  // zig-zag index of raster (r, c), nibble c
 
-__global__ __launch_bounds__(64) void k_pmb2(FrameParams P)
+__global__ __launch_bounds__(64) void k_pmb2(FrameParams P0)
 {
+    const FrameParams P = batch_view(P0, blockIdx.y);
     const int lane = threadIdx.x;
     const int mbi = xcd_mb_index(blockIdx.x, P.mbw * P.mbh), mx = mbi % P.mbw, my = mbi / P.mbw;
     const int bx = 16 * mx, by = 16 * my, cs = P.cw / 2;

@@ -163,6 +163,8 @@ struct mi355x_h264_encoder {
     mi355x_h264_config cfg{};
     int mbw = 0, mbh = 0, cw = 0, ch = 0, nmb = 0, level_idc = 0;
     int device = 0;
+    int G = 1;                               // lockstep batch: closed GOPs / streams encoded together
+    size_t st_y = 0, st_c = 0, st_bitbuf_bytes = 0, st_au = 0, st_handoff = 0;  // per-item strides
     hipStream_t stream = nullptr;
     uint8_t* d_planes[2][3] = {{nullptr}};  // ping-pong: [cur][plane]
     uint8_t* d_pre[3] = {nullptr};           // copy of the reconstruction before the loop filter (debug)
@@ -173,7 +175,6 @@ struct mi355x_h264_encoder {
     uint16_t* d_slotbits = nullptr;
     uint32_t* d_mbbits = nullptr;
     unsigned long long* d_handoff = nullptr; // row-to-row hand-off of the wavefront kernels
-    unsigned* d_progress = nullptr;          // [2][mbh]: deblock rows, intra rows
     unsigned* d_err = nullptr;
     uint32_t* d_bs = nullptr;                // boundary strengths, 32 B per macroblock
     unsigned serial = 0;
@@ -186,7 +187,7 @@ struct mi355x_h264_encoder {
     Slot slots[NSLOT];
     int next_slot = 0;
     std::vector<uint8_t> sps_pps;            // Annex-B SPS + PPS NALs
-    std::vector<uint8_t> esc_buf;            // slow path: escaped access unit
+    std::vector<std::vector<uint8_t>> esc_buf;  // slow path: escaped access unit, per batch item
     long frames = 0;
     int frame_in_gop = 0, frame_num = 0, idr_id = 0, idr_step = 1, force_idr = 0;
     int qp = 26;
@@ -254,14 +255,14 @@ void build_parameter_sets(mi355x_h264_encoder* e)
 }
 
 // slice_header() of 7.3.3 for this build's fixed choices; returns bit count (< 64)
-int build_slice_header(const mi355x_h264_encoder* e, bool idr, uint64_t* bits)
+int build_slice_header(const mi355x_h264_encoder* e, bool idr, int idr_id, uint64_t* bits)
 {
     HostBits h;
     h.ue(0);
     h.ue(idr ? 7 : 5);
     h.ue(0);
     h.put(8, (uint32_t)e->frame_num);
-    if (idr) h.ue((uint32_t)e->idr_id);
+    if (idr) h.ue((uint32_t)idr_id);
     if (!idr) { h.put(1, 0); h.put(1, 0); }
     if (idr) { h.put(1, 0); h.put(1, 0); } else h.put(1, 0);
     h.se(e->qp - 26);
@@ -294,7 +295,7 @@ struct StatScope {
 };
 
 // enqueue everything for one picture whose I420 samples are at d_src
-int submit(mi355x_h264_encoder* e, const uint8_t* d_src, int slot_idx)
+int submit(mi355x_h264_encoder* e, const uint8_t* d_src, size_t src_item_stride, int slot_idx)
 {
     Slot& S = e->slots[slot_idx];
     const bool idr = e->force_idr || e->frames == 0 || e->frame_in_gop >= e->cfg.gop;
@@ -306,6 +307,8 @@ int submit(mi355x_h264_encoder* e, const uint8_t* d_src, int slot_idx)
     P.cw = e->cw; P.ch = e->ch; P.mbw = e->mbw; P.mbh = e->mbh;
     for (int p = 0; p < 3; p++) { P.rec[p] = e->d_planes[cur][p]; P.ref[p] = e->d_planes[prev][p]; }
     P.mb = e->d_mb; P.levels = e->d_levels; P.mvd = e->d_mvd;
+    P.st_src = src_item_stride; P.st_y = e->st_y; P.st_c = e->st_c; P.st_mb = e->nmb;
+    const unsigned G = (unsigned)e->G;
     fill_quant(P.qy, e->qp);
     fill_quant(P.qc, h_chroma_qp[e->qp]);
     P.lambda = h_lambda[e->qp];
@@ -314,40 +317,45 @@ int submit(mi355x_h264_encoder* e, const uint8_t* d_src, int slot_idx)
     // (the payload buffer of this slot was left zeroed by the k_pack of its previous use)
 
     if (idr) {
-        StatScope sc(e, &S, MI355X_H264_K_INTRA, (uint32_t)(e->diag_mode ? e->mbw + e->mbh - 1 : 1), (uint32_t)e->nmb);
+        StatScope sc(e, &S, MI355X_H264_K_INTRA, (uint32_t)(e->diag_mode ? e->mbw + e->mbh - 1 : 1), (uint32_t)(e->nmb * e->G));
         if (e->diag_mode) {
             for (int s = 0; s < e->mbw + e->mbh - 1; s++) {
                 const int ymin = std::max(0, s - e->mbw + 1), ymax = std::min(e->mbh - 1, s);
-                hipLaunchKernelGGL(k_intra_diag, dim3(ymax - ymin + 1), dim3(64), 0, st, P, s);
+                hipLaunchKernelGGL(k_intra_diag, dim3(ymax - ymin + 1, G), dim3(64), 0, st, P, s);
             }
         } else {
             IntraRowParams R{};
-            R.p = P; R.handoff = e->d_handoff; R.err = S.h_err;
+            R.p = P; R.handoff = e->d_handoff; R.st_handoff = e->st_handoff; R.err = S.h_err;
             e->serial = e->serial == 0xFFFFFFFFu ? 1 : e->serial + 1;
             R.serial = e->serial;
-            hipLaunchKernelGGL(k_intra_rows, dim3(e->mbh), dim3(64), 0, st, R);
+            hipLaunchKernelGGL(k_intra_rows, dim3(e->mbh, G), dim3(64), 0, st, R);
         }
     } else {
-        { StatScope sc(e, &S, MI355X_H264_K_ME, 1, (uint32_t)e->nmb);
-          hipLaunchKernelGGL(k_me, dim3(e->nmb), dim3(64), 0, st, P); }
-        { StatScope sc(e, &S, MI355X_H264_K_PMB, 1, (uint32_t)e->nmb);
+        { StatScope sc(e, &S, MI355X_H264_K_ME, 1, (uint32_t)(e->nmb * e->G));
+          hipLaunchKernelGGL(k_me, dim3(e->nmb, G), dim3(64), 0, st, P); }
+        { StatScope sc(e, &S, MI355X_H264_K_PMB, 1, (uint32_t)(e->nmb * e->G));
           if (getenv("MI355X_H264_DBG_PRED")) P.lambda = -1;
-          if (e->pmb_v1) hipLaunchKernelGGL(k_pmb, dim3(e->nmb), dim3(64), 0, st, P);
-          else hipLaunchKernelGGL(k_pmb2, dim3(e->nmb), dim3(64), 0, st, P); }
+          if (e->pmb_v1) hipLaunchKernelGGL(k_pmb, dim3(e->nmb, G), dim3(64), 0, st, P);
+          else hipLaunchKernelGGL(k_pmb2, dim3(e->nmb, G), dim3(64), 0, st, P); }
     }
     // entropy coding
-    uint64_t hdr = 0;
-    const int hdr_len = build_slice_header(e, idr, &hdr);
+    HdrBatch H{};
+    for (int g = 0; g < e->G; g++) {
+        uint64_t hdr = 0;
+        H.len[g] = (unsigned char)build_slice_header(e, idr, (e->idr_id + g * e->idr_step) & 0xFF, &hdr);
+        H.bits[g] = hdr;
+    }
     {
-        StatScope sc(e, &S, MI355X_H264_K_CAVLC, 4, (uint32_t)e->nmb);
+        StatScope sc(e, &S, MI355X_H264_K_CAVLC, 4, (uint32_t)(e->nmb * e->G));
         CavlcParams C{};
         C.mb = e->d_mb; C.levels = e->d_levels; C.mvd = e->d_mvd; C.mbw = e->mbw; C.nmb = e->nmb; C.p_slice = idr ? 0 : 1;
         C.slotbits = e->d_slotbits; C.mbbits = e->d_mbbits; C.bitbuf = S.d_bitbuf;
         C.bs = (!e->cfg.disable_deblock && !e->diag_mode) ? (uint8_t*)e->d_bs : nullptr;
+        C.st_mb = e->nmb; C.st_bitbuf = e->st_bitbuf_bytes / 4;
         const int grid = (e->nmb + 1) / 2;
-        hipLaunchKernelGGL(k_cavlc<false>, dim3(grid), dim3(64), 0, st, C);
-        hipLaunchKernelGGL(k_bit_scan, dim3(1), dim3(1024), 0, st, C, (unsigned long long)hdr, hdr_len, S.d_info);
-        hipLaunchKernelGGL(k_cavlc<true>, dim3(grid), dim3(64), 0, st, C);
+        hipLaunchKernelGGL(k_cavlc<false>, dim3(grid, G), dim3(64), 0, st, C);
+        hipLaunchKernelGGL(k_bit_scan, dim3(G), dim3(1024), 0, st, C, H, S.d_info);
+        hipLaunchKernelGGL(k_cavlc<true>, dim3(grid, G), dim3(64), 0, st, C);
         // access unit layout in the pinned buffer: [pad][SPS PPS (IDR only)][00 00 00 01 hdr][payload...]
         const size_t pre = (idr ? e->sps_pps.size() : 0) + 5;
         const size_t pad = (16 - (pre & 15)) & 15;
@@ -355,14 +363,15 @@ int submit(mi355x_h264_encoder* e, const uint8_t* d_src, int slot_idx)
         S.payload_off = pad + pre;
         S.idr = idr;
         S.nal_hdr = idr ? ((3 << 5) | 5) : ((2 << 5) | 1);
-        hipLaunchKernelGGL(k_pack, dim3(1), dim3(1024), 0, st, (uint8_t*)S.d_bitbuf, S.h_au + S.payload_off, (const SliceInfo*)S.d_info, S.h_info);
+        hipLaunchKernelGGL(k_pack, dim3(G), dim3(1024), 0, st, (uint8_t*)S.d_bitbuf, e->st_bitbuf_bytes, S.h_au + S.payload_off, e->st_au,
+                           (const SliceInfo*)S.d_info, S.h_info);
     }
     if (e->keep_pre)
         for (int p = 0; p < 3; p++)
-            HIPCHK(e, hipMemcpyAsync(e->d_pre[p], e->d_planes[cur][p], (size_t)e->cw * e->ch / (p ? 4 : 1), hipMemcpyDeviceToDevice, st));
+            HIPCHK(e, hipMemcpyAsync(e->d_pre[p], e->d_planes[cur][p], (p ? e->st_c : e->st_y) * e->G, hipMemcpyDeviceToDevice, st));
     if (!e->cfg.disable_deblock) {
         const int steps = e->mbw + 2 * (e->mbh - 1);
-        StatScope sc(e, &S, MI355X_H264_K_DEBLOCK, (uint32_t)(e->diag_mode ? steps : 1), (uint32_t)e->nmb);
+        StatScope sc(e, &S, MI355X_H264_K_DEBLOCK, (uint32_t)(e->diag_mode ? steps : 1), (uint32_t)(e->nmb * e->G));
         DbParams D{};
         for (int p = 0; p < 3; p++) D.pl[p] = e->d_planes[cur][p];
         D.mb = e->d_mb; D.cw = e->cw; D.ch = e->ch; D.mbw = e->mbw; D.mbh = e->mbh;
@@ -378,11 +387,12 @@ int submit(mi355x_h264_encoder* e, const uint8_t* d_src, int slot_idx)
         } else {
             DbRowParams R{};
             R.d = D; R.handoff = e->d_handoff; R.err = S.h_err;
+            R.st_y = e->st_y; R.st_c = e->st_c; R.st_handoff = e->st_handoff; R.st_mb = e->nmb;
             e->serial = e->serial == 0xFFFFFFFFu ? 1 : e->serial + 1;
             R.serial = e->serial;
             R.bs = e->d_bs;
-            if (idr) hipLaunchKernelGGL(k_deblock_rows<true>, dim3(e->mbh), dim3(64), 0, st, R);
-            else hipLaunchKernelGGL(k_deblock_rows<false>, dim3(e->mbh), dim3(64), 0, st, R);
+            if (idr) hipLaunchKernelGGL(k_deblock_rows<true>, dim3(e->mbh, G), dim3(64), 0, st, R);
+            else hipLaunchKernelGGL(k_deblock_rows<false>, dim3(e->mbh, G), dim3(64), 0, st, R);
         }
     }
     HIPCHK(e, hipEventRecord(S.done, st));
@@ -390,15 +400,15 @@ int submit(mi355x_h264_encoder* e, const uint8_t* d_src, int slot_idx)
     S.busy = true;
     // bookkeeping for the next picture
     e->cur ^= 1;
-    if (idr) e->idr_id = (e->idr_id + e->idr_step) & 0xFF;
+    if (idr) e->idr_id = (e->idr_id + e->idr_step * e->G) & 0xFF;
     e->frame_num = (e->frame_num + 1) & 255;
     e->frame_in_gop++;
     e->frames++;
     return MI355X_H264_OK;
 }
 
-// wait for a slot and finish its access unit on the host
-int collect(mi355x_h264_encoder* e, int slot_idx, uint8_t** out, uint32_t* out_len, int* frame_type)
+// wait for a slot (all batch items of one lockstep picture); stats are folded in once
+int wait_slot(mi355x_h264_encoder* e, int slot_idx)
 {
     Slot& S = e->slots[slot_idx];
     if (!S.busy) return fail(e, MI355X_H264_E_INTERNAL, "collect on an idle slot");
@@ -412,13 +422,20 @@ int collect(mi355x_h264_encoder* e, int slot_idx, uint8_t** out, uint32_t* out_l
         e->ev_pool.push_back(ev.a); e->ev_pool.push_back(ev.b);
     }
     S.evs.clear();
-    e->stats.frames++;
-    const SliceInfo info = *S.h_info;
+    e->stats.frames += (uint64_t)e->G;
     if (*S.h_err) return fail(e, MI355X_H264_E_INTERNAL, "wavefront kernel hand-off timed out (flag %u)", *S.h_err);
-    S.used_bytes = info.total_bytes;
+    return MI355X_H264_OK;
+}
+
+// finish the access unit of batch item g of a waited slot on the host
+int finish_item(mi355x_h264_encoder* e, int slot_idx, int g, uint8_t** out, uint32_t* out_len, int* frame_type)
+{
+    Slot& S = e->slots[slot_idx];
+    const SliceInfo info = S.h_info[g];
     if (info.error) return fail(e, MI355X_H264_E_INTERNAL, "device reported error %u", info.error);
     if ((size_t)info.total_bytes + 64 > e->bitbuf_cap) return fail(e, MI355X_H264_E_OVERFLOW, "slice of %u bytes exceeds buffer", info.total_bytes);
-    uint8_t* au = S.h_au + S.au_start;
+    uint8_t* base = S.h_au + (size_t)g * e->st_au;
+    uint8_t* au = base + S.au_start;
     size_t pos = 0;
     if (S.idr) { memcpy(au, e->sps_pps.data(), e->sps_pps.size()); pos = e->sps_pps.size(); }
     au[pos++] = 0; au[pos++] = 0; au[pos++] = 0; au[pos++] = 1; au[pos++] = (uint8_t)S.nal_hdr;
@@ -426,14 +443,22 @@ int collect(mi355x_h264_encoder* e, int slot_idx, uint8_t** out, uint32_t* out_l
         *out = au;
         *out_len = (uint32_t)(pos + info.total_bytes);
     } else {  // rare: some 00 00 0x pattern needs an emulation prevention byte
-        e->esc_buf.resize(pos + (size_t)info.total_bytes * 3 / 2 + 16);
-        memcpy(e->esc_buf.data(), au, pos);
-        const size_t n = nal_escape(S.h_au + S.payload_off, info.total_bytes, e->esc_buf.data() + pos);
-        *out = e->esc_buf.data();
+        std::vector<uint8_t>& eb = e->esc_buf[g];
+        eb.resize(pos + (size_t)info.total_bytes * 3 / 2 + 16);
+        memcpy(eb.data(), au, pos);
+        const size_t n = nal_escape(base + S.payload_off, info.total_bytes, eb.data() + pos);
+        *out = eb.data();
         *out_len = (uint32_t)(pos + n);
     }
     if (frame_type) *frame_type = S.idr ? MI355X_H264_FRAME_IDR : MI355X_H264_FRAME_P;
     return MI355X_H264_OK;
+}
+
+int collect(mi355x_h264_encoder* e, int slot_idx, uint8_t** out, uint32_t* out_len, int* frame_type)
+{
+    int rc = wait_slot(e, slot_idx);
+    if (rc) return rc;
+    return finish_item(e, slot_idx, 0, out, out_len, frame_type);
 }
 
 int pick_level(int mbs, int fps)
@@ -477,6 +502,9 @@ int mi355x_h264_create(const mi355x_h264_config* cfg, mi355x_h264_encoder** out)
     e->mbw = (cfg->width + 15) / 16; e->mbh = (cfg->height + 15) / 16;
     e->cw = e->mbw * 16; e->ch = e->mbh * 16; e->nmb = e->mbw * e->mbh;
     e->level_idc = std::max(32, pick_level(e->nmb, cfg->fps > 0 ? cfg->fps : 30));
+    e->G = cfg->batch > 1 ? cfg->batch : 1;
+    if (e->G > 32) { delete e; return MI355X_H264_E_ARG; }
+    e->esc_buf.resize((size_t)e->G);
     build_parameter_sets(e);
 #define CK(call)                                                              \
     do {                                                                      \
@@ -490,41 +518,44 @@ int mi355x_h264_create(const mi355x_h264_config* cfg, mi355x_h264_encoder** out)
     CK(hipSetDevice(e->device));
     CK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     const size_t ysz = (size_t)e->cw * e->ch;
+    const size_t Gn = (size_t)e->G;
+    e->st_y = ysz + 256; e->st_c = ysz / 4 + 256;
     for (int b = 0; b < 2; b++)
         for (int p = 0; p < 3; p++) {
-            CK(hipMalloc((void**)&e->d_planes[b][p], (p ? ysz / 4 : ysz) + 256));
-            CK(hipMemset(e->d_planes[b][p], 0, (p ? ysz / 4 : ysz) + 256));
+            CK(hipMalloc((void**)&e->d_planes[b][p], (p ? e->st_c : e->st_y) * Gn));
+            CK(hipMemset(e->d_planes[b][p], 0, (p ? e->st_c : e->st_y) * Gn));
         }
-    for (int p = 0; p < 3; p++) CK(hipMalloc((void**)&e->d_pre[p], (p ? ysz / 4 : ysz) + 256));
-    CK(hipMalloc((void**)&e->d_mb, (size_t)e->nmb * sizeof(MbInfo)));
-    CK(hipMemset(e->d_mb, 0, (size_t)e->nmb * sizeof(MbInfo)));
-    CK(hipMalloc((void**)&e->d_levels, (size_t)e->nmb * LV_STRIDE * sizeof(int16_t)));
-    CK(hipMalloc((void**)&e->d_mvd, (size_t)e->nmb * 2 * sizeof(int16_t)));
-    CK(hipMalloc((void**)&e->d_slotbits, (size_t)e->nmb * 32 * sizeof(uint16_t)));
-    CK(hipMalloc((void**)&e->d_mbbits, (size_t)e->nmb * sizeof(uint32_t)));
-    CK(hipMalloc((void**)&e->d_handoff, (size_t)e->nmb * 24 * sizeof(unsigned long long)));
-    CK(hipMemset(e->d_handoff, 0, (size_t)e->nmb * 24 * sizeof(unsigned long long)));
-    CK(hipMalloc((void**)&e->d_progress, (size_t)2 * e->mbh * sizeof(unsigned)));
-    CK(hipMemset(e->d_progress, 0, (size_t)2 * e->mbh * sizeof(unsigned)));
+    for (int p = 0; p < 3; p++) CK(hipMalloc((void**)&e->d_pre[p], (p ? e->st_c : e->st_y) * Gn));
+    CK(hipMalloc((void**)&e->d_mb, Gn * e->nmb * sizeof(MbInfo)));
+    CK(hipMemset(e->d_mb, 0, Gn * e->nmb * sizeof(MbInfo)));
+    CK(hipMalloc((void**)&e->d_levels, Gn * e->nmb * LV_STRIDE * sizeof(int16_t)));
+    CK(hipMalloc((void**)&e->d_mvd, Gn * e->nmb * 2 * sizeof(int16_t)));
+    CK(hipMalloc((void**)&e->d_slotbits, Gn * e->nmb * 32 * sizeof(uint16_t)));
+    CK(hipMalloc((void**)&e->d_mbbits, Gn * e->nmb * sizeof(uint32_t)));
+    e->st_handoff = (size_t)e->nmb * 24;
+    CK(hipMalloc((void**)&e->d_handoff, Gn * e->st_handoff * sizeof(unsigned long long)));
+    CK(hipMemset(e->d_handoff, 0, Gn * e->st_handoff * sizeof(unsigned long long)));
     CK(hipMalloc((void**)&e->d_err, sizeof(unsigned)));
-    CK(hipMalloc((void**)&e->d_bs, (size_t)e->nmb * 32));
     CK(hipMemset(e->d_err, 0, sizeof(unsigned)));
-    e->diag_mode = getenv("MI355X_H264_DIAG") != nullptr;
+    CK(hipMalloc((void**)&e->d_bs, Gn * e->nmb * 32));
+    e->diag_mode = getenv("MI355X_H264_DIAG") != nullptr && e->G == 1;
     e->pmb_v1 = getenv("MI355X_H264_PMB_V1") != nullptr;
     e->frame_bytes = (size_t)cfg->width * cfg->height * 3 / 2;
     CK(hipMalloc((void**)&e->d_stage, e->frame_bytes + 256));
     CK(hipMalloc((void**)&e->d_stage2, e->frame_bytes + 256));
     CK(hipHostMalloc((void**)&e->h_stage, e->frame_bytes + 256, hipHostMallocDefault));
     e->bitbuf_cap = ysz * 2 + (1 << 16);
+    e->st_bitbuf_bytes = (e->bitbuf_cap + 256 + 255) & ~(size_t)255;
     e->au_cap = e->bitbuf_cap + e->sps_pps.size() + 64;
+    e->st_au = (e->au_cap + 256 + 255) & ~(size_t)255;
     for (auto& S : e->slots) {
-        CK(hipMalloc((void**)&S.d_bitbuf, e->bitbuf_cap + 256));
-        CK(hipMemset(S.d_bitbuf, 0, e->bitbuf_cap + 256));
-        CK(hipMalloc((void**)&S.d_info, sizeof(SliceInfo)));
-        CK(hipHostMalloc((void**)&S.h_info, sizeof(SliceInfo), hipHostMallocDefault));
+        CK(hipMalloc((void**)&S.d_bitbuf, e->st_bitbuf_bytes * Gn));
+        CK(hipMemset(S.d_bitbuf, 0, e->st_bitbuf_bytes * Gn));
+        CK(hipMalloc((void**)&S.d_info, sizeof(SliceInfo) * Gn));
+        CK(hipHostMalloc((void**)&S.h_info, sizeof(SliceInfo) * Gn, hipHostMallocDefault));
         CK(hipHostMalloc((void**)&S.h_err, sizeof(unsigned), hipHostMallocDefault));
         *S.h_err = 0;
-        CK(hipHostMalloc((void**)&S.h_au, e->au_cap + 256, hipHostMallocDefault));
+        CK(hipHostMalloc((void**)&S.h_au, e->st_au * Gn, hipHostMallocDefault));
         CK(hipEventCreateWithFlags(&S.done, hipEventDisableTiming));
     }
     CK(hipDeviceSynchronize());
@@ -543,7 +574,7 @@ void mi355x_h264_destroy(mi355x_h264_encoder* e)
     for (int p = 0; p < 3; p++) (void)hipFree(e->d_pre[p]);
     (void)hipFree(e->d_mb); (void)hipFree(e->d_levels); (void)hipFree(e->d_mvd);
     (void)hipFree(e->d_slotbits); (void)hipFree(e->d_mbbits); (void)hipFree(e->d_stage); (void)hipFree(e->d_stage2);
-    (void)hipFree(e->d_handoff); (void)hipFree(e->d_progress); (void)hipFree(e->d_err); (void)hipFree(e->d_bs);
+    (void)hipFree(e->d_handoff); (void)hipFree(e->d_err); (void)hipFree(e->d_bs);
     if (e->h_stage) (void)hipHostFree(e->h_stage);
     for (auto& S : e->slots) {
         (void)hipFree(S.d_bitbuf); (void)hipFree(S.d_info);
@@ -564,7 +595,8 @@ int mi355x_h264_encode_device(mi355x_h264_encoder* e, const void* d_i420, uint8_
     HIPCHK(e, hipSetDevice(e->device));
     const int slot = e->next_slot;
     e->next_slot = (e->next_slot + 1) % NSLOT;
-    int rc = submit(e, (const uint8_t*)d_i420, slot);
+    if (e->G != 1) return fail(e, MI355X_H264_E_ARG, "single-picture calls need a batch-1 encoder");
+    int rc = submit(e, (const uint8_t*)d_i420, 0, slot);
     if (rc) return rc;
     return collect(e, slot, out, out_len, frame_type);
 }
@@ -614,6 +646,7 @@ int mi355x_h264_encode_batch_device(mi355x_h264_encoder* e, const void* d_frames
                                     size_t out_cap, uint32_t* sizes, size_t* total_len)
 {
     if (!e || !d_frames || !host_out || !sizes || count < 0) return fail(e, MI355X_H264_E_ARG, "null argument");
+    if (e->G != 1) return fail(e, MI355X_H264_E_ARG, "use mi355x_h264_encode_gops_device with a batched encoder");
     HIPCHK(e, hipSetDevice(e->device));
     size_t pos = 0;
     int pending[NSLOT], npend = 0, head = 0;
@@ -635,12 +668,50 @@ int mi355x_h264_encode_batch_device(mi355x_h264_encoder* e, const void* d_frames
         const int slot = e->next_slot;
         e->next_slot = (e->next_slot + 1) % NSLOT;
         pending[i % NSLOT] = slot;
-        int rc = submit(e, (const uint8_t*)d_frames + (size_t)i * stride, slot);
+        int rc = submit(e, (const uint8_t*)d_frames + (size_t)i * stride, 0, slot);
         if (rc) return rc;
         npend++;
     }
     while (npend) { int rc = drain_one(); if (rc) return rc; }
     if (total_len) *total_len = pos;
+    return MI355X_H264_OK;
+}
+
+int mi355x_h264_encode_gops_device(mi355x_h264_encoder* e, const void* d_frames, size_t frame_stride, size_t gop_stride, int frames_per_gop,
+                                   uint8_t* host_out, size_t out_cap_per_gop, uint32_t* sizes, size_t* gop_bytes)
+{
+    if (!e || !d_frames || !host_out || !sizes || !gop_bytes || frames_per_gop < 1) return fail(e, MI355X_H264_E_ARG, "null argument");
+    HIPCHK(e, hipSetDevice(e->device));
+    const int G = e->G;
+    for (int g = 0; g < G; g++) gop_bytes[g] = 0;
+    e->force_idr = 1;                     // every call starts closed GOPs
+    int pending[NSLOT], npend = 0, head = 0;
+    auto drain_one = [&]() -> int {
+        const int slot = pending[head % NSLOT];
+        int rc = wait_slot(e, slot);
+        if (rc) return rc;
+        for (int g = 0; g < G; g++) {
+            uint8_t* p = nullptr; uint32_t n = 0;
+            rc = finish_item(e, slot, g, &p, &n, nullptr);
+            if (rc) return rc;
+            if (gop_bytes[g] + n > out_cap_per_gop) return fail(e, MI355X_H264_E_OVERFLOW, "gop output buffer too small");
+            memcpy(host_out + (size_t)g * out_cap_per_gop + gop_bytes[g], p, n);
+            sizes[(size_t)g * frames_per_gop + head] = n;
+            gop_bytes[g] += n;
+        }
+        head++; npend--;
+        return 0;
+    };
+    for (int i = 0; i < frames_per_gop; i++) {
+        if (npend == NSLOT - 1) { int rc = drain_one(); if (rc) return rc; }
+        const int slot = e->next_slot;
+        e->next_slot = (e->next_slot + 1) % NSLOT;
+        pending[i % NSLOT] = slot;
+        int rc = submit(e, (const uint8_t*)d_frames + (size_t)i * frame_stride, gop_stride, slot);
+        if (rc) return rc;
+        npend++;
+    }
+    while (npend) { int rc = drain_one(); if (rc) return rc; }
     return MI355X_H264_OK;
 }
 

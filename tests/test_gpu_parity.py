@@ -153,6 +153,36 @@ def test_gop_sharding_equals_serial():
     assert b"".join(parts[k] for k in sorted(parts)) == want
 
 
+def test_lockstep_batch_equals_serial():
+    """config.batch = 4: four closed GOPs of one stream encoded in lockstep (grid.y = 4) must concatenate to
+    exactly the stream a batch-1 encoder (and the oracle) produces"""
+    import torch
+    w, h, gop, G = 352, 288, 5, 4
+    frames = synth.sequence("s1", w, h, gop * G)
+    fbytes = w * h * 3 // 2
+    orc = OracleEncoder(w, h, qp=27, gop=gop)
+    want = [orc.encode(f)[0] for f in frames]
+    dev = torch.from_numpy(np.stack(frames)).cuda()
+    enc = capi.Encoder(w, h, qp=27, gop=gop, batch=G)
+    cap = gop * fbytes
+    out = np.zeros(G * cap, np.uint8)
+    sizes = np.zeros(G * gop, np.uint32)
+    gb = np.zeros(G, np.uint64)
+    enc.encode_gops_device(dev.data_ptr(), fbytes, gop * fbytes, gop, out, cap, sizes, gb)
+    for g in range(G):
+        got = out[g * cap: g * cap + int(gb[g])].tobytes()
+        assert got == b"".join(want[g * gop:(g + 1) * gop]), "GOP %d" % g
+        assert [int(x) for x in sizes[g * gop:(g + 1) * gop]] == [len(x) for x in want[g * gop:(g + 1) * gop]]
+    # a second call continues the idr_pic_id sequence (GOPs G..2G-1 of the same stream)
+    more = synth.sequence("s1", w, h, gop * G, start=gop * G)
+    want2 = [orc.encode(f)[0] for f in more]
+    dev2 = torch.from_numpy(np.stack(more)).cuda()
+    enc.encode_gops_device(dev2.data_ptr(), fbytes, gop * fbytes, gop, out, cap, sizes, gb)
+    for g in range(G):
+        assert out[g * cap: g * cap + int(gb[g])].tobytes() == b"".join(want2[g * gop:(g + 1) * gop]), "second call GOP %d" % g
+    enc.close()
+
+
 def test_4k_one_gop_start():
     """BASELINE.json configs[4] size (3840x2160): IDR + P decode round trip and oracle equality on the IDR"""
     w, h = 3840, 2160
