@@ -69,8 +69,10 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--gops-in-flight", type=int, default=int(os.environ.get("BENCH_GOPS_IN_FLIGHT", "16")),
-                    help="closed GOPs of the stream encoded concurrently per GPU (each on its own HIP stream)")
+    ap.add_argument("--gops-in-flight", type=int, default=int(os.environ.get("BENCH_GOPS_IN_FLIGHT", "32")),
+                    help="closed GOPs of the stream encoded in lockstep per GPU (one encoder instance, grid.y = G)")
+    ap.add_argument("--instances", type=int, default=int(os.environ.get("BENCH_INSTANCES", "1")),
+                    help="encoder instances (HIP streams) the GOPs in flight are split over; each encodes its share in lockstep")
     ap.add_argument("--cpu-frames", type=int, default=8, help="pictures per CPU-baseline thread")
     args = ap.parse_args()
 
@@ -92,38 +94,70 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    # synthetic workload, resident in HBM before any timing
+    # synthetic workload, resident in HBM before any timing: G closed GOPs of 30 pictures.  GOP 0 is the S1
+    # sequence; GOP g is the same sequence with every plane rolled horizontally by 16*g luma samples, so each
+    # GOP is distinct data (G x 93 MB) without G x the host-side generation time.
+    G = max(1, args.gops_in_flight)
     frames = synth.sequence("s1", WIDTH, HEIGHT, FRAMES_PER_STEP)
     fbytes = WIDTH * HEIGHT * 3 // 2
     stride = (fbytes + 255) // 256 * 256
+    gop_stride = stride * FRAMES_PER_STEP
     host = np.zeros((FRAMES_PER_STEP, stride), np.uint8)
     for i, f in enumerate(frames):
         host[i, :fbytes] = f
-    dev = torch.from_numpy(host).to("cuda:%d" % local_rank)
+    dev0 = torch.from_numpy(host).to("cuda:%d" % local_rank)
+    dev = torch.empty((G, FRAMES_PER_STEP, stride), dtype=torch.uint8, device=dev0.device)
+    ysz, csz = WIDTH * HEIGHT, WIDTH * HEIGHT // 4
+    for g in range(G):
+        dev[g] = dev0
+        if g:
+            dev[g, :, :ysz] = torch.roll(dev0[:, :ysz].view(FRAMES_PER_STEP, HEIGHT, WIDTH), 16 * g, dims=2).reshape(FRAMES_PER_STEP, ysz)
+            for o in (ysz, ysz + csz):
+                dev[g, :, o:o + csz] = torch.roll(dev0[:, o:o + csz].view(FRAMES_PER_STEP, HEIGHT // 2, WIDTH // 2), 8 * g, dims=2).reshape(FRAMES_PER_STEP, csz)
     torch.cuda.synchronize()
 
-    G = max(1, args.gops_in_flight)
-    encs = [capi.Encoder(WIDTH, HEIGHT, qp=QP, gop=GOP, device=local_rank) for _ in range(G)]
-    enc = encs[0]
-    outs = [np.zeros(FRAMES_PER_STEP * fbytes // 2, np.uint8) for _ in range(G)]
-    sizes = [np.zeros(FRAMES_PER_STEP, np.uint32) for _ in range(G)]
-    results = [0] * G
+    # I encoder instances (own HIP stream each), each encoding G/I GOPs in lockstep: every kernel launch of an
+    # instance covers all its pictures of one time step (grid.y = G/I); instances overlap each other's
+    # dependency-bound deblocking wavefront with throughput-bound kernels.
+    I = max(1, min(args.instances, G))
+    while G % I:
+        I -= 1
+    B = G // I
+    insts = [capi.Encoder(WIDTH, HEIGHT, qp=QP, gop=GOP, device=local_rank, batch=B) for _ in range(I)]
+    for i, e_ in enumerate(insts):
+        e_.set_idr_pic_id(i * B, 1)
+    enc = insts[0]
+    cap = FRAMES_PER_STEP * fbytes // 2
+    outs = [np.zeros(B * cap, np.uint8) for _ in range(I)]
+    sizes = [np.zeros(B * FRAMES_PER_STEP, np.uint32) for _ in range(I)]
+    gop_bytes = [np.zeros(B, np.uint64) for _ in range(I)]
+    enc1 = capi.Encoder(WIDTH, HEIGHT, qp=QP, gop=GOP, device=local_rank) if G > 1 else None
+    out1 = np.zeros(cap, np.uint8)
+    sizes1 = np.zeros(FRAMES_PER_STEP, np.uint32)
 
-    def one_gop(i):
-        encs[i].force_idr()  # every GOP is closed: IDR + 29 P
-        results[i] = encs[i].encode_batch_device(dev.data_ptr(), stride, FRAMES_PER_STEP, outs[i], sizes[i])
+    def run_inst(i):
+        insts[i].encode_gops_device(dev.data_ptr() + i * B * gop_stride, stride, gop_stride, FRAMES_PER_STEP, outs[i], cap,
+                                    sizes[i], gop_bytes[i])
 
     def step():
-        # one step = G closed GOPs of the stream, encoded concurrently (G host threads, G HIP streams)
-        if G == 1:
-            one_gop(0)
+        if I == 1:
+            run_inst(0)
         else:
-            ths = [threading.Thread(target=one_gop, args=(i,)) for i in range(G)]
+            ths = [threading.Thread(target=run_inst, args=(i,)) for i in range(I)]
             for t in ths:
                 t.start()
             for t in ths:
                 t.join()
-        return results[0]
+        return int(gop_bytes[0][0])
+
+    def one_gop(_):
+        e1 = enc1 if enc1 is not None else enc
+        if enc1 is None:
+            return step()
+        e1.force_idr()
+        return e1.encode_batch_device(dev.data_ptr(), stride, FRAMES_PER_STEP, out1, sizes1)
+
+    encs = insts + ([enc1] if enc1 is not None else [])
 
     for _ in range(args.warmup):
         step()
@@ -149,6 +183,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     st = enc.stats(reset=True)
+    if enc1 is not None:
+        enc1.stats(reset=True)
     # latency mode for reference: one GOP in flight, kernels alone on the GPU (also gives the
     # MC+DCT kernel's duration without other streams' kernels sharing the chip)
     fence()
@@ -158,7 +194,7 @@ def main():
         one_gop(0)
     fence()
     lat_dt = time.perf_counter() - t1
-    st1 = enc.stats(reset=True)
+    st1 = (enc1 if enc1 is not None else enc).stats(reset=True)
     for e_ in encs:
         e_.close()
 
@@ -169,12 +205,19 @@ def main():
         nmb = (WIDTH // 16) * ((HEIGHT + 15) // 16)
         pmb = k["pmb"]
         pmb_ms = pmb["ms"] / max(1, pmb["launches"])
-        achieved = PMB_BYTES_PER_MB * nmb / (pmb_ms * 1e-3) / 1e9 if pmb_ms > 0 else 0.0
+        achieved = PMB_BYTES_PER_MB * nmb * B / (pmb_ms * 1e-3) / 1e9 if pmb_ms > 0 else 0.0
         per_kernel = {}
         for name, v in k.items():
             if v["launches"]:
                 per_kernel[name] = {"ms_per_picture": round(v["ms"] * nmb / max(1, v["mbs"]), 4),
                                     "launches_per_picture": round(v["launches"] * nmb / max(1, v["mbs"]), 1)}
+        traffic = None
+        try:  # HBM bytes per k_pmb2 launch from the committed PMC passes (profiles/), valid for the same batch size
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+            if tj.get("lockstep_batch") == B:
+                traffic = tj["traffic_bytes_per_launch"]
+        except Exception:
+            traffic = None
         res = {
             "metric": "encoded fps @1080p I420 baseline-profile, 1/2/4/8 MI355X vs OpenH264 CPU",
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -183,13 +226,14 @@ def main():
             "config": {"workload": "1080p30 I420 synthetic S1 pan+noise, baseline profile, fixed QP 26, "
                                    "GOP 30 (1 IDR + 29 P per step), single slice, 1 ref, deblock on, CAVLC; "
                                    "one stream per GPU, pictures resident in HBM",
-                       "width": WIDTH, "height": HEIGHT, "qp": QP, "gop": GOP, "frames_per_step": FRAMES_PER_STEP * G, "gops_in_flight": G,
+                       "width": WIDTH, "height": HEIGHT, "qp": QP, "gop": GOP, "frames_per_step": FRAMES_PER_STEP * G, "gops_in_flight": G, "instances": I, "lockstep_batch": B,
                        "streams": world, "bytes_per_gop": int(nbytes), "parity": "bit-exact vs CPU oracle "
                        "(oracle unpinned vs OpenH264: no libopenh264 available)"},
             "roofline": {"kernel": "k_pmb2 (MC + fDCT + quant + dequant + iDCT + recon)", "bound": "hbm",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                         "bytes_per_launch": PMB_BYTES_PER_MB * nmb, "avg_launch_ms": round(pmb_ms, 5)},
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "bytes_per_launch": PMB_BYTES_PER_MB * nmb * B, "macroblocks_per_launch": nmb * B,
+                         "avg_launch_ms": round(pmb_ms, 5)},
             "kernels": per_kernel,
             "single_gop_in_flight_fps": round(lat_steps * FRAMES_PER_STEP / lat_dt, 2),
         }

@@ -282,7 +282,7 @@ __global__ __launch_bounds__(64) void k_deblock_rows(DbRowParams R)
     u64 pf_g = 0;
     auto prefetch = [&](int mx) {
         pf_y = *(const uint32_t*)(D.pl[0] + (size_t)(16 * my + yr) * D.cw + 16 * mx + yc4);
-        if (lane < 32) pf_c = *(const uint32_t*)(D.pl[1 + cpl_l] + (size_t)(8 * my + cr_l) * cs + 8 * mx + cc4);
+        if (lane < 32) pf_c = *(const uint32_t*)((cpl_l ? D.pl[2] : D.pl[1]) + (size_t)(8 * my + cr_l) * cs + 8 * mx + cc4);
         const uint4* b = (const uint4*)(bsw + ((size_t)my * D.mbw + mx) * 8);
         pf_b0 = b[0]; pf_b1 = b[1];
         if (my > 0 && lane < 24) pf_g = AT_LOAD(handoff + ((size_t)(my - 1) * D.mbw + mx) * 24 + gk);
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(64) void k_deblock_rows(DbRowParams R)
                 if (lane < 16) *(uint32_t*)(D.pl[0] + (size_t)(16 * my - 4 + (gk >> 2)) * D.cw + 16 * mx + (gk & 3) * 4) = *(const uint32_t*)&SY(-4 + (gk >> 2), (gk & 3) * 4);
                 else if (lane < 24) {
                     const int k = gk - 16, pl = k >> 2, r = (k >> 1) & 1, c4 = (k & 1) * 4;
-                    *(uint32_t*)(D.pl[1 + pl] + (size_t)(8 * my - 2 + r) * cs + 8 * mx + c4) = *(const uint32_t*)&SC(pl, -2 + r, c4);
+                    *(uint32_t*)((pl ? D.pl[2] : D.pl[1]) + (size_t)(8 * my - 2 + r) * cs + 8 * mx + c4) = *(const uint32_t*)&SC(pl, -2 + r, c4);
                 }
             }
         }
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(64) void k_deblock_rows(DbRowParams R)
             const int nrow = last_row ? 16 : 12, ncrow = last_row ? 8 : 6;
             if (yr < nrow) *(uint32_t*)(D.pl[0] + (size_t)(16 * my + yr) * D.cw + 16 * pmx + yc4) = *(const uint32_t*)&SY(yr, co + yc4);
             if (lane < 32 && cr_l < ncrow)
-                *(uint32_t*)(D.pl[1 + cpl_l] + (size_t)(8 * my + cr_l) * cs + 8 * pmx + cc4) = *(const uint32_t*)&SC(cpl_l, cr_l, cco + cc4);
+                *(uint32_t*)((cpl_l ? D.pl[2] : D.pl[1]) + (size_t)(8 * my + cr_l) * cs + 8 * pmx + cc4) = *(const uint32_t*)&SC(cpl_l, cr_l, cco + cc4);
             if (!last_row && lane < 24) {
                 uint32_t v;
                 if (lane < 16) v = *(const uint32_t*)&SY(12 + (gk >> 2), co + (gk & 3) * 4);

@@ -219,7 +219,7 @@ __device__ __forceinline__ void intra_mb_core(const FrameParams& P, int mx, int 
             pp = S.py + y * 16 + x; ppitch = 16; ldst = S.rec_y + y * 16 + x;
         } else {
             const int x = (cb & 1) * 4, y = (cb >> 1) * 4;
-            dst = P.rec[1 + cpl] + (size_t)(8 * my + y) * cs + 8 * mx + x; dp = cs;
+            dst = (cpl ? P.rec[2] : P.rec[1]) + (size_t)(8 * my + y) * cs + 8 * mx + x; dp = cs;
             pp = S.pc + cpl * 64 + y * 8 + x; ppitch = 8; ldst = S.rec_c + cpl * 64 + y * 8 + x;
         }
 #pragma unroll
@@ -266,11 +266,11 @@ __global__ __launch_bounds__(64) void k_intra_diag(FrameParams P0, int s)
         else if (lane < 33) S.left[lane - 17] = mx > 0 ? R[(size_t)(by + lane - 17) * P.cw + bx - 1] : 0;
         else if (lane < 33 + 18) {
             const int k = lane - 33, pl = k / 9, i = k % 9;
-            S.ctop[pl][i] = (my > 0 && (i > 0 || mx > 0)) ? P.rec[1 + pl][(size_t)(8 * my - 1) * cs + 8 * mx - 1 + i] : 0;
+            S.ctop[pl][i] = (my > 0 && (i > 0 || mx > 0)) ? (pl ? P.rec[2] : P.rec[1])[(size_t)(8 * my - 1) * cs + 8 * mx - 1 + i] : 0;
         }
         if (lane < 16) {
             const int pl = lane >> 3, i = lane & 7;
-            S.cleft[pl][i] = mx > 0 ? P.rec[1 + pl][(size_t)(8 * my + i) * cs + 8 * mx - 1] : 0;
+            S.cleft[pl][i] = mx > 0 ? (pl ? P.rec[2] : P.rec[1])[(size_t)(8 * my + i) * cs + 8 * mx - 1] : 0;
         }
     }
     __syncthreads();

@@ -89,7 +89,7 @@ __global__ __launch_bounds__(64, 4) void k_me(FrameParams P0)
     if (lane < 32) {  // co-located chroma
         const int pl = lane >> 4, row = (lane >> 1) & 7, xs = (lane & 1) * 4;
         *(uint32_t*)(s_refc + pl * 64 + row * 8 + xs) =
-            *(const uint32_t*)(P.ref[1 + pl] + (size_t)(8 * my + row) * (P.cw / 2) + 8 * mx + xs);
+            *(const uint32_t*)((pl ? P.ref[2] : P.ref[1]) + (size_t)(8 * my + row) * (P.cw / 2) + 8 * mx + xs);
     }
     __syncthreads();
     const uint8_t* winb = (const uint8_t*)s_win;

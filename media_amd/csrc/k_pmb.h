@@ -108,13 +108,13 @@ __global__ __launch_bounds__(64) void k_pmb(FrameParams P0)
         if (cinterior) {
             if (lane < 54) {   // 2 planes x 9 rows x 3 dwords
                 const int pl = lane / 27, k = lane - pl * 27, r = k / 3, c = k - r * 3;
-                *(uint32_t*)(s_cw[pl] + r * 12 + 4 * c) = *(const uint32_t*)(P.ref[1 + pl] + (size_t)(cy0 + r) * cs + cxa + 4 * c);
+                *(uint32_t*)(s_cw[pl] + r * 12 + 4 * c) = *(const uint32_t*)((pl ? P.ref[2] : P.ref[1]) + (size_t)(cy0 + r) * cs + cxa + 4 * c);
             }
         } else {
             for (int i = lane; i < 2 * 81; i += 64) {
                 const int pl = i / 81, k = i - pl * 81, r = k / 9, c = k - r * 9;
                 s_cw[pl][r * 12 + cxo + c] =
-                    P.ref[1 + pl][(size_t)clip3(0, P.ch / 2 - 1, cy0 + r) * cs + clip3(0, cs - 1, cx0 + c)];
+                    (pl ? P.ref[2] : P.ref[1])[(size_t)clip3(0, P.ch / 2 - 1, cy0 + r) * cs + clip3(0, cs - 1, cx0 + c)];
             }
         }
     }
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(64) void k_pmb(FrameParams P0)
             pp = s_py + y * 16 + x; ppitch = 16;
         } else {
             const int x = (cb & 1) * 4, y = (cb >> 1) * 4;
-            dst = P.rec[1 + cpl] + (size_t)(8 * my + y) * cs + 8 * mx + x; dp = cs;
+            dst = (cpl ? P.rec[2] : P.rec[1]) + (size_t)(8 * my + y) * cs + 8 * mx + x; dp = cs;
             pp = s_pc + cpl * 64 + y * 8 + x; ppitch = 8;
         }
 #pragma unroll

@@ -148,7 +148,7 @@ __global__ __launch_bounds__(64) void k_pmb2(FrameParams P0)
     }
     if (cinterior && lane < 54) {
         const int pl = lane / 27, k = lane - pl * 27, rr = k / 3, c = k - rr * 3;
-        cwv = *(const uint32_t*)(P.ref[1 + pl] + (size_t)(cy0 + rr) * cs + cxa + 4 * c);
+        cwv = *(const uint32_t*)((pl ? P.ref[2] : P.ref[1]) + (size_t)(cy0 + rr) * cs + cxa + 4 * c);
     }
     uint32_t src4, csrc4 = 0;
     {
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(64) void k_pmb2(FrameParams P0)
     } else {
         for (int i = lane; i < 2 * 81; i += 64) {
             const int pl = i / 81, k = i - pl * 81, rr = k / 9, c = k - rr * 9;
-            s_cw[pl][rr * 12 + cxo + c] = P.ref[1 + pl][(size_t)clip3(0, P.ch / 2 - 1, cy0 + rr) * cs + clip3(0, cs - 1, cx0 + c)];
+            s_cw[pl][rr * 12 + cxo + c] = (pl ? P.ref[2] : P.ref[1])[(size_t)clip3(0, P.ch / 2 - 1, cy0 + rr) * cs + clip3(0, cs - 1, cx0 + c)];
         }
     }
     __syncthreads();
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(64) void k_pmb2(FrameParams P0)
     }
     idct_quad(cd, r);
     if (lane < 32)
-        *(uint32_t*)(P.rec[1 + cpl] + (size_t)(8 * my + cy) * cs + 8 * mx + cx) =
+        *(uint32_t*)((cpl ? P.rec[2] : P.rec[1]) + (size_t)(8 * my + cy) * cs + 8 * mx + cx) =
             pack4(clip255(byte_of(cpred4, 0) + cd[0]), clip255(byte_of(cpred4, 1) + cd[1]), clip255(byte_of(cpred4, 2) + cd[2]), clip255(byte_of(cpred4, 3) + cd[3]));
     const unsigned long long cmask = __ballot(lane < 32 && cnz != 0);
     const int cbp_chroma = cmask ? 2 : (any_dc ? 1 : 0);

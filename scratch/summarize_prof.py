@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Condense a gpurun_out/prof_<tag>/ directory (scratch/prof.sh) into profiles/<tag>_*.{csv,json}."""
+import csv, collections, glob, json, os, sys
+tag = sys.argv[1]
+src = "gpurun_out/prof_%s" % tag
+os.makedirs("profiles", exist_ok=True)
+# 1. kernel stats (rocprofv3 --kernel-trace --stats), as produced
+ks = glob.glob(src + "/stats/*/*kernel_stats.csv")[0]
+rows = list(csv.DictReader(open(ks)))
+with open("profiles/%s_kernel_stats.csv" % tag, "w") as f:
+    w = csv.writer(f)
+    w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
+    for r in rows:
+        w.writerow([r["Name"], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
+# split k_pmb2 launches by grid size (batched main region vs single-GOP phase) from the trace
+tr = glob.glob(src + "/stats/*/*kernel_trace.csv")[0]
+by = collections.defaultdict(list)
+for r in csv.DictReader(open(tr)):
+    by[(r["Kernel_Name"].split("(")[0], int(r["Grid_Size_Y"]))].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+split = {"%s grid.y=%d" % (k[0].replace("void ", "").replace("h264::", ""), k[1] // 1): {"calls": len(v), "avg_us": round(sum(v) / len(v) / 1e3, 2)}
+         for k, v in sorted(by.items()) if k[0].replace("void ", "").startswith("h264::")}
+# 2. PMC passes
+def pmc(path, name):
+    d = collections.defaultdict(list)
+    for r in csv.DictReader(open(glob.glob(path)[0])):
+        if r["Counter_Name"] == name:
+            d[(r["Kernel_Name"].split("(")[0].replace("void ", "").replace("h264::", ""), int(r["Grid_Size"]))].append(float(r["Counter_Value"]))
+    return d
+out = {"tag": tag, "command": "python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline (stats); --steps 1 (each --pmc pass)",
+       "kernel_avg_by_batch": split, "pmc": {}}
+fetch = pmc(src + "/pmc_fetch/*/*counter_collection.csv", "FETCH_SIZE")
+write = pmc(src + "/pmc_write/*/*counter_collection.csv", "WRITE_SIZE")
+for k in sorted(set(fetch) | set(write)):
+    f_kb = sum(fetch[k]) / len(fetch[k]) if k in fetch else None
+    w_kb = sum(write[k]) / len(write[k]) if k in write else None
+    out["pmc"]["%s grid=%d threads" % k] = {"FETCH_SIZE_KB_raw": None if f_kb is None else round(f_kb, 1),
+                                      "WRITE_SIZE_KB": None if w_kb is None else round(w_kb, 1)}
+sq = glob.glob(src + "/pmc_sq/*/*counter_collection.csv")
+if sq:
+    d = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(sq[0])):
+        d[(r["Kernel_Name"].split("(")[0].replace("void ", "").replace("h264::", ""), int(r["Grid_Size"]))][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    out["sq"] = {"%s grid=%d threads" % k: {c: round(sum(v) / len(v)) for c, v in cs.items()} for k, cs in sorted(d.items())}
+json.dump(out, open("profiles/%s_summary.json" % tag, "w"), indent=1)
+print(json.dumps({k: v for k, v in out["pmc"].items() if "pmb2" in k or "k_me" in k}, indent=1))
+print(json.dumps({k: v for k, v in split.items() if "pmb2" in k or "k_me" in k or "deblock" in k}, indent=1))
