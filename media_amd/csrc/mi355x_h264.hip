@@ -152,6 +152,7 @@ struct Slot {
     bool idr = false;
     bool busy = false;
     hipEvent_t done = nullptr;
+    hipEvent_t recon_ready = nullptr, bs_ready = nullptr, entropy_done = nullptr;   // fork / join of the entropy-coding stream
     // stats events of this frame: pairs (start, stop, kernel id, launches, mbs)
     struct Ev { hipEvent_t a, b; int k; uint32_t launches, mbs; };
     std::vector<Ev> evs;
@@ -166,6 +167,7 @@ struct mi355x_h264_encoder {
     int G = 1;                               // lockstep batch: closed GOPs / streams encoded together
     size_t st_y = 0, st_c = 0, st_bitbuf_bytes = 0, st_au = 0, st_handoff = 0;  // per-item strides
     hipStream_t stream = nullptr;
+    hipStream_t stream_ec = nullptr;         // entropy coding runs here, beside the deblocking wavefront
     uint8_t* d_planes[2][3] = {{nullptr}};  // ping-pong: [cur][plane]
     uint8_t* d_pre[3] = {nullptr};           // copy of the reconstruction before the loop filter (debug)
     int cur = 0;                             // index written by the picture being encoded
@@ -283,14 +285,15 @@ hipEvent_t get_event(mi355x_h264_encoder* e)
 }
 
 struct StatScope {
-    mi355x_h264_encoder* e; Slot* s; int k; uint32_t launches, mbs; hipEvent_t a = nullptr, b = nullptr;
-    StatScope(mi355x_h264_encoder* e_, Slot* s_, int k_, uint32_t l, uint32_t m) : e(e_), s(s_), k(k_), launches(l), mbs(m)
+    mi355x_h264_encoder* e; Slot* s; int k; uint32_t launches, mbs; hipStream_t st; hipEvent_t a = nullptr, b = nullptr;
+    StatScope(mi355x_h264_encoder* e_, Slot* s_, int k_, uint32_t l, uint32_t m, hipStream_t st_ = nullptr)
+        : e(e_), s(s_), k(k_), launches(l), mbs(m), st(st_ ? st_ : e_->stream)
     {
-        if (e->stats_on) { a = get_event(e); b = get_event(e); if (a) (void)hipEventRecord(a, e->stream); }
+        if (e->stats_on) { a = get_event(e); b = get_event(e); if (a) (void)hipEventRecord(a, st); }
     }
     ~StatScope()
     {
-        if (e->stats_on && a && b) { (void)hipEventRecord(b, e->stream); s->evs.push_back({a, b, k, launches, mbs}); }
+        if (e->stats_on && a && b) { (void)hipEventRecord(b, st); s->evs.push_back({a, b, k, launches, mbs}); }
     }
 };
 
@@ -345,17 +348,22 @@ int submit(mi355x_h264_encoder* e, const uint8_t* d_src, size_t src_item_stride,
         H.len[g] = (unsigned char)build_slice_header(e, idr, (e->idr_id + g * e->idr_step) & 0xFF, &hdr);
         H.bits[g] = hdr;
     }
+    // entropy coding needs only levels / MbInfo, the loop filter only the reconstruction: run them side by side
+    hipStream_t ec = e->stream_ec;
+    HIPCHK(e, hipEventRecord(S.recon_ready, st));
+    HIPCHK(e, hipStreamWaitEvent(ec, S.recon_ready, 0));
     {
-        StatScope sc(e, &S, MI355X_H264_K_CAVLC, 4, (uint32_t)(e->nmb * e->G));
+        StatScope sc(e, &S, MI355X_H264_K_CAVLC, 4, (uint32_t)(e->nmb * e->G), ec);
         CavlcParams C{};
         C.mb = e->d_mb; C.levels = e->d_levels; C.mvd = e->d_mvd; C.mbw = e->mbw; C.nmb = e->nmb; C.p_slice = idr ? 0 : 1;
         C.slotbits = e->d_slotbits; C.mbbits = e->d_mbbits; C.bitbuf = S.d_bitbuf;
         C.bs = (!e->cfg.disable_deblock && !e->diag_mode) ? (uint8_t*)e->d_bs : nullptr;
         C.st_mb = e->nmb; C.st_bitbuf = e->st_bitbuf_bytes / 4;
         const int grid = (e->nmb + 1) / 2;
-        hipLaunchKernelGGL(k_cavlc<false>, dim3(grid, G), dim3(64), 0, st, C);
-        hipLaunchKernelGGL(k_bit_scan, dim3(G), dim3(1024), 0, st, C, H, S.d_info);
-        hipLaunchKernelGGL(k_cavlc<true>, dim3(grid, G), dim3(64), 0, st, C);
+        hipLaunchKernelGGL(k_cavlc<false>, dim3(grid, G), dim3(64), 0, ec, C);
+        HIPCHK(e, hipEventRecord(S.bs_ready, ec));   // the count pass also produced the boundary strengths
+        hipLaunchKernelGGL(k_bit_scan, dim3(G), dim3(1024), 0, ec, C, H, S.d_info);
+        hipLaunchKernelGGL(k_cavlc<true>, dim3(grid, G), dim3(64), 0, ec, C);
         // access unit layout in the pinned buffer: [pad][SPS PPS (IDR only)][00 00 00 01 hdr][payload...]
         const size_t pre = (idr ? e->sps_pps.size() : 0) + 5;
         const size_t pad = (16 - (pre & 15)) & 15;
@@ -363,13 +371,15 @@ int submit(mi355x_h264_encoder* e, const uint8_t* d_src, size_t src_item_stride,
         S.payload_off = pad + pre;
         S.idr = idr;
         S.nal_hdr = idr ? ((3 << 5) | 5) : ((2 << 5) | 1);
-        hipLaunchKernelGGL(k_pack, dim3(G), dim3(1024), 0, st, (uint8_t*)S.d_bitbuf, e->st_bitbuf_bytes, S.h_au + S.payload_off, e->st_au,
+        hipLaunchKernelGGL(k_pack, dim3(G), dim3(1024), 0, ec, (uint8_t*)S.d_bitbuf, e->st_bitbuf_bytes, S.h_au + S.payload_off, e->st_au,
                            (const SliceInfo*)S.d_info, S.h_info);
     }
+    HIPCHK(e, hipEventRecord(S.entropy_done, ec));
     if (e->keep_pre)
         for (int p = 0; p < 3; p++)
             HIPCHK(e, hipMemcpyAsync(e->d_pre[p], e->d_planes[cur][p], (p ? e->st_c : e->st_y) * e->G, hipMemcpyDeviceToDevice, st));
     if (!e->cfg.disable_deblock) {
+        HIPCHK(e, hipStreamWaitEvent(st, S.bs_ready, 0));
         const int steps = e->mbw + 2 * (e->mbh - 1);
         StatScope sc(e, &S, MI355X_H264_K_DEBLOCK, (uint32_t)(e->diag_mode ? steps : 1), (uint32_t)(e->nmb * e->G));
         DbParams D{};
@@ -395,6 +405,7 @@ int submit(mi355x_h264_encoder* e, const uint8_t* d_src, size_t src_item_stride,
             else hipLaunchKernelGGL(k_deblock_rows<false>, dim3(e->mbh, G), dim3(64), 0, st, R);
         }
     }
+    HIPCHK(e, hipStreamWaitEvent(st, S.entropy_done, 0));   // join: the next picture rewrites MbInfo / levels
     HIPCHK(e, hipEventRecord(S.done, st));
     HIPCHK(e, hipGetLastError());
     S.busy = true;
@@ -517,6 +528,7 @@ int mi355x_h264_create(const mi355x_h264_config* cfg, mi355x_h264_encoder** out)
     } while (0)
     CK(hipSetDevice(e->device));
     CK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    CK(hipStreamCreateWithFlags(&e->stream_ec, hipStreamNonBlocking));
     const size_t ysz = (size_t)e->cw * e->ch;
     const size_t Gn = (size_t)e->G;
     e->st_y = ysz + 256; e->st_c = ysz / 4 + 256;
@@ -557,6 +569,9 @@ int mi355x_h264_create(const mi355x_h264_config* cfg, mi355x_h264_encoder** out)
         *S.h_err = 0;
         CK(hipHostMalloc((void**)&S.h_au, e->st_au * Gn, hipHostMallocDefault));
         CK(hipEventCreateWithFlags(&S.done, hipEventDisableTiming));
+        CK(hipEventCreateWithFlags(&S.recon_ready, hipEventDisableTiming));
+        CK(hipEventCreateWithFlags(&S.bs_ready, hipEventDisableTiming));
+        CK(hipEventCreateWithFlags(&S.entropy_done, hipEventDisableTiming));
     }
     CK(hipDeviceSynchronize());
 #undef CK
@@ -582,9 +597,13 @@ void mi355x_h264_destroy(mi355x_h264_encoder* e)
         if (S.h_err) (void)hipHostFree(S.h_err);
         if (S.h_au) (void)hipHostFree(S.h_au);
         if (S.done) (void)hipEventDestroy(S.done);
+        if (S.recon_ready) (void)hipEventDestroy(S.recon_ready);
+        if (S.bs_ready) (void)hipEventDestroy(S.bs_ready);
+        if (S.entropy_done) (void)hipEventDestroy(S.entropy_done);
         for (auto& ev : S.evs) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
     }
     for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
+    if (e->stream_ec) { (void)hipStreamSynchronize(e->stream_ec); (void)hipStreamDestroy(e->stream_ec); }
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
