@@ -183,6 +183,41 @@ def test_lockstep_batch_equals_serial():
     enc.close()
 
 
+def test_concurrent_instances_under_uneven_load():
+    """the row-wavefront kernels hand samples between workgroups inside one launch; run several encoder
+    instances of different geometry concurrently (uneven load on the chip, L1-warm consumers) and check
+    every access unit against the oracle"""
+    import threading
+    jobs = [(352, 288, "s1", 26, 8), (640, 368, "s1", 30, 6), (176, 144, "s3", 24, 10), (1280, 720, "s1", 26, 4)]
+    want = {}
+    for j in jobs:
+        w, h, kind, qp, n = j
+        orc = OracleEncoder(w, h, qp=qp, gop=3)
+        want[j] = [orc.encode(f)[0] for f in synth.sequence(kind, w, h, n)]
+    errors = []
+
+    def run(j, rounds):
+        try:
+            w, h, kind, qp, n = j
+            frames = synth.sequence(kind, w, h, n)
+            for _ in range(rounds):
+                enc = capi.Encoder(w, h, qp=qp, gop=3)
+                for i, f in enumerate(frames):
+                    if enc.encode(f)[0] != want[j][i]:
+                        errors.append((j, i))
+                        return
+                enc.close()
+        except Exception as ex:  # noqa: BLE001
+            errors.append((j, repr(ex)))
+
+    ths = [threading.Thread(target=run, args=(j, 6 if j[0] < 1000 else 3)) for j in jobs]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errors, errors
+
+
 def test_4k_one_gop_start():
     """BASELINE.json configs[4] size (3840x2160): IDR + P decode round trip and oracle equality on the IDR"""
     w, h = 3840, 2160
