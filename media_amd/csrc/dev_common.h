@@ -64,6 +64,17 @@ __device__ __forceinline__ FrameParams batch_view(FrameParams P, int g)
     return P;
 }
 
+// Synchronisation inside a ONE-WAVE workgroup.  LDS instructions of one wave execute in program order,
+// so a ds_write is visible to a later ds_read of any lane of the same wave; all that is needed is to stop
+// the compiler from reordering them.  Unlike __syncthreads() this emits no s_waitcnt vmcnt(0), so global
+// loads requested ahead of time (prefetch of the next macroblock) stay in flight across it.
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __device__ __forceinline__ int clip3(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
 __device__ __forceinline__ int clip255(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
 __device__ __forceinline__ int iabs(int v) { return v < 0 ? -v : v; }

@@ -276,32 +276,42 @@ __global__ __launch_bounds__(64) void k_deblock_rows(DbRowParams R)
     uint8_t* hcol = isC ? &SC(fpl, -4, fln) : &SY(-4, fln);                 // H phase: top of this lane's column
     const int hstride = isC ? DR_CP : DR_LP;
 
-    // prefetch registers for the macroblock about to be processed
+    // Software pipeline: the samples, boundary strengths and hand-off granules of macroblock mx+1 are
+    // requested (straight-line, unconditional loads) after macroblock mx has been put into LDS, travel
+    // while mx is filtered, and are waited for BEFORE this iteration's stores are issued, so no iteration
+    // ever waits for its own stores (vmcnt counts loads and stores together, in order).
     uint32_t pf_y = 0, pf_c = 0;
     uint4 pf_b0 = {0, 0, 0, 0}, pf_b1 = pf_b0;
     u64 pf_g = 0;
+    const int grow = my > 0 ? my - 1 : 0;          // row 0 reads (and ignores) its own slots
+    const int glane = lane < 24 ? lane : lane - 24 < 24 ? lane - 24 : lane - 48;
     auto prefetch = [&](int mx) {
         pf_y = *(const uint32_t*)(D.pl[0] + (size_t)(16 * my + yr) * D.cw + 16 * mx + yc4);
-        if (lane < 32) pf_c = *(const uint32_t*)((cpl_l ? D.pl[2] : D.pl[1]) + (size_t)(8 * my + cr_l) * cs + 8 * mx + cc4);
+        pf_c = *(const uint32_t*)((cpl_l ? D.pl[2] : D.pl[1]) + (size_t)(8 * my + cr_l) * cs + 8 * mx + cc4);   // lanes >= 32 mirror lanes < 32
         const uint4* b = (const uint4*)(bsw + ((size_t)my * D.mbw + mx) * 8);
         pf_b0 = b[0]; pf_b1 = b[1];
-        if (my > 0 && lane < 24) pf_g = AT_LOAD(handoff + ((size_t)(my - 1) * D.mbw + mx) * 24 + gk);
+        pf_g = AT_LOAD(handoff + ((size_t)grow * D.mbw + mx) * 24 + glane);
+    };
+    auto consume = [&]() {   // forces the waits for the prefetched registers to sit here
+        asm volatile("" : "+v"(pf_y), "+v"(pf_c), "+v"(pf_g));
+        asm volatile("" : "+v"(pf_b0.x), "+v"(pf_b0.y), "+v"(pf_b0.z), "+v"(pf_b0.w));
+        asm volatile("" : "+v"(pf_b1.x), "+v"(pf_b1.y), "+v"(pf_b1.z), "+v"(pf_b1.w));
     };
     prefetch(0);
+    consume();
+    uint32_t cur_y = pf_y, cur_c = pf_c;
+    uint4 b0 = pf_b0, b1 = pf_b1;
+    u64 g = pf_g;
 
     for (int mx = 0; mx <= D.mbw; mx++) {
         const bool have_cur = mx < D.mbw;
         if (have_cur) {
-            const uint32_t cur_y = pf_y, cur_c = pf_c;
-            const uint4 b0 = pf_b0, b1 = pf_b1;
-            u64 g = pf_g;
-            if (mx + 1 < D.mbw) prefetch(mx + 1);
             // 1. previous macroblock moves to the left half of the tile
             if (mx > 0) {
                 *(uint32_t*)&SY(yr, yc4 - 16) = *(const uint32_t*)&SY(yr, yc4);
                 if (lane < 32) *(uint32_t*)&SC(cpl_l, cr_l, cc4 - 8) = *(const uint32_t*)&SC(cpl_l, cr_l, cc4);
             }
-            __syncthreads();
+            wave_sync();
             // 2. current macroblock into LDS
             *(uint32_t*)&SY(yr, yc4) = cur_y;
             if (lane < 32) *(uint32_t*)&SC(cpl_l, cr_l, cc4) = cur_c;
@@ -313,12 +323,14 @@ __global__ __launch_bounds__(64) void k_deblock_rows(DbRowParams R)
                     if (__ballot(bad) == 0ull) break;
                     if (++spins > (1u << 20)) { timed_out = true; break; }
                     __builtin_amdgcn_s_sleep(1);
-                    if (lane < 24) g = AT_LOAD(handoff + ((size_t)(my - 1) * D.mbw + mx) * 24 + gk);
+                    g = AT_LOAD(handoff + ((size_t)grow * D.mbw + mx) * 24 + glane);
                 }
                 if (lane < 16) *(uint32_t*)&SY(-4 + (gk >> 2), (gk & 3) * 4) = (uint32_t)g;
                 else if (lane < 24) *(uint32_t*)&SC((gk - 16) >> 2, -2 + (((gk - 16) >> 1) & 1), ((gk - 16) & 1) * 4) = (uint32_t)g;
             }
-            __syncthreads();
+            // requests for the next macroblock leave now and are collected after the filter
+            if (mx + 1 < D.mbw) prefetch(mx + 1);
+            wave_sync();
             const bool any_v = (b0.x | b0.y | b0.z | b0.w) != 0, any_h = (b1.x | b1.y | b1.z | b1.w) != 0;
             // 4. vertical edges: lane = one line of samples, four edges in registers.
             //    chroma lines take part in steps 0 and 1 (chroma edges 0 and 4 <-> luma edges 0 and 8)
@@ -341,7 +353,7 @@ __global__ __launch_bounds__(64) void k_deblock_rows(DbRowParams R)
                     if (w < 3 || !isC)
                         *(uint32_t*)(vrow + 4 * w) = (uint32_t)px[4 * w] | ((uint32_t)px[4 * w + 1] << 8) | ((uint32_t)px[4 * w + 2] << 16) | ((uint32_t)px[4 * w + 3] << 24);
             }
-            __syncthreads();
+            wave_sync();
             // 5. horizontal edges: lane = one column of samples (rows -4..15; chroma uses rows -4..7 of its tile)
             if (any_h && lane < 32) {
                 int px[20];
@@ -360,7 +372,8 @@ __global__ __launch_bounds__(64) void k_deblock_rows(DbRowParams R)
                     if (both || !isC) hcol[r * hstride] = (uint8_t)px[r];
                 }
             }
-            __syncthreads();
+            wave_sync();
+            consume();   // the next macroblock's data has arrived; nothing below waits for memory any more
             // 6. the top apron (rows 12..15 / 6..7 of the macroblock above) is final: store it
             if (my > 0) {
                 if (lane < 16) *(uint32_t*)(D.pl[0] + (size_t)(16 * my - 4 + (gk >> 2)) * D.cw + 16 * mx + (gk & 3) * 4) = *(const uint32_t*)&SY(-4 + (gk >> 2), (gk & 3) * 4);
@@ -385,7 +398,8 @@ __global__ __launch_bounds__(64) void k_deblock_rows(DbRowParams R)
                 AT_STORE(handoff + ((size_t)my * D.mbw + pmx) * 24 + gk, ((u64)R.serial << 32) | v);
             }
         }
-        __syncthreads();
+        cur_y = pf_y; cur_c = pf_c; b0 = pf_b0; b1 = pf_b1; g = pf_g;
+        wave_sync();
     }
     if (timed_out && lane == 0) *R.err = 1u;  // pinned host word, read after the picture's event
 #undef SY

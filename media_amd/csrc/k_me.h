@@ -140,10 +140,6 @@ __global__ __launch_bounds__(64, 4) void k_me(FrameParams P0)
         }
     }
 
-#ifdef ME_TIMING_NO_SEARCH
-    if (lane == 0) { MbInfo* m = P.mb + mbi; m->mvx = 0; m->mvy = 0; m->type = MB_P16; }
-    return;
-#endif
     // ---- 2. integer full search ----
     unsigned best;
     {
@@ -198,10 +194,6 @@ __global__ __launch_bounds__(64, 4) void k_me(FrameParams P0)
         best = wave_min_u32(best);
     }
     const int ix = (int)(best & 31) - ME_R, iy = (int)((best >> 5) & 31) - ME_R;
-#ifdef ME_TIMING_NO_SUBPEL
-    if (lane == 0) { MbInfo* m = P.mb + mbi; m->mvx = (int16_t)(4 * ix); m->mvy = (int16_t)(4 * iy); m->type = MB_P16; }
-    return;
-#endif
 
     // ---- 3. half-sample planes on an 18x18 grid, origin (ix-1, iy-1); four samples per lane-task ----
     const int oo = (iy + ME_R + ME_AP - 1) * ME_WS + ix + ME_R + ME_AP - 1;   // window byte offset of grid (0,0)

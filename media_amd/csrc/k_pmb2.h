@@ -255,7 +255,6 @@ __global__ __launch_bounds__(64) void k_pmb2(FrameParams P0)
     nz += __builtin_amdgcn_mov_dpp(nz, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
     nz += __builtin_amdgcn_mov_dpp(nz, 0x4E, 0xf, 0xf, false);   // quad_perm [2,3,0,1]  -> TotalCoeff of the block in all 4 lanes
     idct_quad(d, r);
-    if (P.lambda < 0) { d[0] = d[1] = d[2] = d[3] = 0; }   // debug: reconstruction = prediction
     *(uint32_t*)(P.rec[0] + (size_t)(by + ly) * P.cw + bx + lx) =
         pack4(clip255(byte_of(pred4, 0) + d[0]), clip255(byte_of(pred4, 1) + d[1]), clip255(byte_of(pred4, 2) + d[2]), clip255(byte_of(pred4, 3) + d[3]));
     const unsigned long long ymask = __ballot(nz != 0);

@@ -337,7 +337,6 @@ int submit(mi355x_h264_encoder* e, const uint8_t* d_src, size_t src_item_stride,
         { StatScope sc(e, &S, MI355X_H264_K_ME, 1, (uint32_t)(e->nmb * e->G));
           hipLaunchKernelGGL(k_me, dim3(e->nmb, G), dim3(64), 0, st, P); }
         { StatScope sc(e, &S, MI355X_H264_K_PMB, 1, (uint32_t)(e->nmb * e->G));
-          if (getenv("MI355X_H264_DBG_PRED")) P.lambda = -1;
           if (e->pmb_v1) hipLaunchKernelGGL(k_pmb, dim3(e->nmb, G), dim3(64), 0, st, P);
           else hipLaunchKernelGGL(k_pmb2, dim3(e->nmb, G), dim3(64), 0, st, P); }
     }

@@ -1,5 +1,6 @@
 import sys
-sys.path.insert(0, "/root/repo")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from media_amd import synth, capi
 for (w, h) in [(1920, 16), (1920, 32), (1920, 64), (1920, 256), (1920, 1080), (3840, 16), (640, 1080)]:

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Condense a gpurun_out/prof_<tag>/ directory (scratch/prof.sh) into profiles/<tag>_*.{csv,json}."""
+"""Condense a gpurun_out/prof_<tag>/ directory (tools/prof.sh) into profiles/<tag>_*.{csv,json}."""
 import csv, collections, glob, json, os, sys
 tag = sys.argv[1]
 src = "gpurun_out/prof_%s" % tag
