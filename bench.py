@@ -209,8 +209,9 @@ def main():
         per_kernel = {}
         for name, v in k.items():
             if v["launches"]:
-                per_kernel[name] = {"ms_per_picture": round(v["ms"] * nmb / max(1, v["mbs"]), 4),
-                                    "launches_per_picture": round(v["launches"] * nmb / max(1, v["mbs"]), 1)}
+                per_kernel[name] = {"ms_per_picture": round(v["ms"] * nmb / max(1, v["mbs"]), 5),
+                                    "ms_per_launch": round(v["ms"] / v["launches"], 4),
+                                    "pictures_per_launch": round(v["mbs"] / nmb / v["launches"], 2)}
         traffic = None
         try:  # HBM bytes per k_pmb2 launch from the committed PMC passes (profiles/), valid for the same batch size
             tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
@@ -223,9 +224,9 @@ def main():
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "1080p30 I420 synthetic S1 pan+noise, baseline profile, fixed QP 26, "
-                                   "GOP 30 (1 IDR + 29 P per step), single slice, 1 ref, deblock on, CAVLC; "
-                                   "one stream per GPU, pictures resident in HBM",
+            "config": {"workload": "1080p30 I420 synthetic S1 pan+noise, baseline profile, fixed QP 26, closed GOPs of 30 "
+                                   "(1 IDR + 29 P), single slice, 1 ref, deblock on, CAVLC; per GPU one stream whose "
+                                   "closed GOPs are encoded %d at a time in lockstep, pictures resident in HBM" % G,
                        "width": WIDTH, "height": HEIGHT, "qp": QP, "gop": GOP, "frames_per_step": FRAMES_PER_STEP * G, "gops_in_flight": G, "instances": I, "lockstep_batch": B,
                        "streams": world, "bytes_per_gop": int(nbytes), "parity": "bit-exact vs CPU oracle "
                        "(oracle unpinned vs OpenH264: no libopenh264 available)"},
