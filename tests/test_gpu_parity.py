@@ -94,6 +94,19 @@ def test_nv12_ingest_main_profile_1080p60():
     enc.close()
 
 
+def test_reference_forms_of_the_kernels(monkeypatch):
+    """the simpler first forms (one launch per wavefront step, lane-per-block MC+DCT) stay selectable for
+    debugging and must give the same stream"""
+    monkeypatch.setenv("MI355X_H264_DIAG", "1")
+    monkeypatch.setenv("MI355X_H264_PMB_V1", "1")
+    w, h = 208, 160
+    enc = capi.Encoder(w, h, qp=27, gop=3)
+    orc = OracleEncoder(w, h, qp=27, gop=3)
+    for f in synth.sequence("s1", w, h, 5):
+        assert enc.encode(f)[0] == orc.encode(f)[0]
+    enc.close()
+
+
 def test_no_deblock_variant():
     w, h = 160, 96
     enc = capi.Encoder(w, h, qp=32, disable_deblock=1)
