@@ -67,8 +67,15 @@ def frame_s3(width, height, index):
     return (_hash_u32(1 + index, n) & np.uint32(255)).astype(np.uint8)
 
 
+def frame_ramp(width, height, index):
+    """diagonal ramp whose slope grows with the picture index, flat chroma.  Not one of the SURVEY inputs:
+    it exists because its slices contain 00 00 0x byte patterns, i.e. it exercises emulation prevention."""
+    y = (np.add.outer(np.arange(height), np.arange(width)) * (index + 1) // 4 % 256).astype(np.uint8).ravel()
+    return np.concatenate([y, np.full(width * height // 2, 128, np.uint8)])
+
+
 def sequence(kind, width, height, count, start=0):
-    fn = {"s1": frame_s1, "s2": frame_s2, "s3": frame_s3}[kind]
+    fn = {"s1": frame_s1, "s2": frame_s2, "s3": frame_s3, "ramp": frame_ramp}[kind]
     return [fn(width, height, start + i) for i in range(count)]
 
 

@@ -107,6 +107,21 @@ def test_reference_forms_of_the_kernels(monkeypatch):
     enc.close()
 
 
+def test_emulation_prevention_slow_path():
+    """slices whose payload needs 00 00 03 escapes: k_pack counts the sites, the host inserts the bytes"""
+    w, h = 176, 144
+    for qp in (26, 30):
+        enc = capi.Encoder(w, h, qp=qp, gop=100)
+        orc = OracleEncoder(w, h, qp=qp, gop=100)
+        escaped = 0
+        for f in synth.sequence("ramp", w, h, 6):
+            bs, _ = enc.encode(f)
+            assert bs == orc.encode(f)[0]
+            escaped += b"\x00\x00\x03" in bs[bs.rfind(b"\x00\x00\x00\x01") + 5:]
+        assert escaped >= 2
+        enc.close()
+
+
 def test_no_deblock_variant():
     w, h = 160, 96
     enc = capi.Encoder(w, h, qp=32, disable_deblock=1)

@@ -67,6 +67,21 @@ def test_forced_idr_and_qp_change():
     assert kinds == [True, False, True, False, False]
 
 
+def test_emulation_prevention_inside_slices():
+    """the 'ramp' input makes slice payloads that contain 00 00 0x: the escaped stream must round-trip"""
+    w, h = 176, 144
+    enc = OracleEncoder(w, h, qp=30, gop=100)
+    dec = OracleDecoder()
+    escaped = 0
+    for f in synth.sequence("ramp", w, h, 6):
+        bs, _ = enc.encode(f)
+        escaped += b"\x00\x00\x03" in bs[bs.rfind(b"\x00\x00\x00\x01") + 5:]
+        assert dec.decode(bs) == 1
+        for p in range(3):
+            assert np.array_equal(dec.plane(p), enc.recon(p))
+    assert escaped >= 2
+
+
 def test_decoder_rejects_garbage():
     dec = OracleDecoder()
     with pytest.raises(RuntimeError):
