@@ -74,6 +74,8 @@ def main():
     ap.add_argument("--instances", type=int, default=int(os.environ.get("BENCH_INSTANCES", "1")),
                     help="encoder instances (HIP streams) the GOPs in flight are split over; each encodes its share in lockstep")
     ap.add_argument("--cpu-frames", type=int, default=8, help="pictures per CPU-baseline thread")
+    ap.add_argument("--content", default="s1", choices=["s1", "s2", "s3"],
+                    help="synthetic input of SURVEY.md 8(d); s1 pan+noise is the headline workload")
     args = ap.parse_args()
 
     import numpy as np
@@ -98,7 +100,7 @@ def main():
     # sequence; GOP g is the same sequence with every plane rolled horizontally by 16*g luma samples, so each
     # GOP is distinct data (G x 93 MB) without G x the host-side generation time.
     G = max(1, args.gops_in_flight)
-    frames = synth.sequence("s1", WIDTH, HEIGHT, FRAMES_PER_STEP)
+    frames = synth.sequence(args.content, WIDTH, HEIGHT, FRAMES_PER_STEP)
     fbytes = WIDTH * HEIGHT * 3 // 2
     stride = (fbytes + 255) // 256 * 256
     gop_stride = stride * FRAMES_PER_STEP
@@ -127,7 +129,7 @@ def main():
     for i, e_ in enumerate(insts):
         e_.set_idr_pic_id(i * B, 1)
     enc = insts[0]
-    cap = FRAMES_PER_STEP * fbytes // 2
+    cap = FRAMES_PER_STEP * fbytes * 2 if args.content == "s3" else FRAMES_PER_STEP * fbytes // 2   # random noise does not compress
     outs = [np.zeros(B * cap, np.uint8) for _ in range(I)]
     sizes = [np.zeros(B * FRAMES_PER_STEP, np.uint32) for _ in range(I)]
     gop_bytes = [np.zeros(B, np.uint64) for _ in range(I)]
@@ -227,7 +229,7 @@ def main():
             "config": {"workload": "1080p30 I420 synthetic S1 pan+noise, baseline profile, fixed QP 26, closed GOPs of 30 "
                                    "(1 IDR + 29 P), single slice, 1 ref, deblock on, CAVLC; per GPU one stream whose "
                                    "closed GOPs are encoded %d at a time in lockstep, pictures resident in HBM" % G,
-                       "width": WIDTH, "height": HEIGHT, "qp": QP, "gop": GOP, "frames_per_step": FRAMES_PER_STEP * G, "gops_in_flight": G, "instances": I, "lockstep_batch": B,
+                       "content": args.content, "width": WIDTH, "height": HEIGHT, "qp": QP, "gop": GOP, "frames_per_step": FRAMES_PER_STEP * G, "gops_in_flight": G, "instances": I, "lockstep_batch": B,
                        "streams": world, "bytes_per_gop": int(nbytes), "parity": "bit-exact vs CPU oracle "
                        "(oracle unpinned vs OpenH264: no libopenh264 available)"},
             "roofline": {"kernel": "k_pmb2 (MC + fDCT + quant + dequant + iDCT + recon)", "bound": "hbm",

@@ -61,30 +61,46 @@ __global__ __launch_bounds__(64, 4) void k_me(FrameParams P0)
     __shared__ __attribute__((aligned(16))) uint8_t s_pl[4 * ME_PLS + 16];        // planes G,b,h,j: 18 rows, pitch 20
 
     load_src_mb(P, mx, my, s_src, s_srcc, lane);
-    // reference window, clamped at the picture edge (unrestricted motion vectors).  All 13 requests of a
-    // lane are issued before the first is consumed (one HBM/L2 latency instead of thirteen).
+    // reference window, clamped at the picture edge (unrestricted motion vectors); all requests of a lane are
+    // issued before the first is consumed (one memory latency).  Macroblocks whose window (widened to 64 B
+    // rows) lies inside the picture use a fixed pattern: lane = (dword column 0..15, row group 0..3), 14 rows
+    // each, one address increment per request.
     {
-        const bool interior = bx - ME_R - ME_AP >= 0 && bx + 16 + ME_R + ME_AP <= P.cw;
-        uint32_t v[13];
+        const int wx0 = bx - ME_R - ME_AP, wy0 = by - ME_R - ME_AP;
+        const bool inside = wx0 >= 0 && wx0 + 64 <= P.cw && wy0 >= 0 && wy0 + ME_WS <= P.ch;
+        if (inside) {
+            const int c = lane & 15, rg = lane >> 4;
+            const uint8_t* rp = P.ref[0] + (size_t)(wy0 + rg) * P.cw + wx0 + 4 * c;
+            const size_t step = (size_t)4 * P.cw;
+            uint32_t v[14];
 #pragma unroll
-        for (int t = 0; t < 13; t++) {
-            const int i = lane + 64 * t;
-            const int row = i / ME_WDW, dw = i - row * ME_WDW;
-            const int gy = clip3(0, P.ch - 1, by - ME_R - ME_AP + row);
-            const int gx = bx - ME_R - ME_AP + dw * 4;
-            const uint8_t* rp = P.ref[0] + (size_t)gy * P.cw;
-            v[t] = 0;
-            if (i < ME_WS * ME_WDW) {
-                if (interior) v[t] = *(const uint32_t*)(rp + gx);
-                else {
+            for (int t = 0; t < 14; t++) v[t] = *(const uint32_t*)(rp + t * step);
+            if (c < ME_WDW)
 #pragma unroll
-                    for (int k = 0; k < 4; k++) v[t] |= (uint32_t)rp[clip3(0, P.cw - 1, gx + k)] << (8 * k);
+                for (int t = 0; t < 14; t++) s_win[(rg + 4 * t) * ME_WDW + c] = v[t];
+        } else {
+            const bool interior = wx0 >= 0 && bx + 16 + ME_R + ME_AP <= P.cw;
+            uint32_t v[13];
+#pragma unroll
+            for (int t = 0; t < 13; t++) {
+                const int i = lane + 64 * t;
+                const int row = i / ME_WDW, dw = i - row * ME_WDW;
+                const int gy = clip3(0, P.ch - 1, wy0 + row);
+                const int gx = wx0 + dw * 4;
+                const uint8_t* rp = P.ref[0] + (size_t)gy * P.cw;
+                v[t] = 0;
+                if (i < ME_WS * ME_WDW) {
+                    if (interior) v[t] = *(const uint32_t*)(rp + gx);
+                    else {
+#pragma unroll
+                        for (int k = 0; k < 4; k++) v[t] |= (uint32_t)rp[clip3(0, P.cw - 1, gx + k)] << (8 * k);
+                    }
                 }
             }
-        }
 #pragma unroll
-        for (int t = 0; t < 13; t++)
-            if (lane + 64 * t < ME_WS * ME_WDW) s_win[lane + 64 * t] = v[t];
+            for (int t = 0; t < 13; t++)
+                if (lane + 64 * t < ME_WS * ME_WDW) s_win[lane + 64 * t] = v[t];
+        }
     }
     if (lane < 32) {  // co-located chroma
         const int pl = lane >> 4, row = (lane >> 1) & 7, xs = (lane & 1) * 4;
@@ -273,10 +289,10 @@ __global__ __launch_bounds__(64, 4) void k_me(FrameParams P0)
             int s = hadamard_abs(d);
             s = group_sum<16>(s);
             const unsigned cost = (unsigned)(s >> 1) + (unsigned)(P.lambda * (se_len(qx) + se_len(qy)));
-            unsigned key = c < ncand ? ((cost << 4) | (unsigned)ord) : 0xFFFFFFFFu;
-            key = wave_min_u32(key);
-            bestk = key < bestk ? key : bestk;
+            const unsigned key = c < ncand ? ((cost << 4) | (unsigned)ord) : 0xFFFFFFFFu;
+            bestk = key < bestk ? key : bestk;   // per-lane running minimum; reduced once per pass
         }
+        bestk = wave_min_u32(bestk);
         const int ord = (int)(bestk & 15);
         best_cost = bestk >> 4;
         if (ord) {
