@@ -146,7 +146,7 @@ enum {
     MI355X_H264_DBG_PRE_V = 7
 };
 int mi355x_h264_debug_keep_pre(mi355x_h264_encoder *enc, int on);
-/* copies the named device buffer of the last encoded picture to dst; returns bytes or <0 */
+/* copies the named device buffer of the last encoded picture (batch item 0) to dst; returns bytes or <0 */
 int64_t mi355x_h264_debug_read(mi355x_h264_encoder *enc, int what, void *dst, size_t cap);
 
 /* per-kernel device time accumulated since the last reset, measured with HIP

@@ -137,7 +137,6 @@ void fill_quant(Quant& q, int qp)
 }
 
 constexpr int NSLOT = 3;          // access-unit slots in flight
-constexpr int MAX_EV = 64;
 
 struct Slot {
     uint32_t* d_bitbuf = nullptr;   // device slice payload (zeroed before use)
@@ -145,7 +144,6 @@ struct Slot {
     SliceInfo* h_info = nullptr;    // pinned
     unsigned* h_err = nullptr;      // pinned copy of the wavefront kernels' timeout flag
     uint8_t* h_au = nullptr;        // pinned access unit buffer
-    size_t used_bytes = 0;          // payload bytes of the last use (for re-zeroing)
     size_t payload_off = 0;         // offset of the slice payload inside h_au
     size_t au_start = 0;            // offset of the first byte of the access unit
     int nal_hdr = 0;
@@ -177,7 +175,6 @@ struct mi355x_h264_encoder {
     uint16_t* d_slotbits = nullptr;
     uint32_t* d_mbbits = nullptr;
     unsigned long long* d_handoff = nullptr; // row-to-row hand-off of the wavefront kernels
-    unsigned* d_err = nullptr;
     uint32_t* d_bs = nullptr;                // boundary strengths, 32 B per macroblock
     unsigned serial = 0;
     bool diag_mode = false;                  // debug: one launch per wavefront step instead
@@ -546,8 +543,6 @@ int mi355x_h264_create(const mi355x_h264_config* cfg, mi355x_h264_encoder** out)
     e->st_handoff = (size_t)e->nmb * 24;
     CK(hipMalloc((void**)&e->d_handoff, Gn * e->st_handoff * sizeof(unsigned long long)));
     CK(hipMemset(e->d_handoff, 0, Gn * e->st_handoff * sizeof(unsigned long long)));
-    CK(hipMalloc((void**)&e->d_err, sizeof(unsigned)));
-    CK(hipMemset(e->d_err, 0, sizeof(unsigned)));
     CK(hipMalloc((void**)&e->d_bs, Gn * e->nmb * 32));
     e->diag_mode = getenv("MI355X_H264_DIAG") != nullptr && e->G == 1;
     e->pmb_v1 = getenv("MI355X_H264_PMB_V1") != nullptr;
@@ -588,7 +583,7 @@ void mi355x_h264_destroy(mi355x_h264_encoder* e)
     for (int p = 0; p < 3; p++) (void)hipFree(e->d_pre[p]);
     (void)hipFree(e->d_mb); (void)hipFree(e->d_levels); (void)hipFree(e->d_mvd);
     (void)hipFree(e->d_slotbits); (void)hipFree(e->d_mbbits); (void)hipFree(e->d_stage); (void)hipFree(e->d_stage2);
-    (void)hipFree(e->d_handoff); (void)hipFree(e->d_err); (void)hipFree(e->d_bs);
+    (void)hipFree(e->d_handoff); (void)hipFree(e->d_bs);
     if (e->h_stage) (void)hipHostFree(e->h_stage);
     for (auto& S : e->slots) {
         (void)hipFree(S.d_bitbuf); (void)hipFree(S.d_info);
