@@ -71,7 +71,7 @@ typedef struct mi355x_h264_config {
     int32_t device;          /* HIP device ordinal                                  */
     int32_t disable_deblock; /* iLoopFilterDisableIdc (ref :295), 0 = filter on     */
     int32_t batch;           /* closed GOPs (or independent streams) encoded in lockstep by one instance,
-                              * 1..32; > 1 is driven through mi355x_h264_encode_gops_device only      */
+                              * 1..64; > 1 is driven through mi355x_h264_encode_gops_device only      */
     int32_t reserved[4];
 } mi355x_h264_config;
 

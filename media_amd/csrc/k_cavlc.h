@@ -262,7 +262,8 @@ __device__ __forceinline__ CavlcParams batch_view(CavlcParams C, int g)
     if (C.bs) C.bs += (size_t)g * C.st_mb * 32;
     return C;
 }
-struct HdrBatch { unsigned long long bits[32]; unsigned char len[32]; };  // slice header of every batch item
+enum { MAX_BATCH = 64 };
+struct HdrBatch { unsigned long long bits[MAX_BATCH]; unsigned char len[MAX_BATCH]; };  // slice header of every batch item
 
 // 8.7.2.1 boundary strength of one 4-sample edge segment; l = (dir, edge, segment) within the macroblock.
 // Computed here because this pass already walks (macroblock, 32 lanes) over final MbInfo.

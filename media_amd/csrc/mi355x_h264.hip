@@ -510,7 +510,7 @@ int mi355x_h264_create(const mi355x_h264_config* cfg, mi355x_h264_encoder** out)
     e->cw = e->mbw * 16; e->ch = e->mbh * 16; e->nmb = e->mbw * e->mbh;
     e->level_idc = std::max(32, pick_level(e->nmb, cfg->fps > 0 ? cfg->fps : 30));
     e->G = cfg->batch > 1 ? cfg->batch : 1;
-    if (e->G > 32) { delete e; return MI355X_H264_E_ARG; }
+    if (e->G > MAX_BATCH) { delete e; return MI355X_H264_E_ARG; }
     e->esc_buf.resize((size_t)e->G);
     build_parameter_sets(e);
 #define CK(call)                                                              \
