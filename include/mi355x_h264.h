@@ -128,6 +128,11 @@ int mi355x_h264_set_qp(mi355x_h264_encoder *enc, int qp);
  * sharded over several encoder instances / GPUs (instance i of G: next = i, step = G) the
  * concatenated output equals the serial stream byte for byte. */
 int mi355x_h264_set_idr_pic_id(mi355x_h264_encoder *enc, int next, int step);
+/* Scene-change statistic of the last finished picture, one value per batch item: the sum over the
+ * macroblocks that went through motion search of min(final SATD-based motion cost, 16383); 0 for IDR
+ * pictures.  The plugin class compares it with a threshold and re-codes the picture as IDR
+ * (bEnableSceneChangeDetect = 1 in the reference preset, VideoEncoderOpenH264.cpp:283). */
+int mi355x_h264_last_me_cost(const mi355x_h264_encoder *enc, uint32_t *cost);
 const char *mi355x_h264_last_error(const mi355x_h264_encoder *enc);
 
 /* coded picture geometry (multiples of 16) */

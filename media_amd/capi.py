@@ -24,7 +24,7 @@ EXPORTS = [
     "mi355x_h264_force_idr", "mi355x_h264_last_error", "mi355x_h264_coded_width", "mi355x_h264_coded_height",
     "mi355x_h264_debug_keep_pre", "mi355x_h264_debug_read", "mi355x_h264_stats_enable", "mi355x_h264_stats_read",
     "mi355x_h264_set_qp", "mi355x_h264_set_idr_pic_id", "mi355x_h264_encode_nv12", "mi355x_h264_encode_nv12_device",
-    "mi355x_h264_encode_gops_device",
+    "mi355x_h264_encode_gops_device", "mi355x_h264_last_me_cost",
 ]
 
 
@@ -63,6 +63,7 @@ def lib():
         L.mi355x_h264_encode_batch_device.argtypes = [vp, vp, C.c_size_t, C.c_int, vp, C.c_size_t, vp,
                                                       C.POINTER(C.c_size_t)]
         L.mi355x_h264_encode_gops_device.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_int, vp, C.c_size_t, vp, vp]
+        L.mi355x_h264_last_me_cost.argtypes = [vp, vp]
         L.mi355x_h264_force_idr.argtypes = [vp]
         L.mi355x_h264_set_qp.argtypes = [vp, C.c_int]
         L.mi355x_h264_set_idr_pic_id.argtypes = [vp, C.c_int, C.c_int]
@@ -146,6 +147,11 @@ class Encoder:
         self._check(lib().mi355x_h264_encode_gops_device(self.h, C.c_void_p(dev_ptr), frame_stride, gop_stride, frames_per_gop,
                                                          out_buf.ctypes.data, out_cap_per_gop, sizes.ctypes.data,
                                                          gop_bytes.ctypes.data))
+
+    def me_cost(self):
+        a = np.zeros(self.batch, np.uint32)
+        self._check(lib().mi355x_h264_last_me_cost(self.h, a.ctypes.data))
+        return a
 
     def force_idr(self):
         self._check(lib().mi355x_h264_force_idr(self.h))

@@ -43,6 +43,7 @@ struct FrameParams {
     MbInfo* mb;
     int16_t* levels;     // LV_STRIDE int16 per macroblock
     int16_t* mvd;        // 2 int16 per macroblock (mv - predictor)
+    unsigned* me_cost;   // per batch item: sum over searched macroblocks of min(final motion cost, 16383)
     Quant qy, qc;        // luma / chroma quantisers
     int lambda;
     // lockstep batch (gridDim.y = number of independent closed GOPs / streams encoded together):
@@ -61,6 +62,7 @@ __device__ __forceinline__ FrameParams batch_view(FrameParams P, int g)
     P.mb += (size_t)g * P.st_mb;
     P.levels += (size_t)g * P.st_mb * LV_STRIDE;
     P.mvd += (size_t)g * P.st_mb * 2;
+    P.me_cost += g;
     return P;
 }
 

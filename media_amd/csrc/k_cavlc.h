@@ -363,10 +363,12 @@ struct SliceInfo {       // lives in pinned host memory, written by the device
     uint32_t total_bytes;
     uint32_t epb_count;  // positions needing an emulation prevention byte
     uint32_t error;
+    uint32_t me_cost;    // scene-change statistic gathered by k_me (0 for IDR pictures)
+    uint32_t pad[3];
 };
 
 // one workgroup of 1024: exclusive scan of mbbits (in place -> offsets), header, tail
-__global__ __launch_bounds__(1024) void k_bit_scan(CavlcParams C0, HdrBatch H, SliceInfo* info0)
+__global__ __launch_bounds__(1024) void k_bit_scan(CavlcParams C0, HdrBatch H, SliceInfo* info0, unsigned* me_cost0)
 {
     const CavlcParams C = batch_view(C0, blockIdx.x);
     const unsigned long long hdr_bits = H.bits[blockIdx.x];
@@ -415,6 +417,8 @@ __global__ __launch_bounds__(1024) void k_bit_scan(CavlcParams C0, HdrBatch H, S
         info->total_bytes = (total + 7) >> 3;
         info->epb_count = 0;
         info->error = 0;
+        info->me_cost = me_cost0[blockIdx.x];
+        me_cost0[blockIdx.x] = 0;   // ready for the next picture's motion search (ordered by the stream join)
     }
 }
 

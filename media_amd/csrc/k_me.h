@@ -304,6 +304,7 @@ __global__ __launch_bounds__(64, 4) void k_me(FrameParams P0)
     if (lane == 0) {
         MbInfo* m = P.mb + mbi;
         m->mvx = (int16_t)cx; m->mvy = (int16_t)cy; m->type = MB_P16;
+        atomicAdd(P.me_cost, best_cost < 16383u ? best_cost : 16383u);   // scene-change statistic of the picture
     }
 }
 

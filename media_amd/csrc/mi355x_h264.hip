@@ -176,6 +176,8 @@ struct mi355x_h264_encoder {
     uint32_t* d_mbbits = nullptr;
     unsigned long long* d_handoff = nullptr; // row-to-row hand-off of the wavefront kernels
     uint32_t* d_bs = nullptr;                // boundary strengths, 32 B per macroblock
+    unsigned* d_me_cost = nullptr;           // [G] scene-change statistic
+    std::vector<uint32_t> last_me_cost;      // of the last finished picture, per batch item
     unsigned serial = 0;
     bool diag_mode = false;                  // debug: one launch per wavefront step instead
     bool pmb_v1 = false;                     // debug: first form of the MC+DCT kernel (k_pmb.h)
@@ -306,7 +308,7 @@ int submit(mi355x_h264_encoder* e, const uint8_t* d_src, size_t src_item_stride,
     P.src = d_src; P.w = e->cfg.width; P.h = e->cfg.height;
     P.cw = e->cw; P.ch = e->ch; P.mbw = e->mbw; P.mbh = e->mbh;
     for (int p = 0; p < 3; p++) { P.rec[p] = e->d_planes[cur][p]; P.ref[p] = e->d_planes[prev][p]; }
-    P.mb = e->d_mb; P.levels = e->d_levels; P.mvd = e->d_mvd;
+    P.mb = e->d_mb; P.levels = e->d_levels; P.mvd = e->d_mvd; P.me_cost = e->d_me_cost;
     P.st_src = src_item_stride; P.st_y = e->st_y; P.st_c = e->st_c; P.st_mb = e->nmb;
     const unsigned G = (unsigned)e->G;
     fill_quant(P.qy, e->qp);
@@ -358,7 +360,7 @@ int submit(mi355x_h264_encoder* e, const uint8_t* d_src, size_t src_item_stride,
         const int grid = (e->nmb + 1) / 2;
         hipLaunchKernelGGL(k_cavlc<false>, dim3(grid, G), dim3(64), 0, ec, C);
         HIPCHK(e, hipEventRecord(S.bs_ready, ec));   // the count pass also produced the boundary strengths
-        hipLaunchKernelGGL(k_bit_scan, dim3(G), dim3(1024), 0, ec, C, H, S.d_info);
+        hipLaunchKernelGGL(k_bit_scan, dim3(G), dim3(1024), 0, ec, C, H, S.d_info, e->d_me_cost);
         hipLaunchKernelGGL(k_cavlc<true>, dim3(grid, G), dim3(64), 0, ec, C);
         // access unit layout in the pinned buffer: [pad][SPS PPS (IDR only)][00 00 00 01 hdr][payload...]
         const size_t pre = (idr ? e->sps_pps.size() : 0) + 5;
@@ -439,6 +441,7 @@ int finish_item(mi355x_h264_encoder* e, int slot_idx, int g, uint8_t** out, uint
 {
     Slot& S = e->slots[slot_idx];
     const SliceInfo info = S.h_info[g];
+    e->last_me_cost[g] = info.me_cost;
     if (info.error) return fail(e, MI355X_H264_E_INTERNAL, "device reported error %u", info.error);
     if ((size_t)info.total_bytes + 64 > e->bitbuf_cap) return fail(e, MI355X_H264_E_OVERFLOW, "slice of %u bytes exceeds buffer", info.total_bytes);
     uint8_t* base = S.h_au + (size_t)g * e->st_au;
@@ -544,6 +547,9 @@ int mi355x_h264_create(const mi355x_h264_config* cfg, mi355x_h264_encoder** out)
     CK(hipMalloc((void**)&e->d_handoff, Gn * e->st_handoff * sizeof(unsigned long long)));
     CK(hipMemset(e->d_handoff, 0, Gn * e->st_handoff * sizeof(unsigned long long)));
     CK(hipMalloc((void**)&e->d_bs, Gn * e->nmb * 32));
+    CK(hipMalloc((void**)&e->d_me_cost, Gn * sizeof(unsigned)));
+    CK(hipMemset(e->d_me_cost, 0, Gn * sizeof(unsigned)));
+    e->last_me_cost.assign(Gn, 0);
     e->diag_mode = getenv("MI355X_H264_DIAG") != nullptr && e->G == 1;
     e->pmb_v1 = getenv("MI355X_H264_PMB_V1") != nullptr;
     e->frame_bytes = (size_t)cfg->width * cfg->height * 3 / 2;
@@ -583,7 +589,7 @@ void mi355x_h264_destroy(mi355x_h264_encoder* e)
     for (int p = 0; p < 3; p++) (void)hipFree(e->d_pre[p]);
     (void)hipFree(e->d_mb); (void)hipFree(e->d_levels); (void)hipFree(e->d_mvd);
     (void)hipFree(e->d_slotbits); (void)hipFree(e->d_mbbits); (void)hipFree(e->d_stage); (void)hipFree(e->d_stage2);
-    (void)hipFree(e->d_handoff); (void)hipFree(e->d_bs);
+    (void)hipFree(e->d_handoff); (void)hipFree(e->d_bs); (void)hipFree(e->d_me_cost);
     if (e->h_stage) (void)hipHostFree(e->h_stage);
     for (auto& S : e->slots) {
         (void)hipFree(S.d_bitbuf); (void)hipFree(S.d_info);
@@ -732,6 +738,13 @@ int mi355x_h264_force_idr(mi355x_h264_encoder* e)
 {
     if (!e) return MI355X_H264_E_ARG;
     e->force_idr = 1;
+    return MI355X_H264_OK;
+}
+
+int mi355x_h264_last_me_cost(const mi355x_h264_encoder* e, uint32_t* cost)
+{
+    if (!e || !cost) return MI355X_H264_E_ARG;
+    for (int g = 0; g < e->G; g++) cost[g] = e->last_me_cost[g];
     return MI355X_H264_OK;
 }
 

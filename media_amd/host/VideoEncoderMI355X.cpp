@@ -180,6 +180,8 @@ bool VideoEncoderMI355X::InitParams()
     }
     m_qp = cfg.qp;
     m_bufferBits = 0;
+    // bEnableSceneChangeDetect = 1 in the reference preset (ref :283); "0" in this extension key turns it off
+    m_sceneDetect = GetStrEncParam("persist.vmi.video.encode.scenedetect") != "0";
     const int rc = mi355x_h264_create(&cfg, &m_encoder);
     if (rc != MI355X_H264_OK) {
         ERR("mi355x_h264_create failed, rc = %d", rc);
@@ -272,6 +274,22 @@ EncoderRetCode VideoEncoderMI355X::EncodeOneFrame(const uint8_t *inputData, uint
     if (rc != MI355X_H264_OK) {
         ERR("encoder encode frame failed, rc = %d (%s)", rc, mi355x_h264_last_error(m_encoder));
         return VIDEO_ENCODER_ENCODE_FAIL;
+    }
+    if (m_sceneDetect && frameType == MI355X_H264_FRAME_P) {
+        // scene change: the motion search found no good match anywhere -> code this picture as IDR instead
+        uint32_t cost = 0;
+        const uint32_t mbs = ((m_encParams.width + 15) / 16) * ((m_encParams.height + 15) / 16);
+        if (mi355x_h264_last_me_cost(m_encoder, &cost) == MI355X_H264_OK &&
+            static_cast<uint64_t>(cost) > static_cast<uint64_t>(MI355X::SCENE_CUT_COST_PER_MB) * mbs) {
+            INFO("scene change detected (motion cost %u over %u macroblocks), re-coding as IDR", cost, mbs);
+            (void) mi355x_h264_force_idr(m_encoder);
+            const int rc2 = mi355x_h264_encode(m_encoder, y, stride, u, stride / 2, v, stride / 2, outputData, outputSize, &frameType);
+            if (rc2 != MI355X_H264_OK) {
+                ERR("encoder encode frame failed, rc = %d (%s)", rc2, mi355x_h264_last_error(m_encoder));
+                return VIDEO_ENCODER_ENCODE_FAIL;
+            }
+            m_sceneCuts++;
+        }
     }
     RateControlUpdate(*outputSize, frameType == MI355X_H264_FRAME_IDR);
     return VIDEO_ENCODER_SUCCESS;

@@ -30,6 +30,8 @@ namespace MI355X {
     constexpr int32_t QP_MIN = 12;
     constexpr int32_t QP_MAX = 48;
     constexpr int32_t QP_START = 30;
+    // scene change: mean motion cost per macroblock above this re-codes the picture as IDR
+    constexpr uint32_t SCENE_CUT_COST_PER_MB = 3000;
 }
 
 class VideoEncoderMI355X : public VideoEncoder {
@@ -51,6 +53,8 @@ public:
 
     // picture QP used for the last encoded picture (test hook for the rate controller)
     int32_t LastFrameQp() const { return m_lastQp; }
+    // number of pictures re-coded as IDR by the scene-change detector (test hook)
+    uint32_t SceneCuts() const { return m_sceneCuts; }
 
 private:
     struct EncodeParams {
@@ -82,6 +86,8 @@ private:
     int32_t m_qp = MI355X::QP_START;
     int32_t m_lastQp = 0;
     int64_t m_bufferBits = 0;    // virtual buffer fullness relative to the target rate
+    bool m_sceneDetect = true;   // bEnableSceneChangeDetect = 1 in the reference preset (ref :283)
+    uint32_t m_sceneCuts = 0;
 };
 
 #endif  // VIDEO_ENCODER_MI355X_H

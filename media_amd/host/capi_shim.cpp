@@ -24,6 +24,11 @@ int32_t vc_last_qp(void *enc)
     auto *m = dynamic_cast<VideoEncoderMI355X *>(static_cast<VideoEncoder *>(enc));
     return m != nullptr ? m->LastFrameQp() : -1;
 }
+uint32_t vc_scene_cuts(void *enc)
+{
+    auto *m = dynamic_cast<VideoEncoderMI355X *>(static_cast<VideoEncoder *>(enc));
+    return m != nullptr ? m->SceneCuts() : 0;
+}
 void vc_prop_set(const char *key, const char *value) { SetEncParam(key, value); }
 int32_t vc_prop_get_int(const char *key) { return GetIntEncParam(key); }
 int32_t vc_prop_get_str(const char *key, char *buf, int32_t cap)

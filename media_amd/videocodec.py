@@ -31,6 +31,8 @@ def lib():
         L.vc_encode.argtypes = [vp, vp, C.c_uint32, C.POINTER(vp), C.POINTER(C.c_uint32)]
         L.vc_encode.restype = C.c_uint32
         L.vc_last_qp.argtypes = [vp]
+        L.vc_scene_cuts.argtypes = [vp]
+        L.vc_scene_cuts.restype = C.c_uint32
         L.vc_prop_set.argtypes = [C.c_char_p, C.c_char_p]
         L.vc_prop_set.restype = None
         L.vc_prop_get_int.argtypes = [C.c_char_p]
@@ -62,6 +64,7 @@ def set_video_mode(width, height, fps=30, bitrate=5000000, gop=30, profile="base
     prop_set("persist.vmi.video.encode.param_adjusting", "0")
     prop_set("persist.vmi.video.encode.keyframe", "0")
     prop_set("persist.vmi.video.encode.qp", "" if qp is None else qp)
+    prop_set("persist.vmi.video.encode.scenedetect", "1")
 
 
 class VideoEncoder:
@@ -95,6 +98,9 @@ class VideoEncoder:
 
     def last_qp(self):
         return lib().vc_last_qp(self.h)
+
+    def scene_cuts(self):
+        return lib().vc_scene_cuts(self.h)
 
     def delete(self):
         rc = lib().vc_delete(self.h)

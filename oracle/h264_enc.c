@@ -154,6 +154,7 @@ struct h264o_enc {
     uint8_t *rbsp;
     size_t rbsp_cap;
     int64_t last_slice_bits;
+    uint32_t me_cost; /* scene-change statistic of the last picture */
 };
 
 static int pick_level(int mbs, int fps)
@@ -224,6 +225,7 @@ const uint8_t *h264o_enc_recon_pre(const h264o_enc *e, int p) { return e->rec[p]
 const h264o_mbinfo *h264o_enc_mbinfo(const h264o_enc *e) { return e->mb; }
 const int16_t *h264o_enc_levels(const h264o_enc *e) { return e->levels; }
 int64_t h264o_enc_last_slice_bits(const h264o_enc *e) { return e->last_slice_bits; }
+uint32_t h264o_enc_last_me_cost(const h264o_enc *e) { return e->me_cost; }
 
 /* ------------------------------------------------------------ headers 7.3.2 */
 static void write_sps(h264o_enc *e, bitw *b)
@@ -519,7 +521,7 @@ static int zero_mv_all_zero(h264o_enc *e, int mx, int my)
     return 1;
 }
 
-static mv_t motion_search(h264o_enc *e, int mx, int my)
+static mv_t motion_search(h264o_enc *e, int mx, int my, int *final_cost)
 {
     int cw = e->cw, ch = e->ch, lambda = o_lambda[e->cfg.qp];
     const uint8_t *s = e->src[0] + (16 * my) * cw + 16 * mx;
@@ -582,6 +584,7 @@ static mv_t motion_search(h264o_enc *e, int mx, int my)
         cx = bcx;
         cy = bcy;
     }
+    *final_cost = best_cost;
     mv_t r = {(int16_t)cx, (int16_t)cy};
     return r;
 }
@@ -743,6 +746,7 @@ int64_t h264o_enc_encode(h264o_enc *e, const uint8_t *y, int ys, const uint8_t *
     int idr = force_idr || e->frames == 0 || e->frame_in_gop >= e->cfg.gop;
     if (idr) { e->frame_in_gop = 0; e->frame_num = 0; }
     if (is_idr) *is_idr = idr;
+    e->me_cost = 0;
     size_t pos = 0;
     bitw b;
     if (idr) {
@@ -768,7 +772,9 @@ int64_t h264o_enc_encode(h264o_enc *e, const uint8_t *y, int ys, const uint8_t *
                 memset(mb, 0, sizeof(*mb));
                 mb->type = H264O_MB_P16;
                 if (!zero_mv_all_zero(e, mx, my)) {
-                    mv_t m = motion_search(e, mx, my);
+                    int cost = 0;
+                    mv_t m = motion_search(e, mx, my, &cost);
+                    e->me_cost += (uint32_t)(cost < 16383 ? cost : 16383);
                     mb->mvx = m.x;
                     mb->mvy = m.y;
                 }

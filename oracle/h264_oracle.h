@@ -80,6 +80,8 @@ const h264o_mbinfo *h264o_enc_mbinfo(const h264o_enc *e);
 const int16_t *h264o_enc_levels(const h264o_enc *e);
 /* bits of slice_data() of the last slice, before trailing bits (for tests) */
 int64_t h264o_enc_last_slice_bits(const h264o_enc *e);
+/* scene-change statistic (mirrors mi355x_h264_last_me_cost) */
+uint32_t h264o_enc_last_me_cost(const h264o_enc *e);
 
 /* ---- stand-alone stage functions (kernel-level parity, known-answer tests) ---- */
 void h264o_fdct4x4(const int16_t in[16], int16_t out[16]);

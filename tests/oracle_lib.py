@@ -53,6 +53,8 @@ def lib():
         L.h264o_enc_levels.restype = vp
         L.h264o_enc_levels.argtypes = [vp]
         L.h264o_enc_set_qp.argtypes = [vp, C.c_int]
+        L.h264o_enc_last_me_cost.argtypes = [vp]
+        L.h264o_enc_last_me_cost.restype = C.c_uint32
         L.h264o_enc_set_idr_id.argtypes = [vp, C.c_int, C.c_int]
         L.h264o_enc_last_slice_bits.restype = C.c_int64
         L.h264o_enc_last_slice_bits.argtypes = [vp]
@@ -141,6 +143,9 @@ class OracleEncoder:
 
     def set_idr_id(self, nxt, step=1):
         lib().h264o_enc_set_idr_id(self.h, nxt, step)
+
+    def me_cost(self):
+        return lib().h264o_enc_last_me_cost(self.h)
 
     def slice_bits(self):
         return lib().h264o_enc_last_slice_bits(self.h)

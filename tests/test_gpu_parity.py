@@ -122,6 +122,16 @@ def test_emulation_prevention_slow_path():
         enc.close()
 
 
+def test_scene_change_statistic_matches_oracle():
+    w, h = 320, 240
+    enc = capi.Encoder(w, h, qp=26, gop=100)
+    orc = OracleEncoder(w, h, qp=26, gop=100)
+    for f in synth.sequence("s1", w, h, 3) + synth.sequence("s3", w, h, 1):
+        assert enc.encode(f)[0] == orc.encode(f)[0]
+        assert int(enc.me_cost()[0]) == orc.me_cost()
+    enc.close()
+
+
 def test_no_deblock_variant():
     w, h = 160, 96
     enc = capi.Encoder(w, h, qp=32, disable_deblock=1)

@@ -63,6 +63,27 @@ def test_keyframe_and_param_adjust_handshake():
     e.delete()
 
 
+def test_scene_change_recodes_as_idr():
+    """bEnableSceneChangeDetect = 1 (VideoEncoderOpenH264.cpp:283): a cut in the content makes the motion
+    cost explode; the class re-codes that picture as IDR.  The oracle replays the same rule."""
+    w, h = 352, 288
+    nmb = (w // 16) * (h // 16)
+    e = _new(w, h, qp=28, gop=300)
+    orc = OracleEncoder(w, h, qp=28, gop=300)
+    frames = synth.sequence("s1", w, h, 3) + synth.sequence("s3", w, h, 1) + synth.sequence("s1", w, h, 2, start=500)
+    kinds = []
+    for f in frames:
+        rc, bs = e.encode(f)
+        assert rc == vc.SUCCESS
+        obs, idr = orc.encode(f)
+        if not idr and orc.me_cost() > 3000 * nmb:
+            obs, idr = orc.encode(f, force_idr=True)
+        assert bs == obs
+        kinds.append(bs[4] & 31)
+    assert kinds == [7, 1, 1, 7, 7, 1] and e.scene_cuts() == 2
+    e.delete()
+
+
 def test_bitrate_mode_tracks_target_and_replays_on_oracle():
     """reference preset: RC_BITRATE_MODE (VideoEncoderOpenH264.cpp:274).  The controller is host
     logic; the oracle replays its QP decisions and must produce the same stream."""
