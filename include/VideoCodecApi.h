@@ -11,17 +11,17 @@
 #include <cstdint>
 
 enum EncoderRetCode : uint32_t {
-    VIDEO_ENCODER_SUCCESS = 0x00,
-    VIDEO_ENCODER_CREATE_FAIL = 0x01,            /* could not create the encoder object   */
-    VIDEO_ENCODER_INIT_FAIL = 0x02,              /* InitEncoder failed                     */
-    VIDEO_ENCODER_START_FAIL = 0x03,
-    VIDEO_ENCODER_ENCODE_FAIL = 0x04,            /* EncodeOneFrame failed                  */
-    VIDEO_ENCODER_STOP_FAIL = 0x05,
-    VIDEO_ENCODER_DESTROY_FAIL = 0x06,
-    VIDEO_ENCODER_REGISTER_FAIL = 0x07,
-    VIDEO_ENCODER_RESET_FAIL = 0x08,
-    VIDEO_ENCODER_FORCE_KEY_FRAME_FAIL = 0x09,
-    VIDEO_ENCODER_SET_ENCODE_PARAMS_FAIL = 0x0A
+    VIDEO_ENCODER_SUCCESS = 0,
+    VIDEO_ENCODER_CREATE_FAIL = 1,            /* could not create the encoder object   */
+    VIDEO_ENCODER_INIT_FAIL = 2,              /* InitEncoder failed                     */
+    VIDEO_ENCODER_START_FAIL = 3,
+    VIDEO_ENCODER_ENCODE_FAIL = 4,            /* EncodeOneFrame failed                  */
+    VIDEO_ENCODER_STOP_FAIL = 5,
+    VIDEO_ENCODER_DESTROY_FAIL = 6,
+    VIDEO_ENCODER_REGISTER_FAIL = 7,
+    VIDEO_ENCODER_RESET_FAIL = 8,
+    VIDEO_ENCODER_FORCE_KEY_FRAME_FAIL = 9,
+    VIDEO_ENCODER_SET_ENCODE_PARAMS_FAIL = 10
 };
 
 class VideoEncoder {

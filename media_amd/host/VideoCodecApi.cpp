@@ -1,60 +1,82 @@
-// media_amd/host/VideoCodecApi.cpp -- the factory of the plugin surface
-// (mirrors /root/reference/video_codec/VideoCodecApi.cpp:14-55).  The reference
-// dispatches 0 OpenH264 / 1 NETINT H.264 / 2 NETINT H.265; this build adds
-// 3 = MI355X.  The CPU and ASIC backends are not part of this library (their
-// engines are third-party binaries absent here), so 0..2 fail to create; in the
-// reference tree the maintainer adds only the `case 3` arm.
+// media_amd/host/VideoCodecApi.cpp -- factory of the plugin surface.
+//
+// Behaviour contract (what /root/reference/video_codec/VideoCodecApi.cpp:21-55 does): the integer property
+// ro.vmi.demo.video.encode.format names the backend; an unknown value or a failed allocation yields
+// VIDEO_ENCODER_CREATE_FAIL; DestroyVideoEncoder deletes the object and accepts nullptr.  The reference knows
+// 0 (OpenH264), 1 (NETINT H.264) and 2 (NETINT H.265); this build registers 3 = MI355X.  The engines behind
+// 0..2 are third-party binaries that do not exist here, so those slots are known-but-unavailable; in the
+// reference tree the maintainer keeps its switch and adds one case.
 #define LOG_TAG "VideoCodecApi"
 #include "VideoCodecApi.h"
+#include <array>
 #include <new>
 #include "MediaLog.h"
 #include "Property.h"
 #include "VideoEncoderMI355X.h"
 
 namespace {
-enum EncoderType : uint32_t {
-    ENCODER_TYPE_OPENH264 = 0,
-    ENCODER_TYPE_NETINTH264 = 1,
-    ENCODER_TYPE_NETINTH265 = 2,
-    ENCODER_TYPE_MI355X = 3   // hand-written HIP path on AMD Instinct MI355X
+
+using Maker = VideoEncoder *(*)();
+
+struct Backend {
+    int32_t id;          // value of ro.vmi.demo.video.encode.format
+    const char *name;
+    Maker make;          // nullptr: recognised by the reference, not built into this library
 };
+
+VideoEncoder *MakeMI355X() { return new (std::nothrow) VideoEncoderMI355X(); }
+
+const std::array<Backend, 4> kBackends = {{
+    {0, "OpenH264 (CPU)", nullptr},
+    {1, "NETINT T408 H.264", nullptr},
+    {2, "NETINT T408 H.265", nullptr},
+    {3, "AMD Instinct MI355X (HIP)", &MakeMI355X},
+}};
+
+const Backend *FindBackend(int32_t id)
+{
+    for (const Backend &b : kBackends) {
+        if (b.id == id) {
+            return &b;
+        }
+    }
+    return nullptr;
 }
+
+}  // namespace
 
 EncoderRetCode CreateVideoEncoder(VideoEncoder **encoder)
 {
     if (encoder == nullptr) {
-        ERR("create video encoder failed: null output pointer");
+        ERR("CreateVideoEncoder: no place to return the encoder");
         return VIDEO_ENCODER_CREATE_FAIL;
     }
-    uint32_t encType = static_cast<uint32_t>(GetIntEncParam("ro.vmi.demo.video.encode.format"));
-    INFO("create video encoder: encoder type %u", encType);
-    switch (encType) {
-        case ENCODER_TYPE_MI355X:
-            *encoder = new (std::nothrow) VideoEncoderMI355X();
-            break;
-        case ENCODER_TYPE_OPENH264:
-        case ENCODER_TYPE_NETINTH264:
-        case ENCODER_TYPE_NETINTH265:
-            ERR("create video encoder failed: encoder type %u is not built into this library", encType);
-            return VIDEO_ENCODER_CREATE_FAIL;
-        default:
-            ERR("create video encoder failed: unknown encoder type %u", encType);
-            return VIDEO_ENCODER_CREATE_FAIL;
-    }
-    if (*encoder == nullptr) {
-        ERR("create video encoder failed: encoder type %u", encType);
+    const int32_t wanted = GetIntEncParam("ro.vmi.demo.video.encode.format");
+    const Backend *backend = FindBackend(wanted);
+    if (backend == nullptr) {
+        ERR("CreateVideoEncoder: encoder format %d is not known", wanted);
         return VIDEO_ENCODER_CREATE_FAIL;
     }
+    if (backend->make == nullptr) {
+        ERR("CreateVideoEncoder: backend %d (%s) is not part of this library", wanted, backend->name);
+        return VIDEO_ENCODER_CREATE_FAIL;
+    }
+    VideoEncoder *made = backend->make();
+    if (made == nullptr) {
+        ERR("CreateVideoEncoder: out of memory creating backend %d (%s)", wanted, backend->name);
+        return VIDEO_ENCODER_CREATE_FAIL;
+    }
+    INFO("CreateVideoEncoder: backend %d (%s)", wanted, backend->name);
+    *encoder = made;
     return VIDEO_ENCODER_SUCCESS;
 }
 
 EncoderRetCode DestroyVideoEncoder(VideoEncoder *encoder)
 {
-    if (encoder == nullptr) {
-        WARN("input encoder is null");
-        return VIDEO_ENCODER_SUCCESS;
+    if (encoder != nullptr) {
+        delete encoder;
+    } else {
+        WARN("DestroyVideoEncoder: nothing to destroy");
     }
-    delete encoder;
-    encoder = nullptr;
     return VIDEO_ENCODER_SUCCESS;
 }

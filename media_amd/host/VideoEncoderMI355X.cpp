@@ -1,12 +1,16 @@
 // media_amd/host/VideoEncoderMI355X.cpp -- see VideoEncoderMI355X.h.
-// Behaviour follows /root/reference/video_codec/VideoEncoderOpenH264.cpp line by
-// line where the wrapper is concerned:
-//   :62-122  property reads (video / instruction mode), validation, write-back of
-//            last good bitrate/gop/profile to the persist.vmi.video.encode.* keys
-//   :131-157 InitEncoder        :304-352 EncodeOneFrame (size guard, param_adjusting
-//            poll, reset, keyframe poll, encode)   :388-404 ResetEncoder
-//   :406-429 ForceKeyFrame / SetEncodeParams       :379-386 Release (idempotent)
-// What differs is only the engine behind it: the HIP path via include/mi355x_h264.h.
+//
+// Wrapper behaviour reproduced from /root/reference/video_codec/VideoEncoderOpenH264.cpp:
+//   * two property modes, "video" and "instruction", select where width/height/fps and bitrate/gop/profile are
+//     read from (:62-122); anything else fails initialisation
+//   * width/height must lie in 16..4096 and fps be 30 or 60, else InitEncoder fails (:159-171)
+//   * bitrate 1..10 Mbps, gop 30..3000, profile baseline|main|high; a bad value is NOT an error: the last good
+//     values are written back to the persist.vmi.video.encode.* keys and used (:107-120, :173-195)
+//   * EncodeOneFrame: size guard (:307), then param_adjusting poll -> reset -> keyframe poll -> encode (:312-351);
+//     a failing property read during the poll returns INIT_FAIL from EncodeOneFrame (:314-317)
+//   * any parameter change = destroy + init + start; the next output starts with SPS/PPS + IDR (:388-404)
+//   * Start/Stop only log (:298-302, :367-371); Destroy is idempotent (:379-386)
+//   * the output buffer belongs to the encoder and stays valid until the next call (:349-350)
 #define LOG_TAG "VideoEncoderMI355X"
 #include "VideoEncoderMI355X.h"
 #include <algorithm>
@@ -14,178 +18,159 @@
 #include "Property.h"
 
 namespace {
-    constexpr uint32_t COMPRESS_RATIO = 2;
-    constexpr uint32_t PRIMARY_COLOURS = 3;
-    const std::string ENCODE_PROFILE_BASELINE = "baseline";
-    const std::string ENCODE_PROFILE_MAIN = "main";
-    const std::string ENCODE_PROFILE_HIGH = "high";
-}
 
-VideoEncoderMI355X::VideoEncoderMI355X()
-{
-    INFO("VideoEncoderMI355X constructor");
-}
+// property names per phone mode
+struct KeySet {
+    const char *width, *height, *fps, *bitrate, *gop, *profile;
+};
+constexpr KeySet kVideoKeys = {"ro.hardware.width", "ro.hardware.height", "ro.hardware.fps",
+                               "persist.vmi.video.encode.bitrate", "persist.vmi.video.encode.gopsize",
+                               "persist.vmi.video.encode.profile"};
+constexpr KeySet kInstructionKeys = {"persist.vmi.demo.video.encode.width", "persist.vmi.demo.video.encode.height",
+                                     "persist.vmi.demo.video.encode.framerate", "persist.vmi.demo.video.encode.bitrate",
+                                     "persist.vmi.demo.video.encode.gopsize", "persist.vmi.demo.video.encode.profile"};
+constexpr const char *kAdjustKey = "persist.vmi.video.encode.param_adjusting";
+constexpr const char *kKeyframeKey = "persist.vmi.video.encode.keyframe";
+
+bool Within(int32_t v, int32_t lo, int32_t hi) { return v >= lo && v <= hi; }
+
+int ProfileIdc(const std::string &name) { return name == "high" ? 100 : (name == "main" ? 77 : 66); }
+
+bool KnownProfile(const std::string &name) { return name == "baseline" || name == "main" || name == "high"; }
+
+}  // namespace
+
+constexpr int32_t VideoEncoderMI355X::Limits::kFps[2];
+
+VideoEncoderMI355X::VideoEncoderMI355X() { INFO("MI355X encoder object created"); }
 
 VideoEncoderMI355X::~VideoEncoderMI355X()
 {
-    Release();
-    INFO("VideoEncoderMI355X destructor");
+    CloseEngine();
+    INFO("MI355X encoder object gone");
 }
 
-bool VideoEncoderMI355X::GetRoEncParam()
+VideoEncoderMI355X::PhoneMode VideoEncoderMI355X::ReadPhoneMode()
 {
-    int32_t width = 0;
-    int32_t height = 0;
-    int32_t framerate = 0;
-    std::string phoneMode = GetStrEncParam("ro.sys.vmi.cloudphone");
-    if (phoneMode == "video") {
-        width = GetIntEncParam("ro.hardware.width");
-        height = GetIntEncParam("ro.hardware.height");
-        framerate = GetIntEncParam("ro.hardware.fps");
-    } else if (phoneMode == "instruction") {
-        width = GetIntEncParam("persist.vmi.demo.video.encode.width");
-        height = GetIntEncParam("persist.vmi.demo.video.encode.height");
-        framerate = GetIntEncParam("persist.vmi.demo.video.encode.framerate");
-    } else {
-        ERR("Invalid property value[%s] for property[ro.sys.vmi.cloudphone], get property failed!", phoneMode.c_str());
+    const std::string mode = GetStrEncParam("ro.sys.vmi.cloudphone");
+    if (mode == "video") {
+        return PhoneMode::Video;
+    }
+    if (mode == "instruction") {
+        return PhoneMode::Instruction;
+    }
+    ERR("property ro.sys.vmi.cloudphone = [%s] is neither video nor instruction", mode.c_str());
+    return PhoneMode::Invalid;
+}
+
+bool VideoEncoderMI355X::ReadGeometry(Settings &into) const
+{
+    const PhoneMode mode = ReadPhoneMode();
+    if (mode == PhoneMode::Invalid) {
         return false;
     }
-    if (!VerifyEncodeRoParams(width, height, framerate)) {
-        ERR("encoder params is not supported");
+    const KeySet &k = mode == PhoneMode::Video ? kVideoKeys : kInstructionKeys;
+    const int32_t w = GetIntEncParam(k.width), h = GetIntEncParam(k.height), fps = GetIntEncParam(k.fps);
+    bool ok = true;
+    if (!Within(w, Limits::kSideMin, Limits::kSideMax) || !Within(h, Limits::kSideMin, Limits::kSideMax)) {
+        ERR("picture size %dx%d is outside %d..%d", w, h, Limits::kSideMin, Limits::kSideMax);
+        ok = false;
+    }
+    if (fps != Limits::kFps[0] && fps != Limits::kFps[1]) {
+        ERR("frame rate %d is not %d or %d", fps, Limits::kFps[0], Limits::kFps[1]);
+        ok = false;
+    }
+    if (!ok) {
         return false;
     }
-    m_tmpEncParams.width = static_cast<uint32_t>(width);
-    m_tmpEncParams.height = static_cast<uint32_t>(height);
-    m_tmpEncParams.framerate = static_cast<uint32_t>(framerate);
+    into.width = static_cast<uint32_t>(w);
+    into.height = static_cast<uint32_t>(h);
+    into.fps = static_cast<uint32_t>(fps);
     return true;
 }
 
-bool VideoEncoderMI355X::GetPersistEncParam()
+bool VideoEncoderMI355X::ReadTunables(Settings &into)
 {
-    std::string bitrate;
-    std::string gopsize;
-    std::string profile;
-    std::string phoneMode = GetStrEncParam("ro.sys.vmi.cloudphone");
-    if (phoneMode == "video") {
-        bitrate = GetStrEncParam("persist.vmi.video.encode.bitrate");
-        gopsize = GetStrEncParam("persist.vmi.video.encode.gopsize");
-        profile = GetStrEncParam("persist.vmi.video.encode.profile");
-    } else if (phoneMode == "instruction") {
-        bitrate = GetStrEncParam("persist.vmi.demo.video.encode.bitrate");
-        gopsize = GetStrEncParam("persist.vmi.demo.video.encode.gopsize");
-        profile = GetStrEncParam("persist.vmi.demo.video.encode.profile");
-    } else {
-        ERR("Invalid property value[%s] for property[ro.sys.vmi.cloudphone], get property failed!", phoneMode.c_str());
+    const PhoneMode mode = ReadPhoneMode();
+    if (mode == PhoneMode::Invalid) {
         return false;
     }
-    if (!VerifyEncodeParams(bitrate, gopsize, profile)) {
-        // not an error: the last good values are written back and init proceeds (ref :111-115)
-        SetEncParam("persist.vmi.video.encode.bitrate", std::to_string(m_encParams.bitrate).c_str());
-        SetEncParam("persist.vmi.video.encode.gopsize", std::to_string(m_encParams.gopsize).c_str());
-        SetEncParam("persist.vmi.video.encode.profile", m_encParams.profile.c_str());
+    const KeySet &k = mode == PhoneMode::Video ? kVideoKeys : kInstructionKeys;
+    const std::string bitrate = GetStrEncParam(k.bitrate), gop = GetStrEncParam(k.gop), profile = GetStrEncParam(k.profile);
+    bool ok = true;
+    if (!Within(StrToInt(bitrate), Limits::kBitrateMin, Limits::kBitrateMax)) {
+        WARN("bitrate [%s] rejected, keeping %u", bitrate.c_str(), m_active.bitrate);
+        ok = false;
+    }
+    if (!Within(StrToInt(gop), Limits::kGopMin, Limits::kGopMax)) {
+        WARN("gop size [%s] rejected, keeping %u", gop.c_str(), m_active.gop);
+        ok = false;
+    }
+    if (!KnownProfile(profile)) {
+        WARN("profile [%s] rejected, keeping %s", profile.c_str(), m_active.profile.c_str());
+        ok = false;
+    }
+    if (ok) {
+        into.bitrate = static_cast<uint32_t>(StrToInt(bitrate));
+        into.gop = static_cast<uint32_t>(StrToInt(gop));
+        into.profile = profile;
     } else {
-        m_tmpEncParams.bitrate = static_cast<uint32_t>(StrToInt(bitrate));
-        m_tmpEncParams.gopsize = static_cast<uint32_t>(StrToInt(gopsize));
-        m_tmpEncParams.profile = profile;
+        // the reference publishes the values it keeps using, always under the video-mode keys (:111-115)
+        SetEncParam(kVideoKeys.bitrate, std::to_string(m_active.bitrate).c_str());
+        SetEncParam(kVideoKeys.gop, std::to_string(m_active.gop).c_str());
+        SetEncParam(kVideoKeys.profile, m_active.profile.c_str());
     }
     return true;
 }
 
-bool VideoEncoderMI355X::EncodeParamsChange()
-{
-    return (m_tmpEncParams.bitrate != m_encParams.bitrate) || (m_tmpEncParams.gopsize != m_encParams.gopsize) ||
-           (m_tmpEncParams.profile != m_encParams.profile) || (m_tmpEncParams.width != m_encParams.width) ||
-           (m_tmpEncParams.height != m_encParams.height) || (m_tmpEncParams.framerate != m_encParams.framerate);
-}
+bool VideoEncoderMI355X::EncodeParamsChange() { return !m_pending.SameAs(m_active); }
 
 EncoderRetCode VideoEncoderMI355X::InitEncoder()
 {
-    if ((!GetRoEncParam()) || (!GetPersistEncParam())) {
-        ERR("init encoder failed: GetEncParam failed");
+    if (!ReadGeometry(m_pending) || !ReadTunables(m_pending)) {
+        ERR("InitEncoder: configuration could not be read");
         return VIDEO_ENCODER_INIT_FAIL;
     }
-    m_encParams = m_tmpEncParams;
-    m_frameSize = m_encParams.width * m_encParams.height * PRIMARY_COLOURS / COMPRESS_RATIO;
-    m_yLength = m_encParams.width * m_encParams.height;
-    if (!InitParams()) {
-        ERR("init encoder failed: init params failed");
+    m_active = m_pending;
+    m_lumaBytes = m_active.width * m_active.height;
+    m_frameBytes = m_lumaBytes * 3 / 2;
+    if (!OpenEngine()) {
+        ERR("InitEncoder: the HIP encode engine could not be opened");
         return VIDEO_ENCODER_INIT_FAIL;
     }
-    INFO("init encoder success");
+    INFO("InitEncoder: %ux%u @%u, %u bps, gop %u, %s", m_active.width, m_active.height, m_active.fps, m_active.bitrate,
+         m_active.gop, m_active.profile.c_str());
     return VIDEO_ENCODER_SUCCESS;
 }
 
-bool VideoEncoderMI355X::VerifyEncodeRoParams(int32_t width, int32_t height, int32_t framerate)
+bool VideoEncoderMI355X::OpenEngine()
 {
-    bool isEncodeParamsTrue = true;
-    if (width > static_cast<int32_t>(MI355X::WH_MAX) || height > static_cast<int32_t>(MI355X::WH_MAX) ||
-        width < static_cast<int32_t>(MI355X::WH_MIN) || height < static_cast<int32_t>(MI355X::WH_MIN)) {
-        ERR("Invalid property value[%dx%d] for property[width,height], get property failed!", width, height);
-        isEncodeParamsTrue = false;
-    }
-    if (framerate != static_cast<int32_t>(MI355X::FRAMERATE_MIN) && framerate != static_cast<int32_t>(MI355X::FRAMERATE_MAX)) {
-        ERR("Invalid property value[%d] for property[framerate], get property failed!", framerate);
-        isEncodeParamsTrue = false;
-    }
-    return isEncodeParamsTrue;
-}
-
-bool VideoEncoderMI355X::VerifyEncodeParams(std::string &bitrate, std::string &gopsize, std::string &profile)
-{
-    bool isEncodeParamsTrue = true;
-    if ((StrToInt(bitrate) < static_cast<int32_t>(MI355X::BITRATE_MIN)) || (StrToInt(bitrate) > static_cast<int32_t>(MI355X::BITRATE_MAX))) {
-        WARN("Invalid property value[%s] for property[bitrate], use last correct encode bitrate[%u]", bitrate.c_str(),
-             m_encParams.bitrate);
-        isEncodeParamsTrue = false;
-    }
-    if ((StrToInt(gopsize) < static_cast<int32_t>(MI355X::GOPSIZE_MIN)) || (StrToInt(gopsize) > static_cast<int32_t>(MI355X::GOPSIZE_MAX))) {
-        WARN("Invalid property value[%s] for property[gopsize], use last correct encode gopsize[%u]", gopsize.c_str(),
-             m_encParams.gopsize);
-        isEncodeParamsTrue = false;
-    }
-    if (profile != ENCODE_PROFILE_BASELINE && profile != ENCODE_PROFILE_MAIN && profile != ENCODE_PROFILE_HIGH) {
-        WARN("Invalid property value[%s] for property[profile], use last correct encode profile[%s]", profile.c_str(),
-             m_encParams.profile.c_str());
-        isEncodeParamsTrue = false;
-    }
-    return isEncodeParamsTrue;
-}
-
-bool VideoEncoderMI355X::InitParams()
-{
-    // the preset of VideoEncoderOpenH264::InitParams / InitParamExt (ref :228-296), expressed in
-    // the C ABI's config: one layer, single slice, one reference, loop filter on, CAVLC
+    // the preset of InitParams / InitParamExt (ref :228-296) in the C ABI's terms: one layer, one slice per
+    // picture, one reference frame, loop filter on, CAVLC, IDR every gop pictures
     mi355x_h264_config cfg;
     mi355x_h264_default_config(&cfg);
-    cfg.width = static_cast<int32_t>(m_encParams.width);
-    cfg.height = static_cast<int32_t>(m_encParams.height);
-    cfg.fps = static_cast<int32_t>(m_encParams.framerate);
-    cfg.bitrate = static_cast<int32_t>(m_encParams.bitrate);
-    cfg.gop = static_cast<int32_t>(m_encParams.gopsize);
-    cfg.profile_idc = m_encParams.profile == ENCODE_PROFILE_HIGH ? 100 : (m_encParams.profile == ENCODE_PROFILE_MAIN ? 77 : 66);
+    cfg.width = static_cast<int32_t>(m_active.width);
+    cfg.height = static_cast<int32_t>(m_active.height);
+    cfg.fps = static_cast<int32_t>(m_active.fps);
+    cfg.bitrate = static_cast<int32_t>(m_active.bitrate);
+    cfg.gop = static_cast<int32_t>(m_active.gop);
+    cfg.profile_idc = ProfileIdc(m_active.profile);
     cfg.disable_deblock = 0;
-    const int32_t dev = GetIntEncParam("persist.vmi.video.encode.device");
-    cfg.device = dev >= 0 ? dev : 0;
-    // extension knob: a valid QP here selects fixed-QP coding,
-    // otherwise the reference's bitrate mode is used
+    cfg.batch = 1;
+    cfg.device = std::max(0, GetIntEncParam("persist.vmi.video.encode.device"));
+    // extension keys: a valid QP selects fixed-QP coding instead of the preset's
+    // bitrate mode; "0" switches the scene-change IDR off
     const int32_t qp = GetIntEncParam("persist.vmi.video.encode.qp");
-    if (qp >= 10 && qp <= 51) {
-        m_fixedQp = qp;
-        cfg.rc_mode = MI355X_H264_RC_FIXED_QP;
-        cfg.qp = qp;
-    } else {
-        m_fixedQp = -1;
-        cfg.rc_mode = MI355X_H264_RC_BITRATE;
-        cfg.qp = MI355X::QP_START;
-    }
+    m_fixedQp = Within(qp, 10, 51) ? qp : -1;
+    cfg.rc_mode = m_fixedQp >= 0 ? MI355X_H264_RC_FIXED_QP : MI355X_H264_RC_BITRATE;
+    cfg.qp = m_fixedQp >= 0 ? m_fixedQp : Limits::kQpStart;
     m_qp = cfg.qp;
     m_bufferBits = 0;
-    // bEnableSceneChangeDetect = 1 in the reference preset (ref :283); "0" in this extension key turns it off
     m_sceneDetect = GetStrEncParam("persist.vmi.video.encode.scenedetect") != "0";
-    const int rc = mi355x_h264_create(&cfg, &m_encoder);
+    const int rc = mi355x_h264_create(&cfg, &m_engine);
     if (rc != MI355X_H264_OK) {
-        ERR("mi355x_h264_create failed, rc = %d", rc);
-        m_encoder = nullptr;
+        ERR("mi355x_h264_create returned %d", rc);
+        m_engine = nullptr;
         return false;
     }
     return true;
@@ -193,166 +178,180 @@ bool VideoEncoderMI355X::InitParams()
 
 EncoderRetCode VideoEncoderMI355X::StartEncoder()
 {
-    INFO("start encoder success");
-    return VIDEO_ENCODER_SUCCESS;
-}
-
-// Frame-level rate control for RC_BITRATE_MODE.  Integer arithmetic only, so a test can
-// replay the QP sequence.  Target per picture = bitrate / fps; IDR pictures are budgeted
-// four pictures' worth.  PARITY UNPINNED: OpenH264's own RC model is not available.
-void VideoEncoderMI355X::RateControlUpdate(uint32_t frameBytes, bool isIdr)
-{
-    if (m_fixedQp >= 0) return;
-    const int64_t target = static_cast<int64_t>(m_encParams.bitrate) / std::max<uint32_t>(1, m_encParams.framerate);
-    const int64_t bits = static_cast<int64_t>(frameBytes) * 8;
-    m_bufferBits += bits - target;
-    m_bufferBits = std::max<int64_t>(m_bufferBits, -static_cast<int64_t>(m_encParams.bitrate));
-    const int64_t budget = isIdr ? 4 * target : target;
-    int32_t step = 0;
-    if (bits * 2 > budget * 3) step = 2;            // > 1.5x
-    else if (bits * 10 > budget * 11) step = 1;     // > 1.1x
-    else if (bits * 3 < budget * 2) step = -2;      // < 0.67x
-    else if (bits * 10 < budget * 9) step = -1;     // < 0.9x
-    // virtual buffer: more than half a second of debt / credit biases the step
-    if (m_bufferBits * 2 > static_cast<int64_t>(m_encParams.bitrate)) step += 1;
-    if (m_bufferBits * 2 < -static_cast<int64_t>(m_encParams.bitrate)) step -= 1;
-    m_qp = std::min(MI355X::QP_MAX, std::max(MI355X::QP_MIN, m_qp + step));
-}
-
-EncoderRetCode VideoEncoderMI355X::EncodeOneFrame(const uint8_t *inputData, uint32_t inputSize, uint8_t **outputData,
-                                                  uint32_t *outputSize)
-{
-    if (inputSize < static_cast<size_t>(m_frameSize)) {
-        ERR("input size error: input size(%u) < frame size(%u)", inputSize, m_frameSize);
-        return VIDEO_ENCODER_ENCODE_FAIL;
-    }
-
-    std::string isParamChange = GetStrEncParam("persist.vmi.video.encode.param_adjusting");
-    if (isParamChange == "1") {
-        if (!GetPersistEncParam()) {
-            ERR("init encoder failed: GetEncParam failed");
-            return VIDEO_ENCODER_INIT_FAIL;  // quirk kept from the reference (:314-317)
-        }
-        SetEncodeParams();
-        SetEncParam("persist.vmi.video.encode.param_adjusting", "0");
-    } else if (isParamChange != "0") {
-        WARN("Invalid property value[%s] for encode param adjusting", isParamChange.c_str());
-        SetEncParam("persist.vmi.video.encode.param_adjusting", "0");
-    }
-
-    if (m_resetFlag) {
-        if (ResetEncoder() != VIDEO_ENCODER_SUCCESS) {
-            ERR("reset encoder failed while encoding");
-            return VIDEO_ENCODER_ENCODE_FAIL;
-        }
-        m_resetFlag = false;
-    }
-
-    std::string isKeyframeChange = GetStrEncParam("persist.vmi.video.encode.keyframe");
-    if (isKeyframeChange == "1") {
-        INFO("Encoder set key frame");
-        ForceKeyFrame();
-        SetEncParam("persist.vmi.video.encode.keyframe", "0");
-    } else if (isKeyframeChange != "0") {
-        WARN("Invalid property value[%s] for property[keyFrame], set to [0]", isKeyframeChange.c_str());
-        SetEncParam("persist.vmi.video.encode.keyframe", "0");
-    }
-
-    if (m_encoder == nullptr) {
-        ERR("encode before init");
-        return VIDEO_ENCODER_ENCODE_FAIL;
-    }
-    // plane pointers exactly as InitSrcPic computes them (ref :354-365): tight I420
-    const uint8_t *y = inputData;
-    const uint8_t *u = y + m_yLength;
-    const uint8_t *v = u + (m_yLength >> COMPRESS_RATIO);
-    const int stride = static_cast<int>(m_encParams.width);
-    (void) mi355x_h264_set_qp(m_encoder, m_qp);
-    m_lastQp = m_qp;
-    int frameType = 0;
-    const int rc = mi355x_h264_encode(m_encoder, y, stride, u, stride / 2, v, stride / 2, outputData, outputSize, &frameType);
-    if (rc != MI355X_H264_OK) {
-        ERR("encoder encode frame failed, rc = %d (%s)", rc, mi355x_h264_last_error(m_encoder));
-        return VIDEO_ENCODER_ENCODE_FAIL;
-    }
-    if (m_sceneDetect && frameType == MI355X_H264_FRAME_P) {
-        // scene change: the motion search found no good match anywhere -> code this picture as IDR instead
-        uint32_t cost = 0;
-        const uint32_t mbs = ((m_encParams.width + 15) / 16) * ((m_encParams.height + 15) / 16);
-        if (mi355x_h264_last_me_cost(m_encoder, &cost) == MI355X_H264_OK &&
-            static_cast<uint64_t>(cost) > static_cast<uint64_t>(MI355X::SCENE_CUT_COST_PER_MB) * mbs) {
-            INFO("scene change detected (motion cost %u over %u macroblocks), re-coding as IDR", cost, mbs);
-            (void) mi355x_h264_force_idr(m_encoder);
-            const int rc2 = mi355x_h264_encode(m_encoder, y, stride, u, stride / 2, v, stride / 2, outputData, outputSize, &frameType);
-            if (rc2 != MI355X_H264_OK) {
-                ERR("encoder encode frame failed, rc = %d (%s)", rc2, mi355x_h264_last_error(m_encoder));
-                return VIDEO_ENCODER_ENCODE_FAIL;
-            }
-            m_sceneCuts++;
-        }
-    }
-    RateControlUpdate(*outputSize, frameType == MI355X_H264_FRAME_IDR);
+    INFO("StartEncoder");
     return VIDEO_ENCODER_SUCCESS;
 }
 
 EncoderRetCode VideoEncoderMI355X::StopEncoder()
 {
-    INFO("stop encoder success");
+    INFO("StopEncoder");
     return VIDEO_ENCODER_SUCCESS;
+}
+
+// Frame-level rate control for the bitrate mode.  Integer arithmetic only, so a test can replay the QP
+// sequence on the oracle.  Target per picture = bitrate / fps; an IDR picture is budgeted four pictures' worth.
+// PARITY UNPINNED: OpenH264's own rate-control model is not available.
+void VideoEncoderMI355X::RateControlUpdate(uint32_t frameBytes, bool isIdr)
+{
+    if (m_fixedQp >= 0) {
+        return;
+    }
+    const int64_t rate = static_cast<int64_t>(m_active.bitrate);
+    const int64_t target = rate / std::max<uint32_t>(1, m_active.fps);
+    const int64_t bits = static_cast<int64_t>(frameBytes) * 8;
+    m_bufferBits = std::max<int64_t>(m_bufferBits + bits - target, -rate);
+    const int64_t budget = isIdr ? 4 * target : target;
+    int32_t step = 0;
+    if (bits * 2 > budget * 3) {
+        step = 2;   // more than 1.5x the budget
+    } else if (bits * 10 > budget * 11) {
+        step = 1;   // more than 1.1x
+    } else if (bits * 3 < budget * 2) {
+        step = -2;  // less than 2/3
+    } else if (bits * 10 < budget * 9) {
+        step = -1;  // less than 0.9x
+    }
+    // half a second of debt (credit) in the virtual buffer pushes one step further
+    if (m_bufferBits * 2 > rate) {
+        step += 1;
+    }
+    if (m_bufferBits * 2 < -rate) {
+        step -= 1;
+    }
+    m_qp = std::min(Limits::kQpMax, std::max(Limits::kQpMin, m_qp + step));
+}
+
+bool VideoEncoderMI355X::PollParamAdjust()
+{
+    const std::string flag = GetStrEncParam(kAdjustKey);
+    if (flag == "1") {
+        if (!ReadTunables(m_pending)) {
+            return false;
+        }
+        (void) SetEncodeParams();
+    } else if (flag == "0") {
+        return true;
+    } else {
+        WARN("%s = [%s] is neither 0 nor 1", kAdjustKey, flag.c_str());
+    }
+    SetEncParam(kAdjustKey, "0");
+    return true;
+}
+
+void VideoEncoderMI355X::PollKeyframeRequest()
+{
+    const std::string flag = GetStrEncParam(kKeyframeKey);
+    if (flag == "0") {
+        return;
+    }
+    if (flag == "1") {
+        (void) ForceKeyFrame();
+    } else {
+        WARN("%s = [%s] is neither 0 nor 1", kKeyframeKey, flag.c_str());
+    }
+    SetEncParam(kKeyframeKey, "0");
+}
+
+int VideoEncoderMI355X::EncodePicture(const uint8_t *i420, uint8_t **out, uint32_t *outLen, int *frameType)
+{
+    // tight I420 exactly as the reference's InitSrcPic lays the planes out (ref :354-365)
+    const int pitch = static_cast<int>(m_active.width);
+    const uint8_t *u = i420 + m_lumaBytes;
+    const uint8_t *v = u + m_lumaBytes / 4;
+    return mi355x_h264_encode(m_engine, i420, pitch, u, pitch / 2, v, pitch / 2, out, outLen, frameType);
+}
+
+EncoderRetCode VideoEncoderMI355X::EncodeOneFrame(const uint8_t *inputData, uint32_t inputSize, uint8_t **outputData,
+                                                  uint32_t *outputSize)
+{
+    if (inputSize < m_frameBytes) {
+        ERR("EncodeOneFrame: %u input bytes, a picture needs %u", inputSize, m_frameBytes);
+        return VIDEO_ENCODER_ENCODE_FAIL;
+    }
+    if (!PollParamAdjust()) {
+        ERR("EncodeOneFrame: configuration could not be re-read");
+        return VIDEO_ENCODER_INIT_FAIL;  // quirk kept from the reference
+    }
+    if (m_needReset) {
+        if (ResetEncoder() != VIDEO_ENCODER_SUCCESS) {
+            ERR("EncodeOneFrame: reset after a parameter change failed");
+            return VIDEO_ENCODER_ENCODE_FAIL;
+        }
+        m_needReset = false;
+    }
+    PollKeyframeRequest();
+    if (m_engine == nullptr) {
+        ERR("EncodeOneFrame: encoder is not initialised");
+        return VIDEO_ENCODER_ENCODE_FAIL;
+    }
+    (void) mi355x_h264_set_qp(m_engine, m_qp);
+    m_lastQp = m_qp;
+    int frameType = 0;
+    int rc = EncodePicture(inputData, outputData, outputSize, &frameType);
+    if (rc == MI355X_H264_OK && m_sceneDetect && frameType == MI355X_H264_FRAME_P) {
+        // scene change: the motion search found no good match anywhere -> code this picture as IDR instead
+        uint32_t cost = 0;
+        const uint64_t mbs = static_cast<uint64_t>((m_active.width + 15) / 16) * ((m_active.height + 15) / 16);
+        if (mi355x_h264_last_me_cost(m_engine, &cost) == MI355X_H264_OK && cost > Limits::kSceneCutCostPerMb * mbs) {
+            INFO("scene change (motion cost %u over %llu macroblocks): picture re-coded as IDR", cost,
+                 static_cast<unsigned long long>(mbs));
+            (void) mi355x_h264_force_idr(m_engine);
+            rc = EncodePicture(inputData, outputData, outputSize, &frameType);
+            m_sceneCuts++;
+        }
+    }
+    if (rc != MI355X_H264_OK) {
+        ERR("EncodeOneFrame: engine returned %d (%s)", rc, mi355x_h264_last_error(m_engine));
+        return VIDEO_ENCODER_ENCODE_FAIL;
+    }
+    RateControlUpdate(*outputSize, frameType == MI355X_H264_FRAME_IDR);
+    return VIDEO_ENCODER_SUCCESS;
+}
+
+void VideoEncoderMI355X::CloseEngine()
+{
+    if (m_engine != nullptr) {
+        mi355x_h264_destroy(m_engine);
+        m_engine = nullptr;
+    }
 }
 
 void VideoEncoderMI355X::DestroyEncoder()
 {
-    Release();
-    INFO("destroy encoder success");
-}
-
-void VideoEncoderMI355X::Release()
-{
-    if (m_encoder != nullptr) {
-        mi355x_h264_destroy(m_encoder);
-        m_encoder = nullptr;
-    }
+    CloseEngine();
+    INFO("DestroyEncoder");
 }
 
 EncoderRetCode VideoEncoderMI355X::ResetEncoder()
 {
-    INFO("resetting encoder");
+    INFO("ResetEncoder");
     DestroyEncoder();
-    EncoderRetCode ret = InitEncoder();
-    if (ret != VIDEO_ENCODER_SUCCESS) {
-        ERR("init encoder failed %#x while resetting", ret);
+    if (InitEncoder() != VIDEO_ENCODER_SUCCESS || StartEncoder() != VIDEO_ENCODER_SUCCESS) {
+        ERR("ResetEncoder: could not bring the encoder back up");
         return VIDEO_ENCODER_RESET_FAIL;
     }
-    ret = StartEncoder();
-    if (ret != VIDEO_ENCODER_SUCCESS) {
-        ERR("start encoder failed %#x while resetting", ret);
-        return VIDEO_ENCODER_RESET_FAIL;
-    }
-    INFO("reset encoder success");
     return VIDEO_ENCODER_SUCCESS;
 }
 
 EncoderRetCode VideoEncoderMI355X::ForceKeyFrame()
 {
-    if (m_encoder == nullptr || mi355x_h264_force_idr(m_encoder) != MI355X_H264_OK) {
-        ERR("encoder force intra frame failed");
+    if (m_engine == nullptr || mi355x_h264_force_idr(m_engine) != MI355X_H264_OK) {
+        ERR("ForceKeyFrame: engine refused");
         return VIDEO_ENCODER_FORCE_KEY_FRAME_FAIL;
     }
-    INFO("force key frame success");
+    INFO("ForceKeyFrame: next picture is an IDR");
     return VIDEO_ENCODER_SUCCESS;
 }
 
 EncoderRetCode VideoEncoderMI355X::SetEncodeParams()
 {
     if (EncodeParamsChange()) {
-        m_encParams = m_tmpEncParams;
-        m_resetFlag = true;
-        INFO("Handle encoder config change: [bitrate, gopsize, profile] = [%u,%u,%s]", m_encParams.bitrate,
-             m_encParams.gopsize, m_encParams.profile.c_str());
+        m_active = m_pending;
+        m_needReset = true;
+        INFO("parameters changed: %u bps, gop %u, %s (encoder restarts on the next picture)", m_active.bitrate, m_active.gop,
+             m_active.profile.c_str());
     } else {
-        INFO("Using encoder config: [bitrate, gopsize, profile] = [%u,%u,%s]", m_encParams.bitrate,
-             m_encParams.gopsize, m_encParams.profile.c_str());
+        INFO("parameters unchanged: %u bps, gop %u, %s", m_active.bitrate, m_active.gop, m_active.profile.c_str());
     }
     return VIDEO_ENCODER_SUCCESS;
 }

@@ -1,41 +1,30 @@
 /*
- * media_amd/host/VideoEncoderMI355X.h -- the MI355X backend of the VideoEncoder
- * plugin surface: a peer of the reference's VideoEncoderOpenH264
- * (/root/reference/video_codec/VideoEncoderOpenH264.h:27-196) with the same
- * operator API, property-driven configuration, live re-configuration handshake
- * and buffer ownership, calling the HIP encode path through the C ABI of
- * include/mi355x_h264.h instead of the ISVCEncoder vtable.
+ * media_amd/host/VideoEncoderMI355X.h -- the MI355X backend of the VideoEncoder plugin surface, a peer of the
+ * reference's OpenH264 adapter (/root/reference/video_codec/VideoEncoderOpenH264.h:27-196): same operator
+ * API, same property-driven configuration, same live re-configuration handshake and buffer ownership.  The
+ * engine behind it is the HIP encode path reached through the C ABI of include/mi355x_h264.h.
  */
 #ifndef VIDEO_ENCODER_MI355X_H
 #define VIDEO_ENCODER_MI355X_H
 
 #include <atomic>
+#include <cstdint>
 #include <string>
 #include "VideoCodecApi.h"
 #include "mi355x_h264.h"
 
-namespace MI355X {
-    // limits and defaults of the reference adapter (VideoEncoderOpenH264.h:12-25, .cpp:16-23)
-    constexpr uint32_t DEFAULT_WIDTH = 720;
-    constexpr uint32_t DEFAULT_HEIGHT = 1280;
-    constexpr uint32_t WH_MIN = 16;
-    constexpr uint32_t WH_MAX = 4096;
-    constexpr uint32_t FRAMERATE_MIN = 30;
-    constexpr uint32_t FRAMERATE_MAX = 60;
-    constexpr uint32_t GOPSIZE_MIN = 30;
-    constexpr uint32_t GOPSIZE_MAX = 3000;
-    constexpr uint32_t BITRATE_MIN = 1000000;
-    constexpr uint32_t BITRATE_MAX = 10000000;
-    constexpr uint32_t BITRATE_DEFAULT_264 = 5000000;
-    constexpr int32_t QP_MIN = 12;
-    constexpr int32_t QP_MAX = 48;
-    constexpr int32_t QP_START = 30;
-    // scene change: mean motion cost per macroblock above this re-codes the picture as IDR
-    constexpr uint32_t SCENE_CUT_COST_PER_MB = 3000;
-}
-
 class VideoEncoderMI355X : public VideoEncoder {
 public:
+    // limits of the reference adapter (VideoEncoderOpenH264.h:12-25, .cpp:16-23) and this backend's own
+    struct Limits {
+        static constexpr int32_t kSideMin = 16, kSideMax = 4096;            // picture width / height
+        static constexpr int32_t kFps[2] = {30, 60};                        // the only accepted frame rates
+        static constexpr int32_t kGopMin = 30, kGopMax = 3000;
+        static constexpr int32_t kBitrateMin = 1000000, kBitrateMax = 10000000;
+        static constexpr int32_t kQpMin = 12, kQpMax = 48, kQpStart = 30;  // rate-control range
+        static constexpr uint32_t kSceneCutCostPerMb = 3000;               // mean motion cost that triggers an IDR
+    };
+
     VideoEncoderMI355X();
     ~VideoEncoderMI355X() override;
 
@@ -47,46 +36,49 @@ public:
     void DestroyEncoder() override;
     EncoderRetCode ResetEncoder() override;
 
+    // same extras as the reference adapter exposes (VideoEncoderOpenH264.h:84-101)
     EncoderRetCode ForceKeyFrame();
     EncoderRetCode SetEncodeParams();
     bool EncodeParamsChange();
 
-    // picture QP used for the last encoded picture (test hook for the rate controller)
+    // test hooks
     int32_t LastFrameQp() const { return m_lastQp; }
-    // number of pictures re-coded as IDR by the scene-change detector (test hook)
     uint32_t SceneCuts() const { return m_sceneCuts; }
 
 private:
-    struct EncodeParams {
-        uint32_t framerate = 0;
-        uint32_t bitrate = 0;
-        uint32_t gopsize = 0;
-        std::string profile = "";
-        uint32_t width = 0;
-        uint32_t height = 0;
+    // what the properties configure; defaults = reference defaults (720x1280 portrait, 30 fps, 5 Mbps, GOP 30)
+    struct Settings {
+        uint32_t width = 720, height = 1280, fps = 30;
+        uint32_t bitrate = 5000000, gop = 30;
+        std::string profile = "baseline";
+        bool SameAs(const Settings &o) const
+        {
+            return width == o.width && height == o.height && fps == o.fps && bitrate == o.bitrate && gop == o.gop &&
+                   profile == o.profile;
+        }
     };
+    enum class PhoneMode { Video, Instruction, Invalid };
 
-    bool GetRoEncParam();
-    bool GetPersistEncParam();
-    bool VerifyEncodeRoParams(int32_t width, int32_t height, int32_t framerate);
-    bool VerifyEncodeParams(std::string &bitrate, std::string &gopsize, std::string &profile);
-    bool InitParams();
-    void Release();
+    static PhoneMode ReadPhoneMode();
+    bool ReadGeometry(Settings &into) const;          // width / height / fps   (read-only properties)
+    bool ReadTunables(Settings &into);                // bitrate / gop / profile (live-adjustable properties)
+    bool OpenEngine();
+    void CloseEngine();
+    bool PollParamAdjust();                           // persist.vmi.video.encode.param_adjusting handshake
+    void PollKeyframeRequest();                       // persist.vmi.video.encode.keyframe handshake
+    int EncodePicture(const uint8_t *i420, uint8_t **out, uint32_t *outLen, int *frameType);
     void RateControlUpdate(uint32_t frameBytes, bool isIdr);
 
-    EncodeParams m_encParams = {MI355X::FRAMERATE_MIN, MI355X::BITRATE_DEFAULT_264, MI355X::GOPSIZE_MIN, "baseline",
-                                MI355X::DEFAULT_WIDTH, MI355X::DEFAULT_HEIGHT};
-    EncodeParams m_tmpEncParams = m_encParams;
-    std::atomic<bool> m_resetFlag = { false };
-    mi355x_h264_encoder *m_encoder = nullptr;
-    uint32_t m_yLength = 0;
-    uint32_t m_frameSize = 0;
-    // rate control (RC_BITRATE_MODE of the reference preset, VideoEncoderOpenH264.cpp:274)
-    int32_t m_fixedQp = -1;      // >= 0: extension property persist.vmi.video.encode.qp selects fixed QP
-    int32_t m_qp = MI355X::QP_START;
-    int32_t m_lastQp = 0;
-    int64_t m_bufferBits = 0;    // virtual buffer fullness relative to the target rate
-    bool m_sceneDetect = true;   // bEnableSceneChangeDetect = 1 in the reference preset (ref :283)
+    Settings m_active;                 // what the engine was opened with
+    Settings m_pending;                // last values read from the properties
+    std::atomic<bool> m_needReset{false};
+    mi355x_h264_encoder *m_engine = nullptr;
+    uint32_t m_lumaBytes = 0, m_frameBytes = 0;
+    // rate control (the reference preset runs RC_BITRATE_MODE, VideoEncoderOpenH264.cpp:274)
+    int32_t m_fixedQp = -1;            // >= 0: extension property persist.vmi.video.encode.qp selects fixed QP
+    int32_t m_qp = Limits::kQpStart, m_lastQp = 0;
+    int64_t m_bufferBits = 0;          // virtual buffer fullness relative to the target rate
+    bool m_sceneDetect = true;         // bEnableSceneChangeDetect = 1 in the reference preset (ref :283)
     uint32_t m_sceneCuts = 0;
 };
 
