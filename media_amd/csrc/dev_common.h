@@ -43,7 +43,7 @@ struct FrameParams {
     MbInfo* mb;
     int16_t* levels;     // LV_STRIDE int16 per macroblock
     int16_t* mvd;        // 2 int16 per macroblock (mv - predictor)
-    unsigned* me_cost;   // per batch item: sum over searched macroblocks of min(final motion cost, 16383)
+    uint16_t* me_cost;   // per macroblock: min(final motion cost, 16383), 0 where the zero-motion test hit (summed by k_bit_scan)
     Quant qy, qc;        // luma / chroma quantisers
     int lambda;
     // lockstep batch (gridDim.y = number of independent closed GOPs / streams encoded together):
@@ -62,7 +62,7 @@ __device__ __forceinline__ FrameParams batch_view(FrameParams P, int g)
     P.mb += (size_t)g * P.st_mb;
     P.levels += (size_t)g * P.st_mb * LV_STRIDE;
     P.mvd += (size_t)g * P.st_mb * 2;
-    P.me_cost += g;
+    P.me_cost += (size_t)g * P.st_mb;
     return P;
 }
 

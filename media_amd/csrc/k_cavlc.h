@@ -368,20 +368,28 @@ struct SliceInfo {       // lives in pinned host memory, written by the device
 };
 
 // one workgroup of 1024: exclusive scan of mbbits (in place -> offsets), header, tail
-__global__ __launch_bounds__(1024) void k_bit_scan(CavlcParams C0, HdrBatch H, SliceInfo* info0, unsigned* me_cost0)
+__global__ __launch_bounds__(1024) void k_bit_scan(CavlcParams C0, HdrBatch H, SliceInfo* info0, const uint16_t* me_cost0)
 {
     const CavlcParams C = batch_view(C0, blockIdx.x);
     const unsigned long long hdr_bits = H.bits[blockIdx.x];
     const int hdr_len = H.len[blockIdx.x];
     SliceInfo* info = info0 + blockIdx.x;
     __shared__ unsigned s_part[1024];
+    __shared__ unsigned s_cost;
     const int t = threadIdx.x;
+    if (t == 0) s_cost = 0;
     const int per = (C.nmb + 1023) / 1024;
     const int b0 = t * per, b1 = min(C.nmb, b0 + per);
     unsigned sum = 0;
     for (int i = b0; i < b1; i++) sum += C.mbbits[i];
     s_part[t] = sum;
     __syncthreads();
+    if (C.p_slice) {   // scene-change statistic: sum of the per-macroblock motion costs k_me left
+        const uint16_t* mc = me_cost0 + (size_t)blockIdx.x * C.st_mb;
+        unsigned cs = 0;
+        for (int i = b0; i < b1; i++) cs += mc[i];
+        if (cs) atomicAdd(&s_cost, cs);
+    }
     for (int o = 1; o < 1024; o <<= 1) {
         const unsigned v = t >= o ? s_part[t - o] : 0;
         __syncthreads();
@@ -417,8 +425,7 @@ __global__ __launch_bounds__(1024) void k_bit_scan(CavlcParams C0, HdrBatch H, S
         info->total_bytes = (total + 7) >> 3;
         info->epb_count = 0;
         info->error = 0;
-        info->me_cost = me_cost0[blockIdx.x];
-        me_cost0[blockIdx.x] = 0;   // ready for the next picture's motion search (ordered by the stream join)
+        info->me_cost = s_cost;   // complete: every thread passed the scan's barriers after its atomicAdd
     }
 }
 

@@ -151,6 +151,7 @@ __global__ __launch_bounds__(64, 4) void k_me(FrameParams P0)
             if (lane == 0) {
                 MbInfo* m = P.mb + mbi;
                 m->mvx = 0; m->mvy = 0; m->type = MB_P16;
+                P.me_cost[mbi] = 0;
             }
             return;
         }
@@ -252,59 +253,82 @@ __global__ __launch_bounds__(64, 4) void k_me(FrameParams P0)
     }
     __syncthreads();
 
-    // ---- 4. sub-pel refinement: 4 candidates per round, 16 lanes (4x4 blocks) each ----
-    const int grp = lane >> 4, blk = lane & 15, b4x = (blk & 3) * 4, b4y = (blk >> 2) * 4;
-    uint32_t sp[4];
+    // ---- 4. sub-pel refinement: 8 candidates per round; lane = (candidate, pair of 4x4 blocks).  The two
+    // blocks of a lane (b and b+8) ride in the low / high 16 bits of every register: differences, the 4x4
+    // Hadamard (v_pk_add/sub_u16) and the absolute sum (v_sad_u16 against the bias that sample 0 carries
+    // through the transform: every Hadamard output contains +d0) handle both at once. ----
+    const int cand = lane >> 3, bp = lane & 7, b4x = (bp & 3) * 4, b4y = (bp >> 2) * 4;
+    typedef unsigned short pk16 __attribute__((ext_vector_type(2)));
+    const uint32_t sel0 = 0x0c040c00u;                    // byte 0 <- low operand byte 0, byte 2 <- high operand byte 0
+    pk16 S[16];
 #pragma unroll
-    for (int y = 0; y < 4; y++) sp[y] = *(const uint32_t*)(s_src + (b4y + y) * 16 + b4x);
+    for (int y = 0; y < 4; y++) {
+        const uint32_t lo = *(const uint32_t*)(s_src + (b4y + y) * 16 + b4x), hi = *(const uint32_t*)(s_src + (b4y + 8 + y) * 16 + b4x);
+#pragma unroll
+        for (int x = 0; x < 4; x++) S[4 * y + x] = __builtin_bit_cast(pk16, __builtin_amdgcn_perm(hi, lo, sel0 + 0x00010001u * x));
+    }
+    S[0] = __builtin_bit_cast(pk16, __builtin_bit_cast(uint32_t, S[0]) ^ 0x80008000u);
     int cx = 4 * ix, cy = 4 * iy;
-    unsigned best_cost = 0;
+    unsigned best_cost = 0, bestk = 0xFFFFFFFFu;
 #pragma unroll 1
-    for (int pass = 0; pass < 2; pass++) {
-        const int step = pass == 0 ? 2 : 1;
-        const int ncand = pass == 0 ? 9 : 8;
-        unsigned bestk = pass == 0 ? 0xFFFFFFFFu : (best_cost << 4);
-#pragma unroll 1
-        for (int c0 = 0; c0 < ncand; c0 += 4) {
-            const int c = c0 + grp;                     // candidate index in this pass
-            const int ord = c < ncand ? (pass == 0 ? c : c + 1) : 0;  // 0 = centre (also for idle groups)
-            const int n = ord - 1;                      // neighbour 0..7
-            // neighbour order (-1,-1)(0,-1)(1,-1)(-1,0)(1,0)(-1,1)(0,1)(1,1)
-            const int nn = n >= 4 ? n + 1 : n;
-            const int ddx = ord == 0 ? 0 : (nn % 3) - 1, ddy = ord == 0 ? 0 : (nn / 3) - 1;
-            const int qx = cx + step * ddx, qy = cy + step * ddy;
-            const int ox = qx - 4 * ix, oy = qy - 4 * iy;
-            const int gx = 1 + (ox >> 2), gy = 1 + (oy >> 2);
-            int t0, t1;
-            qpel_taps(ox & 3, oy & 3, t0, t1);
-            int d[16];
-            const int gb = (gy + b4y) * ME_GP + gx + b4x;
+    for (int round = 0; round < 3; round++) {
+        // round 0: the 8 half-sample neighbours; round 1: the centre itself; round 2: the 8 quarter-sample neighbours
+        const int step = round == 2 ? 1 : 2;
+        const int ord = round == 1 ? 0 : cand + 1;        // 0 = centre
+        const bool live = round != 1 || cand == 0;
+        // neighbour order (-1,-1)(0,-1)(1,-1)(-1,0)(1,0)(-1,1)(0,1)(1,1)
+        const int nn = cand >= 4 ? cand + 1 : cand;
+        const int ddx = ord == 0 ? 0 : (nn % 3) - 1, ddy = ord == 0 ? 0 : (nn / 3) - 1;
+        const int qx = cx + step * ddx, qy = cy + step * ddy;
+        const int ox = qx - 4 * ix, oy = qy - 4 * iy;
+        const int gx = 1 + (ox >> 2), gy = 1 + (oy >> 2);
+        int t0, t1;
+        qpel_taps(ox & 3, oy & 3, t0, t1);
+        const int gb = (gy + b4y) * ME_GP + gx + b4x;
+        pk16 d[16];
 #pragma unroll
-            for (int y = 0; y < 4; y++) {
-                const uint32_t pa = lds_ld4(s_pl, t0 + gb + y * ME_GP), pb = lds_ld4(s_pl, t1 + gb + y * ME_GP);
-                const uint32_t pr = avg4(pa, pb);
+        for (int y = 0; y < 4; y++) {
+            const uint32_t pl = avg4(lds_ld4(s_pl, t0 + gb + y * ME_GP), lds_ld4(s_pl, t1 + gb + y * ME_GP));
+            const uint32_t ph = avg4(lds_ld4(s_pl, t0 + gb + (y + 8) * ME_GP), lds_ld4(s_pl, t1 + gb + (y + 8) * ME_GP));
 #pragma unroll
-                for (int x = 0; x < 4; x++) d[4 * y + x] = byte_of(sp[y], x) - byte_of(pr, x);
-            }
-            int s = hadamard_abs(d);
-            s = group_sum<16>(s);
-            const unsigned cost = (unsigned)(s >> 1) + (unsigned)(P.lambda * (se_len(qx) + se_len(qy)));
-            const unsigned key = c < ncand ? ((cost << 4) | (unsigned)ord) : 0xFFFFFFFFu;
-            bestk = key < bestk ? key : bestk;   // per-lane running minimum; reduced once per pass
+            for (int x = 0; x < 4; x++)
+                d[4 * y + x] = S[4 * y + x] - __builtin_bit_cast(pk16, __builtin_amdgcn_perm(ph, pl, sel0 + 0x00010001u * x));
         }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const pk16 s0 = d[4 * i] + d[4 * i + 3], s1 = d[4 * i + 1] + d[4 * i + 2];
+            const pk16 d0 = d[4 * i] - d[4 * i + 3], d1 = d[4 * i + 1] - d[4 * i + 2];
+            d[4 * i] = s0 + s1; d[4 * i + 1] = d0 + d1; d[4 * i + 2] = s0 - s1; d[4 * i + 3] = d0 - d1;
+        }
+        uint32_t sum = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const pk16 s0 = d[j] + d[12 + j], s1 = d[4 + j] + d[8 + j];
+            const pk16 d0 = d[j] - d[12 + j], d1 = d[4 + j] - d[8 + j];
+            sum = __builtin_amdgcn_sad_u16(__builtin_bit_cast(uint32_t, s0 + s1), 0x80008000u, sum);
+            sum = __builtin_amdgcn_sad_u16(__builtin_bit_cast(uint32_t, d0 + d1), 0x80008000u, sum);
+            sum = __builtin_amdgcn_sad_u16(__builtin_bit_cast(uint32_t, s0 - s1), 0x80008000u, sum);
+            sum = __builtin_amdgcn_sad_u16(__builtin_bit_cast(uint32_t, d0 - d1), 0x80008000u, sum);
+        }
+        const int s = group_sum<8>((int)sum);
+        const unsigned cost = (unsigned)(s >> 1) + (unsigned)(P.lambda * (se_len(qx) + se_len(qy)));
+        const unsigned key = live ? ((cost << 4) | (unsigned)ord) : 0xFFFFFFFFu;
+        bestk = key < bestk ? key : bestk;               // per-lane running minimum; reduced once per pass
+        if (round == 0) continue;
         bestk = wave_min_u32(bestk);
-        const int ord = (int)(bestk & 15);
+        const int w = (int)(bestk & 15);
         best_cost = bestk >> 4;
-        if (ord) {
-            const int n = ord - 1, nn = n >= 4 ? n + 1 : n;
-            cx += step * ((nn % 3) - 1);
-            cy += step * ((nn / 3) - 1);
+        if (w) {
+            const int n = w - 1, wn = n >= 4 ? n + 1 : n;
+            cx += step * ((wn % 3) - 1);
+            cy += step * ((wn / 3) - 1);
         }
+        bestk = best_cost << 4;                          // the next pass starts from "stay" (order 0)
     }
     if (lane == 0) {
         MbInfo* m = P.mb + mbi;
         m->mvx = (int16_t)cx; m->mvy = (int16_t)cy; m->type = MB_P16;
-        atomicAdd(P.me_cost, best_cost < 16383u ? best_cost : 16383u);   // scene-change statistic of the picture
+        P.me_cost[mbi] = (uint16_t)(best_cost < 16383u ? best_cost : 16383u);   // scene-change statistic, summed by k_bit_scan
     }
 }
 

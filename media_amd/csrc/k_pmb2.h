@@ -36,7 +36,7 @@ __device__ __forceinline__ uint32_t pack4(int a, int b, int c, int d)
 }
 __device__ __forceinline__ uint32_t avg4(uint32_t a, uint32_t b)  // per-byte (a + b + 1) >> 1
 {
-    return (a | b) - (((a ^ b) >> 1) & 0x7F7F7F7Fu);
+    return __builtin_amdgcn_lerp(a, b, 0x01010101u);   // v_lerp_u8: rounding bit = bit 0 of the third operand's bytes
 }
 
 // unclipped horizontal 6-tap sums for 4 consecutive outputs; `o` = LDS byte offset of the sample 2 left of output 0

@@ -176,7 +176,7 @@ struct mi355x_h264_encoder {
     uint32_t* d_mbbits = nullptr;
     unsigned long long* d_handoff = nullptr; // row-to-row hand-off of the wavefront kernels
     uint32_t* d_bs = nullptr;                // boundary strengths, 32 B per macroblock
-    unsigned* d_me_cost = nullptr;           // [G] scene-change statistic
+    uint16_t* d_me_cost = nullptr;           // [G][nmb] per-macroblock motion cost (scene-change statistic)
     std::vector<uint32_t> last_me_cost;      // of the last finished picture, per batch item
     unsigned serial = 0;
     bool diag_mode = false;                  // debug: one launch per wavefront step instead
@@ -547,8 +547,8 @@ int mi355x_h264_create(const mi355x_h264_config* cfg, mi355x_h264_encoder** out)
     CK(hipMalloc((void**)&e->d_handoff, Gn * e->st_handoff * sizeof(unsigned long long)));
     CK(hipMemset(e->d_handoff, 0, Gn * e->st_handoff * sizeof(unsigned long long)));
     CK(hipMalloc((void**)&e->d_bs, Gn * e->nmb * 32));
-    CK(hipMalloc((void**)&e->d_me_cost, Gn * sizeof(unsigned)));
-    CK(hipMemset(e->d_me_cost, 0, Gn * sizeof(unsigned)));
+    CK(hipMalloc((void**)&e->d_me_cost, Gn * e->nmb * sizeof(uint16_t)));
+    CK(hipMemset(e->d_me_cost, 0, Gn * e->nmb * sizeof(uint16_t)));
     e->last_me_cost.assign(Gn, 0);
     e->diag_mode = getenv("MI355X_H264_DIAG") != nullptr && e->G == 1;
     e->pmb_v1 = getenv("MI355X_H264_PMB_V1") != nullptr;
