@@ -100,9 +100,8 @@ __constant__ const uint8_t c_zigzag_inv[16] = {0, 1, 5, 6, 2, 4, 7, 12, 3, 8, 11
 // length in bits of se(v)
 __device__ __forceinline__ int se_len(int v)
 {
-    if (v == 0) return 1;
-    const unsigned k1 = v > 0 ? 2u * (unsigned)v : 2u * (unsigned)(-v) + 1u;  // codeNum + 1
-    return 2 * (31 - __clz((int)k1)) + 1;
+    const unsigned k1 = v > 0 ? 2u * (unsigned)v : 1u - 2u * (unsigned)v;  // codeNum + 1 (>= 1, so no branch for v == 0)
+    return 63 - 2 * __builtin_clz(k1);
 }
 
 // forward 4x4 core transform, in place on 16 ints (raster)

@@ -7,7 +7,8 @@
 //   1. zero-motion test: does (src - ref) quantise to nothing?  -> mv = 0, done
 //   2. full search dx,dy in [-16,15]: lane = (dx, half of dy range); each lane
 //      keeps 16 SAD accumulators (v_sad_u8, four pixels per instruction) and
-//      walks 31 window rows, every row feeding up to 16 candidates
+//      walks 31 window rows, every row feeding up to 16 candidates; the source
+//      macroblock sits in SGPRs
 //   3. half- then quarter-pel refinement on SATD over half-sample planes built
 //      once in LDS (18x18 grid of G/b/h/j, 8.4.2.2.1)
 // Decisions use only the previous picture and this macroblock's source, so the
@@ -56,6 +57,7 @@ __global__ __launch_bounds__(64, 4) void k_me(FrameParams P0)
     __shared__ __attribute__((aligned(16))) uint32_t s_win[ME_WS * ME_WDW];  // 56 x 56 bytes
     __shared__ __attribute__((aligned(16))) uint8_t s_src[256];
     __shared__ __attribute__((aligned(16))) uint8_t s_srcc[128];
+    __shared__ __attribute__((aligned(16))) uint32_t s_ytab[32];
     __shared__ __attribute__((aligned(16))) uint8_t s_refc[128];
     __shared__ __attribute__((aligned(16))) int16_t s_b1[(ME_GS + 5) * ME_GP];   // pitch 20 int16
     __shared__ __attribute__((aligned(16))) uint8_t s_pl[4 * ME_PLS + 16];        // planes G,b,h,j: 18 rows, pitch 20
@@ -157,56 +159,71 @@ __global__ __launch_bounds__(64, 4) void k_me(FrameParams P0)
         }
     }
 
-    // ---- 2. integer full search ----
+    // ---- 2. integer full search: lane = (dx, half of the dy range); 16 SAD accumulators per lane, one pass over
+    // 31 window rows, every row feeding up to 16 candidates (v_sad_u8, four samples per instruction) ----
     unsigned best;
     {
         const int dxi = lane & 31, half = lane >> 5;
         const int col = dxi + ME_AP, cdw = col >> 2, sh = col & 3;
-        // the source macroblock is wave-uniform: keep its 64 dwords in SGPRs (v_sad_u8 takes one scalar operand)
+        // motion-vector cost and candidate index of every dy, shifted into key position: one table per macroblock
+        if (lane < 32) s_ytab[lane] = ((uint32_t)__mul24(P.lambda, se_len(4 * (lane - ME_R))) << 10) | ((uint32_t)lane << 5);
+        // the source macroblock is wave-uniform: keep its 64 dwords in SGPRs (v_sad_u8 takes one scalar operand).
+        // Macroblocks inside the picture read it with scalar loads straight from the source picture.
         uint32_t srow[16][4];
+        const uint8_t* sp0 = P.src + (size_t)by * P.w + bx;
+        if (bx + 16 <= P.w && by + 16 <= P.h && ((P.w | (int)(uintptr_t)P.src) & 3) == 0) {
 #pragma unroll
-        for (int j = 0; j < 16; j++) {
-            const uint4 v = *(const uint4*)(s_src + 16 * j);
-            srow[j][0] = __builtin_amdgcn_readfirstlane(v.x); srow[j][1] = __builtin_amdgcn_readfirstlane(v.y);
-            srow[j][2] = __builtin_amdgcn_readfirstlane(v.z); srow[j][3] = __builtin_amdgcn_readfirstlane(v.w);
+            for (int j = 0; j < 16; j++) {
+                const uint4 v = *(const uint4*)(sp0 + (size_t)j * P.w);
+                srow[j][0] = v.x; srow[j][1] = v.y; srow[j][2] = v.z; srow[j][3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const uint4 v = *(const uint4*)(s_src + 16 * j);
+                srow[j][0] = __builtin_amdgcn_readfirstlane(v.x); srow[j][1] = __builtin_amdgcn_readfirstlane(v.y);
+                srow[j][2] = __builtin_amdgcn_readfirstlane(v.z); srow[j][3] = __builtin_amdgcn_readfirstlane(v.w);
+            }
         }
-        const int dx = dxi - ME_R;
-        const int rx = se_len(4 * dx);
+        const uint32_t kbase = ((uint32_t)__mul24(P.lambda, se_len(4 * (dxi - ME_R))) << 10) + (uint32_t)dxi;
+        const uint32_t* wb = s_win + (ME_AP + half * 16) * ME_WDW + cdw;
+        uint32_t acc[16];
+#pragma unroll
+        for (int kk = 0; kk < 16; kk++) acc[kk] = 0;
+        // window rows stream through two register sets: row r+1 is requested before row r is consumed; the
+        // scheduling barrier stops the compiler from hoisting every row's LDS read to the top (95 live registers)
+        uint32_t w[2][5];
+#pragma unroll
+        for (int c = 0; c < 5; c++) w[0][c] = wb[c];
+#pragma unroll
+        for (int r = 0; r < 31; r++) {
+            if (r + 1 < 31) {
+#pragma unroll
+                for (int c = 0; c < 5; c++) w[(r + 1) & 1][c] = wb[(r + 1) * ME_WDW + c];
+            }
+            const uint32_t* wr = w[r & 1];
+            const uint32_t a0 = __builtin_amdgcn_alignbyte(wr[1], wr[0], sh), a1 = __builtin_amdgcn_alignbyte(wr[2], wr[1], sh);
+            const uint32_t a2 = __builtin_amdgcn_alignbyte(wr[3], wr[2], sh), a3 = __builtin_amdgcn_alignbyte(wr[4], wr[3], sh);
+#pragma unroll
+            for (int kk = 0; kk < 16; kk++) {
+                const int j = r - kk;       // source row met by candidate kk on window row r
+                if (j >= 0 && j < 16) {
+                    acc[kk] = __builtin_amdgcn_sad_u8(a0, srow[j][0], acc[kk]);
+                    acc[kk] = __builtin_amdgcn_sad_u8(a1, srow[j][1], acc[kk]);
+                    acc[kk] = __builtin_amdgcn_sad_u8(a2, srow[j][2], acc[kk]);
+                    acc[kk] = __builtin_amdgcn_sad_u8(a3, srow[j][3], acc[kk]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // key = (SAD + lambda * bits(mv)) << 10 | dy index << 5 | dx index; the table entry carries the dy part
         best = 0xFFFFFFFFu;
-        // four dy candidates at a time: 19 window rows feed 4 accumulators; rows stream through
-        // registers (compiler memory barriers keep the LDS reads next to their use, so VGPR use stays small)
-#pragma unroll 1
-        for (int g = 0; g < 4; g++) {
-            const uint32_t* wb = s_win + (ME_AP + half * 16 + 4 * g) * ME_WDW + cdw;
-            uint32_t acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
 #pragma unroll
-            for (int r = 0; r < 19; r++) {
-                const uint32_t* wr = wb + r * ME_WDW;
-                const uint32_t w0 = wr[0], w1 = wr[1], w2 = wr[2], w3 = wr[3], w4 = wr[4];
-                const uint32_t a0 = __builtin_amdgcn_alignbyte(w1, w0, sh), a1 = __builtin_amdgcn_alignbyte(w2, w1, sh);
-                const uint32_t a2 = __builtin_amdgcn_alignbyte(w3, w2, sh), a3 = __builtin_amdgcn_alignbyte(w4, w3, sh);
-#define ME_SAD4(ACC, J)                                                   \
-    do {                                                                  \
-        ACC = __builtin_amdgcn_sad_u8(a0, srow[J][0], ACC);              \
-        ACC = __builtin_amdgcn_sad_u8(a1, srow[J][1], ACC);              \
-        ACC = __builtin_amdgcn_sad_u8(a2, srow[J][2], ACC);              \
-        ACC = __builtin_amdgcn_sad_u8(a3, srow[J][3], ACC);              \
-    } while (0)
-                if (r >= 0 && r < 16) ME_SAD4(acc0, r);
-                if (r >= 1 && r < 17) ME_SAD4(acc1, r - 1);
-                if (r >= 2 && r < 18) ME_SAD4(acc2, r - 2);
-                if (r >= 3 && r < 19) ME_SAD4(acc3, r - 3);
-#undef ME_SAD4
-                asm volatile("" ::: "memory");
-            }
-            const uint32_t accs[4] = {acc0, acc1, acc2, acc3};
-#pragma unroll
-            for (int kk = 0; kk < 4; kk++) {
-                const int dy = half * 16 + 4 * g + kk - ME_R;
-                const unsigned cost = accs[kk] + (unsigned)(P.lambda * (rx + se_len(4 * dy)));
-                const unsigned key = (cost << 10) | (unsigned)(((dy + ME_R) << 5) | dxi);
-                best = key < best ? key : best;
-            }
+        for (int q = 0; q < 4; q++) {
+            const uint4 t = *(const uint4*)(s_ytab + half * 16 + 4 * q);
+            const uint32_t k0 = (acc[4 * q] << 10) + (t.x + kbase), k1 = (acc[4 * q + 1] << 10) + (t.y + kbase);
+            const uint32_t k2 = (acc[4 * q + 2] << 10) + (t.z + kbase), k3 = (acc[4 * q + 3] << 10) + (t.w + kbase);
+            best = min(min(best, k0), min(k1, min(k2, k3)));
         }
         best = wave_min_u32(best);
     }
