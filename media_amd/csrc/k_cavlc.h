@@ -328,6 +328,7 @@ __device__ __forceinline__ void code_slot(S& s, const CavlcParams& C, int mbi, i
 template <bool WRITE>
 __global__ __launch_bounds__(64) void k_cavlc(CavlcParams C0)
 {
+    __builtin_amdgcn_s_setprio(1);
     const CavlcParams C = batch_view(C0, blockIdx.y);
     const int lane = threadIdx.x, slot = lane & 31;
     const int mbi = blockIdx.x * 2 + (lane >> 5);

@@ -248,6 +248,8 @@ enum { DR_LP = 40, DR_CP = 24 };  // LDS pitches; luma tile cols -16..15 (+4 pad
 template <bool BS4>
 __global__ __launch_bounds__(64) void k_deblock_rows(DbRowParams R)
 {
+    // dependency-bound: when a throughput kernel of another stream shares the SIMD, this wave issues first
+    __builtin_amdgcn_s_setprio(3);
     DbParams D = R.d;
     {
         const size_t g = blockIdx.y;

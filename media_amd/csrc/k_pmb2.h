@@ -112,6 +112,7 @@ __constant__ const uint16_t c_zz_row[4] = {0x6510, 0xC742, 0xDB83, 0xFEA9};  // 
 
 __global__ __launch_bounds__(64) void k_pmb2(FrameParams P0)
 {
+    __builtin_amdgcn_s_setprio(2);   // short and on the way to the loop filter: ahead of another stream's motion search
     const FrameParams P = batch_view(P0, blockIdx.y);
     const int lane = threadIdx.x;
     const int mbi = xcd_mb_index(blockIdx.x, P.mbw * P.mbh), mx = mbi % P.mbw, my = mbi / P.mbw;
