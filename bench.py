@@ -4,11 +4,16 @@
 
 A "step" is one pass of the hot path over one batch: G closed 30-picture GOPs (1 IDR +
 29 P each, the reference's default uiIntraPeriod, VideoEncoderOpenH264.h:18) of the
-stream, encoded concurrently (G = --gops-in-flight encoder instances / HIP streams;
-closed GOPs are independent under fixed QP and concatenate to the serial stream), with
-all pictures already resident in HBM.  N GPUs = N independent streams, one process per
-GPU, no data-path collective (weak scaling); torch.distributed is used only for the
-barrier and the max-over-ranks clock.  G = 1 is measured too (single_gop_in_flight_fps).
+stream with all pictures already resident in HBM.  The G GOPs are split over I encoder
+instances (--instances, default 2); an instance encodes its G/I GOPs in lockstep (every
+kernel launch covers the same picture index of all of them, grid.y = G/I) and the
+instances run free beside each other on their own HIP streams, so the dependency-bound
+deblocking wavefront of one overlaps the throughput-bound motion search of the other.
+Closed GOPs are independent under fixed QP and concatenate to the serial stream.
+N GPUs = N independent streams, one process per GPU, no data-path collective (weak
+scaling); torch.distributed is used only for the barrier and the max-over-ranks clock.
+G = 1 is measured too (single_gop_in_flight_fps), and the kernels of one instance running
+alone (roofline_exclusive / kernels_exclusive).
 
 Prints ONE JSON line (rank 0) carrying `roofline` for the MC+DCT kernel (k_pmb) and
 `cpu_baseline` (the CPU oracle timed on this box's host cores, rank 0, N=1 only).
@@ -69,9 +74,9 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--gops-in-flight", type=int, default=int(os.environ.get("BENCH_GOPS_IN_FLIGHT", "32")),
-                    help="closed GOPs of the stream encoded in lockstep per GPU (one encoder instance, grid.y = G)")
-    ap.add_argument("--instances", type=int, default=int(os.environ.get("BENCH_INSTANCES", "1")),
+    ap.add_argument("--gops-in-flight", type=int, default=int(os.environ.get("BENCH_GOPS_IN_FLIGHT", "64")),
+                    help="closed GOPs of the stream resident and encoded per step per GPU")
+    ap.add_argument("--instances", type=int, default=int(os.environ.get("BENCH_INSTANCES", "2")),
                     help="encoder instances (HIP streams) the GOPs in flight are split over; each encodes its share in lockstep")
     ap.add_argument("--cpu-frames", type=int, default=8, help="pictures per CPU-baseline thread")
     ap.add_argument("--content", default="s1", choices=["s1", "s2", "s3"],
@@ -141,16 +146,24 @@ def main():
         insts[i].encode_gops_device(dev.data_ptr() + i * B * gop_stride, stride, gop_stride, FRAMES_PER_STEP, outs[i], cap,
                                     sizes[i], gop_bytes[i])
 
-    def step():
+    def steps(n):
+        """n steps: every instance encodes its share of the GOPs n times, free-running beside the others"""
         if I == 1:
-            run_inst(0)
+            for _ in range(n):
+                run_inst(0)
         else:
-            ths = [threading.Thread(target=run_inst, args=(i,)) for i in range(I)]
+            def work(i):
+                for _ in range(n):
+                    run_inst(i)
+            ths = [threading.Thread(target=work, args=(i,)) for i in range(I)]
             for t in ths:
                 t.start()
             for t in ths:
                 t.join()
         return int(gop_bytes[0][0])
+
+    def step():
+        return steps(1)
 
     def one_gop(_):
         e1 = enc1 if enc1 is not None else enc
@@ -175,9 +188,7 @@ def main():
 
     fence()
     t0 = time.perf_counter()
-    nbytes = 0
-    for _ in range(args.steps):
-        nbytes = step()
+    nbytes = steps(args.steps)
     fence()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -187,6 +198,12 @@ def main():
     st = enc.stats(reset=True)
     if enc1 is not None:
         enc1.stats(reset=True)
+    # the same kernels with the chip to themselves: instance 0 alone, one step (only when instances overlap)
+    st_ex = None
+    if I > 1:
+        run_inst(0)
+        torch.cuda.synchronize()
+        st_ex = enc.stats(reset=True)
     # latency mode for reference: one GOP in flight, kernels alone on the GPU (also gives the
     # MC+DCT kernel's duration without other streams' kernels sharing the chip)
     fence()
@@ -227,8 +244,9 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "1080p30 I420 synthetic S1 pan+noise, baseline profile, fixed QP 26, closed GOPs of 30 "
-                                   "(1 IDR + 29 P), single slice, 1 ref, deblock on, CAVLC; per GPU one stream whose "
-                                   "closed GOPs are encoded %d at a time in lockstep, pictures resident in HBM" % G,
+                                   "(1 IDR + 29 P), single slice, 1 ref, deblock on, CAVLC; per GPU one stream, %d of its "
+                                   "closed GOPs per step on %d encoder instance(s), each encoding its %d GOPs in lockstep "
+                                   "(grid.y) on its own HIP streams; pictures resident in HBM" % (G, I, B),
                        "content": args.content, "width": WIDTH, "height": HEIGHT, "qp": QP, "gop": GOP, "frames_per_step": FRAMES_PER_STEP * G, "gops_in_flight": G, "instances": I, "lockstep_batch": B,
                        "streams": world, "bytes_per_gop": int(nbytes), "parity": "bit-exact vs CPU oracle "
                        "(oracle unpinned vs OpenH264: no libopenh264 available)"},
@@ -240,6 +258,15 @@ def main():
             "kernels": per_kernel,
             "single_gop_in_flight_fps": round(lat_steps * FRAMES_PER_STEP / lat_dt, 2),
         }
+        if st_ex is not None:
+            pe = st_ex["kernels"]["pmb"]
+            ms_e = pe["ms"] / max(1, pe["launches"])
+            a_e = PMB_BYTES_PER_MB * nmb * B / (ms_e * 1e-3) / 1e9
+            res["roofline_exclusive"] = {"kernel": "k_pmb2, same launches with one instance running alone (no other stream's kernels "
+                                                   "sharing the CUs during the launch)", "achieved": round(a_e, 1), "peak": HBM_PEAK_GBS,
+                                         "unit": "GB/s", "frac": round(a_e / HBM_PEAK_GBS, 4), "avg_launch_ms": round(ms_e, 5)}
+            res["kernels_exclusive"] = {name: {"ms_per_launch": round(v["ms"] / v["launches"], 4)}
+                                        for name, v in st_ex["kernels"].items() if v["launches"]}
         p1 = st1["kernels"]["pmb"]
         if p1["launches"]:
             ms1 = p1["ms"] / p1["launches"]
