@@ -195,7 +195,13 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device="cuda:%d" % local_rank)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    # per-kernel HIP-event statistics of the timed region, summed over all instances
     st = enc.stats(reset=True)
+    for e_ in insts[1:]:
+        o = e_.stats(reset=True)
+        for name, v in o["kernels"].items():
+            for key in ("ms", "launches", "mbs"):
+                st["kernels"][name][key] += v[key]
     if enc1 is not None:
         enc1.stats(reset=True)
     # the same kernels with the chip to themselves: instance 0 alone, one step (only when instances overlap)

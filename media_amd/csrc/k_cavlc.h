@@ -368,18 +368,22 @@ struct SliceInfo {       // lives in pinned host memory, written by the device
     uint32_t pad[3];
 };
 
-// one workgroup of 1024: exclusive scan of mbbits (in place -> offsets), header, tail
-__global__ __launch_bounds__(1024) void k_bit_scan(CavlcParams C0, HdrBatch H, SliceInfo* info0, const uint16_t* me_cost0)
+// one workgroup of SCAN_NT threads per picture: exclusive scan of mbbits (in place -> offsets), header, tail.
+// Kept small (4 waves): a workgroup is dispatched only when one CU has room for all of its waves, and beside
+// another instance's motion search a 16-wave workgroup waits long for that.
+enum { SCAN_NT = 256 };
+__global__ __launch_bounds__(SCAN_NT) void k_bit_scan(CavlcParams C0, HdrBatch H, SliceInfo* info0, const uint16_t* me_cost0)
 {
+    __builtin_amdgcn_s_setprio(1);
     const CavlcParams C = batch_view(C0, blockIdx.x);
     const unsigned long long hdr_bits = H.bits[blockIdx.x];
     const int hdr_len = H.len[blockIdx.x];
     SliceInfo* info = info0 + blockIdx.x;
-    __shared__ unsigned s_part[1024];
+    __shared__ unsigned s_part[SCAN_NT];
     __shared__ unsigned s_cost;
     const int t = threadIdx.x;
     if (t == 0) s_cost = 0;
-    const int per = (C.nmb + 1023) / 1024;
+    const int per = (C.nmb + SCAN_NT - 1) / SCAN_NT;
     const int b0 = t * per, b1 = min(C.nmb, b0 + per);
     unsigned sum = 0;
     for (int i = b0; i < b1; i++) sum += C.mbbits[i];
@@ -391,7 +395,7 @@ __global__ __launch_bounds__(1024) void k_bit_scan(CavlcParams C0, HdrBatch H, S
         for (int i = b0; i < b1; i++) cs += mc[i];
         if (cs) atomicAdd(&s_cost, cs);
     }
-    for (int o = 1; o < 1024; o <<= 1) {
+    for (int o = 1; o < SCAN_NT; o <<= 1) {
         const unsigned v = t >= o ? s_part[t - o] : 0;
         __syncthreads();
         s_part[t] += v;
@@ -410,7 +414,7 @@ __global__ __launch_bounds__(1024) void k_bit_scan(CavlcParams C0, HdrBatch H, S
         if (hdr_len > 32) { s.put(hdr_len - 32, (unsigned)(hdr_bits >> 32)); s.put(32, (unsigned)hdr_bits); }
         else s.put(hdr_len, (unsigned)hdr_bits);
         s.flush();
-        unsigned total = (unsigned)hdr_len + s_part[1023];
+        unsigned total = (unsigned)hdr_len + s_part[SCAN_NT - 1];
         s.init(total);
         BitCount c;
         c.init(0);
@@ -432,7 +436,7 @@ __global__ __launch_bounds__(1024) void k_bit_scan(CavlcParams C0, HdrBatch H, S
 
 // Copy the payload to the pinned access unit, count emulation-prevention sites, publish SliceInfo to
 // pinned host memory and leave the device bit buffer zeroed for its next use (one workgroup).
-__global__ __launch_bounds__(1024) void k_pack(uint8_t* bitbuf0, size_t st_bitbuf_bytes, uint8_t* dst0, size_t st_dst, const SliceInfo* info0,
+__global__ __launch_bounds__(SCAN_NT) void k_pack(uint8_t* bitbuf0, size_t st_bitbuf_bytes, uint8_t* dst0, size_t st_dst, const SliceInfo* info0,
                                                SliceInfo* host_info0)
 {
     uint8_t* bitbuf = bitbuf0 + (size_t)blockIdx.x * st_bitbuf_bytes;

@@ -360,7 +360,7 @@ int submit(mi355x_h264_encoder* e, const uint8_t* d_src, size_t src_item_stride,
         const int grid = (e->nmb + 1) / 2;
         hipLaunchKernelGGL(k_cavlc<false>, dim3(grid, G), dim3(64), 0, ec, C);
         HIPCHK(e, hipEventRecord(S.bs_ready, ec));   // the count pass also produced the boundary strengths
-        hipLaunchKernelGGL(k_bit_scan, dim3(G), dim3(1024), 0, ec, C, H, S.d_info, e->d_me_cost);
+        hipLaunchKernelGGL(k_bit_scan, dim3(G), dim3(SCAN_NT), 0, ec, C, H, S.d_info, e->d_me_cost);
         hipLaunchKernelGGL(k_cavlc<true>, dim3(grid, G), dim3(64), 0, ec, C);
         // access unit layout in the pinned buffer: [pad][SPS PPS (IDR only)][00 00 00 01 hdr][payload...]
         const size_t pre = (idr ? e->sps_pps.size() : 0) + 5;
@@ -369,7 +369,7 @@ int submit(mi355x_h264_encoder* e, const uint8_t* d_src, size_t src_item_stride,
         S.payload_off = pad + pre;
         S.idr = idr;
         S.nal_hdr = idr ? ((3 << 5) | 5) : ((2 << 5) | 1);
-        hipLaunchKernelGGL(k_pack, dim3(G), dim3(1024), 0, ec, (uint8_t*)S.d_bitbuf, e->st_bitbuf_bytes, S.h_au + S.payload_off, e->st_au,
+        hipLaunchKernelGGL(k_pack, dim3(G), dim3(SCAN_NT), 0, ec, (uint8_t*)S.d_bitbuf, e->st_bitbuf_bytes, S.h_au + S.payload_off, e->st_au,
                            (const SliceInfo*)S.d_info, S.h_info);
     }
     HIPCHK(e, hipEventRecord(S.entropy_done, ec));
