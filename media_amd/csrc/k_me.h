@@ -112,44 +112,66 @@ __global__ __launch_bounds__(64, 4) void k_me(FrameParams P0)
     __syncthreads();
     const uint8_t* winb = (const uint8_t*)s_win;
 
-    // ---- 1. zero-motion test (lanes 0..15 luma blocks, 16..23 chroma blocks) ----
+    // ---- 1. zero-motion test: does the residual at mv = 0 quantise to nothing?  lane = (4x4 block, row); luma rides
+    // in the low and chroma (lanes 0..31) in the high 16 bits of every register, so one packed forward transform
+    // (row pass in the lane, column pass over the DPP quad) serves both ----
     {
-        int nz = 0, dc = 0;
-        if (lane < 24) {
-            int d[16];
-            const uint8_t *s, *r;
-            int sp, rp;
-            if (lane < 16) {
-                const int x = blk_x(lane) * 4, y = blk_y(lane) * 4;
-                s = s_src + y * 16 + x; sp = 16;
-                r = winb + (ME_R + ME_AP + y) * ME_WS + ME_R + ME_AP + x; rp = ME_WS;
-            } else {
-                const int pl = (lane - 16) >> 2, b = lane & 3;
-                s = s_srcc + pl * 64 + (b >> 1) * 32 + (b & 1) * 4; sp = 8;
-                r = s_refc + pl * 64 + (b >> 1) * 32 + (b & 1) * 4; rp = 8;
-            }
-#pragma unroll
-            for (int y = 0; y < 4; y++)
-#pragma unroll
-                for (int x = 0; x < 4; x++) d[4 * y + x] = (int)s[y * sp + x] - (int)r[y * rp + x];
-            fdct4x4(d);
-            const Quant& q = lane < 16 ? P.qy : P.qc;
-#pragma unroll
-            for (int i = (0); i < 16; i++) {
-                if (i == 0 && lane >= 16) continue;
-                nz |= iabs(d[i]) >= q.thr_inter[pos_class(i)];
-            }
-            dc = d[0];
+        typedef unsigned short pk16 __attribute__((ext_vector_type(2)));
+        const int r = lane & 3, b4 = lane >> 2;
+        const uint32_t sy = *(const uint32_t*)(s_src + ((b4 >> 2) * 4 + r) * 16 + (b4 & 3) * 4);
+        const uint32_t ry = s_win[(ME_R + ME_AP + (b4 >> 2) * 4 + r) * ME_WDW + (ME_R + ME_AP) / 4 + (b4 & 3)];
+        uint32_t sc = 0, rc = 0;
+        if (lane < 32) {   // (plane, block, row) = (lane >> 4, (lane >> 2) & 3, r)
+            const int o = (lane >> 4) * 64 + (((lane >> 3) & 1) * 4 + r) * 8 + ((lane >> 2) & 1) * 4;
+            sc = *(const uint32_t*)(s_srcc + o); rc = *(const uint32_t*)(s_refc + o);
         }
-        // chroma DC: 2x2 Hadamard across the four block lanes of each plane
-        const int base = 16 + ((lane - 16) & 4);
-        const int d0 = __shfl(dc, base), d1 = __shfl(dc, base + 1), d2 = __shfl(dc, base + 2), d3 = __shfl(dc, base + 3);
-        if (lane >= 16 && lane < 24) {
+        pk16 d[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t sel = 0x0c040c00u + 0x00010001u * k;   // byte k of the low operand -> bits 0..7, of the high -> 16..23
+            d[k] = __builtin_bit_cast(pk16, __builtin_amdgcn_perm(sc, sy, sel)) - __builtin_bit_cast(pk16, __builtin_amdgcn_perm(rc, ry, sel));
+        }
+        {
+            const pk16 s0 = d[0] + d[3], s1 = d[1] + d[2], d0 = d[0] - d[3], d1 = d[1] - d[2];
+            d[0] = s0 + s1; d[1] = d0 + d0 + d1; d[2] = s0 - s1; d[3] = d0 - d1 - d1;
+        }
+        const uint32_t one = 0x00010001u;
+        const pk16 sA = __builtin_bit_cast(pk16, (r & 1) ? 0xFFFFFFFFu : one);                          // +-1
+        const pk16 mA = __builtin_bit_cast(pk16, r == 1 ? 2u * one : one);
+        const pk16 mB = __builtin_bit_cast(pk16, r < 2 ? one : (r == 2 ? 0xFFFFFFFFu : 0xFFFEFFFEu));    // 1 1 -1 -2
+        // thresholds - 1 per position class (0 even/even, 1 odd/odd, 2 mixed), luma | chroma << 16
+        const uint32_t t0 = (uint32_t)(P.qy.thr_inter[0] - 1) | ((uint32_t)(P.qc.thr_inter[0] - 1) << 16);
+        const uint32_t t1 = (uint32_t)(P.qy.thr_inter[1] - 1) | ((uint32_t)(P.qc.thr_inter[1] - 1) << 16);
+        const uint32_t t2 = (uint32_t)(P.qy.thr_inter[2] - 1) | ((uint32_t)(P.qc.thr_inter[2] - 1) << 16);
+        const pk16 th_even = __builtin_bit_cast(pk16, (r & 1) ? t2 : t0), th_odd = __builtin_bit_cast(pk16, (r & 1) ? t1 : t2);
+        uint32_t over = 0;
+        int dc = 0;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const pk16 q0 = __builtin_bit_cast(pk16, quad_bcast<0>(__builtin_bit_cast(int, d[c])));
+            const pk16 q1 = __builtin_bit_cast(pk16, quad_bcast<1>(__builtin_bit_cast(int, d[c])));
+            const pk16 q2 = __builtin_bit_cast(pk16, quad_bcast<2>(__builtin_bit_cast(int, d[c])));
+            const pk16 q3 = __builtin_bit_cast(pk16, quad_bcast<3>(__builtin_bit_cast(int, d[c])));
+            const pk16 A = q0 + sA * q3, B = q1 + sA * q2;
+            const pk16 w = mA * A + mB * B;                        // row r of the 4x4 core transform, column c
+            if (c == 0) dc = (int)(short)w.y;                     // chroma DC of the block where r == 0
+            typedef short spk16 __attribute__((ext_vector_type(2)));
+            const spk16 ws = __builtin_bit_cast(spk16, w);
+            const pk16 aw = __builtin_bit_cast(pk16, __builtin_elementwise_max(ws, -ws));
+            uint32_t ov = __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(aw, (c & 1) ? th_odd : th_even));   // != 0 <=> |w| >= thr
+            if (c == 0 && r == 0) ov &= 0xFFFFu;                   // the chroma DC goes through the 2x2 Hadamard instead
+            over |= ov;
+        }
+        // chroma DC: block DCs sit in lanes plane * 16 + block * 4
+        bool dcnz = false;
+#pragma unroll
+        for (int pl = 0; pl < 2; pl++) {
+            const int d0 = __builtin_amdgcn_readlane(dc, pl * 16), d1 = __builtin_amdgcn_readlane(dc, pl * 16 + 4);
+            const int d2 = __builtin_amdgcn_readlane(dc, pl * 16 + 8), d3 = __builtin_amdgcn_readlane(dc, pl * 16 + 12);
             const int t = P.qc.thr_dc_inter;
-            nz |= iabs(d0 + d1 + d2 + d3) >= t || iabs(d0 - d1 + d2 - d3) >= t || iabs(d0 + d1 - d2 - d3) >= t ||
-                  iabs(d0 - d1 - d2 + d3) >= t;
+            dcnz |= iabs(d0 + d1 + d2 + d3) >= t || iabs(d0 - d1 + d2 - d3) >= t || iabs(d0 + d1 - d2 - d3) >= t || iabs(d0 - d1 - d2 + d3) >= t;
         }
-        if (__ballot(nz) == 0ull) {
+        if (!dcnz && __ballot(over != 0) == 0ull) {
             if (lane == 0) {
                 MbInfo* m = P.mb + mbi;
                 m->mvx = 0; m->mvy = 0; m->type = MB_P16;
