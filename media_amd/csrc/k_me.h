@@ -48,6 +48,8 @@ __device__ __forceinline__ void qpel_taps(int fx, int fy, int& o0, int& o1)
 }
 
 
+typedef const __attribute__((address_space(3))) uint32_t* lds_u32p;   // dword pointer into LDS
+
 // ---- packed 16-bit helpers for the half-sample planes ----
 typedef unsigned short me_pk16 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ me_pk16 me_pk(uint32_t v) { return __builtin_bit_cast(me_pk16, v); }
@@ -248,7 +250,10 @@ __global__ __launch_bounds__(64, 4) void k_me(FrameParams P0)
             }
         }
         const uint32_t kbase = ((uint32_t)__mul24(P.lambda, se_len(4 * (dxi - ME_R))) << 10) + (uint32_t)dxi;
-        const uint32_t* wb = s_win + (ME_AP + half * 16) * ME_WDW + cdw;
+        // two row bases (rows 0..15, 16..30) keep every row's dword offset inside the 8-bit ds_read2 offset fields
+        lds_u32p wb0 = (lds_u32p)(s_win + (ME_AP + half * 16) * ME_WDW + cdw), wb1 = wb0 + 16 * ME_WDW;
+        asm("" : "+v"(wb0));
+        asm("" : "+v"(wb1));
         uint32_t acc[16];
 #pragma unroll
         for (int kk = 0; kk < 16; kk++) acc[kk] = 0;
@@ -256,12 +261,12 @@ __global__ __launch_bounds__(64, 4) void k_me(FrameParams P0)
         // scheduling barrier stops the compiler from hoisting every row's LDS read to the top (95 live registers)
         uint32_t w[2][5];
 #pragma unroll
-        for (int c = 0; c < 5; c++) w[0][c] = wb[c];
+        for (int c = 0; c < 5; c++) w[0][c] = wb0[c];
 #pragma unroll
         for (int r = 0; r < 31; r++) {
             if (r + 1 < 31) {
 #pragma unroll
-                for (int c = 0; c < 5; c++) w[(r + 1) & 1][c] = wb[(r + 1) * ME_WDW + c];
+                for (int c = 0; c < 5; c++) w[(r + 1) & 1][c] = r + 1 < 16 ? wb0[(r + 1) * ME_WDW + c] : wb1[(r + 1 - 16) * ME_WDW + c];
             }
             const uint32_t* wr = w[r & 1];
             const uint32_t a0 = __builtin_amdgcn_alignbyte(wr[1], wr[0], sh), a1 = __builtin_amdgcn_alignbyte(wr[2], wr[1], sh);
@@ -318,8 +323,11 @@ __global__ __launch_bounds__(64, 4) void k_me(FrameParams P0)
         uint32_t Hv;
         {
             uint32_t c[6];
+            const int o = oo + (y - 2) * ME_WS + seg;
+            lds_u32p pc = (lds_u32p)(winb + (o & ~3));   // window rows are ME_WS = 56 bytes apart
+            asm("" : "+v"(pc));
 #pragma unroll
-            for (int k = 0; k < 6; k++) c[k] = lds_ld4(winb, oo + (y - 2 + k) * ME_WS + seg);
+            for (int k = 0; k < 6; k++) c[k] = __builtin_amdgcn_alignbyte(pc[k * ME_WDW + 1], pc[k * ME_WDW], o & 3);
             me_pk16 lo[6], hi[6];
 #pragma unroll
             for (int k = 0; k < 6; k++) { lo[k] = byte_pair(0, c[k], 0); hi[k] = byte_pair(0, c[k], 2); }
@@ -385,11 +393,18 @@ __global__ __launch_bounds__(64, 4) void k_me(FrameParams P0)
         int t0, t1;
         qpel_taps(ox & 3, oy & 3, t0, t1);
         const int gb = (gy + b4y) * ME_GP + gx + b4x;
+        // plane rows are ME_GP = 20 bytes apart: one dword base pointer and byte shift per tap, rows by constant index
+        lds_u32p pa = (lds_u32p)(s_pl + ((t0 + gb) & ~3));
+        lds_u32p pb = (lds_u32p)(s_pl + ((t1 + gb) & ~3));
+        asm("" : "+v"(pa));   // keep the array's own LDS offset in the register, so that the row offsets fit the ds_read2 fields
+        asm("" : "+v"(pb));
+        const int sa = (t0 + gb) & 3, sb = (t1 + gb) & 3;
         pk16 d[16];
 #pragma unroll
         for (int y = 0; y < 4; y++) {
-            const uint32_t pl = avg4(lds_ld4(s_pl, t0 + gb + y * ME_GP), lds_ld4(s_pl, t1 + gb + y * ME_GP));
-            const uint32_t ph = avg4(lds_ld4(s_pl, t0 + gb + (y + 8) * ME_GP), lds_ld4(s_pl, t1 + gb + (y + 8) * ME_GP));
+            const int rl = (ME_GP / 4) * y, rh = (ME_GP / 4) * (y + 8);
+            const uint32_t pl = avg4(__builtin_amdgcn_alignbyte(pa[rl + 1], pa[rl], sa), __builtin_amdgcn_alignbyte(pb[rl + 1], pb[rl], sb));
+            const uint32_t ph = avg4(__builtin_amdgcn_alignbyte(pa[rh + 1], pa[rh], sa), __builtin_amdgcn_alignbyte(pb[rh + 1], pb[rh], sb));
 #pragma unroll
             for (int x = 0; x < 4; x++)
                 d[4 * y + x] = S[4 * y + x] - __builtin_bit_cast(pk16, __builtin_amdgcn_perm(ph, pl, sel0 + 0x00010001u * x));
