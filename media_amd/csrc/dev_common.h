@@ -271,10 +271,12 @@ __device__ __forceinline__ Mv predict_mv(const FrameParams& P, int mx, int my, M
 {
     const bool avA = mx > 0, avB = my > 0, avC0 = my > 0 && mx + 1 < P.mbw, avD = mx > 0 && my > 0;
     const MbInfo* base = P.mb + (size_t)my * P.mbw + mx;
-    const uint2 wA = *(const uint2*)(avA ? base - 1 : base);
-    const uint2 wB = *(const uint2*)(avB ? base - P.mbw : base);
-    const uint2 wC = *(const uint2*)(avC0 ? base - P.mbw + 1 : base);
-    const uint2 wD = *(const uint2*)(avD ? base - P.mbw - 1 : base);
+    // every lane loads the same words: hand them to the scalar unit, which then does the whole prediction
+    auto uni = [](const uint2 v) { return make_uint2((uint32_t)__builtin_amdgcn_readfirstlane((int)v.x), (uint32_t)__builtin_amdgcn_readfirstlane((int)v.y)); };
+    const uint2 wA = uni(*(const uint2*)(avA ? base - 1 : base));
+    const uint2 wB = uni(*(const uint2*)(avB ? base - P.mbw : base));
+    const uint2 wC = uni(*(const uint2*)(avC0 ? base - P.mbw + 1 : base));
+    const uint2 wD = uni(*(const uint2*)(avD ? base - P.mbw - 1 : base));
     auto unpack = [](const uint2 w, bool av, int& ref, Mv& mv) {
         const int type = (int)(w.y & 255);
         ref = -1; mv.x = 0; mv.y = 0;

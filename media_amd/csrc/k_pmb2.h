@@ -124,7 +124,8 @@ __global__ __launch_bounds__(64) void k_pmb2(FrameParams P0)
     __shared__ __attribute__((aligned(16))) int16_t s_lv[LV_STRIDE];
 
     MbInfo* m = P.mb + mbi;
-    const int mvx = m->mvx, mvy = m->mvy;
+    const int mvw = __builtin_amdgcn_readfirstlane(*(const int*)m);   // mvx | mvy << 16, wave-uniform
+    const int mvx = (int)(int16_t)(mvw & 0xFFFF), mvy = mvw >> 16;
     Mv skip;
     const Mv pred = predict_mv(P, mx, my, skip);
 
