@@ -48,47 +48,6 @@ __device__ __forceinline__ void qpel_taps(int fx, int fy, int& o0, int& o1)
 }
 
 
-typedef const __attribute__((address_space(3))) uint32_t* lds_u32p;   // dword pointer into LDS
-
-// ---- packed 16-bit helpers for the half-sample planes ----
-typedef unsigned short me_pk16 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ me_pk16 me_pk(uint32_t v) { return __builtin_bit_cast(me_pk16, v); }
-__device__ __forceinline__ uint32_t me_u32(me_pk16 v) { return __builtin_bit_cast(uint32_t, v); }
-// bytes j, j+1 (0 <= j <= 6) of the 8-byte window {hi:lo}, zero-extended into the two 16-bit halves
-__device__ __forceinline__ me_pk16 byte_pair(uint32_t hi, uint32_t lo, int j)
-{
-    return me_pk(__builtin_amdgcn_perm(hi, lo, 0x0c000c00u + (uint32_t)j + ((uint32_t)(j + 1) << 16)));
-}
-// 6-tap (1,-5,20,20,-5,1) of six packed operands; every partial sum of 8-bit samples fits 16 bits
-__device__ __forceinline__ me_pk16 tap6_pk(me_pk16 a, me_pk16 b, me_pk16 c, me_pk16 d, me_pk16 e, me_pk16 f)
-{
-    const me_pk16 m5 = me_pk(0xFFFBFFFBu), p20 = me_pk(0x00140014u);
-    return (a + f) + m5 * (b + e) + p20 * (c + d);
-}
-// two packed unclipped sums -> (x + 16) >> 5 clamped to 0..255, as two bytes in bits 0..15
-__device__ __forceinline__ uint32_t round5_sat(me_pk16 v)
-{
-    typedef short spk __attribute__((ext_vector_type(2)));
-    const spk r = __builtin_bit_cast(spk, v + me_pk(0x00100010u)) >> 5;
-    uint32_t o;
-    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(o) : "v"(__builtin_bit_cast(uint32_t, r)));
-    return o;
-}
-__device__ __forceinline__ uint32_t bytes4(uint32_t lo2, uint32_t hi2) { return __builtin_amdgcn_perm(hi2, lo2, 0x05040100u); }
-// acc + (int16 half of x) * (int16 c): v_mad_i32_i16, the half chosen by op_sel
-__device__ __forceinline__ int mad16_lo(uint32_t x, int c, int acc)
-{
-    int o;
-    asm("v_mad_i32_i16 %0, %1, %2, %3" : "=v"(o) : "v"(x), "v"(c), "v"(acc));
-    return o;
-}
-__device__ __forceinline__ int mad16_hi(uint32_t x, int c, int acc)
-{
-    int o;
-    asm("v_mad_i32_i16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(o) : "v"(x), "v"(c), "v"(acc));
-    return o;
-}
-
 __global__ __launch_bounds__(64, 4) void k_me(FrameParams P0)
 {
     const FrameParams P = batch_view(P0, blockIdx.y);
@@ -300,15 +259,7 @@ __global__ __launch_bounds__(64, 4) void k_me(FrameParams P0)
     const int oo = (iy + ME_R + ME_AP - 1) * ME_WS + ix + ME_R + ME_AP - 1;   // window byte offset of grid (0,0)
     for (int i = lane; i < (ME_GS + 5) * 5; i += 64) {
         const int rr = i / 5, seg = (i - rr * 5) * 4;                          // b1 row rr <-> grid row rr - 2
-        const int o = oo + (rr - 2) * ME_WS + seg - 2;                         // sample 2 left of output 0
-        const uint32_t* p = (const uint32_t*)(winb + (o & ~3));
-        const int sh = o & 3;
-        const uint32_t d0 = p[0], d1 = p[1], d2 = p[2], d3 = p[3];
-        const uint32_t a0 = __builtin_amdgcn_alignbyte(d1, d0, sh), a1 = __builtin_amdgcn_alignbyte(d2, d1, sh), a2 = __builtin_amdgcn_alignbyte(d3, d2, sh);
-        // V[j] = samples (j, j+1) of the nine the four outputs need
-        const me_pk16 V0 = byte_pair(a1, a0, 0), V1 = byte_pair(a1, a0, 1), V2 = byte_pair(a1, a0, 2), V3 = byte_pair(a1, a0, 3);
-        const me_pk16 V4 = byte_pair(a2, a1, 0), V5 = byte_pair(a2, a1, 1), V6 = byte_pair(a2, a1, 2), V7 = byte_pair(a2, a1, 3);
-        *(uint2*)(s_b1 + rr * ME_GP + seg) = make_uint2(me_u32(tap6_pk(V0, V1, V2, V3, V4, V5)), me_u32(tap6_pk(V2, V3, V4, V5, V6, V7)));
+        *(uint2*)(s_b1 + rr * ME_GP + seg) = htap4_pk(winb, oo + (rr - 2) * ME_WS + seg - 2);
     }
     __syncthreads();
     for (int i = lane; i < ME_GS * 5; i += 64) {
@@ -317,10 +268,8 @@ __global__ __launch_bounds__(64, 4) void k_me(FrameParams P0)
         uint2 rw[6];
 #pragma unroll
         for (int k = 0; k < 6; k++) rw[k] = *(const uint2*)(s_b1 + (y + k) * ME_GP + seg);
-        // b: the horizontal sums of this row, rounded
-        const uint32_t Bv = bytes4(round5_sat(me_pk(rw[2].x)), round5_sat(me_pk(rw[2].y)));
-        // h: vertical 6-tap on the integer samples
-        uint32_t Hv;
+        const uint32_t Bv = round5_pk(rw[2]);                                   // b: the horizontal sums of this row, rounded
+        uint32_t Hv;                                                            // h: vertical 6-tap on the integer samples
         {
             uint32_t c[6];
             const int o = oo + (y - 2) * ME_WS + seg;
@@ -328,32 +277,9 @@ __global__ __launch_bounds__(64, 4) void k_me(FrameParams P0)
             asm("" : "+v"(pc));
 #pragma unroll
             for (int k = 0; k < 6; k++) c[k] = __builtin_amdgcn_alignbyte(pc[k * ME_WDW + 1], pc[k * ME_WDW], o & 3);
-            me_pk16 lo[6], hi[6];
-#pragma unroll
-            for (int k = 0; k < 6; k++) { lo[k] = byte_pair(0, c[k], 0); hi[k] = byte_pair(0, c[k], 2); }
-            Hv = bytes4(round5_sat(tap6_pk(lo[0], lo[1], lo[2], lo[3], lo[4], lo[5])), round5_sat(tap6_pk(hi[0], hi[1], hi[2], hi[3], hi[4], hi[5])));
+            Hv = round5_pk(vtap4_pk(c));
         }
-        // j: vertical 6-tap on the unclipped horizontal sums (32-bit), (x + 512) >> 10
-        uint32_t Jv;
-        {
-            int t[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                int acc = 512;
-#pragma unroll
-                for (int m = 0; m < 6; m++) {
-                    const uint32_t x = (k & 2) ? rw[m].y : rw[m].x;
-                    const int cf = (m == 0 || m == 5) ? 1 : ((m == 1 || m == 4) ? -5 : 20);
-                    acc = (k & 1) ? mad16_hi(x, cf, acc) : mad16_lo(x, cf, acc);
-                }
-                t[k] = acc >> 10;
-            }
-            typedef short spk __attribute__((ext_vector_type(2)));
-            uint32_t j01, j23;
-            asm("v_sat_pk_u8_i16 %0, %1" : "=v"(j01) : "v"((uint32_t)(t[0] & 0xFFFF) | ((uint32_t)t[1] << 16)));
-            asm("v_sat_pk_u8_i16 %0, %1" : "=v"(j23) : "v"((uint32_t)(t[2] & 0xFFFF) | ((uint32_t)t[3] << 16)));
-            Jv = bytes4(j01, j23);
-        }
+        const uint32_t Jv = jtap4(rw);                                          // j: vertical 6-tap on the unclipped horizontal sums
         *(uint32_t*)(s_pl + y * ME_GP + seg) = Gv;
         *(uint32_t*)(s_pl + ME_PLS + y * ME_GP + seg) = Bv;
         *(uint32_t*)(s_pl + 2 * ME_PLS + y * ME_GP + seg) = Hv;

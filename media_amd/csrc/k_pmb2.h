@@ -76,6 +76,89 @@ __device__ __forceinline__ uint32_t round5_pack(const int t[4])
                  opaque(clip255((t[3] + 16) >> 5)));
 }
 
+typedef const __attribute__((address_space(3))) uint32_t* lds_u32p;   // dword pointer into LDS
+
+// ---- packed 16-bit helpers for the half-sample filters (8.4.2.2.1) ----
+typedef unsigned short me_pk16 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ me_pk16 me_pk(uint32_t v) { return __builtin_bit_cast(me_pk16, v); }
+__device__ __forceinline__ uint32_t me_u32(me_pk16 v) { return __builtin_bit_cast(uint32_t, v); }
+// bytes j, j+1 (0 <= j <= 6) of the 8-byte window {hi:lo}, zero-extended into the two 16-bit halves
+__device__ __forceinline__ me_pk16 byte_pair(uint32_t hi, uint32_t lo, int j)
+{
+    return me_pk(__builtin_amdgcn_perm(hi, lo, 0x0c000c00u + (uint32_t)j + ((uint32_t)(j + 1) << 16)));
+}
+// 6-tap (1,-5,20,20,-5,1) of six packed operands; every partial sum of 8-bit samples fits 16 bits
+__device__ __forceinline__ me_pk16 tap6_pk(me_pk16 a, me_pk16 b, me_pk16 c, me_pk16 d, me_pk16 e, me_pk16 f)
+{
+    const me_pk16 m5 = me_pk(0xFFFBFFFBu), p20 = me_pk(0x00140014u);
+    return (a + f) + m5 * (b + e) + p20 * (c + d);
+}
+// two packed unclipped sums -> (x + 16) >> 5 clamped to 0..255, as two bytes in bits 0..15
+__device__ __forceinline__ uint32_t round5_sat(me_pk16 v)
+{
+    typedef short spk __attribute__((ext_vector_type(2)));
+    const spk r = __builtin_bit_cast(spk, v + me_pk(0x00100010u)) >> 5;
+    uint32_t o;
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(o) : "v"(__builtin_bit_cast(uint32_t, r)));
+    return o;
+}
+__device__ __forceinline__ uint32_t bytes4(uint32_t lo2, uint32_t hi2) { return __builtin_amdgcn_perm(hi2, lo2, 0x05040100u); }
+// acc + (int16 half of x) * (int16 c): v_mad_i32_i16, the half chosen by op_sel
+__device__ __forceinline__ int mad16_lo(uint32_t x, int c, int acc)
+{
+    int o;
+    asm("v_mad_i32_i16 %0, %1, %2, %3" : "=v"(o) : "v"(x), "v"(c), "v"(acc));
+    return o;
+}
+__device__ __forceinline__ int mad16_hi(uint32_t x, int c, int acc)
+{
+    int o;
+    asm("v_mad_i32_i16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(o) : "v"(x), "v"(c), "v"(acc));
+    return o;
+}
+
+// four horizontal 6-tap sums (unclipped) as two packed words; `o` = LDS byte offset of the sample 2 left of output 0
+__device__ __forceinline__ uint2 htap4_pk(const uint8_t* base, int o)
+{
+    const uint32_t* p = (const uint32_t*)(base + (o & ~3));
+    const int sh = o & 3;
+    const uint32_t d0 = p[0], d1 = p[1], d2 = p[2], d3 = p[3];
+    const uint32_t a0 = __builtin_amdgcn_alignbyte(d1, d0, sh), a1 = __builtin_amdgcn_alignbyte(d2, d1, sh), a2 = __builtin_amdgcn_alignbyte(d3, d2, sh);
+    // V[j] = samples (j, j+1) of the nine the four outputs need
+    const me_pk16 V0 = byte_pair(a1, a0, 0), V1 = byte_pair(a1, a0, 1), V2 = byte_pair(a1, a0, 2), V3 = byte_pair(a1, a0, 3);
+    const me_pk16 V4 = byte_pair(a2, a1, 0), V5 = byte_pair(a2, a1, 1), V6 = byte_pair(a2, a1, 2), V7 = byte_pair(a2, a1, 3);
+    return make_uint2(me_u32(tap6_pk(V0, V1, V2, V3, V4, V5)), me_u32(tap6_pk(V2, V3, V4, V5, V6, V7)));
+}
+// four vertical 6-tap sums from six rows of four samples each
+__device__ __forceinline__ uint2 vtap4_pk(const uint32_t c[6])
+{
+    me_pk16 lo[6], hi[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) { lo[k] = byte_pair(0, c[k], 0); hi[k] = byte_pair(0, c[k], 2); }
+    return make_uint2(me_u32(tap6_pk(lo[0], lo[1], lo[2], lo[3], lo[4], lo[5])), me_u32(tap6_pk(hi[0], hi[1], hi[2], hi[3], hi[4], hi[5])));
+}
+__device__ __forceinline__ uint32_t round5_pk(uint2 sums) { return bytes4(round5_sat(me_pk(sums.x)), round5_sat(me_pk(sums.y))); }
+// centre sample j: vertical 6-tap over six rows of packed unclipped horizontal sums (32-bit), (x + 512) >> 10, clamped
+__device__ __forceinline__ uint32_t jtap4(const uint2 rw[6])
+{
+    int t[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        int acc = 512;
+#pragma unroll
+        for (int m = 0; m < 6; m++) {
+            const uint32_t x = (k & 2) ? rw[m].y : rw[m].x;
+            const int cf = (m == 0 || m == 5) ? 1 : ((m == 1 || m == 4) ? -5 : 20);
+            acc = (k & 1) ? mad16_hi(x, cf, acc) : mad16_lo(x, cf, acc);
+        }
+        t[k] = acc >> 10;
+    }
+    uint32_t j01, j23;
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(j01) : "v"((uint32_t)(t[0] & 0xFFFF) | ((uint32_t)t[1] << 16)));
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(j23) : "v"((uint32_t)(t[2] & 0xFFFF) | ((uint32_t)t[3] << 16)));
+    return bytes4(j01, j23);
+}
+
 // forward 4x4 core transform of the quad's block: in d[4] = this lane's residual row, out d[4] = row `r` of W
 __device__ __forceinline__ void fdct_quad(int d[4], int r)
 {
@@ -200,9 +283,7 @@ __global__ __launch_bounds__(64) void k_pmb2(FrameParams P0)
     if (need_j) {  // stage the unclipped horizontal sums of all 21 window rows (84 row segments)
         for (int i = lane; i < 84; i += 64) {
             const int rr = i >> 2, seg = (i & 3) * 4;
-            int t[4];
-            htap4(s_w, rr * 28 + wxo + seg, t);
-            *(uint2*)(s_b1 + rr * 16 + seg) = make_uint2((uint32_t)(t[0] & 0xFFFF) | ((uint32_t)t[1] << 16), (uint32_t)(t[2] & 0xFFFF) | ((uint32_t)t[3] << 16));
+            *(uint2*)(s_b1 + rr * 16 + seg) = htap4_pk(s_w, rr * 28 + wxo + seg);
         }
         __syncthreads();
     }
@@ -212,19 +293,20 @@ __global__ __launch_bounds__(64) void k_pmb2(FrameParams P0)
         uint32_t Gv = 0, Bv = 0, Hv = 0, Jv = 0;
         const bool use_b = fx != 0 && fy != 2, use_h = fy != 0 && fx != 2;
         if (fx == 0 || fy == 0) Gv = lds_ld4(s_w, g + (fx == 3 ? 1 : 0) + (fy == 3 ? 28 : 0));
-        if (use_b) { int t[4]; htap4(s_w, g - 2 + (fy == 3 ? 28 : 0), t); Bv = round5_pack(t); }
-        if (use_h) { int t[4]; vtap4(s_w, g - 56 + (fx == 3 ? 1 : 0), 28, t); Hv = round5_pack(t); }
+        if (use_b) Bv = round5_pk(htap4_pk(s_w, g - 2 + (fy == 3 ? 28 : 0)));
+        if (use_h) {
+            uint32_t c[6];
+            const int o = g - 56 + (fx == 3 ? 1 : 0);
+#pragma unroll
+            for (int i = 0; i < 6; i++) c[i] = lds_ld4(s_w, o + i * 28);
+            Hv = round5_pk(vtap4_pk(c));
+        }
         if (need_j) {
-            int t[4];
             const int16_t* q = s_b1 + ly * 16 + lx;  // row (ly-2)+2
-            short4 rw[6];
+            uint2 rw[6];
 #pragma unroll
-            for (int i = 0; i < 6; i++) rw[i] = *(const short4*)(q + i * 16);
-            const int16_t* e0 = (const int16_t*)&rw[0]; const int16_t* e1 = (const int16_t*)&rw[1]; const int16_t* e2 = (const int16_t*)&rw[2];
-            const int16_t* e3 = (const int16_t*)&rw[3]; const int16_t* e4 = (const int16_t*)&rw[4]; const int16_t* e5 = (const int16_t*)&rw[5];
-#pragma unroll
-            for (int k = 0; k < 4; k++) t[k] = opaque(clip255((e0[k] + e5[k] - 5 * (e1[k] + e4[k]) + 20 * (e2[k] + e3[k]) + 512) >> 10));
-            Jv = pack4(t[0], t[1], t[2], t[3]);
+            for (int i = 0; i < 6; i++) rw[i] = *(const uint2*)(q + i * 16);
+            Jv = jtap4(rw);
         }
         if (fx == 0 && fy == 0) pred4 = Gv;
         else if (fy == 0) pred4 = fx == 2 ? Bv : avg4(Gv, Bv);
