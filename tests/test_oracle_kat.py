@@ -261,3 +261,24 @@ def test_sps_geometry_1080p():
     assert dec.decode(bs) == 1
     assert dec.size == (1920, 1080)
     assert ol.lib().h264o_dec_coded_height(dec.h) == 1088
+
+
+def test_openh264_differential_tool_reports_honestly():
+    """the run-time differential dlopens libopenh264.so exactly as the reference does
+    (VideoEncoderOpenH264.cpp:197-226).  No such library exists in this image or on the GPU box, so the only
+    legitimate answer here is "absent"; a box that has one must answer with real numbers."""
+    import json
+    import os
+    import subprocess
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "openh264_differential")
+    if not os.path.exists(tool):
+        import pytest
+        pytest.skip("oracle/_ref/openh264_differential not built (needs /root/reference headers at build time)")
+    out = subprocess.run([tool], capture_output=True, text=True, timeout=60)
+    if out.returncode == 2:      # a library was loaded and the tool now asks for its arguments
+        assert "usage" in out.stderr
+        return
+    rec = json.loads(out.stdout.strip().splitlines()[-1])
+    assert rec["oracle"] in ("absent", "openh264")
+    if rec["oracle"] == "absent":
+        assert rec["reason"]
