@@ -193,167 +193,201 @@ __device__ __forceinline__ void idct_quad(int d[4], int r)
 
 __constant__ const uint16_t c_zz_row[4] = {0x6510, 0xC742, 0xDB83, 0xFEA9};  // zig-zag index of raster (r, c), nibble c
 
+// One wavefront per PAIR of raster-consecutive macroblocks (2q, 2q+1): the luma chain runs once per macroblock
+// on all 64 lanes (lane = 4x4 block, row); the chroma chain needs 32 lanes per macroblock, so both macroblocks'
+// chroma share ONE pass (lanes 0..31 first, 32..63 second macroblock) instead of two half-empty ones.
 __global__ __launch_bounds__(64) void k_pmb2(FrameParams P0)
 {
     __builtin_amdgcn_s_setprio(2);   // short and on the way to the loop filter: ahead of another stream's motion search
     const FrameParams P = batch_view(P0, blockIdx.y);
     const int lane = threadIdx.x;
-    const int mbi = xcd_mb_index(blockIdx.x, P.mbw * P.mbh), mx = mbi % P.mbw, my = mbi / P.mbw;
-    const int bx = 16 * mx, by = 16 * my, cs = P.cw / 2;
+    const int nmb = P.mbw * P.mbh;
+    const int q = xcd_mb_index(blockIdx.x, (nmb + 1) >> 1);
+    const int cs = P.cw / 2;
+    const bool two = 2 * q + 1 < nmb;   // the last pair of an odd macroblock count has one member
 
-    __shared__ __attribute__((aligned(16))) uint8_t s_w[21 * 28 + 12];     // luma window, pitch 28
-    __shared__ __attribute__((aligned(16))) uint8_t s_cw[2][9 * 12 + 12];  // chroma windows, pitch 12
-    __shared__ __attribute__((aligned(16))) int16_t s_b1[21 * 16];         // unclipped horizontal sums (centre positions)
-    __shared__ __attribute__((aligned(16))) int16_t s_lv[LV_STRIDE];
+    __shared__ __attribute__((aligned(16))) uint8_t s_w[2][21 * 28 + 12];     // luma windows, pitch 28
+    __shared__ __attribute__((aligned(16))) uint8_t s_cw[2][2][9 * 12 + 12];  // chroma windows, pitch 12
+    __shared__ __attribute__((aligned(16))) int16_t s_b1[2][21 * 16];         // unclipped horizontal sums (centre positions)
+    __shared__ __attribute__((aligned(16))) int16_t s_lv[2][LV_STRIDE];
 
-    MbInfo* m = P.mb + mbi;
-    const int mvw = __builtin_amdgcn_readfirstlane(*(const int*)m);   // mvx | mvy << 16, wave-uniform
-    const int mvx = (int)(int16_t)(mvw & 0xFFFF), mvy = mvw >> 16;
-    Mv skip;
-    const Mv pred = predict_mv(P, mx, my, skip);
-
-    // lane geometry: luma (blk, r) -> samples (lx..lx+3, ly); chroma lane cl -> plane, block, row
+    // lane geometry: luma (blk, r) -> samples (lx..lx+3, ly); chroma: macroblock hh, plane, block, row
     const int blk = lane >> 2, r = lane & 3, lx = blk_x(blk) * 4, ly = blk_y(blk) * 4 + r;
-    const int cpl = (lane >> 4) & 1, cblk = (lane >> 2) & 3, cx = (cblk & 1) * 4, cy = (cblk >> 1) * 4 + r;
+    const int hh = lane >> 5, cpl = (lane >> 4) & 1, cblk = (lane >> 2) & 3, cx = (cblk & 1) * 4, cy = (cblk >> 1) * 4 + r;
+
+    // ---- wave-uniform context of both macroblocks (scalar unit) ----
+    int mbi[2], mx[2], my[2], mvx[2], mvy[2], wxo[2], cxo[2];
+    Mv pred[2], skip[2];
+    MbInfo* m[2];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        mbi[h] = 2 * q + ((h && two) ? 1 : 0);
+        mx[h] = mbi[h] % P.mbw; my[h] = mbi[h] / P.mbw;
+        m[h] = P.mb + mbi[h];
+        const int mvw = __builtin_amdgcn_readfirstlane(*(const int*)m[h]);   // mvx | mvy << 16
+        mvx[h] = (int)(int16_t)(mvw & 0xFFFF); mvy[h] = mvw >> 16;
+        pred[h] = predict_mv(P, mx[h], my[h], skip[h]);
+    }
 
     // ---- all global requests first: reference windows, source samples ----
-    const int x0 = bx + (mvx >> 2) - 2, y0 = by + (mvy >> 2) - 2;
-    const int xa = x0 & ~3, wxo = x0 - xa;
-    const int cx0 = 8 * mx + (mvx >> 3), cy0 = 8 * my + (mvy >> 3);
-    const int cxa = cx0 & ~3, cxo = cx0 - cxa;
-    const bool interior = xa >= 0 && xa + 28 <= P.cw && y0 >= 0 && y0 + 21 <= P.ch;
-    const bool cinterior = cxa >= 0 && cxa + 12 <= cs && cy0 >= 0 && cy0 + 9 <= P.ch / 2;
-    uint32_t wv[3] = {0, 0, 0}, cwv = 0;
-    if (interior) {
+    uint32_t wv[2][3], cwv[2], src4[2], csrc4 = 0;
+    bool interior[2], cinterior[2];
+    int x0[2], y0[2], cx0[2], cy0[2];
 #pragma unroll
-        for (int t = 0; t < 3; t++) {
-            const int i = lane + 64 * t, rr = i / 7, c = i - rr * 7;
-            if (i < 147) wv[t] = *(const uint32_t*)(P.ref[0] + (size_t)(y0 + rr) * P.cw + xa + 4 * c);
-        }
-    }
-    if (cinterior && lane < 54) {
-        const int pl = lane / 27, k = lane - pl * 27, rr = k / 3, c = k - rr * 3;
-        cwv = *(const uint32_t*)((pl ? P.ref[2] : P.ref[1]) + (size_t)(cy0 + rr) * cs + cxa + 4 * c);
-    }
-    uint32_t src4, csrc4 = 0;
-    {
-        const uint8_t* Y = P.src;
-        const int gy = by + ly, gx = bx + lx;
-        const uint8_t* p = Y + (size_t)(gy < P.h ? gy : P.h - 1) * P.w + gx;
-        if (gx + 3 < P.w && (((uintptr_t)p) & 3) == 0) src4 = *(const uint32_t*)p;
-        else src4 = pack4(src_px(Y, P.w, P.h, gx, gy), src_px(Y, P.w, P.h, gx + 1, gy), src_px(Y, P.w, P.h, gx + 2, gy), src_px(Y, P.w, P.h, gx + 3, gy));
-        if (lane < 32) {
-            const int pw = P.w / 2, ph = P.h / 2;
-            const uint8_t* C = Y + (size_t)P.w * P.h + (cpl ? (size_t)pw * ph : 0);
-            const int cgy = 8 * my + cy, cgx = 8 * mx + cx;
-            const uint8_t* q = C + (size_t)(cgy < ph ? cgy : ph - 1) * pw + cgx;
-            if (cgx + 3 < pw && (((uintptr_t)q) & 3) == 0) csrc4 = *(const uint32_t*)q;
-            else csrc4 = pack4(src_px(C, pw, ph, cgx, cgy), src_px(C, pw, ph, cgx + 1, cgy), src_px(C, pw, ph, cgx + 2, cgy), src_px(C, pw, ph, cgx + 3, cgy));
-        }
-    }
-    if (lane < LV_STRIDE * 2 / 16) ((uint4*)s_lv)[lane] = make_uint4(0, 0, 0, 0);
-    if (interior) {
+    for (int h = 0; h < 2; h++) {
+        const int bx = 16 * mx[h], by = 16 * my[h];
+        x0[h] = bx + (mvx[h] >> 2) - 2; y0[h] = by + (mvy[h] >> 2) - 2;
+        const int xa = x0[h] & ~3;
+        wxo[h] = x0[h] - xa;
+        cx0[h] = 8 * mx[h] + (mvx[h] >> 3); cy0[h] = 8 * my[h] + (mvy[h] >> 3);
+        const int cxa = cx0[h] & ~3;
+        cxo[h] = cx0[h] - cxa;
+        interior[h] = xa >= 0 && xa + 28 <= P.cw && y0[h] >= 0 && y0[h] + 21 <= P.ch;
+        cinterior[h] = cxa >= 0 && cxa + 12 <= cs && cy0[h] >= 0 && cy0[h] + 9 <= P.ch / 2;
+        wv[h][0] = wv[h][1] = wv[h][2] = 0; cwv[h] = 0;
+        if (interior[h]) {
 #pragma unroll
-        for (int t = 0; t < 3; t++) {
-            const int i = lane + 64 * t, rr = i / 7, c = i - rr * 7;
-            if (i < 147) *(uint32_t*)(s_w + rr * 28 + 4 * c) = wv[t];
+            for (int t = 0; t < 3; t++) {
+                const int i = lane + 64 * t, rr = (int)(((unsigned)i * 9363u) >> 16), c = i - rr * 7;   // i / 7 for i < 192
+                if (i < 147) wv[h][t] = *(const uint32_t*)(P.ref[0] + (size_t)(y0[h] + rr) * P.cw + xa + 4 * c);
+            }
         }
-    } else {
-        for (int i = lane; i < 21 * 21; i += 64) {
-            const int rr = i / 21, c = i - rr * 21;
-            s_w[rr * 28 + wxo + c] = P.ref[0][(size_t)clip3(0, P.ch - 1, y0 + rr) * P.cw + clip3(0, P.cw - 1, x0 + c)];
+        if (cinterior[h] && lane < 54) {
+            const int pl = lane >= 27, k = lane - pl * 27, rr = (int)(((unsigned)k * 21846u) >> 16), c = k - rr * 3;   // k / 3 for k < 27
+            cwv[h] = *(const uint32_t*)((pl ? P.ref[2] : P.ref[1]) + (size_t)(cy0[h] + rr) * cs + cxa + 4 * c);
+        }
+        {
+            const uint8_t* Y = P.src;
+            const int gy = by + ly, gx = bx + lx;
+            const uint8_t* p = Y + (size_t)(gy < P.h ? gy : P.h - 1) * P.w + gx;
+            if (gx + 3 < P.w && (((uintptr_t)p) & 3) == 0) src4[h] = *(const uint32_t*)p;
+            else src4[h] = pack4(src_px(Y, P.w, P.h, gx, gy), src_px(Y, P.w, P.h, gx + 1, gy), src_px(Y, P.w, P.h, gx + 2, gy), src_px(Y, P.w, P.h, gx + 3, gy));
         }
     }
-    if (cinterior) {
-        if (lane < 54) {
-            const int pl = lane / 27, k = lane - pl * 27, rr = k / 3, c = k - rr * 3;
-            *(uint32_t*)(s_cw[pl] + rr * 12 + 4 * c) = cwv;
+    {   // chroma source samples of this lane's macroblock
+        const int cmx = hh ? mx[1] : mx[0], cmy = hh ? my[1] : my[0];
+        const int pw = P.w / 2, ph = P.h / 2;
+        const uint8_t* C = P.src + (size_t)P.w * P.h + (cpl ? (size_t)pw * ph : 0);
+        const int cgy = 8 * cmy + cy, cgx = 8 * cmx + cx;
+        const uint8_t* qq = C + (size_t)(cgy < ph ? cgy : ph - 1) * pw + cgx;
+        if (cgx + 3 < pw && (((uintptr_t)qq) & 3) == 0) csrc4 = *(const uint32_t*)qq;
+        else csrc4 = pack4(src_px(C, pw, ph, cgx, cgy), src_px(C, pw, ph, cgx + 1, cgy), src_px(C, pw, ph, cgx + 2, cgy), src_px(C, pw, ph, cgx + 3, cgy));
+    }
+    for (int i = lane; i < 2 * (LV_STRIDE * 2 / 16); i += 64) ((uint4*)&s_lv[0][0])[i] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        if (interior[h]) {
+#pragma unroll
+            for (int t = 0; t < 3; t++) {
+                const int i = lane + 64 * t, rr = (int)(((unsigned)i * 9363u) >> 16), c = i - rr * 7;
+                if (i < 147) *(uint32_t*)(s_w[h] + rr * 28 + 4 * c) = wv[h][t];
+            }
+        } else {
+            for (int i = lane; i < 21 * 21; i += 64) {
+                const int rr = i / 21, c = i - rr * 21;
+                s_w[h][rr * 28 + wxo[h] + c] = P.ref[0][(size_t)clip3(0, P.ch - 1, y0[h] + rr) * P.cw + clip3(0, P.cw - 1, x0[h] + c)];
+            }
         }
-    } else {
-        for (int i = lane; i < 2 * 81; i += 64) {
-            const int pl = i / 81, k = i - pl * 81, rr = k / 9, c = k - rr * 9;
-            s_cw[pl][rr * 12 + cxo + c] = (pl ? P.ref[2] : P.ref[1])[(size_t)clip3(0, P.ch / 2 - 1, cy0 + rr) * cs + clip3(0, cs - 1, cx0 + c)];
+        if (cinterior[h]) {
+            if (lane < 54) {
+                const int pl = lane >= 27, k = lane - pl * 27, rr = (int)(((unsigned)k * 21846u) >> 16), c = k - rr * 3;
+                *(uint32_t*)(s_cw[h][pl] + rr * 12 + 4 * c) = cwv[h];
+            }
+        } else {
+            for (int i = lane; i < 2 * 81; i += 64) {
+                const int pl = i / 81, k = i - pl * 81, rr = k / 9, c = k - rr * 9;
+                s_cw[h][pl][rr * 12 + cxo[h] + c] = (pl ? P.ref[2] : P.ref[1])[(size_t)clip3(0, P.ch / 2 - 1, cy0[h] + rr) * cs + clip3(0, cs - 1, cx0[h] + c)];
+            }
         }
     }
     __syncthreads();
 
-    // ---- luma prediction (8.4.2.2.1): 4 samples per lane, branches are wave-uniform ----
-    const int fx = mvx & 3, fy = mvy & 3;
-    const bool need_j = (fx == 2 && fy != 0) || (fy == 2 && fx != 0);
-    if (need_j) {  // stage the unclipped horizontal sums of all 21 window rows (84 row segments)
-        for (int i = lane; i < 84; i += 64) {
-            const int rr = i >> 2, seg = (i & 3) * 4;
-            *(uint2*)(s_b1 + rr * 16 + seg) = htap4_pk(s_w, rr * 28 + wxo + seg);
-        }
-        __syncthreads();
-    }
-    uint32_t pred4;
-    {
-        const int g = (ly + 2) * 28 + wxo + lx + 2;  // LDS offset of integer sample G(lx, ly)
-        uint32_t Gv = 0, Bv = 0, Hv = 0, Jv = 0;
-        const bool use_b = fx != 0 && fy != 2, use_h = fy != 0 && fx != 2;
-        if (fx == 0 || fy == 0) Gv = lds_ld4(s_w, g + (fx == 3 ? 1 : 0) + (fy == 3 ? 28 : 0));
-        if (use_b) Bv = round5_pk(htap4_pk(s_w, g - 2 + (fy == 3 ? 28 : 0)));
-        if (use_h) {
-            uint32_t c[6];
-            const int o = g - 56 + (fx == 3 ? 1 : 0);
+    // ---- luma, one macroblock at a time: prediction (8.4.2.2.1, wave-uniform branches) -> residual -> fdct -> quant
+    // -> dequant -> idct -> reconstruction ----
+    int cbp_luma[2];
 #pragma unroll
-            for (int i = 0; i < 6; i++) c[i] = lds_ld4(s_w, o + i * 28);
-            Hv = round5_pk(vtap4_pk(c));
+    for (int h = 0; h < 2; h++) {
+        const int fx = mvx[h] & 3, fy = mvy[h] & 3;
+        const bool need_j = (fx == 2 && fy != 0) || (fy == 2 && fx != 0);
+        if (need_j) {  // stage the unclipped horizontal sums of all 21 window rows (84 row segments)
+            for (int i = lane; i < 84; i += 64) {
+                const int rr = i >> 2, seg = (i & 3) * 4;
+                *(uint2*)(s_b1[h] + rr * 16 + seg) = htap4_pk(s_w[h], rr * 28 + wxo[h] + seg);
+            }
+            __syncthreads();
         }
-        if (need_j) {
-            const int16_t* q = s_b1 + ly * 16 + lx;  // row (ly-2)+2
-            uint2 rw[6];
+        uint32_t pred4;
+        {
+            const int g = (ly + 2) * 28 + wxo[h] + lx + 2;  // LDS offset of integer sample G(lx, ly)
+            uint32_t Gv = 0, Bv = 0, Hv = 0, Jv = 0;
+            const bool use_b = fx != 0 && fy != 2, use_h = fy != 0 && fx != 2;
+            if (fx == 0 || fy == 0) Gv = lds_ld4(s_w[h], g + (fx == 3 ? 1 : 0) + (fy == 3 ? 28 : 0));
+            if (use_b) Bv = round5_pk(htap4_pk(s_w[h], g - 2 + (fy == 3 ? 28 : 0)));
+            if (use_h) {
+                uint32_t c[6];
+                const int o = g - 56 + (fx == 3 ? 1 : 0);
 #pragma unroll
-            for (int i = 0; i < 6; i++) rw[i] = *(const uint2*)(q + i * 16);
-            Jv = jtap4(rw);
+                for (int i = 0; i < 6; i++) c[i] = lds_ld4(s_w[h], o + i * 28);
+                Hv = round5_pk(vtap4_pk(c));
+            }
+            if (need_j) {
+                const int16_t* qq = s_b1[h] + ly * 16 + lx;  // row (ly-2)+2
+                uint2 rw[6];
+#pragma unroll
+                for (int i = 0; i < 6; i++) rw[i] = *(const uint2*)(qq + i * 16);
+                Jv = jtap4(rw);
+            }
+            if (fx == 0 && fy == 0) pred4 = Gv;
+            else if (fy == 0) pred4 = fx == 2 ? Bv : avg4(Gv, Bv);
+            else if (fx == 0) pred4 = fy == 2 ? Hv : avg4(Gv, Hv);
+            else if (fx == 2 && fy == 2) pred4 = Jv;
+            else if (fx == 2) pred4 = avg4(Bv, Jv);
+            else if (fy == 2) pred4 = avg4(Hv, Jv);
+            else pred4 = avg4(Bv, Hv);
         }
-        if (fx == 0 && fy == 0) pred4 = Gv;
-        else if (fy == 0) pred4 = fx == 2 ? Bv : avg4(Gv, Bv);
-        else if (fx == 0) pred4 = fy == 2 ? Hv : avg4(Gv, Hv);
-        else if (fx == 2 && fy == 2) pred4 = Jv;
-        else if (fx == 2) pred4 = avg4(Bv, Jv);
-        else if (fy == 2) pred4 = avg4(Hv, Jv);
-        else pred4 = avg4(Bv, Hv);
+        int d[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) d[k] = byte_of(src4[h], k) - byte_of(pred4, k);
+        fdct_quad(d, r);
+        int nz = 0;
+        const int zz = c_zz_row[r];
+        {
+            const Quant& qn = P.qy;
+            const int mf0 = (r & 1) ? qn.mf[2] : qn.mf[0], mf1 = (r & 1) ? qn.mf[1] : qn.mf[2];
+            const int dq0 = (r & 1) ? qn.dq[2] : qn.dq[0], dq1 = (r & 1) ? qn.dq[1] : qn.dq[2];
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const int l = quant1(d[c], (c & 1) ? mf1 : mf0, qn.f_inter, qn.qbits);
+                s_lv[h][LV_LUMA + blk * 16 + ((zz >> (4 * c)) & 15)] = (int16_t)l;
+                nz += l != 0;
+                d[c] = l * ((c & 1) ? dq1 : dq0);
+            }
+        }
+        nz += __builtin_amdgcn_mov_dpp(nz, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
+        nz += __builtin_amdgcn_mov_dpp(nz, 0x4E, 0xf, 0xf, false);   // quad_perm [2,3,0,1]  -> TotalCoeff of the block in all 4 lanes
+        idct_quad(d, r);
+        const unsigned long long ymask = __ballot(nz != 0);
+        cbp_luma[h] = ((ymask & 0xFFFFull) ? 1 : 0) | (((ymask >> 16) & 0xFFFFull) ? 2 : 0) | (((ymask >> 32) & 0xFFFFull) ? 4 : 0) |
+                      (((ymask >> 48) & 0xFFFFull) ? 8 : 0);
+        if (h == 0 || two) {
+            *(uint32_t*)(P.rec[0] + (size_t)(16 * my[h] + ly) * P.cw + 16 * mx[h] + lx) =
+                pack4(clip255(byte_of(pred4, 0) + d[0]), clip255(byte_of(pred4, 1) + d[1]), clip255(byte_of(pred4, 2) + d[2]), clip255(byte_of(pred4, 3) + d[3]));
+            if (r == 0) m[h]->tc[blk] = (uint8_t)nz;
+        }
     }
 
-    // ---- luma: residual -> fdct -> quant -> dequant -> idct -> recon ----
-    int d[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) d[k] = byte_of(src4, k) - byte_of(pred4, k);
-    fdct_quad(d, r);
-    int nz = 0;
-    const int zz = c_zz_row[r];
-    {
-        const Quant& q = P.qy;
-        const int mf0 = (r & 1) ? q.mf[2] : q.mf[0], mf1 = (r & 1) ? q.mf[1] : q.mf[2];
-        const int dq0 = (r & 1) ? q.dq[2] : q.dq[0], dq1 = (r & 1) ? q.dq[1] : q.dq[2];
-#pragma unroll
-        for (int c = 0; c < 4; c++) {
-            const int l = quant1(d[c], (c & 1) ? mf1 : mf0, q.f_inter, q.qbits);
-            s_lv[LV_LUMA + blk * 16 + ((zz >> (4 * c)) & 15)] = (int16_t)l;
-            nz += l != 0;
-            d[c] = l * ((c & 1) ? dq1 : dq0);
-        }
-    }
-    nz += __builtin_amdgcn_mov_dpp(nz, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
-    nz += __builtin_amdgcn_mov_dpp(nz, 0x4E, 0xf, 0xf, false);   // quad_perm [2,3,0,1]  -> TotalCoeff of the block in all 4 lanes
-    idct_quad(d, r);
-    *(uint32_t*)(P.rec[0] + (size_t)(by + ly) * P.cw + bx + lx) =
-        pack4(clip255(byte_of(pred4, 0) + d[0]), clip255(byte_of(pred4, 1) + d[1]), clip255(byte_of(pred4, 2) + d[2]), clip255(byte_of(pred4, 3) + d[3]));
-    const unsigned long long ymask = __ballot(nz != 0);
-    const int cbp_luma = ((ymask & 0xFFFFull) ? 1 : 0) | (((ymask >> 16) & 0xFFFFull) ? 2 : 0) | (((ymask >> 32) & 0xFFFFull) ? 4 : 0) |
-                         (((ymask >> 48) & 0xFFFFull) ? 8 : 0);
-    if (r == 0) m->tc[blk] = (uint8_t)nz;
-
-    // ---- chroma (lanes 0..31): bilinear MC, same chain with the DC terms through the 2x2 Hadamard ----
+    // ---- chroma of both macroblocks in one pass: bilinear MC, same chain with the DC terms through the 2x2 Hadamard ----
+    const bool cact = hh == 0 || two;
+    const int cmx = hh ? mx[1] : mx[0], cmy = hh ? my[1] : my[0];
     int cnz = 0, cdc = 0;
-    uint32_t cpred4 = 0;
-    int cd[4] = {0, 0, 0, 0};
-    if (lane < 32) {
-        const int dx = mvx & 7, dy = mvy & 7;
-        const int o = cy * 12 + cxo + cx;
-        const uint32_t A = lds_ld4(s_cw[cpl], o), B = lds_ld4(s_cw[cpl], o + 1), Cc = lds_ld4(s_cw[cpl], o + 12), D = lds_ld4(s_cw[cpl], o + 13);
+    uint32_t cpred4;
+    int cd[4];
+    {
+        const int cmvx = hh ? mvx[1] : mvx[0], cmvy = hh ? mvy[1] : mvy[0];
+        const int dx = cmvx & 7, dy = cmvy & 7;
+        const uint8_t* cwp = s_cw[hh][cpl];
+        const int o = cy * 12 + (hh ? cxo[1] : cxo[0]) + cx;
+        const uint32_t A = lds_ld4(cwp, o), B = lds_ld4(cwp, o + 1), Cc = lds_ld4(cwp, o + 12), D = lds_ld4(cwp, o + 13);
         const int w00 = (8 - dx) * (8 - dy), w10 = dx * (8 - dy), w01 = (8 - dx) * dy, w11 = dx * dy;
         int pv[4];
 #pragma unroll
@@ -362,57 +396,74 @@ __global__ __launch_bounds__(64) void k_pmb2(FrameParams P0)
 #pragma unroll
         for (int k = 0; k < 4; k++) cd[k] = byte_of(csrc4, k) - pv[k];
     }
-    fdct_quad(cd, r);   // all lanes execute the DPP exchanges; lanes >= 32 carry zeros
+    fdct_quad(cd, r);
     cdc = cd[0];        // valid in lanes with r == 0
+    const int zz = c_zz_row[r];
     {
-        const Quant& q = P.qc;
-        const int mf0 = (r & 1) ? q.mf[2] : q.mf[0], mf1 = (r & 1) ? q.mf[1] : q.mf[2];
-        const int dq0 = (r & 1) ? q.dq[2] : q.dq[0], dq1 = (r & 1) ? q.dq[1] : q.dq[2];
+        const Quant& qn = P.qc;
+        const int mf0 = (r & 1) ? qn.mf[2] : qn.mf[0], mf1 = (r & 1) ? qn.mf[1] : qn.mf[2];
+        const int dq0 = (r & 1) ? qn.dq[2] : qn.dq[0], dq1 = (r & 1) ? qn.dq[1] : qn.dq[2];
+        int16_t* lvp = s_lv[hh] + LV_CHROMA_AC + (cpl * 4 + cblk) * 16;
 #pragma unroll
         for (int c = 0; c < 4; c++) {
-            int l = quant1(cd[c], (c & 1) ? mf1 : mf0, q.f_inter, q.qbits);
+            int l = quant1(cd[c], (c & 1) ? mf1 : mf0, qn.f_inter, qn.qbits);
             if (r == 0 && c == 0) l = 0;  // DC goes through the 2x2 Hadamard
-            if (lane < 32) s_lv[LV_CHROMA_AC + (cpl * 4 + cblk) * 16 + ((zz >> (4 * c)) & 15)] = (int16_t)l;
+            lvp[(zz >> (4 * c)) & 15] = (int16_t)l;
             cnz += l != 0;
             cd[c] = l * ((c & 1) ? dq1 : dq0);
         }
     }
     cnz += __builtin_amdgcn_mov_dpp(cnz, 0xB1, 0xf, 0xf, false);
     cnz += __builtin_amdgcn_mov_dpp(cnz, 0x4E, 0xf, 0xf, false);
-    int any_dc = 0;
-    {   // chroma DC: block DCs sit in lanes pl*16 + blk*4 (r == 0)
-        int dcw[2][4];
+    int any_dc[2] = {0, 0};
+    {   // chroma DC: block DCs sit in lanes h*32 + pl*16 + blk*4 (r == 0); the 2x2 transforms run on the scalar unit
+        int mydeq = 0;
 #pragma unroll
-        for (int pl = 0; pl < 2; pl++)
+        for (int h = 0; h < 2; h++)
 #pragma unroll
-            for (int b = 0; b < 4; b++) dcw[pl][b] = __builtin_amdgcn_readlane(cdc, pl * 16 + b * 4);
+            for (int pl = 0; pl < 2; pl++) {
+                int dcw[4], lv[4], deq[4];
 #pragma unroll
-        for (int pl = 0; pl < 2; pl++) {
-            int lv[4], deq[4];
-            chroma_dc(dcw[pl], P.qc, P.qc.f_inter, lv, deq);
-            any_dc |= lv[0] | lv[1] | lv[2] | lv[3];
-            if (lane == pl)
+                for (int b = 0; b < 4; b++) dcw[b] = __builtin_amdgcn_readlane(cdc, h * 32 + pl * 16 + b * 4);
+                chroma_dc(dcw, P.qc, P.qc.f_inter, lv, deq);
+                any_dc[h] |= lv[0] | lv[1] | lv[2] | lv[3];
+                if (lane == h * 32 + pl)
 #pragma unroll
-                for (int i = 0; i < 4; i++) s_lv[LV_CHROMA_DC + pl * 4 + i] = (int16_t)lv[i];
-            if (lane < 32 && cpl == pl && r == 0) cd[0] = cblk == 0 ? deq[0] : (cblk == 1 ? deq[1] : (cblk == 2 ? deq[2] : deq[3]));
-        }
+                    for (int i = 0; i < 4; i++) s_lv[h][LV_CHROMA_DC + pl * 4 + i] = (int16_t)lv[i];
+                if (hh == h && cpl == pl) mydeq = cblk == 0 ? deq[0] : (cblk == 1 ? deq[1] : (cblk == 2 ? deq[2] : deq[3]));
+            }
+        if (r == 0) cd[0] = mydeq;
     }
     idct_quad(cd, r);
-    if (lane < 32)
-        *(uint32_t*)((cpl ? P.rec[2] : P.rec[1]) + (size_t)(8 * my + cy) * cs + 8 * mx + cx) =
+    if (cact)
+        *(uint32_t*)((cpl ? P.rec[2] : P.rec[1]) + (size_t)(8 * cmy + cy) * cs + 8 * cmx + cx) =
             pack4(clip255(byte_of(cpred4, 0) + cd[0]), clip255(byte_of(cpred4, 1) + cd[1]), clip255(byte_of(cpred4, 2) + cd[2]), clip255(byte_of(cpred4, 3) + cd[3]));
-    const unsigned long long cmask = __ballot(lane < 32 && cnz != 0);
-    const int cbp_chroma = cmask ? 2 : (any_dc ? 1 : 0);
-    const int cbp = cbp_luma | (cbp_chroma << 4);
-    if (lane < 32 && r == 0) m->tc[16 + cpl * 4 + cblk] = (uint8_t)(cbp_chroma == 2 ? cnz : 0);
-    if (lane == 0) {
-        m->type = (cbp == 0 && skip.x == mvx && skip.y == mvy) ? MB_PSKIP : MB_P16;
-        m->i16_mode = 0; m->chroma_mode = 0; m->cbp = (uint8_t)cbp;
-        P.mvd[2 * mbi] = (int16_t)(mvx - pred.x);
-        P.mvd[2 * mbi + 1] = (int16_t)(mvy - pred.y);
+    const unsigned long long cmask = __ballot(cnz != 0);
+    int cbp[2];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const unsigned half = (unsigned)(cmask >> (32 * h));
+        const int cbp_chroma = half ? 2 : (any_dc[h] ? 1 : 0);
+        cbp[h] = cbp_luma[h] | (cbp_chroma << 4);
+    }
+    {
+        const int mycbp = hh ? cbp[1] : cbp[0];
+        if (cact && r == 0) (hh ? m[1] : m[0])->tc[16 + cpl * 4 + cblk] = (uint8_t)((mycbp >> 4) == 2 ? cnz : 0);
+    }
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        if (lane == 32 * h && (h == 0 || two)) {
+            MbInfo* mm = m[h];
+            mm->type = (cbp[h] == 0 && skip[h].x == mvx[h] && skip[h].y == mvy[h]) ? MB_PSKIP : MB_P16;
+            mm->i16_mode = 0; mm->chroma_mode = 0; mm->cbp = (uint8_t)cbp[h];
+            P.mvd[2 * mbi[h]] = (int16_t)(mvx[h] - pred[h].x);
+            P.mvd[2 * mbi[h] + 1] = (int16_t)(mvy[h] - pred[h].y);
+        }
     }
     __syncthreads();
-    if (lane < LV_STRIDE * 2 / 16) ((uint4*)(P.levels + (size_t)mbi * LV_STRIDE))[lane] = ((const uint4*)s_lv)[lane];
+    // the two level blocks are consecutive in HBM (macroblocks 2q, 2q+1)
+    const int nv = (two ? 2 : 1) * (LV_STRIDE * 2 / 16);
+    for (int i = lane; i < nv; i += 64) ((uint4*)(P.levels + (size_t)(2 * q) * LV_STRIDE))[i] = ((const uint4*)&s_lv[0][0])[i];
 }
 
 }  // namespace h264

@@ -337,7 +337,7 @@ int submit(mi355x_h264_encoder* e, const uint8_t* d_src, size_t src_item_stride,
           hipLaunchKernelGGL(k_me, dim3(e->nmb, G), dim3(64), 0, st, P); }
         { StatScope sc(e, &S, MI355X_H264_K_PMB, 1, (uint32_t)(e->nmb * e->G));
           if (e->pmb_v1) hipLaunchKernelGGL(k_pmb, dim3(e->nmb, G), dim3(64), 0, st, P);
-          else hipLaunchKernelGGL(k_pmb2, dim3(e->nmb, G), dim3(64), 0, st, P); }
+          else hipLaunchKernelGGL(k_pmb2, dim3((e->nmb + 1) / 2, G), dim3(64), 0, st, P); }   // one wave per macroblock pair
     }
     // entropy coding
     HdrBatch H{};
