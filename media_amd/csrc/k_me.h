@@ -15,7 +15,7 @@
 // kernel is one launch over all macroblocks.
 #pragma once
 #include "dev_common.h"
-#include "k_pmb2.h"   // lds_ld4 / htap4 / vtap4 / avg4 / round5_pack helpers
+#include "k_pmb2.h"   // lds_ld4 / avg4 and the packed half-sample filter helpers
 
 namespace h264 {
 

@@ -39,43 +39,9 @@ __device__ __forceinline__ uint32_t avg4(uint32_t a, uint32_t b)  // per-byte (a
     return __builtin_amdgcn_lerp(a, b, 0x01010101u);   // v_lerp_u8: rounding bit = bit 0 of the third operand's bytes
 }
 
-// unclipped horizontal 6-tap sums for 4 consecutive outputs; `o` = LDS byte offset of the sample 2 left of output 0
-__device__ __forceinline__ void htap4(const uint8_t* base, int o, int out[4])
-{
-    const uint32_t* p = (const uint32_t*)(base + (o & ~3));
-    const int sh = o & 3;
-    const uint32_t d0 = p[0], d1 = p[1], d2 = p[2], d3 = p[3];
-    const uint32_t a0 = __builtin_amdgcn_alignbyte(d1, d0, sh), a1 = __builtin_amdgcn_alignbyte(d2, d1, sh),
-                   a2 = __builtin_amdgcn_alignbyte(d3, d2, sh);
-    const int b[9] = {byte_of(a0, 0), byte_of(a0, 1), byte_of(a0, 2), byte_of(a0, 3), byte_of(a1, 0),
-                      byte_of(a1, 1), byte_of(a1, 2), byte_of(a1, 3), byte_of(a2, 0)};
-#pragma unroll
-    for (int k = 0; k < 4; k++) out[k] = b[k] + b[k + 5] - 5 * (b[k + 1] + b[k + 4]) + 20 * (b[k + 2] + b[k + 3]);
-}
-// vertical 6-tap for 4 columns: o = LDS offset of the sample 2 rows above output, pitch in bytes
-__device__ __forceinline__ void vtap4(const uint8_t* base, int o, int pitch, int out[4])
-{
-    uint32_t r[6];
-#pragma unroll
-    for (int i = 0; i < 6; i++) r[i] = lds_ld4(base, o + i * pitch);
-#pragma unroll
-    for (int k = 0; k < 4; k++)
-        out[k] = byte_of(r[0], k) + byte_of(r[5], k) - 5 * (byte_of(r[1], k) + byte_of(r[4], k)) + 20 * (byte_of(r[2], k) + byte_of(r[3], k));
-}
-// hipcc (ROCm 7.2, gfx950) fuses "shift, clamp to 0..255, pack two bytes" into v_ashr_pk_u8_i32 and then
-// ORs further bytes into its result assuming the upper 16 bits are zero; the instruction leaves them
-// unchanged (observed: bytes 2,3 corrupted).  Keeping the clamped values opaque avoids that selection.
-__device__ __forceinline__ int opaque(int v)
-{
-    asm volatile("" : "+v"(v));
-    return v;
-}
-__device__ __forceinline__ uint32_t round5_pack(const int t[4])
-{
-    return pack4(opaque(clip255((t[0] + 16) >> 5)), opaque(clip255((t[1] + 16) >> 5)), opaque(clip255((t[2] + 16) >> 5)),
-                 opaque(clip255((t[3] + 16) >> 5)));
-}
-
+// Note on rounding: "shift, clamp to 0..255, pack two bytes" written in C makes hipcc (ROCm 7.2, gfx950) select
+// v_ashr_pk_u8_i32 and then OR further bytes into its result assuming the upper 16 bits are zero; the instruction
+// leaves them unchanged (observed: bytes 2,3 corrupted).  The filters below round with v_sat_pk_u8_i16 instead.
 typedef const __attribute__((address_space(3))) uint32_t* lds_u32p;   // dword pointer into LDS
 
 // ---- packed 16-bit helpers for the half-sample filters (8.4.2.2.1) ----

@@ -282,3 +282,50 @@ def test_openh264_differential_tool_reports_honestly():
     assert rec["oracle"] in ("absent", "openh264")
     if rec["oracle"] == "absent":
         assert rec["reason"]
+
+
+def _c_table(name):
+    """integers of `static const ... name[...] = {...};` in oracle/h264_tables.h, flattened"""
+    import os
+    import re
+    txt = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "h264_tables.h")).read()
+    m = re.search(r"\b%s\s*(?:\[[^\]]*\])+\s*=\s*\{(.*?)\};" % re.escape(name), txt, re.S)
+    assert m, name
+    body = re.sub(r"/\*.*?\*/", "", m.group(1), flags=re.S)
+    return [int(t, 0) for t in re.findall(r"-?\b(?:0x[0-9a-fA-F]+|\d+)\b", body)]
+
+
+def test_deblocking_and_qp_tables_against_the_standard():
+    """Table 8-16 (alpha', beta'), Table 8-17 (tC0') and Table 8-15 (QPc as a function of qPI), typed a second
+    time from the standard, independently of oracle/h264_tables.h.  The encoder and the test decoder share that
+    header, so the round trip alone could not catch a wrong entry."""
+    alpha = [0] * 16 + [4, 4, 5, 6, 7, 8, 9, 10, 12, 13, 15, 17, 20, 22, 25, 28, 32, 36, 40, 45, 50, 56, 63, 71, 80, 90,
+                        101, 113, 127, 144, 162, 182, 203, 226, 255, 255]
+    beta = [0] * 16 + [2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13, 14, 14, 15, 15,
+                       16, 16, 17, 17, 18, 18]
+    tc0 = [[0, 0, 0]] * 17 + [[0, 0, 1]] * 4 + [[0, 1, 1]] * 2 + [[1, 1, 1]] * 4 + [[1, 1, 2]] * 4 + [
+        [1, 2, 3], [1, 2, 3], [2, 2, 3], [2, 2, 4], [2, 3, 4], [2, 3, 4], [3, 3, 5], [3, 4, 6], [3, 4, 6], [4, 5, 7], [4, 5, 8],
+        [4, 6, 9], [5, 7, 10], [6, 8, 11], [6, 8, 13], [7, 10, 14], [8, 11, 16], [9, 12, 18], [10, 13, 20], [11, 15, 23],
+        [13, 17, 25]]
+    qpc = list(range(30)) + [29, 30, 31, 32, 32, 33, 34, 34, 35, 35, 36, 36, 37, 37, 37, 38, 38, 38, 39, 39, 39, 39]
+    assert len(alpha) == len(beta) == len(tc0) == len(qpc) == 52
+    assert _c_table("o_alpha") == alpha
+    assert _c_table("o_beta") == beta
+    assert _c_table("o_tc0") == [v for row in tc0 for v in row]
+    assert _c_table("o_chroma_qp") == qpc
+    # 8.5.9 / 8.5.12: dequantiser v(m, class) and the matching forward multipliers
+    assert _c_table("o_dequant_v") == [10, 16, 13, 11, 18, 14, 13, 20, 16, 14, 23, 18, 16, 25, 20, 18, 29, 23]
+    assert _c_table("o_quant_mf") == [13107, 5243, 8066, 11916, 4660, 7490, 10082, 4194, 6554, 9362, 3647, 5825, 8192, 3355,
+                                      5243, 7282, 2893, 4559]
+    assert _c_table("o_zigzag4x4") == [0, 1, 4, 8, 5, 2, 3, 6, 9, 12, 13, 10, 7, 11, 14, 15]
+
+
+def test_coded_block_pattern_mapping_against_the_standard():
+    """Table 9-4 (codeNum -> coded_block_pattern for Intra4x4/16x16 and Inter), typed a second time."""
+    intra = [47, 31, 15, 0, 23, 27, 29, 30, 7, 11, 13, 14, 39, 43, 45, 46, 16, 3, 5, 10, 12, 19, 21, 26, 28, 35, 37, 42, 44, 1, 2,
+             4, 8, 17, 18, 20, 24, 6, 9, 22, 25, 32, 33, 34, 36, 40, 38, 41]
+    inter = [0, 16, 1, 2, 4, 8, 32, 3, 5, 10, 12, 15, 47, 7, 11, 13, 14, 6, 9, 31, 35, 37, 42, 44, 33, 34, 36, 40, 39, 43, 45, 46,
+             17, 18, 20, 24, 19, 21, 26, 28, 23, 27, 29, 30, 22, 25, 38, 41]
+    assert sorted(intra) == sorted(inter) == list(range(48))
+    assert _c_table("o_cbp_code2intra") == intra
+    assert _c_table("o_cbp_code2inter") == inter
