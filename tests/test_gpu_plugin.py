@@ -93,10 +93,14 @@ def test_bitrate_mode_tracks_target_and_replays_on_oracle():
     dec = OracleDecoder()
     total, qps = 0, []
     frames = synth.sequence("s1", w, h, 60)
+    from media_amd.ratecontrol import RateControl
+    mirror = RateControl(bitrate, fps)      # the Python statement of the same controller (media_amd/shard.py carries its state)
     for f in frames:
         rc, bs = e.encode(f)
         assert rc == vc.SUCCESS
         qp = e.last_qp()
+        assert qp == mirror.qp
+        mirror.update(len(bs), (bs[4] & 31) == 7)
         qps.append(qp)
         orc.set_qp(qp)
         assert bs == orc.encode(f)[0]

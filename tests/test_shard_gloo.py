@@ -59,3 +59,83 @@ def test_gop_sharding_two_ranks():
     enc = OracleEncoder(w, h, qp=28, gop=gop)
     serial = b"".join(enc.encode(f)[0] for f in frames)
     assert serial == stream
+
+
+def _rc_encode_gop(frames, gop, fps, engine, k, rc):
+    """one closed GOP in bitrate mode on `engine` (oracle here, the HIP encoder on a GPU box)"""
+    out = []
+    for i, f in enumerate(frames[k * gop:(k + 1) * gop]):
+        engine.set_qp(rc.qp)
+        bs, idr = engine.encode(f, force_idr=(i == 0))
+        rc.update(len(bs), idr)
+        out.append(bs)
+    return b"".join(out)
+
+
+def _rc_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    from media_amd import shard, synth
+    from media_amd.ratecontrol import RateControl
+    from oracle_lib import OracleEncoder
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    w, h, gop, n_gops, fps, bitrate = 96, 64, 4, 5, 30, 120000
+    frames = synth.sequence("s1", w, h, gop * n_gops)
+    enc = OracleEncoder(w, h, qp=30, gop=gop)
+    enc.set_idr_id(rank, world)
+    rc = RateControl(bitrate, fps)
+    mine = shard.encode_gops_bitrate(lambda k, c: _rc_encode_gop(frames, gop, fps, enc, k, c), n_gops, rank, world, rc, dist)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (mine, rc.state()))
+    if rank == 0:
+        parts = {}
+        for g, _ in gathered:
+            parts.update(g)
+        q.put((shard.reassemble(parts), [s for _, s in gathered]))
+    dist.destroy_process_group()
+
+
+def test_bitrate_mode_gop_sharding_broadcasts_rc_state():
+    """the one exchange step of the path: two ranks shard the GOPs of a bitrate-mode stream and broadcast the
+    controller state once per round; the result equals a single-process emulation of the same schedule."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from media_amd import shard, synth
+    from media_amd.ratecontrol import RateControl
+    from oracle_lib import OracleEncoder
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_rc_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    stream, states = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert states[0] == states[1]                      # every rank ends on the broadcast state
+    # single-process emulation: per round every GOP starts from the round's state; the last GOP's end state carries on
+    w, h, gop, n_gops, fps, bitrate = 96, 64, 4, 5, 30, 120000
+    frames = synth.sequence("s1", w, h, gop * n_gops)
+    encs = [OracleEncoder(w, h, qp=30, gop=gop) for _ in range(world)]
+    for r, e in enumerate(encs):
+        e.set_idr_id(r, world)
+    state = RateControl(bitrate, fps).state()
+    parts = {}
+    for j in range((n_gops + world - 1) // world):
+        nxt = state
+        for r in range(world):
+            k = j * world + r
+            if k >= n_gops:
+                continue
+            rc = RateControl(bitrate, fps)
+            rc.set_state(state)
+            parts[k] = _rc_encode_gop(frames, gop, fps, encs[r], k, rc)
+            nxt = rc.state()
+        state = nxt
+    assert shard.reassemble(parts) == stream
+    assert states[0] == state
+    assert state != RateControl(bitrate, fps).state()   # the controller actually moved
