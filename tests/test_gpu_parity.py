@@ -270,3 +270,15 @@ def test_4k_one_gop_start():
         for p in range(3):
             assert np.array_equal(dec.plane(p), enc.debug_read(capi.DBG_RECON_Y + p))
     enc.close()
+
+
+def test_maximum_picture_size_4096():
+    """the largest picture the reference accepts (16..4096 on each side, VideoEncoderOpenH264.cpp:16-23,:159-171):
+    65 536 macroblocks, IDR + P bit-exact against the oracle (oracle: about a second per picture)"""
+    w, h = 4096, 4096
+    enc = capi.Encoder(w, h, qp=32, gop=30)
+    orc = OracleEncoder(w, h, qp=32, gop=30)
+    for f in synth.sequence("s1", w, h, 2):
+        bs, _ = enc.encode(f)
+        assert bs == orc.encode(f)[0]
+    enc.close()
