@@ -58,6 +58,7 @@ enum {
 enum { MI355X_H264_FRAME_IDR = 1, MI355X_H264_FRAME_P = 3 }; /* EVideoFrameType values, codec_def.h:70,72 */
 
 enum { MI355X_H264_RC_FIXED_QP = 0, MI355X_H264_RC_BITRATE = 1 };
+enum { MI355X_H264_INPUT_I420 = 0, MI355X_H264_INPUT_NV12 = 1 };
 
 typedef struct mi355x_h264_config {
     uint32_t struct_size;    /* sizeof(mi355x_h264_config), for ABI growth          */
@@ -72,7 +73,9 @@ typedef struct mi355x_h264_config {
     int32_t disable_deblock; /* iLoopFilterDisableIdc (ref :295), 0 = filter on     */
     int32_t batch;           /* closed GOPs (or independent streams) encoded in lockstep by one instance,
                               * 1..64; > 1 is driven through mi355x_h264_encode_gops_device only      */
-    int32_t reserved[4];
+    int32_t input_format;    /* layout of pictures handed over in DEVICE memory (encode_device, encode_batch_device,
+                              * encode_gops_device): MI355X_H264_INPUT_I420 (default) or MI355X_H264_INPUT_NV12     */
+    int32_t reserved[3];
 } mi355x_h264_config;
 
 typedef struct mi355x_h264_encoder mi355x_h264_encoder;
@@ -94,8 +97,9 @@ int mi355x_h264_encode_device(mi355x_h264_encoder *enc, const void *d_i420, uint
                               uint32_t *out_len, int *frame_type);
 
 /* NV12 ingest (BASELINE.json configs[2]): Y plane followed by one interleaved
- * UV plane.  OpenH264 itself only takes I420 (ref :256,:262); here a de-interleave kernel runs
- * in front of the encoder so the host never touches the samples.  uv_stride in bytes. */
+ * UV plane.  OpenH264 itself only takes I420 (ref :256,:262); here the kernels read the interleaved
+ * chroma rows directly (one 8-byte load + byte permute per four samples): no conversion pass, no extra
+ * HBM traffic, and the host never touches the samples.  uv_stride in bytes. */
 int mi355x_h264_encode_nv12(mi355x_h264_encoder *enc, const uint8_t *y, int y_stride, const uint8_t *uv,
                             int uv_stride, uint8_t **out, uint32_t *out_len, int *frame_type);
 /* tightly packed NV12 in device memory: Y (width*height) then UV (width*height/2) */

@@ -35,7 +35,8 @@ struct Quant {
 };
 
 struct FrameParams {
-    const uint8_t* src;  // tight I420 picture in HBM: Y (w*h), U, V
+    const uint8_t* src;  // tight picture in HBM: Y (w*h), then U, V planes (I420) or one interleaved UV plane (NV12)
+    int src_nv12;        // 1: chroma is read straight from the interleaved plane (no conversion pass)
     int w, h;            // display size
     int cw, ch, mbw, mbh;
     uint8_t* rec[3];        // current picture reconstruction (pitch cw, cw/2, cw/2)
@@ -206,12 +207,38 @@ __device__ __forceinline__ int src_px(const uint8_t* plane, int pw, int ph, int 
     return plane[(size_t)(y < ph ? y : ph - 1) * pw + (x < pw ? x : pw - 1)];
 }
 
+// four source chroma samples (plane pl, columns gx..gx+3 of row gy) packed into one word, clamped like src_px.
+// NV12: one 8-byte read of the interleaved row, even (Cb) or odd (Cr) bytes picked by v_perm_b32.
+__device__ __forceinline__ uint32_t src_chroma4(const FrameParams& P, int pl, int gx, int gy)
+{
+    const int pw = P.w / 2, ph = P.h / 2;
+    const int yy = gy < ph ? gy : ph - 1;
+    const uint8_t* base = P.src + (size_t)P.w * P.h;
+    if (P.src_nv12) {
+        const uint8_t* row = base + (size_t)yy * (2 * pw);
+        const uint8_t* p = row + 2 * gx;
+        if (gx + 3 < pw && (((uintptr_t)p) & 7) == 0) {
+            const uint2 v = *(const uint2*)p;
+            return __builtin_amdgcn_perm(v.y, v.x, pl ? 0x07050301u : 0x06040200u);
+        }
+        uint32_t v = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) v |= (uint32_t)row[2 * (gx + k < pw ? gx + k : pw - 1) + pl] << (8 * k);
+        return v;
+    }
+    const uint8_t* C = base + (pl ? (size_t)pw * ph : 0);
+    const uint8_t* p = C + (size_t)yy * pw + gx;
+    if (gx + 3 < pw && (((uintptr_t)p) & 3) == 0) return *(const uint32_t*)p;
+    uint32_t v = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) v |= (uint32_t)src_px(C, pw, ph, gx + k, gy) << (8 * k);
+    return v;
+}
+
 // Load the source macroblock (mx,my) into LDS: y[256] (pitch 16), c[128] (Cb 8x8 then Cr 8x8).
 __device__ __forceinline__ void load_src_mb(const FrameParams& P, int mx, int my, uint8_t* sy, uint8_t* sc, int lane)
 {
     const uint8_t* Y = P.src;
-    const uint8_t* U = Y + (size_t)P.w * P.h;
-    const uint8_t* V = U + (size_t)(P.w / 2) * (P.h / 2);
     {
         const int row = lane >> 2, xs = (lane & 3) * 4;
         const int gy = 16 * my + row, gx = 16 * mx + xs;
@@ -228,18 +255,7 @@ __device__ __forceinline__ void load_src_mb(const FrameParams& P, int mx, int my
     }
     if (lane < 32) {
         const int pl = lane >> 4, row = (lane >> 1) & 7, xs = (lane & 1) * 4;
-        const uint8_t* C = pl ? V : U;
-        const int pw = P.w / 2, ph = P.h / 2;
-        const int gy = 8 * my + row, gx = 8 * mx + xs;
-        const int yy = gy < ph ? gy : ph - 1;
-        const uint8_t* p = C + (size_t)yy * pw + gx;
-        uint32_t v;
-        if (gx + 3 < pw && (((uintptr_t)p) & 3) == 0) v = *(const uint32_t*)p;
-        else {
-            v = 0;
-#pragma unroll
-            for (int k = 0; k < 4; k++) v |= (uint32_t)src_px(C, pw, ph, gx + k, gy) << (8 * k);
-        }
+        const uint32_t v = src_chroma4(P, pl, 8 * mx + xs, 8 * my + row);
         *(uint32_t*)(sc + pl * 64 + row * 8 + xs) = v;
     }
 }

@@ -303,8 +303,6 @@ __global__ __launch_bounds__(64) void k_intra_rows(IntraRowParams R)
     __shared__ IntraLds S;
     bool timed_out = false;
     const uint8_t* Y = P.src;
-    const uint8_t* U = Y + (size_t)P.w * P.h;
-    const uint8_t* V = U + (size_t)(P.w / 2) * (P.h / 2);
     // source fetch of one macroblock into registers (same clamping as load_src_mb)
     uint32_t pf_y = 0, pf_c = 0;
     unsigned long long pf_g = 0;
@@ -322,16 +320,7 @@ __global__ __launch_bounds__(64) void k_intra_rows(IntraRowParams R)
         }
         if (lane < 32) {
             const int pl = lane >> 4, row = (lane >> 1) & 7, xs = (lane & 1) * 4;
-            const uint8_t* Cp = pl ? V : U;
-            const int pw = P.w / 2, ph = P.h / 2;
-            const int gy = 8 * my + row, gx = 8 * mx + xs;
-            const uint8_t* p = Cp + (size_t)(gy < ph ? gy : ph - 1) * pw + gx;
-            if (gx + 3 < pw && (((uintptr_t)p) & 3) == 0) pf_c = *(const uint32_t*)p;
-            else {
-                pf_c = 0;
-#pragma unroll
-                for (int k = 0; k < 4; k++) pf_c |= (uint32_t)src_px(Cp, pw, ph, gx + k, gy) << (8 * k);
-            }
+            pf_c = src_chroma4(P, pl, 8 * mx + xs, 8 * my + row);
         }
         if (my > 0 && lane < 8) pf_g = __hip_atomic_load(handoff + ((size_t)(my - 1) * P.mbw + mx) * 8 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };

@@ -232,12 +232,7 @@ __global__ __launch_bounds__(64) void k_pmb2(FrameParams P0)
     }
     {   // chroma source samples of this lane's macroblock
         const int cmx = hh ? mx[1] : mx[0], cmy = hh ? my[1] : my[0];
-        const int pw = P.w / 2, ph = P.h / 2;
-        const uint8_t* C = P.src + (size_t)P.w * P.h + (cpl ? (size_t)pw * ph : 0);
-        const int cgy = 8 * cmy + cy, cgx = 8 * cmx + cx;
-        const uint8_t* qq = C + (size_t)(cgy < ph ? cgy : ph - 1) * pw + cgx;
-        if (cgx + 3 < pw && (((uintptr_t)qq) & 3) == 0) csrc4 = *(const uint32_t*)qq;
-        else csrc4 = pack4(src_px(C, pw, ph, cgx, cgy), src_px(C, pw, ph, cgx + 1, cgy), src_px(C, pw, ph, cgx + 2, cgy), src_px(C, pw, ph, cgx + 3, cgy));
+        csrc4 = src_chroma4(P, cpl, 8 * cmx + cx, 8 * cmy + cy);
     }
     for (int i = lane; i < 2 * (LV_STRIDE * 2 / 16); i += 64) ((uint4*)&s_lv[0][0])[i] = make_uint4(0, 0, 0, 0);
 #pragma unroll

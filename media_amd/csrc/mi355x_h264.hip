@@ -28,23 +28,6 @@ using namespace h264;
 
 namespace {
 
-// NV12 -> I420: de-interleave the UV plane (8 bytes = 4 chroma sample pairs per thread); Y is copied as is
-__global__ __launch_bounds__(256) void k_nv12_to_i420(const uint8_t* nv12, uint8_t* i420, int w, int h)
-{
-    const size_t ysz = (size_t)w * h, csz = ysz / 4;
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // index of a 4-pair group (or a 16-byte Y chunk)
-    for (size_t k = i; k * 16 < ysz; k += (size_t)gridDim.x * blockDim.x) {
-        if (k * 16 + 16 <= ysz && ((ysz | (uintptr_t)nv12 | (uintptr_t)i420) & 15) == 0) *(uint4*)(i420 + k * 16) = *(const uint4*)(nv12 + k * 16);
-        else for (size_t b = k * 16; b < ysz && b < k * 16 + 16; b++) i420[b] = nv12[b];
-    }
-    const uint8_t* uv = nv12 + ysz;
-    uint8_t* u = i420 + ysz;
-    uint8_t* v = u + csz;
-    for (size_t k = i; k * 4 < csz; k += (size_t)gridDim.x * blockDim.x) {
-        for (size_t c = k * 4; c < csz && c < k * 4 + 4; c++) { u[c] = uv[2 * c]; v[c] = uv[2 * c + 1]; }
-    }
-}
-
 // ---- host tables (ITU-T H.264 Table 8-15, A-1; quantiser of the reference model) ----
 const uint8_t h_chroma_qp[52] = {0,  1,  2,  3,  4,  5,  6,  7,  8,  9,  10, 11, 12, 13, 14, 15, 16, 17,
                                  18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 29, 30, 31, 32, 32, 33,
@@ -182,7 +165,6 @@ struct mi355x_h264_encoder {
     bool diag_mode = false;                  // debug: one launch per wavefront step instead
     bool pmb_v1 = false;                     // debug: first form of the MC+DCT kernel (k_pmb.h)
     uint8_t* d_stage = nullptr;              // device copy of a host-supplied picture
-    uint8_t* d_stage2 = nullptr;             // device copy of a host-supplied NV12 picture
     uint8_t* h_stage = nullptr;              // pinned staging for strided host input
     size_t frame_bytes = 0, bitbuf_cap = 0, au_cap = 0;
     Slot slots[NSLOT];
@@ -297,7 +279,7 @@ struct StatScope {
 };
 
 // enqueue everything for one picture whose I420 samples are at d_src
-int submit(mi355x_h264_encoder* e, const uint8_t* d_src, size_t src_item_stride, int slot_idx)
+int submit(mi355x_h264_encoder* e, const uint8_t* d_src, size_t src_item_stride, int slot_idx, bool nv12)
 {
     Slot& S = e->slots[slot_idx];
     const bool idr = e->force_idr || e->frames == 0 || e->frame_in_gop >= e->cfg.gop;
@@ -305,7 +287,7 @@ int submit(mi355x_h264_encoder* e, const uint8_t* d_src, size_t src_item_stride,
     e->force_idr = 0;
     const int cur = e->cur, prev = cur ^ 1;
     FrameParams P{};
-    P.src = d_src; P.w = e->cfg.width; P.h = e->cfg.height;
+    P.src = d_src; P.src_nv12 = nv12 ? 1 : 0; P.w = e->cfg.width; P.h = e->cfg.height;
     P.cw = e->cw; P.ch = e->ch; P.mbw = e->mbw; P.mbh = e->mbh;
     for (int p = 0; p < 3; p++) { P.rec[p] = e->d_planes[cur][p]; P.ref[p] = e->d_planes[prev][p]; }
     P.mb = e->d_mb; P.levels = e->d_levels; P.mvd = e->d_mvd; P.me_cost = e->d_me_cost;
@@ -502,6 +484,7 @@ int mi355x_h264_create(const mi355x_h264_config* cfg, mi355x_h264_encoder** out)
         return MI355X_H264_E_ARG;
     if (cfg->qp < 10 || cfg->qp > 51 || cfg->gop < 1) return MI355X_H264_E_ARG;
     if (cfg->profile_idc != 66 && cfg->profile_idc != 77 && cfg->profile_idc != 100) return MI355X_H264_E_ARG;
+    if (cfg->input_format != MI355X_H264_INPUT_I420 && cfg->input_format != MI355X_H264_INPUT_NV12) return MI355X_H264_E_ARG;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev) return MI355X_H264_E_NODEVICE;
     mi355x_h264_encoder* e = new (std::nothrow) mi355x_h264_encoder();
@@ -554,7 +537,6 @@ int mi355x_h264_create(const mi355x_h264_config* cfg, mi355x_h264_encoder** out)
     e->pmb_v1 = getenv("MI355X_H264_PMB_V1") != nullptr;
     e->frame_bytes = (size_t)cfg->width * cfg->height * 3 / 2;
     CK(hipMalloc((void**)&e->d_stage, e->frame_bytes + 256));
-    CK(hipMalloc((void**)&e->d_stage2, e->frame_bytes + 256));
     CK(hipHostMalloc((void**)&e->h_stage, e->frame_bytes + 256, hipHostMallocDefault));
     e->bitbuf_cap = ysz * 2 + (1 << 16);
     e->st_bitbuf_bytes = (e->bitbuf_cap + 256 + 255) & ~(size_t)255;
@@ -588,7 +570,7 @@ void mi355x_h264_destroy(mi355x_h264_encoder* e)
         for (int p = 0; p < 3; p++) (void)hipFree(e->d_planes[b][p]);
     for (int p = 0; p < 3; p++) (void)hipFree(e->d_pre[p]);
     (void)hipFree(e->d_mb); (void)hipFree(e->d_levels); (void)hipFree(e->d_mvd);
-    (void)hipFree(e->d_slotbits); (void)hipFree(e->d_mbbits); (void)hipFree(e->d_stage); (void)hipFree(e->d_stage2);
+    (void)hipFree(e->d_slotbits); (void)hipFree(e->d_mbbits); (void)hipFree(e->d_stage);
     (void)hipFree(e->d_handoff); (void)hipFree(e->d_bs); (void)hipFree(e->d_me_cost);
     if (e->h_stage) (void)hipHostFree(e->h_stage);
     for (auto& S : e->slots) {
@@ -608,16 +590,22 @@ void mi355x_h264_destroy(mi355x_h264_encoder* e)
     delete e;
 }
 
-int mi355x_h264_encode_device(mi355x_h264_encoder* e, const void* d_i420, uint8_t** out, uint32_t* out_len, int* frame_type)
+// one picture already in device memory, in the given layout
+static int encode_one_device(mi355x_h264_encoder* e, const void* d_pic, bool nv12, uint8_t** out, uint32_t* out_len, int* frame_type)
 {
-    if (!e || !d_i420 || !out || !out_len) return fail(e, MI355X_H264_E_ARG, "null argument");
+    if (!e || !d_pic || !out || !out_len) return fail(e, MI355X_H264_E_ARG, "null argument");
     HIPCHK(e, hipSetDevice(e->device));
     const int slot = e->next_slot;
     e->next_slot = (e->next_slot + 1) % NSLOT;
     if (e->G != 1) return fail(e, MI355X_H264_E_ARG, "single-picture calls need a batch-1 encoder");
-    int rc = submit(e, (const uint8_t*)d_i420, 0, slot);
+    int rc = submit(e, (const uint8_t*)d_pic, 0, slot, nv12);
     if (rc) return rc;
     return collect(e, slot, out, out_len, frame_type);
+}
+
+int mi355x_h264_encode_device(mi355x_h264_encoder* e, const void* d_pic, uint8_t** out, uint32_t* out_len, int* frame_type)
+{
+    return encode_one_device(e, d_pic, e && e->cfg.input_format == MI355X_H264_INPUT_NV12, out, out_len, frame_type);
 }
 
 int mi355x_h264_encode(mi355x_h264_encoder* e, const uint8_t* y, int ys, const uint8_t* u, int us, const uint8_t* v, int vs,
@@ -635,15 +623,12 @@ int mi355x_h264_encode(mi355x_h264_encoder* e, const uint8_t* y, int ys, const u
     d += (size_t)(w / 2) * (h / 2);
     for (int r = 0; r < h / 2; r++) memcpy(d + (size_t)r * (w / 2), v + (size_t)r * vs, (size_t)(w / 2));
     HIPCHK(e, hipMemcpyAsync(e->d_stage, e->h_stage, e->frame_bytes, hipMemcpyHostToDevice, e->stream));
-    return mi355x_h264_encode_device(e, e->d_stage, out, out_len, frame_type);
+    return encode_one_device(e, e->d_stage, false, out, out_len, frame_type);
 }
 
 int mi355x_h264_encode_nv12_device(mi355x_h264_encoder* e, const void* d_nv12, uint8_t** out, uint32_t* out_len, int* frame_type)
 {
-    if (!e || !d_nv12 || !out || !out_len) return fail(e, MI355X_H264_E_ARG, "null argument");
-    HIPCHK(e, hipSetDevice(e->device));
-    hipLaunchKernelGGL(k_nv12_to_i420, dim3(512), dim3(256), 0, e->stream, (const uint8_t*)d_nv12, e->d_stage, e->cfg.width, e->cfg.height);
-    return mi355x_h264_encode_device(e, e->d_stage, out, out_len, frame_type);
+    return encode_one_device(e, d_nv12, true, out, out_len, frame_type);   // the kernels read the interleaved chroma themselves
 }
 
 int mi355x_h264_encode_nv12(mi355x_h264_encoder* e, const uint8_t* y, int ys, const uint8_t* uv, int uvs, uint8_t** out,
@@ -657,8 +642,8 @@ int mi355x_h264_encode_nv12(mi355x_h264_encoder* e, const uint8_t* y, int ys, co
     for (int r = 0; r < h; r++) memcpy(d + (size_t)r * w, y + (size_t)r * ys, (size_t)w);
     d += (size_t)w * h;
     for (int r = 0; r < h / 2; r++) memcpy(d + (size_t)r * w, uv + (size_t)r * uvs, (size_t)w);
-    HIPCHK(e, hipMemcpyAsync(e->d_stage2, e->h_stage, e->frame_bytes, hipMemcpyHostToDevice, e->stream));
-    return mi355x_h264_encode_nv12_device(e, e->d_stage2, out, out_len, frame_type);
+    HIPCHK(e, hipMemcpyAsync(e->d_stage, e->h_stage, e->frame_bytes, hipMemcpyHostToDevice, e->stream));
+    return encode_one_device(e, e->d_stage, true, out, out_len, frame_type);
 }
 
 int mi355x_h264_encode_batch_device(mi355x_h264_encoder* e, const void* d_frames, size_t stride, int count, uint8_t* host_out,
@@ -687,7 +672,7 @@ int mi355x_h264_encode_batch_device(mi355x_h264_encoder* e, const void* d_frames
         const int slot = e->next_slot;
         e->next_slot = (e->next_slot + 1) % NSLOT;
         pending[i % NSLOT] = slot;
-        int rc = submit(e, (const uint8_t*)d_frames + (size_t)i * stride, 0, slot);
+        int rc = submit(e, (const uint8_t*)d_frames + (size_t)i * stride, 0, slot, e->cfg.input_format == MI355X_H264_INPUT_NV12);
         if (rc) return rc;
         npend++;
     }
@@ -726,7 +711,7 @@ int mi355x_h264_encode_gops_device(mi355x_h264_encoder* e, const void* d_frames,
         const int slot = e->next_slot;
         e->next_slot = (e->next_slot + 1) % NSLOT;
         pending[i % NSLOT] = slot;
-        int rc = submit(e, (const uint8_t*)d_frames + (size_t)i * frame_stride, gop_stride, slot);
+        int rc = submit(e, (const uint8_t*)d_frames + (size_t)i * frame_stride, gop_stride, slot, e->cfg.input_format == MI355X_H264_INPUT_NV12);
         if (rc) return rc;
         npend++;
     }

@@ -71,8 +71,8 @@ def test_forced_idr_qp_change_and_strided_input():
 
 
 def test_nv12_ingest_main_profile_1080p60():
-    """BASELINE.json configs[2]: 1080p60 NV12, main profile, CABAC off (CAVLC): the de-interleave kernel in
-    front of the encoder must give exactly the I420 result"""
+    """BASELINE.json configs[2]: 1080p60 NV12, main profile, CABAC off (CAVLC): the kernels read the interleaved
+    chroma plane directly and must give exactly the I420 result"""
     w, h = 1920, 1080
     enc = capi.Encoder(w, h, qp=26, gop=30, fps=60, profile_idc=77)
     orc = OracleEncoder(w, h, qp=26, gop=30, fps=60, profile_idc=77)
@@ -84,13 +84,41 @@ def test_nv12_ingest_main_profile_1080p60():
         if i == 0:
             assert bs[:8] == bytes([0, 0, 0, 1, 0x67, 77, 0x40, 42])   # main profile, level 4.2 for 1080p60
     enc.close()
-    # odd geometry through the scalar tail of the kernel
+    # geometry whose chroma rows are not 8-byte aligned / end inside a macroblock: the clamped per-sample path
     w, h = 130, 98
     enc = capi.Encoder(w, h, qp=28)
     orc = OracleEncoder(w, h, qp=28)
     for f in synth.sequence("s1", w, h, 2):
         y, u, v = f[: w * h], f[w * h: w * h * 5 // 4], f[w * h * 5 // 4:]
         assert enc.encode_nv12(np.concatenate([y, np.stack([u, v], axis=1).ravel()]))[0] == orc.encode(f)[0]
+    enc.close()
+
+
+def _to_nv12(f, w, h):
+    y, u, v = f[: w * h], f[w * h: w * h * 5 // 4], f[w * h * 5 // 4:]
+    return np.concatenate([y, np.stack([u, v], axis=1).ravel()])
+
+
+def test_nv12_device_pictures_in_lockstep_batch():
+    """config.input_format = NV12: device-resident NV12 pictures go through the lockstep batch (and the
+    batch-1 device entry points) with no conversion pass and give the I420 stream"""
+    import torch
+    w, h, gop, G = 352, 288, 4, 3
+    frames = synth.sequence("s1", w, h, gop * G)
+    fbytes = w * h * 3 // 2
+    orc = OracleEncoder(w, h, qp=27, gop=gop)
+    want = [orc.encode(f)[0] for f in frames]
+    dev = torch.from_numpy(np.stack([_to_nv12(f, w, h) for f in frames])).cuda()
+    enc = capi.Encoder(w, h, qp=27, gop=gop, batch=G, input_format=1)
+    cap = gop * fbytes
+    out, sizes, gb = np.zeros(G * cap, np.uint8), np.zeros(G * gop, np.uint32), np.zeros(G, np.uint64)
+    enc.encode_gops_device(dev.data_ptr(), fbytes, gop * fbytes, gop, out, cap, sizes, gb)
+    for g in range(G):
+        assert out[g * cap: g * cap + int(gb[g])].tobytes() == b"".join(want[g * gop:(g + 1) * gop]), "GOP %d" % g
+    enc.close()
+    enc = capi.Encoder(w, h, qp=27, gop=gop, input_format=1)
+    for i in range(gop + 1):
+        assert enc.encode_device(dev[i].data_ptr())[0] == want[i]
     enc.close()
 
 
