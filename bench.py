@@ -106,6 +106,10 @@ def main():
     ap.add_argument("--instances", type=int, default=int(os.environ.get("BENCH_INSTANCES", "2")),
                     help="encoder instances (HIP streams) the GOPs in flight are split over; each encodes its share in lockstep")
     ap.add_argument("--cpu-frames", type=int, default=8, help="pictures per CPU-baseline thread")
+    ap.add_argument("--input", default="i420", choices=["i420", "nv12"],
+                    help="layout of the resident pictures; nv12 + --profile main --fps 60 is BASELINE.json configs[2]")
+    ap.add_argument("--profile", default="baseline", choices=["baseline", "main", "high"])
+    ap.add_argument("--fps", type=int, default=30, choices=[30, 60])
     ap.add_argument("--content", default="s1", choices=["s1", "s2", "s3"],
                     help="synthetic input of SURVEY.md 8(d); s1 pan+noise is the headline workload")
     args = ap.parse_args()
@@ -148,7 +152,13 @@ def main():
             dev[g, :, :ysz] = torch.roll(dev0[:, :ysz].view(FRAMES_PER_STEP, HEIGHT, WIDTH), 16 * g, dims=2).reshape(FRAMES_PER_STEP, ysz)
             for o in (ysz, ysz + csz):
                 dev[g, :, o:o + csz] = torch.roll(dev0[:, o:o + csz].view(FRAMES_PER_STEP, HEIGHT // 2, WIDTH // 2), 8 * g, dims=2).reshape(FRAMES_PER_STEP, csz)
+    if args.input == "nv12":   # same samples, chroma interleaved in place (U plane + V plane -> UV plane)
+        uv = torch.stack([dev[:, :, ysz:ysz + csz], dev[:, :, ysz + csz:ysz + 2 * csz]], dim=3).reshape(G, FRAMES_PER_STEP, 2 * csz)
+        dev[:, :, ysz:ysz + 2 * csz] = uv
+        del uv
     torch.cuda.synchronize()
+    profile_idc = {"baseline": 66, "main": 77, "high": 100}[args.profile]
+    enc_kw = dict(qp=QP, gop=GOP, device=local_rank, fps=args.fps, profile_idc=profile_idc, input_format=1 if args.input == "nv12" else 0)
 
     # I encoder instances (own HIP stream each), each encoding G/I GOPs in lockstep: every kernel launch of an
     # instance covers all its pictures of one time step (grid.y = G/I); instances overlap each other's
@@ -157,7 +167,7 @@ def main():
     while G % I:
         I -= 1
     B = G // I
-    insts = [capi.Encoder(WIDTH, HEIGHT, qp=QP, gop=GOP, device=local_rank, batch=B) for _ in range(I)]
+    insts = [capi.Encoder(WIDTH, HEIGHT, batch=B, **enc_kw) for _ in range(I)]
     for i, e_ in enumerate(insts):
         e_.set_idr_pic_id(i * B, 1)
     enc = insts[0]
@@ -165,7 +175,7 @@ def main():
     outs = [np.zeros(B * cap, np.uint8) for _ in range(I)]
     sizes = [np.zeros(B * FRAMES_PER_STEP, np.uint32) for _ in range(I)]
     gop_bytes = [np.zeros(B, np.uint64) for _ in range(I)]
-    enc1 = capi.Encoder(WIDTH, HEIGHT, qp=QP, gop=GOP, device=local_rank) if G > 1 else None
+    enc1 = capi.Encoder(WIDTH, HEIGHT, **enc_kw) if G > 1 else None
     out1 = np.zeros(cap, np.uint8)
     sizes1 = np.zeros(FRAMES_PER_STEP, np.uint32)
 
@@ -276,7 +286,7 @@ def main():
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "1080p30 I420 synthetic S1 pan+noise, baseline profile, fixed QP 26, closed GOPs of 30 "
+            "config": {"workload": "1080p%d %s synthetic S1 pan+noise, %s profile, fixed QP 26, closed GOPs of 30 " % (args.fps, args.input.upper(), args.profile) +
                                    "(1 IDR + 29 P), single slice, 1 ref, deblock on, CAVLC; per GPU one stream, %d of its "
                                    "closed GOPs per step on %d encoder instance(s), each encoding its %d GOPs in lockstep "
                                    "(grid.y) on its own HIP streams; pictures resident in HBM" % (G, I, B),
