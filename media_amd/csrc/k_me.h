@@ -48,7 +48,7 @@ __device__ __forceinline__ void qpel_taps(int fx, int fy, int& o0, int& o1)
 }
 
 
-__global__ __launch_bounds__(64, 4) void k_me(FrameParams P0)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_me(FrameParams P0)
 {
     const FrameParams P = batch_view(P0, blockIdx.y);
     const int lane = threadIdx.x;
@@ -60,8 +60,15 @@ __global__ __launch_bounds__(64, 4) void k_me(FrameParams P0)
     __shared__ __attribute__((aligned(16))) uint8_t s_srcc[128];
     __shared__ __attribute__((aligned(16))) uint32_t s_ytab[32];
     __shared__ __attribute__((aligned(16))) uint8_t s_refc[128];
-    __shared__ __attribute__((aligned(16))) int16_t s_b1[(ME_GS + 5) * ME_GP];   // pitch 20 int16
-    __shared__ __attribute__((aligned(16))) uint8_t s_pl[4 * ME_PLS + 16];        // planes G,b,h,j: 18 rows, pitch 20
+    // one region, two lives: first the survivor list of the integer search (up to ME_TASKCAP keys), then the
+    // half-sample planes (s_b1: unclipped horizontal sums, pitch 20 int16; s_pl: planes G,b,h,j, 18 rows, pitch 20)
+    enum { ME_B1_BYTES = (ME_GS + 5) * ME_GP * 2, ME_PL_BYTES = 4 * ME_PLS + 16 };
+    enum { ME_TASKCAP = 760 };   // 3 040 B: with the rest of the LDS, 24 workgroups (6 waves per SIMD) fit a CU
+    __shared__ __attribute__((aligned(16))) uint8_t s_scr[4 * ME_TASKCAP > ME_B1_BYTES + ME_PL_BYTES ? 4 * ME_TASKCAP : ME_B1_BYTES + ME_PL_BYTES];
+    __shared__ unsigned s_ntask;
+    uint32_t* const s_task = (uint32_t*)s_scr;
+    int16_t* const s_b1 = (int16_t*)s_scr;
+    uint8_t* const s_pl = s_scr + ME_B1_BYTES;
 
     load_src_mb(P, mx, my, s_src, s_srcc, lane);
     // reference window, clamped at the picture edge (unrestricted motion vectors); all requests of a lane are
@@ -209,49 +216,115 @@ __global__ __launch_bounds__(64, 4) void k_me(FrameParams P0)
             }
         }
         const uint32_t kbase = ((uint32_t)__mul24(P.lambda, se_len(4 * (dxi - ME_R))) << 10) + (uint32_t)dxi;
+        if (lane == 0) s_ntask = 0;
         // two row bases (rows 0..15, 16..30) keep every row's dword offset inside the 8-bit ds_read2 offset fields
         lds_u32p wb0 = (lds_u32p)(s_win + (ME_AP + half * 16) * ME_WDW + cdw), wb1 = wb0 + 16 * ME_WDW;
         asm("" : "+v"(wb0));
         asm("" : "+v"(wb1));
+        // Pass 1 - a LOWER BOUND of every candidate's SAD: columns 0..3 and 8..11 of all 16 rows (half the samples,
+        // half the v_sad_u8, half the byte alignments).  Window rows stream through two register sets: row r+1 is
+        // requested before row r is consumed; the scheduling barrier stops the compiler from hoisting every row's
+        // LDS read to the top.
         uint32_t acc[16];
 #pragma unroll
         for (int kk = 0; kk < 16; kk++) acc[kk] = 0;
-        // window rows stream through two register sets: row r+1 is requested before row r is consumed; the
-        // scheduling barrier stops the compiler from hoisting every row's LDS read to the top (95 live registers)
-        uint32_t w[2][5];
+        uint32_t w[2][4];
 #pragma unroll
-        for (int c = 0; c < 5; c++) w[0][c] = wb0[c];
+        for (int c = 0; c < 4; c++) w[0][c] = wb0[c];
 #pragma unroll
         for (int r = 0; r < 31; r++) {
             if (r + 1 < 31) {
 #pragma unroll
-                for (int c = 0; c < 5; c++) w[(r + 1) & 1][c] = r + 1 < 16 ? wb0[(r + 1) * ME_WDW + c] : wb1[(r + 1 - 16) * ME_WDW + c];
+                for (int c = 0; c < 4; c++) w[(r + 1) & 1][c] = r + 1 < 16 ? wb0[(r + 1) * ME_WDW + c] : wb1[(r + 1 - 16) * ME_WDW + c];
             }
             const uint32_t* wr = w[r & 1];
-            const uint32_t a0 = __builtin_amdgcn_alignbyte(wr[1], wr[0], sh), a1 = __builtin_amdgcn_alignbyte(wr[2], wr[1], sh);
-            const uint32_t a2 = __builtin_amdgcn_alignbyte(wr[3], wr[2], sh), a3 = __builtin_amdgcn_alignbyte(wr[4], wr[3], sh);
+            const uint32_t a0 = __builtin_amdgcn_alignbyte(wr[1], wr[0], sh), a2 = __builtin_amdgcn_alignbyte(wr[3], wr[2], sh);
 #pragma unroll
             for (int kk = 0; kk < 16; kk++) {
                 const int j = r - kk;       // source row met by candidate kk on window row r
                 if (j >= 0 && j < 16) {
                     acc[kk] = __builtin_amdgcn_sad_u8(a0, srow[j][0], acc[kk]);
-                    acc[kk] = __builtin_amdgcn_sad_u8(a1, srow[j][1], acc[kk]);
                     acc[kk] = __builtin_amdgcn_sad_u8(a2, srow[j][2], acc[kk]);
-                    acc[kk] = __builtin_amdgcn_sad_u8(a3, srow[j][3], acc[kk]);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        // key = (SAD + lambda * bits(mv)) << 10 | dy index << 5 | dx index; the table entry carries the dy part
-        best = 0xFFFFFFFFu;
+        // bound key = (partial SAD + lambda * bits(mv)) << 10 | dy index << 5 | dx index <= the candidate's true key
+        uint32_t lbk[16];
+        uint32_t bestlb = 0xFFFFFFFFu;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const uint4 t = *(const uint4*)(s_ytab + half * 16 + 4 * q);
-            const uint32_t k0 = (acc[4 * q] << 10) + (t.x + kbase), k1 = (acc[4 * q + 1] << 10) + (t.y + kbase);
-            const uint32_t k2 = (acc[4 * q + 2] << 10) + (t.z + kbase), k3 = (acc[4 * q + 3] << 10) + (t.w + kbase);
-            best = min(min(best, k0), min(k1, min(k2, k3)));
+            lbk[4 * q] = (acc[4 * q] << 10) + (t.x + kbase); lbk[4 * q + 1] = (acc[4 * q + 1] << 10) + (t.y + kbase);
+            lbk[4 * q + 2] = (acc[4 * q + 2] << 10) + (t.z + kbase); lbk[4 * q + 3] = (acc[4 * q + 3] << 10) + (t.w + kbase);
+            bestlb = min(min(bestlb, lbk[4 * q]), min(lbk[4 * q + 1], min(lbk[4 * q + 2], lbk[4 * q + 3])));
+        }
+        bestlb = wave_min_u32(bestlb);
+        // the other half of a candidate's SAD (columns 4..7, 12..15), candidate given by its key's index bits
+        auto rest_of_sad = [&](uint32_t key) -> uint32_t {
+            const int ccol = (int)(key & 31) + ME_AP, csh = ccol & 3;
+            lds_u32p p = (lds_u32p)(s_win + (ME_AP + (int)((key >> 5) & 31)) * ME_WDW + (ccol >> 2) + 1);
+            asm("" : "+v"(p));
+            uint32_t sum = 0;
+            uint32_t v[2][4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) v[0][c] = p[c];
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                if (j + 1 < 16) {
+#pragma unroll
+                    for (int c = 0; c < 4; c++) v[(j + 1) & 1][c] = p[(j + 1) * ME_WDW + c];
+                }
+                const uint32_t* vr = v[j & 1];
+                sum = __builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(vr[1], vr[0], csh), srow[j][1], sum);
+                sum = __builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(vr[3], vr[2], csh), srow[j][3], sum);
+                // pin the order "row j consumed, then row j+2 requested": the optimiser would otherwise sink all the
+                // (pure) SAD arithmetic below the last read and keep 16 rows in registers
+                asm volatile("" : "+v"(sum) : : "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            return sum;
+        };
+        // the candidate with the smallest bound, completed: its true key bounds the optimum from above
+        const uint32_t bound = bestlb + (rest_of_sad(bestlb) << 10);
+        // Pass 2 - only candidates whose bound does not exceed that key can still win (exact: true key >= bound key);
+        // they are compacted into one list and completed 64 at a time
+        {
+            unsigned n = 0;
+#pragma unroll
+            for (int kk = 0; kk < 16; kk++) n += lbk[kk] <= bound;
+            unsigned at = n ? atomicAdd(&s_ntask, n) : 0u;
+#pragma unroll
+            for (int kk = 0; kk < 16; kk++)
+                if (lbk[kk] <= bound) {
+                    if (at < (unsigned)ME_TASKCAP) s_task[at] = lbk[kk];
+                    at++;
+                }
+        }
+        __syncthreads();
+        const unsigned ntask = s_ntask;
+        best = 0xFFFFFFFFu;
+        if (ntask <= (unsigned)ME_TASKCAP) {
+            for (unsigned t0 = 0; t0 < ntask; t0 += 64) {
+                const bool on = t0 + lane < ntask;
+                const uint32_t tk = s_task[on ? t0 + lane : 0];
+                const uint32_t key = tk + (rest_of_sad(tk) << 10);
+                best = on && key < best ? key : best;
+            }
+        } else {
+            // noise-like content: nearly every candidate survives the bound; complete them where they are,
+            // one candidate of every lane per round
+#pragma unroll 1
+            for (int kk = 0; kk < 16; kk++) {
+                uint32_t tk = lbk[0];
+#pragma unroll
+                for (int i = 1; i < 16; i++) tk = kk == i ? lbk[i] : tk;
+                const uint32_t key = tk + (rest_of_sad(tk) << 10);
+                best = tk <= bound && key < best ? key : best;
+            }
         }
         best = wave_min_u32(best);
+        __syncthreads();   // the list's memory becomes the half-sample planes
     }
     const int ix = (int)(best & 31) - ME_R, iy = (int)((best >> 5) & 31) - ME_R;
 
