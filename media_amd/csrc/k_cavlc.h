@@ -91,6 +91,20 @@ struct BitCount {
     __device__ __forceinline__ void put(int len, unsigned) { n += (unsigned)len; }
     __device__ __forceinline__ void flush() {}
 };
+// counts like BitCount and keeps the first 64 bits, left aligned: slots that fit (nearly all of them at usual
+// QPs) are coded ONCE, in the count pass; the write pass only places the stored word
+struct BitPack {
+    unsigned n;
+    unsigned long long acc;
+    __device__ __forceinline__ void init(unsigned) { n = 0; acc = 0; }
+    __device__ __forceinline__ void put(int len, unsigned v)
+    {
+        const int sh = 64 - (int)n - len;
+        if (len > 0 && sh >= 0) acc |= (unsigned long long)v << sh;
+        n += (unsigned)(len > 0 ? len : 0);
+    }
+    __device__ __forceinline__ void flush() {}
+};
 struct BitWrite {
     uint32_t* buf;
     unsigned word, nb;
@@ -249,6 +263,7 @@ struct CavlcParams {
     const int16_t* mvd;
     int mbw, nmb, p_slice;
     uint16_t* slotbits;   // 32 per macroblock
+    unsigned long long* slotcode;   // 32 per macroblock: the slot's bits, left aligned, when slotbits <= 64
     uint32_t* mbbits;     // per macroblock, then (after the scan) bit offsets
     uint32_t* bitbuf;     // zeroed slice payload buffer
     uint8_t* bs;          // boundary strengths for the loop filter, 32 B per macroblock (written by the count pass)
@@ -258,7 +273,7 @@ struct CavlcParams {
 __device__ __forceinline__ CavlcParams batch_view(CavlcParams C, int g)
 {
     C.mb += (size_t)g * C.st_mb; C.levels += (size_t)g * C.st_mb * LV_STRIDE; C.mvd += (size_t)g * C.st_mb * 2;
-    C.slotbits += (size_t)g * C.st_mb * 32; C.mbbits += (size_t)g * C.st_mb; C.bitbuf += (size_t)g * C.st_bitbuf;
+    C.slotbits += (size_t)g * C.st_mb * 32; C.slotcode += (size_t)g * C.st_mb * 32; C.mbbits += (size_t)g * C.st_mb; C.bitbuf += (size_t)g * C.st_bitbuf;
     if (C.bs) C.bs += (size_t)g * C.st_mb * 32;
     return C;
 }
@@ -334,10 +349,11 @@ __global__ __launch_bounds__(64) void k_cavlc(CavlcParams C0)
     const int mbi = blockIdx.x * 2 + (lane >> 5);
     const bool live = mbi < C.nmb;
     if (!WRITE) {
-        BitCount s;
+        BitPack s;
         s.init(0);
         if (live) code_slot(s, C, mbi, slot);
         if (live) C.slotbits[(size_t)mbi * 32 + slot] = (uint16_t)s.n;
+        if (live && s.n && s.n <= 64u) C.slotcode[(size_t)mbi * 32 + slot] = s.acc;
         if (live && C.bs) C.bs[(size_t)mbi * 32 + slot] = (uint8_t)mb_edge_strength(C.mb + mbi, mbi % C.mbw, mbi / C.mbw, C.mbw, slot);
         const int tot = group_sum<32>((int)s.n);
         if (live && slot == 0) C.mbbits[mbi] = (uint32_t)tot;
@@ -350,11 +366,23 @@ __global__ __launch_bounds__(64) void k_cavlc(CavlcParams C0)
             if (slot >= o) incl += t;
         }
         if (live && n) {
-            BitWrite s;
-            s.buf = C.bitbuf;
-            s.init(C.mbbits[mbi] + incl - n);
-            code_slot(s, C, mbi, slot);
-            s.flush();
+            const unsigned pos = C.mbbits[mbi] + incl - n;
+            if (n <= 64u) {   // coded by the count pass: OR the stored word in at its final bit position
+                const unsigned long long code = C.slotcode[(size_t)mbi * 32 + slot];
+                const unsigned off = pos & 31;
+                const unsigned long long hi = code >> off;
+                const uint32_t w0 = (uint32_t)(hi >> 32), w1 = (uint32_t)hi, w2 = off ? (uint32_t)((code << (64 - off)) >> 32) : 0u;
+                uint32_t* dst = C.bitbuf + (pos >> 5);
+                if (w0) atomicOr(dst, __builtin_bswap32(w0));
+                if (w1) atomicOr(dst + 1, __builtin_bswap32(w1));
+                if (w2) atomicOr(dst + 2, __builtin_bswap32(w2));
+            } else {
+                BitWrite s;
+                s.buf = C.bitbuf;
+                s.init(pos);
+                code_slot(s, C, mbi, slot);
+                s.flush();
+            }
         }
     }
 }

@@ -156,6 +156,7 @@ struct mi355x_h264_encoder {
     int16_t* d_levels = nullptr;
     int16_t* d_mvd = nullptr;
     uint16_t* d_slotbits = nullptr;
+    unsigned long long* d_slotcode = nullptr;
     uint32_t* d_mbbits = nullptr;
     unsigned long long* d_handoff = nullptr; // row-to-row hand-off of the wavefront kernels
     uint32_t* d_bs = nullptr;                // boundary strengths, 32 B per macroblock
@@ -336,7 +337,7 @@ int submit(mi355x_h264_encoder* e, const uint8_t* d_src, size_t src_item_stride,
         StatScope sc(e, &S, MI355X_H264_K_CAVLC, 4, (uint32_t)(e->nmb * e->G), ec);
         CavlcParams C{};
         C.mb = e->d_mb; C.levels = e->d_levels; C.mvd = e->d_mvd; C.mbw = e->mbw; C.nmb = e->nmb; C.p_slice = idr ? 0 : 1;
-        C.slotbits = e->d_slotbits; C.mbbits = e->d_mbbits; C.bitbuf = S.d_bitbuf;
+        C.slotbits = e->d_slotbits; C.slotcode = e->d_slotcode; C.mbbits = e->d_mbbits; C.bitbuf = S.d_bitbuf;
         C.bs = (!e->cfg.disable_deblock && !e->diag_mode) ? (uint8_t*)e->d_bs : nullptr;
         C.st_mb = e->nmb; C.st_bitbuf = e->st_bitbuf_bytes / 4;
         const int grid = (e->nmb + 1) / 2;
@@ -525,6 +526,7 @@ int mi355x_h264_create(const mi355x_h264_config* cfg, mi355x_h264_encoder** out)
     CK(hipMalloc((void**)&e->d_levels, Gn * e->nmb * LV_STRIDE * sizeof(int16_t)));
     CK(hipMalloc((void**)&e->d_mvd, Gn * e->nmb * 2 * sizeof(int16_t)));
     CK(hipMalloc((void**)&e->d_slotbits, Gn * e->nmb * 32 * sizeof(uint16_t)));
+    CK(hipMalloc((void**)&e->d_slotcode, Gn * e->nmb * 32 * sizeof(unsigned long long)));
     CK(hipMalloc((void**)&e->d_mbbits, Gn * e->nmb * sizeof(uint32_t)));
     e->st_handoff = (size_t)e->nmb * 24;
     CK(hipMalloc((void**)&e->d_handoff, Gn * e->st_handoff * sizeof(unsigned long long)));
@@ -570,7 +572,7 @@ void mi355x_h264_destroy(mi355x_h264_encoder* e)
         for (int p = 0; p < 3; p++) (void)hipFree(e->d_planes[b][p]);
     for (int p = 0; p < 3; p++) (void)hipFree(e->d_pre[p]);
     (void)hipFree(e->d_mb); (void)hipFree(e->d_levels); (void)hipFree(e->d_mvd);
-    (void)hipFree(e->d_slotbits); (void)hipFree(e->d_mbbits); (void)hipFree(e->d_stage);
+    (void)hipFree(e->d_slotbits); (void)hipFree(e->d_slotcode); (void)hipFree(e->d_mbbits); (void)hipFree(e->d_stage);
     (void)hipFree(e->d_handoff); (void)hipFree(e->d_bs); (void)hipFree(e->d_me_cost);
     if (e->h_stage) (void)hipHostFree(e->h_stage);
     for (auto& S : e->slots) {
