@@ -5,6 +5,7 @@
 //
 // Per macroblock, entirely out of LDS after one coalesced window load:
 //   1. zero-motion test: does (src - ref) quantise to nothing?  -> mv = 0, done
+//   (rate term of 2 and 3: lambda * bits(mv - pmv), pmv = this macroblock's vector in the previous picture)
 //   2. full search dx,dy in [-16,15]: lane = (dx, half of dy range); each lane
 //      keeps 16 SAD accumulators (v_sad_u8, four pixels per instruction) and
 //      walks 31 window rows, every row feeding up to 16 candidates; the source
@@ -70,6 +71,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
     int16_t* const s_b1 = (int16_t*)s_scr;
     uint8_t* const s_pl = s_scr + ME_B1_BYTES;
 
+    // the vector this macroblock had in the previous picture (0 after an IDR): stand-in for the motion vector predictor
+    // in the rate term of the search; final before the launch, so every macroblock stays independent
+    const int pmw = __builtin_amdgcn_readfirstlane(*(const int*)(P.mb + mbi));
+    const int pmx = (int)(int16_t)(pmw & 0xFFFF), pmy = pmw >> 16;
     load_src_mb(P, mx, my, s_src, s_srcc, lane);
     // reference window, clamped at the picture edge (unrestricted motion vectors); all requests of a lane are
     // issued before the first is consumed (one memory latency).  Macroblocks whose window (widened to 64 B
@@ -196,7 +201,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
         const int dxi = lane & 31, half = lane >> 5;
         const int col = dxi + ME_AP, cdw = col >> 2, sh = col & 3;
         // motion-vector cost and candidate index of every dy, shifted into key position: one table per macroblock
-        if (lane < 32) s_ytab[lane] = ((uint32_t)__mul24(P.lambda, se_len(4 * (lane - ME_R))) << 10) | ((uint32_t)lane << 5);
+        if (lane < 32) s_ytab[lane] = ((uint32_t)__mul24(P.lambda, se_len(4 * (lane - ME_R) - pmy)) << 10) | ((uint32_t)lane << 5);
         // the source macroblock is wave-uniform: keep its 64 dwords in SGPRs (v_sad_u8 takes one scalar operand).
         // Macroblocks inside the picture read it with scalar loads straight from the source picture.
         uint32_t srow[16][4];
@@ -215,7 +220,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
                 srow[j][2] = __builtin_amdgcn_readfirstlane(v.z); srow[j][3] = __builtin_amdgcn_readfirstlane(v.w);
             }
         }
-        const uint32_t kbase = ((uint32_t)__mul24(P.lambda, se_len(4 * (dxi - ME_R))) << 10) + (uint32_t)dxi;
+        const uint32_t kbase = ((uint32_t)__mul24(P.lambda, se_len(4 * (dxi - ME_R) - pmx)) << 10) + (uint32_t)dxi;
         if (lane == 0) s_ntask = 0;
         // two row bases (rows 0..15, 16..30) keep every row's dword offset inside the 8-bit ds_read2 offset fields
         lds_u32p wb0 = (lds_u32p)(s_win + (ME_AP + half * 16) * ME_WDW + cdw), wb1 = wb0 + 16 * ME_WDW;
@@ -425,7 +430,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
             sum = __builtin_amdgcn_sad_u16(__builtin_bit_cast(uint32_t, d0 - d1), 0x80008000u, sum);
         }
         const int s = group_sum<8>((int)sum);
-        const unsigned cost = (unsigned)(s >> 1) + (unsigned)(P.lambda * (se_len(qx) + se_len(qy)));
+        const unsigned cost = (unsigned)(s >> 1) + (unsigned)(P.lambda * (se_len(qx - pmx) + se_len(qy - pmy)));
         const unsigned key = live ? ((cost << 4) | (unsigned)ord) : 0xFFFFFFFFu;
         bestk = key < bestk ? key : bestk;               // per-lane running minimum; reduced once per pass
         if (round == 0) continue;

@@ -14,8 +14,9 @@
  * over all macroblocks at once):
  *   - I pictures: Intra16x16 (4 modes by SATD) + chroma (4 modes by SATD)
  *   - P pictures: per MB a zero-motion "all levels quantise to zero" test,
- *     else full search dx,dy in [-16,15] on SAD + lambda*bits(mv), then half-
- *     and quarter-pel refinement on SATD + lambda*bits(mv); P_L0_16x16 only;
+ *     else full search dx,dy in [-16,15] on SAD + lambda*bits(mv - pmv), then half-
+ *     and quarter-pel refinement on SATD + lambda*bits(mv - pmv), pmv = this
+ *     macroblock's vector in the previous picture; P_L0_16x16 only;
  *     P_Skip iff mv == skip predictor and no coefficient survives
  *   - quantiser: reference-model multipliers, offsets 1/3 (intra), 1/6 (inter)
  *   - CAVLC, fixed picture QP, deblocking per 8.7 with offsets 0
@@ -521,7 +522,9 @@ static int zero_mv_all_zero(h264o_enc *e, int mx, int my)
     return 1;
 }
 
-static mv_t motion_search(h264o_enc *e, int mx, int my, int *final_cost)
+/* pmv: the vector this macroblock had in the previous picture (0 after an IDR) - the stand-in for the motion
+ * vector predictor in the rate term: it is final before the picture starts, so every macroblock stays independent */
+static mv_t motion_search(h264o_enc *e, int mx, int my, mv_t pmv, int *final_cost)
 {
     int cw = e->cw, ch = e->ch, lambda = o_lambda[e->cfg.qp];
     const uint8_t *s = e->src[0] + (16 * my) * cw + 16 * mx;
@@ -535,7 +538,7 @@ static mv_t motion_search(h264o_enc *e, int mx, int my, int *final_cost)
     for (int dy = -R; dy < R; dy++)
         for (int dx = -R; dx < R; dx++) {
             int sad = h264o_sad16x16(s, cw, win + (dy + R + AP) * WS + dx + R + AP, WS);
-            uint32_t cost = (uint32_t)(sad + lambda * (se_len(4 * dx) + se_len(4 * dy)));
+            uint32_t cost = (uint32_t)(sad + lambda * (se_len(4 * dx - pmv.x) + se_len(4 * dy - pmv.y)));
             uint32_t key = (cost << 10) | (uint32_t)(((dy + R) << 5) | (dx + R));
             if (key < best_key) best_key = key;
         }
@@ -578,7 +581,7 @@ static mv_t motion_search(h264o_enc *e, int mx, int my, int *final_cost)
                     else v = ((fy == 1 ? B[Y][X] : B[Y + 1][X]) + (fx == 1 ? H[Y][X] : H[Y][X + 1]) + 1) >> 1;
                     pred[16 * y + x] = (uint8_t)v;
                 }
-            int cost = h264o_satd16x16(s, cw, pred, 16) + lambda * (se_len(qx) + se_len(qy));
+            int cost = h264o_satd16x16(s, cw, pred, 16) + lambda * (se_len(qx - pmv.x) + se_len(qy - pmv.y));
             if (k < 0 || cost < best_cost) { best_cost = cost; bcx = qx; bcy = qy; }
         }
         cx = bcx;
@@ -769,11 +772,12 @@ int64_t h264o_enc_encode(h264o_enc *e, const uint8_t *y, int ys, const uint8_t *
         for (int my = 0; my < e->mbh; my++)
             for (int mx = 0; mx < e->mbw; mx++) {
                 h264o_mbinfo *mb = &e->mb[my * e->mbw + mx];
+                const mv_t pmv = {mb->mvx, mb->mvy};   /* previous picture's vector here (intra macroblocks carry 0) */
                 memset(mb, 0, sizeof(*mb));
                 mb->type = H264O_MB_P16;
                 if (!zero_mv_all_zero(e, mx, my)) {
                     int cost = 0;
-                    mv_t m = motion_search(e, mx, my, &cost);
+                    mv_t m = motion_search(e, mx, my, pmv, &cost);
                     e->me_cost += (uint32_t)(cost < 16383 ? cost : 16383);
                     mb->mvx = m.x;
                     mb->mvy = m.y;

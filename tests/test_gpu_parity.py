@@ -137,7 +137,7 @@ def test_reference_forms_of_the_kernels(monkeypatch):
 
 def test_emulation_prevention_slow_path():
     """slices whose payload needs 00 00 03 escapes: k_pack counts the sites, the host inserts the bytes"""
-    w, h = 176, 144
+    w, h = 320, 240
     for qp in (26, 30):
         enc = capi.Encoder(w, h, qp=qp, gop=100)
         orc = OracleEncoder(w, h, qp=qp, gop=100)

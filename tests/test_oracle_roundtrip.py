@@ -69,7 +69,7 @@ def test_forced_idr_and_qp_change():
 
 def test_emulation_prevention_inside_slices():
     """the 'ramp' input makes slice payloads that contain 00 00 0x: the escaped stream must round-trip"""
-    w, h = 176, 144
+    w, h = 320, 240
     enc = OracleEncoder(w, h, qp=30, gop=100)
     dec = OracleDecoder()
     escaped = 0
