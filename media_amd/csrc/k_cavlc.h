@@ -340,6 +340,17 @@ __device__ __forceinline__ void code_slot(S& s, const CavlcParams& C, int mbi, i
     }
 }
 
+// boundary strengths of every macroblock for the loop filter (lane = macroblock, edge segment).  Its own small
+// launch on the reconstruction stream: the filter then never waits for the entropy-coding stream.
+__global__ __launch_bounds__(64) void k_bs(CavlcParams C0)
+{
+    __builtin_amdgcn_s_setprio(2);
+    const CavlcParams C = batch_view(C0, blockIdx.y);
+    const int lane = threadIdx.x, slot = lane & 31;
+    const int mbi = blockIdx.x * 2 + (lane >> 5);
+    if (mbi < C.nmb) C.bs[(size_t)mbi * 32 + slot] = (uint8_t)mb_edge_strength(C.mb + mbi, mbi % C.mbw, mbi / C.mbw, C.mbw, slot);
+}
+
 template <bool WRITE>
 __global__ __launch_bounds__(64) void k_cavlc(CavlcParams C0)
 {
@@ -354,7 +365,6 @@ __global__ __launch_bounds__(64) void k_cavlc(CavlcParams C0)
         if (live) code_slot(s, C, mbi, slot);
         if (live) C.slotbits[(size_t)mbi * 32 + slot] = (uint16_t)s.n;
         if (live && s.n && s.n <= 64u) C.slotcode[(size_t)mbi * 32 + slot] = s.acc;
-        if (live && C.bs) C.bs[(size_t)mbi * 32 + slot] = (uint8_t)mb_edge_strength(C.mb + mbi, mbi % C.mbw, mbi / C.mbw, C.mbw, slot);
         const int tot = group_sum<32>((int)s.n);
         if (live && slot == 0) C.mbbits[mbi] = (uint32_t)tot;
     } else {

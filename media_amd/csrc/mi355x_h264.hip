@@ -133,7 +133,7 @@ struct Slot {
     bool idr = false;
     bool busy = false;
     hipEvent_t done = nullptr;
-    hipEvent_t recon_ready = nullptr, bs_ready = nullptr, entropy_done = nullptr;   // fork / join of the entropy-coding stream
+    hipEvent_t recon_ready = nullptr, entropy_done = nullptr;   // fork / join of the entropy-coding stream
     // stats events of this frame: pairs (start, stop, kernel id, launches, mbs)
     struct Ev { hipEvent_t a, b; int k; uint32_t launches, mbs; };
     std::vector<Ev> evs;
@@ -329,20 +329,22 @@ int submit(mi355x_h264_encoder* e, const uint8_t* d_src, size_t src_item_stride,
         H.len[g] = (unsigned char)build_slice_header(e, idr, (e->idr_id + g * e->idr_step) & 0xFF, &hdr);
         H.bits[g] = hdr;
     }
-    // entropy coding needs only levels / MbInfo, the loop filter only the reconstruction: run them side by side
+    // entropy coding needs only levels / MbInfo, the loop filter the reconstruction and the boundary strengths
+    // (a small launch of its own on this stream): the two run side by side and the filter never waits for the coder
     hipStream_t ec = e->stream_ec;
+    CavlcParams C{};
+    C.mb = e->d_mb; C.levels = e->d_levels; C.mvd = e->d_mvd; C.mbw = e->mbw; C.nmb = e->nmb; C.p_slice = idr ? 0 : 1;
+    C.slotbits = e->d_slotbits; C.slotcode = e->d_slotcode; C.mbbits = e->d_mbbits; C.bitbuf = S.d_bitbuf;
+    C.bs = (uint8_t*)e->d_bs;
+    C.st_mb = e->nmb; C.st_bitbuf = e->st_bitbuf_bytes / 4;
+    const int cavlc_grid = (e->nmb + 1) / 2;
+    if (!e->cfg.disable_deblock && !e->diag_mode) hipLaunchKernelGGL(k_bs, dim3(cavlc_grid, G), dim3(64), 0, st, C);
     HIPCHK(e, hipEventRecord(S.recon_ready, st));
     HIPCHK(e, hipStreamWaitEvent(ec, S.recon_ready, 0));
     {
         StatScope sc(e, &S, MI355X_H264_K_CAVLC, 4, (uint32_t)(e->nmb * e->G), ec);
-        CavlcParams C{};
-        C.mb = e->d_mb; C.levels = e->d_levels; C.mvd = e->d_mvd; C.mbw = e->mbw; C.nmb = e->nmb; C.p_slice = idr ? 0 : 1;
-        C.slotbits = e->d_slotbits; C.slotcode = e->d_slotcode; C.mbbits = e->d_mbbits; C.bitbuf = S.d_bitbuf;
-        C.bs = (!e->cfg.disable_deblock && !e->diag_mode) ? (uint8_t*)e->d_bs : nullptr;
-        C.st_mb = e->nmb; C.st_bitbuf = e->st_bitbuf_bytes / 4;
-        const int grid = (e->nmb + 1) / 2;
+        const int grid = cavlc_grid;
         hipLaunchKernelGGL(k_cavlc<false>, dim3(grid, G), dim3(64), 0, ec, C);
-        HIPCHK(e, hipEventRecord(S.bs_ready, ec));   // the count pass also produced the boundary strengths
         hipLaunchKernelGGL(k_bit_scan, dim3(G), dim3(SCAN_NT), 0, ec, C, H, S.d_info, e->d_me_cost);
         hipLaunchKernelGGL(k_cavlc<true>, dim3(grid, G), dim3(64), 0, ec, C);
         // access unit layout in the pinned buffer: [pad][SPS PPS (IDR only)][00 00 00 01 hdr][payload...]
@@ -360,7 +362,6 @@ int submit(mi355x_h264_encoder* e, const uint8_t* d_src, size_t src_item_stride,
         for (int p = 0; p < 3; p++)
             HIPCHK(e, hipMemcpyAsync(e->d_pre[p], e->d_planes[cur][p], (p ? e->st_c : e->st_y) * e->G, hipMemcpyDeviceToDevice, st));
     if (!e->cfg.disable_deblock) {
-        HIPCHK(e, hipStreamWaitEvent(st, S.bs_ready, 0));
         const int steps = e->mbw + 2 * (e->mbh - 1);
         StatScope sc(e, &S, MI355X_H264_K_DEBLOCK, (uint32_t)(e->diag_mode ? steps : 1), (uint32_t)(e->nmb * e->G));
         DbParams D{};
@@ -554,7 +555,6 @@ int mi355x_h264_create(const mi355x_h264_config* cfg, mi355x_h264_encoder** out)
         CK(hipHostMalloc((void**)&S.h_au, e->st_au * Gn, hipHostMallocDefault));
         CK(hipEventCreateWithFlags(&S.done, hipEventDisableTiming));
         CK(hipEventCreateWithFlags(&S.recon_ready, hipEventDisableTiming));
-        CK(hipEventCreateWithFlags(&S.bs_ready, hipEventDisableTiming));
         CK(hipEventCreateWithFlags(&S.entropy_done, hipEventDisableTiming));
     }
     CK(hipDeviceSynchronize());
@@ -582,7 +582,6 @@ void mi355x_h264_destroy(mi355x_h264_encoder* e)
         if (S.h_au) (void)hipHostFree(S.h_au);
         if (S.done) (void)hipEventDestroy(S.done);
         if (S.recon_ready) (void)hipEventDestroy(S.recon_ready);
-        if (S.bs_ready) (void)hipEventDestroy(S.bs_ready);
         if (S.entropy_done) (void)hipEventDestroy(S.entropy_done);
         for (auto& ev : S.evs) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
     }
