@@ -3,9 +3,10 @@
 // Behaviour contract (what /root/reference/video_codec/VideoCodecApi.cpp:21-55 does): the integer property
 // ro.vmi.demo.video.encode.format names the backend; an unknown value or a failed allocation yields
 // VIDEO_ENCODER_CREATE_FAIL; DestroyVideoEncoder deletes the object and accepts nullptr.  The reference knows
-// 0 (OpenH264), 1 (NETINT H.264) and 2 (NETINT H.265); this build registers 3 = MI355X.  The engines behind
-// 0..2 are third-party binaries that do not exist here, so those slots are known-but-unavailable; in the
-// reference tree the maintainer keeps its switch and adds one case.
+// 0 (OpenH264), 1 (NETINT H.264) and 2 (NETINT H.265); this build registers 3 = MI355X and keeps 0: the OpenH264
+// backend binds libopenh264.so at InitEncoder like the reference and fails there when the library is absent (it is,
+// on this pool).  1 and 2 need NETINT hardware and its closed library: known-but-unavailable.  In the reference
+// tree the maintainer keeps its switch and adds one case.
 #define LOG_TAG "VideoCodecApi"
 #include "VideoCodecApi.h"
 #include <array>
@@ -13,6 +14,9 @@
 #include "MediaLog.h"
 #include "Property.h"
 #include "VideoEncoderMI355X.h"
+#ifdef HAVE_OPENH264_HEADERS
+#include "OpenH264Backend.h"
+#endif
 
 namespace {
 
@@ -25,9 +29,15 @@ struct Backend {
 };
 
 VideoEncoder *MakeMI355X() { return new (std::nothrow) VideoEncoderMI355X(); }
+#ifdef HAVE_OPENH264_HEADERS
+VideoEncoder *MakeOpenH264() { return new (std::nothrow) OpenH264Backend(); }   // binds libopenh264.so in InitEncoder
+constexpr Maker kOpenH264Maker = &MakeOpenH264;
+#else
+constexpr Maker kOpenH264Maker = nullptr;   // built without the OpenH264 ABI headers
+#endif
 
 const std::array<Backend, 4> kBackends = {{
-    {0, "OpenH264 (CPU)", nullptr},
+    {0, "OpenH264 (CPU, needs libopenh264.so at run time)", kOpenH264Maker},
     {1, "NETINT T408 H.264", nullptr},
     {2, "NETINT T408 H.265", nullptr},
     {3, "AMD Instinct MI355X (HIP)", &MakeMI355X},

@@ -92,10 +92,22 @@ def test_property_store_semantics():
 def test_factory_and_init_error_paths():
     from media_amd import videocodec as vc
     # unknown / unbuilt backends -> CREATE_FAIL (VideoCodecApi.cpp:36-38)
-    for fmt in (7, -1, 0, 1, 2):
+    for fmt in (7, -1, 1, 2):
         vc.set_video_mode(1280, 720, fmt=fmt)
         e = vc.VideoEncoder()
         assert e.rc_create == vc.CREATE_FAIL
+    # type 0 = OpenH264 through libopenh264.so, bound at InitEncoder like the reference (:197-226): with the
+    # backend compiled in (OpenH264 ABI headers present at build time) the object is created and InitEncoder fails
+    # because no such library exists on this pool (:203-208); without the headers the slot is unbuilt
+    vc.set_video_mode(1280, 720, fmt=0)
+    e = vc.VideoEncoder()
+    assert e.rc_create in (vc.SUCCESS, vc.CREATE_FAIL)
+    if e.rc_create == vc.SUCCESS:
+        import ctypes.util
+        if ctypes.util.find_library("openh264") is None:
+            assert e.init() == vc.INIT_FAIL
+        e.destroy()
+        assert e.delete() == vc.SUCCESS
     assert vc.lib().vc_delete(None) == vc.SUCCESS              # DestroyVideoEncoder(nullptr) (:48-51)
     vc.set_video_mode(1280, 720, fmt=3)
     e = vc.VideoEncoder()
