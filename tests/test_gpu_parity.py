@@ -309,3 +309,39 @@ def test_maximum_picture_size_4096():
         bs, _ = enc.encode(f)
         assert bs == orc.encode(f)[0]
     enc.close()
+
+
+def test_randomized_configurations():
+    """seeded sweep over geometry (odd macroblock counts, crops, one-macroblock pictures), QP, GOP length, profile,
+    loop filter on/off, I420 / NV12 and lockstep batch size: every access unit against the oracle"""
+    import random
+    import torch
+    rng = random.Random(20261004)
+    sizes = [(16, 16), (32, 16), (16, 48), (48, 80), (50, 34), (178, 98), (130, 66), (256, 32), (34, 226), (320, 176), (98, 130), (2048, 16)]
+    for case in range(36):
+        w, h = sizes[case] if case < len(sizes) else (2 * rng.randint(8, 200), 2 * rng.randint(8, 150))
+        qp = rng.choice([14, 22, 26, 31, 37, 44])
+        gop = rng.choice([1, 2, 3, 5])
+        prof = rng.choice([66, 77, 100])
+        nodb = rng.random() < 0.25
+        nv12 = rng.random() < 0.5
+        G = rng.choice([1, 1, 2, 3])
+        kind = rng.choice(["s1", "s1", "s2", "s3", "ramp"])
+        frames = synth.sequence(kind, w, h, gop * G if G > 1 else 5)
+        tag = "case %d: %dx%d qp %d gop %d profile %d nodeblock %d nv12 %d batch %d %s" % (case, w, h, qp, gop, prof, nodb, nv12, G, kind)
+        orc = OracleEncoder(w, h, qp=qp, gop=gop, profile_idc=prof, disable_deblock=int(nodb))
+        want = [orc.encode(f)[0] for f in frames]
+        pics = [(_to_nv12(f, w, h) if nv12 else f) for f in frames]
+        dev = torch.from_numpy(np.stack(pics)).cuda()
+        fbytes = w * h * 3 // 2
+        enc = capi.Encoder(w, h, qp=qp, gop=gop, profile_idc=prof, disable_deblock=int(nodb), batch=G, input_format=int(nv12))
+        if G == 1:
+            for i in range(len(frames)):
+                assert enc.encode_device(dev[i].data_ptr())[0] == want[i], tag + " picture %d" % i
+        else:
+            cap = max(4096, gop * fbytes * 2)
+            out, szs, gb = np.zeros(G * cap, np.uint8), np.zeros(G * gop, np.uint32), np.zeros(G, np.uint64)
+            enc.encode_gops_device(dev.data_ptr(), fbytes, gop * fbytes, gop, out, cap, szs, gb)
+            for g in range(G):
+                assert out[g * cap: g * cap + int(gb[g])].tobytes() == b"".join(want[g * gop:(g + 1) * gop]), tag + " GOP %d" % g
+        enc.close()
