@@ -6,10 +6,12 @@
 // Every syntax element of a macroblock depends only on data that is final once
 // the reconstruction kernels have run (levels, TotalCoeff of neighbours, motion
 // vector differences, skip flags), so the slice is coded in three launches:
-//   k_cavlc<false>  one lane per (macroblock, block slot): bit LENGTH of each slot
+//   k_cavlc<false>  one lane per (macroblock, block slot): codes the slot once, keeps its
+//                   bit LENGTH and - when they fit 64 - the bits themselves
 //   k_bit_scan      exclusive prefix sum of macroblock lengths -> bit offsets,
 //                   slice header, trailing mb_skip_run and rbsp stop bit
-//   k_cavlc<true>   same traversal, now writing bits at their final position
+//   k_cavlc<true>   places every stored slot at its final bit position (slots longer
+//                   than 64 bits are coded again, straight into the buffer)
 //   k_pack          device bit buffer -> pinned host access unit, counting the
 //                   byte patterns that need emulation prevention (7.4.1)
 #pragma once
@@ -266,7 +268,7 @@ struct CavlcParams {
     unsigned long long* slotcode;   // 32 per macroblock: the slot's bits, left aligned, when slotbits <= 64
     uint32_t* mbbits;     // per macroblock, then (after the scan) bit offsets
     uint32_t* bitbuf;     // zeroed slice payload buffer
-    uint8_t* bs;          // boundary strengths for the loop filter, 32 B per macroblock (written by the count pass)
+    uint8_t* bs;          // boundary strengths for the loop filter, 32 B per macroblock (written by k_bs)
     int st_mb;            // lockstep batch: macroblocks per batch item (all per-MB arrays)
     size_t st_bitbuf;     // 32-bit words between the payload buffers of two batch items
 };
@@ -281,7 +283,6 @@ enum { MAX_BATCH = 64 };
 struct HdrBatch { unsigned long long bits[MAX_BATCH]; unsigned char len[MAX_BATCH]; };  // slice header of every batch item
 
 // 8.7.2.1 boundary strength of one 4-sample edge segment; l = (dir, edge, segment) within the macroblock.
-// Computed here because this pass already walks (macroblock, 32 lanes) over final MbInfo.
 __device__ __forceinline__ int mb_edge_strength(const MbInfo* q, int mx, int my, int mbw, int l)
 {
     const int dir = l >> 4, e = (l >> 2) & 3, k = l & 3;
