@@ -1,8 +1,10 @@
-// media_amd/csrc/k_deblock.h -- in-loop deblocking filter (H.264 8.7), one
-// wavefront per macroblock, launched one wavefront step (mx + 2*my == s) at a
-// time: macroblock (mx,my) filters against samples already finished by its left,
-// top and top-right neighbours, which 8.7 orders strictly (vertical edges of a
-// macroblock, then its horizontal edges, macroblocks in raster order).
+// media_amd/csrc/k_deblock.h -- in-loop deblocking filter (H.264 8.7).  Macroblock (mx,my)
+// filters against samples already finished by its left, top and top-right neighbours, which
+// 8.7 orders strictly (vertical edges of a macroblock, then its horizontal edges, macroblocks
+// in raster order).  Two forms, same results:
+//   k_deblock_rows  (in use) one launch, one persistent wave per macroblock row (further down)
+//   k_deblock_diag  (first form; MI355X_H264_DIAG=1) one wavefront per macroblock, one launch
+//                   per wavefront step mx + 2*my == s
 //
 // SURVEY.md 8a row a6.4 (iLoopFilterDisableIdc = 0 at
 // /root/reference/video_codec/VideoEncoderOpenH264.cpp:295; alpha/beta offsets 0).

@@ -1,7 +1,10 @@
-// media_amd/csrc/k_intra.h -- IDR pictures: Intra16x16 + chroma intra, one
-// wavefront per macroblock, launched one anti-diagonal (mx + my == s) at a time
-// because prediction needs the left / top / top-left reconstruction (8.3.3, 8.3.4).
-// Kernel boundaries carry the dependency, so no in-kernel hand-off is needed.
+// media_amd/csrc/k_intra.h -- IDR pictures: Intra16x16 + chroma intra.  Prediction needs the
+// left / top / top-left reconstruction (8.3.3, 8.3.4), so macroblocks run as a wavefront:
+//   k_intra_rows  (the form in use) one persistent wave per macroblock row, row r one
+//                 macroblock behind row r-1, bottom sample rows handed down as {tag, data}
+//                 granules (same hand-off as the loop filter, k_deblock.h)
+//   k_intra_diag  (first, simpler form; MI355X_H264_DIAG=1) one launch per anti-diagonal
+//                 mx + my == s, kernel boundaries carry the dependency
 //
 // SURVEY.md 8a row a6 / a6.2 (inside ISVCEncoder::EncodeFrame,
 // /root/reference/video_codec/VideoEncoderOpenH264.cpp:344).

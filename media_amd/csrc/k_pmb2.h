@@ -1,13 +1,14 @@
 // media_amd/csrc/k_pmb2.h -- inter macroblock coding, second form of k_pmb.h (same results, bit for bit).
 //
-// One wavefront per macroblock with lane = (4x4 block, row): every lane owns FOUR consecutive samples of
-// one row from motion compensation to reconstruction, so nothing per-sample goes through LDS:
+// One wavefront per PAIR of macroblocks with lane = (4x4 block, row): every lane owns FOUR consecutive samples
+// of one row from motion compensation to reconstruction, so nothing per-sample goes through LDS:
 //   - the reference window is fetched as aligned dwords; a lane reads its samples as dwords and realigns
 //     them with v_alignbyte (no byte-wide LDS traffic)
 //   - the 4x4 transforms run as an in-lane row pass plus a column pass over the four lanes of a quad
 //     (DPP quad_perm broadcasts), forward and inverse
 //   - prediction stays in a register until it is added back for the reconstruction
-// Luma uses all 64 lanes (16 blocks x 4 rows), chroma 32 lanes (2 planes x 4 blocks x 4 rows).
+// Luma uses all 64 lanes (16 blocks x 4 rows) per macroblock; chroma needs 32 (2 planes x 4 blocks x 4 rows),
+// so the two macroblocks of the pair share one chroma pass.
 //
 // SURVEY.md 8a rows a6.2 + a6.3 (inside ISVCEncoder::EncodeFrame,
 // /root/reference/video_codec/VideoEncoderOpenH264.cpp:344).  Algorithmic HBM bytes per macroblock:
