@@ -268,6 +268,7 @@ struct CavlcParams {
     unsigned long long* slotcode;   // 32 per macroblock: the slot's bits, left aligned, when slotbits <= 64
     uint32_t* mbbits;     // per macroblock, then (after the scan) bit offsets
     uint32_t* bitbuf;     // zeroed slice payload buffer
+    int32_t* prevcoded;   // [nmb + 1]: index of the last macroblock before i that is not P_Skip (-1: none); k_skip_scan
     uint8_t* bs;          // boundary strengths for the loop filter, 32 B per macroblock (written by k_bs)
     int st_mb;            // lockstep batch: macroblocks per batch item (all per-MB arrays)
     size_t st_bitbuf;     // 32-bit words between the payload buffers of two batch items
@@ -275,6 +276,7 @@ struct CavlcParams {
 __device__ __forceinline__ CavlcParams batch_view(CavlcParams C, int g)
 {
     C.mb += (size_t)g * C.st_mb; C.levels += (size_t)g * C.st_mb * LV_STRIDE; C.mvd += (size_t)g * C.st_mb * 2;
+    C.prevcoded += (size_t)g * (C.st_mb + 1);
     C.slotbits += (size_t)g * C.st_mb * 32; C.slotcode += (size_t)g * C.st_mb * 32; C.mbbits += (size_t)g * C.st_mb; C.bitbuf += (size_t)g * C.st_bitbuf;
     if (C.bs) C.bs += (size_t)g * C.st_mb * 32;
     return C;
@@ -308,9 +310,7 @@ __device__ __forceinline__ void code_slot(S& s, const CavlcParams& C, int mbi, i
     const bool i16 = m->type == MB_I16;
     if (slot == 0) {
         if (C.p_slice) {
-            unsigned run = 0;
-            for (int j = mbi - 1; j >= 0 && C.mb[j].type == MB_PSKIP; j--) run++;
-            put_ue(s, run);
+            put_ue(s, (unsigned)(mbi - 1 - C.prevcoded[mbi]));   // mb_skip_run: the P_Skip macroblocks right before this one
         }
         if (i16) {
             const unsigned t = 1u + m->i16_mode + 4u * (unsigned)cbpc + (cbpl ? 12u : 0u);
@@ -350,6 +350,35 @@ __global__ __launch_bounds__(64) void k_bs(CavlcParams C0)
     const int lane = threadIdx.x, slot = lane & 31;
     const int mbi = blockIdx.x * 2 + (lane >> 5);
     if (mbi < C.nmb) C.bs[(size_t)mbi * 32 + slot] = (uint8_t)mb_edge_strength(C.mb + mbi, mbi % C.mbw, mbi / C.mbw, C.mbw, slot);
+}
+
+// P slices: prevcoded[i] = index of the last macroblock before i that is not P_Skip (a prefix maximum over the
+// picture, one 256-thread workgroup per picture), so that mb_skip_run costs no walk over the skipped macroblocks
+// (a static screen is one long run).
+__global__ __launch_bounds__(256) void k_skip_scan(CavlcParams C0)
+{
+    const CavlcParams C = batch_view(C0, blockIdx.x);
+    __shared__ int s_last[256];
+    const int t = threadIdx.x;
+    const int per = (C.nmb + 255) / 256;
+    const int b0 = min(C.nmb, t * per), b1 = min(C.nmb, b0 + per);
+    int last = -1;
+    for (int i = b0; i < b1; i++)
+        if (C.mb[i].type != MB_PSKIP) last = i;
+    s_last[t] = last;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {       // inclusive prefix maximum
+        const int v = t >= o ? s_last[t - o] : -1;
+        __syncthreads();
+        s_last[t] = max(s_last[t], v);
+        __syncthreads();
+    }
+    int run = t ? s_last[t - 1] : -1;         // last coded macroblock before this thread's range
+    for (int i = b0; i < b1; i++) {
+        C.prevcoded[i] = run;
+        if (C.mb[i].type != MB_PSKIP) run = i;
+    }
+    if (t == 255) C.prevcoded[C.nmb] = s_last[255];
 }
 
 template <bool WRITE>
@@ -458,8 +487,7 @@ __global__ __launch_bounds__(SCAN_NT) void k_bit_scan(CavlcParams C0, HdrBatch H
         BitCount c;
         c.init(0);
         if (C.p_slice) {
-            unsigned skips = 0;
-            for (int j = C.nmb - 1; j >= 0 && C.mb[j].type == MB_PSKIP; j--) skips++;
+            const unsigned skips = (unsigned)(C.nmb - 1 - C.prevcoded[C.nmb]);   // P_Skip macroblocks that end the slice
             if (skips) { put_ue(s, skips); put_ue(c, skips); }
         }
         s.put(1, 1);  // rbsp_stop_one_bit

@@ -158,6 +158,7 @@ struct mi355x_h264_encoder {
     uint16_t* d_slotbits = nullptr;
     unsigned long long* d_slotcode = nullptr;
     uint32_t* d_mbbits = nullptr;
+    int32_t* d_prevcoded = nullptr;          // [G][nmb + 1] skip-run helper (k_skip_scan)
     unsigned long long* d_handoff = nullptr; // row-to-row hand-off of the wavefront kernels
     uint32_t* d_bs = nullptr;                // boundary strengths, 32 B per macroblock
     uint16_t* d_me_cost = nullptr;           // [G][nmb] per-macroblock motion cost (scene-change statistic)
@@ -335,7 +336,7 @@ int submit(mi355x_h264_encoder* e, const uint8_t* d_src, size_t src_item_stride,
     CavlcParams C{};
     C.mb = e->d_mb; C.levels = e->d_levels; C.mvd = e->d_mvd; C.mbw = e->mbw; C.nmb = e->nmb; C.p_slice = idr ? 0 : 1;
     C.slotbits = e->d_slotbits; C.slotcode = e->d_slotcode; C.mbbits = e->d_mbbits; C.bitbuf = S.d_bitbuf;
-    C.bs = (uint8_t*)e->d_bs;
+    C.bs = (uint8_t*)e->d_bs; C.prevcoded = e->d_prevcoded;
     C.st_mb = e->nmb; C.st_bitbuf = e->st_bitbuf_bytes / 4;
     const int cavlc_grid = (e->nmb + 1) / 2;
     if (!e->cfg.disable_deblock && !e->diag_mode) hipLaunchKernelGGL(k_bs, dim3(cavlc_grid, G), dim3(64), 0, st, C);
@@ -344,6 +345,7 @@ int submit(mi355x_h264_encoder* e, const uint8_t* d_src, size_t src_item_stride,
     {
         StatScope sc(e, &S, MI355X_H264_K_CAVLC, 4, (uint32_t)(e->nmb * e->G), ec);
         const int grid = cavlc_grid;
+        if (!idr) hipLaunchKernelGGL(k_skip_scan, dim3(G), dim3(256), 0, ec, C);
         hipLaunchKernelGGL(k_cavlc<false>, dim3(grid, G), dim3(64), 0, ec, C);
         hipLaunchKernelGGL(k_bit_scan, dim3(G), dim3(SCAN_NT), 0, ec, C, H, S.d_info, e->d_me_cost);
         hipLaunchKernelGGL(k_cavlc<true>, dim3(grid, G), dim3(64), 0, ec, C);
@@ -529,6 +531,7 @@ int mi355x_h264_create(const mi355x_h264_config* cfg, mi355x_h264_encoder** out)
     CK(hipMalloc((void**)&e->d_slotbits, Gn * e->nmb * 32 * sizeof(uint16_t)));
     CK(hipMalloc((void**)&e->d_slotcode, Gn * e->nmb * 32 * sizeof(unsigned long long)));
     CK(hipMalloc((void**)&e->d_mbbits, Gn * e->nmb * sizeof(uint32_t)));
+    CK(hipMalloc((void**)&e->d_prevcoded, Gn * (e->nmb + 1) * sizeof(int32_t)));
     e->st_handoff = (size_t)e->nmb * 24;
     CK(hipMalloc((void**)&e->d_handoff, Gn * e->st_handoff * sizeof(unsigned long long)));
     CK(hipMemset(e->d_handoff, 0, Gn * e->st_handoff * sizeof(unsigned long long)));
@@ -572,7 +575,7 @@ void mi355x_h264_destroy(mi355x_h264_encoder* e)
         for (int p = 0; p < 3; p++) (void)hipFree(e->d_planes[b][p]);
     for (int p = 0; p < 3; p++) (void)hipFree(e->d_pre[p]);
     (void)hipFree(e->d_mb); (void)hipFree(e->d_levels); (void)hipFree(e->d_mvd);
-    (void)hipFree(e->d_slotbits); (void)hipFree(e->d_slotcode); (void)hipFree(e->d_mbbits); (void)hipFree(e->d_stage);
+    (void)hipFree(e->d_slotbits); (void)hipFree(e->d_slotcode); (void)hipFree(e->d_mbbits); (void)hipFree(e->d_prevcoded); (void)hipFree(e->d_stage);
     (void)hipFree(e->d_handoff); (void)hipFree(e->d_bs); (void)hipFree(e->d_me_cost);
     if (e->h_stage) (void)hipHostFree(e->h_stage);
     for (auto& S : e->slots) {
