@@ -343,13 +343,20 @@ __device__ __forceinline__ void code_slot(S& s, const CavlcParams& C, int mbi, i
 
 // boundary strengths of every macroblock for the loop filter (lane = macroblock, edge segment).  Its own small
 // launch on the reconstruction stream: the filter then never waits for the entropy-coding stream.
-__global__ __launch_bounds__(64) void k_bs(CavlcParams C0)
+// anybs[item] is set to the picture's serial as soon as any strength of the picture is non-zero: a picture without
+// any (a static screen) needs no loop filter pass at all, and k_deblock_rows returns at once.
+__global__ __launch_bounds__(64) void k_bs(CavlcParams C0, unsigned* anybs, unsigned serial)
 {
     __builtin_amdgcn_s_setprio(2);
     const CavlcParams C = batch_view(C0, blockIdx.y);
     const int lane = threadIdx.x, slot = lane & 31;
     const int mbi = blockIdx.x * 2 + (lane >> 5);
-    if (mbi < C.nmb) C.bs[(size_t)mbi * 32 + slot] = (uint8_t)mb_edge_strength(C.mb + mbi, mbi % C.mbw, mbi / C.mbw, C.mbw, slot);
+    int bs = 0;
+    if (mbi < C.nmb) {
+        bs = mb_edge_strength(C.mb + mbi, mbi % C.mbw, mbi / C.mbw, C.mbw, slot);
+        C.bs[(size_t)mbi * 32 + slot] = (uint8_t)bs;
+    }
+    if (__ballot(bs != 0) != 0ull && lane == 0) anybs[blockIdx.y] = serial;   // same value from every writer: a plain store
 }
 
 // P slices: prevcoded[i] = index of the last macroblock before i that is not P_Skip (a prefix maximum over the

@@ -209,6 +209,7 @@ struct DbRowParams {
     const uint32_t* bs;  // [nmb][8]: boundary strengths (k_cavlc count pass), word dir*4+edge, byte = segment along the edge
     unsigned* err;
     unsigned serial;     // changes every picture, never 0
+    const unsigned* anybs;   // [item] == serial when the picture has any non-zero boundary strength (k_bs)
     // lockstep batch strides (gridDim.y items)
     size_t st_y, st_c, st_handoff;   // bytes, bytes, u64 words
     int st_mb;
@@ -252,6 +253,7 @@ __global__ __launch_bounds__(64) void k_deblock_rows(DbRowParams R)
 {
     // dependency-bound: when a throughput kernel of another stream shares the SIMD, this wave issues first
     __builtin_amdgcn_s_setprio(3);
+    if (R.anybs[blockIdx.y] != R.serial) return;   // no edge of this picture is filtered: nothing to do, nobody waits
     DbParams D = R.d;
     {
         const size_t g = blockIdx.y;

@@ -158,6 +158,7 @@ struct mi355x_h264_encoder {
     uint16_t* d_slotbits = nullptr;
     unsigned long long* d_slotcode = nullptr;
     uint32_t* d_mbbits = nullptr;
+    unsigned* d_anybs = nullptr;             // [G] picture serial when any boundary strength is non-zero
     int32_t* d_prevcoded = nullptr;          // [G][nmb + 1] skip-run helper (k_skip_scan)
     unsigned long long* d_handoff = nullptr; // row-to-row hand-off of the wavefront kernels
     uint32_t* d_bs = nullptr;                // boundary strengths, 32 B per macroblock
@@ -339,7 +340,12 @@ int submit(mi355x_h264_encoder* e, const uint8_t* d_src, size_t src_item_stride,
     C.bs = (uint8_t*)e->d_bs; C.prevcoded = e->d_prevcoded;
     C.st_mb = e->nmb; C.st_bitbuf = e->st_bitbuf_bytes / 4;
     const int cavlc_grid = (e->nmb + 1) / 2;
-    if (!e->cfg.disable_deblock && !e->diag_mode) hipLaunchKernelGGL(k_bs, dim3(cavlc_grid, G), dim3(64), 0, st, C);
+    unsigned db_serial = 0;
+    if (!e->cfg.disable_deblock && !e->diag_mode) {
+        e->serial = e->serial == 0xFFFFFFFFu ? 1 : e->serial + 1;   // the serial the loop filter of this picture will run under
+        db_serial = e->serial;
+        hipLaunchKernelGGL(k_bs, dim3(cavlc_grid, G), dim3(64), 0, st, C, e->d_anybs, db_serial);
+    }
     HIPCHK(e, hipEventRecord(S.recon_ready, st));
     HIPCHK(e, hipStreamWaitEvent(ec, S.recon_ready, 0));
     {
@@ -382,9 +388,8 @@ int submit(mi355x_h264_encoder* e, const uint8_t* d_src, size_t src_item_stride,
             DbRowParams R{};
             R.d = D; R.handoff = e->d_handoff; R.err = S.h_err;
             R.st_y = e->st_y; R.st_c = e->st_c; R.st_handoff = e->st_handoff; R.st_mb = e->nmb;
-            e->serial = e->serial == 0xFFFFFFFFu ? 1 : e->serial + 1;
-            R.serial = e->serial;
-            R.bs = e->d_bs;
+            R.serial = db_serial;
+            R.bs = e->d_bs; R.anybs = e->d_anybs;
             if (idr) hipLaunchKernelGGL(k_deblock_rows<true>, dim3(e->mbh, G), dim3(64), 0, st, R);
             else hipLaunchKernelGGL(k_deblock_rows<false>, dim3(e->mbh, G), dim3(64), 0, st, R);
         }
@@ -531,6 +536,8 @@ int mi355x_h264_create(const mi355x_h264_config* cfg, mi355x_h264_encoder** out)
     CK(hipMalloc((void**)&e->d_slotbits, Gn * e->nmb * 32 * sizeof(uint16_t)));
     CK(hipMalloc((void**)&e->d_slotcode, Gn * e->nmb * 32 * sizeof(unsigned long long)));
     CK(hipMalloc((void**)&e->d_mbbits, Gn * e->nmb * sizeof(uint32_t)));
+    CK(hipMalloc((void**)&e->d_anybs, Gn * sizeof(unsigned)));
+    CK(hipMemset(e->d_anybs, 0, Gn * sizeof(unsigned)));
     CK(hipMalloc((void**)&e->d_prevcoded, Gn * (e->nmb + 1) * sizeof(int32_t)));
     e->st_handoff = (size_t)e->nmb * 24;
     CK(hipMalloc((void**)&e->d_handoff, Gn * e->st_handoff * sizeof(unsigned long long)));
@@ -575,7 +582,7 @@ void mi355x_h264_destroy(mi355x_h264_encoder* e)
         for (int p = 0; p < 3; p++) (void)hipFree(e->d_planes[b][p]);
     for (int p = 0; p < 3; p++) (void)hipFree(e->d_pre[p]);
     (void)hipFree(e->d_mb); (void)hipFree(e->d_levels); (void)hipFree(e->d_mvd);
-    (void)hipFree(e->d_slotbits); (void)hipFree(e->d_slotcode); (void)hipFree(e->d_mbbits); (void)hipFree(e->d_prevcoded); (void)hipFree(e->d_stage);
+    (void)hipFree(e->d_slotbits); (void)hipFree(e->d_slotcode); (void)hipFree(e->d_mbbits); (void)hipFree(e->d_prevcoded); (void)hipFree(e->d_anybs); (void)hipFree(e->d_stage);
     (void)hipFree(e->d_handoff); (void)hipFree(e->d_bs); (void)hipFree(e->d_me_cost);
     if (e->h_stage) (void)hipHostFree(e->h_stage);
     for (auto& S : e->slots) {
