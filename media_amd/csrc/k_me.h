@@ -188,6 +188,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
             if (lane == 0) {
                 MbInfo* m = P.mb + mbi;
                 m->mvx = 0; m->mvy = 0; m->type = MB_P16;
+                m->i16_mode = 1;   // for k_pmb2: the zero-motion residual quantises to nothing (it resets the field)
                 P.me_cost[mbi] = 0;
             }
             return;
@@ -447,6 +448,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
     if (lane == 0) {
         MbInfo* m = P.mb + mbi;
         m->mvx = (int16_t)cx; m->mvy = (int16_t)cy; m->type = MB_P16;
+        m->i16_mode = 0;
         P.me_cost[mbi] = (uint16_t)(best_cost < 16383u ? best_cost : 16383u);   // scene-change statistic, summed by k_bit_scan
     }
 }

@@ -184,6 +184,7 @@ __global__ __launch_bounds__(64) void k_pmb2(FrameParams P0)
 
     // ---- wave-uniform context of both macroblocks (scalar unit) ----
     int mbi[2], mx[2], my[2], mvx[2], mvy[2], wxo[2], cxo[2];
+    bool zres[2];   // k_me found that the zero-motion residual quantises to nothing: prediction = reconstruction
     Mv pred[2], skip[2];
     MbInfo* m[2];
 #pragma unroll
@@ -193,6 +194,7 @@ __global__ __launch_bounds__(64) void k_pmb2(FrameParams P0)
         m[h] = P.mb + mbi[h];
         const int mvw = __builtin_amdgcn_readfirstlane(*(const int*)m[h]);   // mvx | mvy << 16
         mvx[h] = (int)(int16_t)(mvw & 0xFFFF); mvy[h] = mvw >> 16;
+        zres[h] = ((__builtin_amdgcn_readfirstlane(((const int*)m[h])[1]) >> 8) & 255) != 0;   // MbInfo.i16_mode, set by k_me
         pred[h] = predict_mv(P, mx[h], my[h], skip[h]);
     }
 
@@ -307,11 +309,12 @@ __global__ __launch_bounds__(64) void k_pmb2(FrameParams P0)
             else if (fy == 2) pred4 = avg4(Hv, Jv);
             else pred4 = avg4(Bv, Hv);
         }
-        int d[4];
+        int d[4] = {0, 0, 0, 0};
+        int nz = 0;
+        if (!zres[h]) {
 #pragma unroll
         for (int k = 0; k < 4; k++) d[k] = byte_of(src4[h], k) - byte_of(pred4, k);
         fdct_quad(d, r);
-        int nz = 0;
         const int zz = c_zz_row[r];
         {
             const Quant& qn = P.qy;
@@ -328,6 +331,7 @@ __global__ __launch_bounds__(64) void k_pmb2(FrameParams P0)
         nz += __builtin_amdgcn_mov_dpp(nz, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
         nz += __builtin_amdgcn_mov_dpp(nz, 0x4E, 0xf, 0xf, false);   // quad_perm [2,3,0,1]  -> TotalCoeff of the block in all 4 lanes
         idct_quad(d, r);
+        }
         const unsigned long long ymask = __ballot(nz != 0);
         cbp_luma[h] = ((ymask & 0xFFFFull) ? 1 : 0) | (((ymask >> 16) & 0xFFFFull) ? 2 : 0) | (((ymask >> 32) & 0xFFFFull) ? 4 : 0) |
                       (((ymask >> 48) & 0xFFFFull) ? 8 : 0);
@@ -358,6 +362,9 @@ __global__ __launch_bounds__(64) void k_pmb2(FrameParams P0)
 #pragma unroll
         for (int k = 0; k < 4; k++) cd[k] = byte_of(csrc4, k) - pv[k];
     }
+    const bool czero = zres[0] && (zres[1] || !two);   // both macroblocks: nothing to code, prediction = reconstruction
+    int any_dc[2] = {0, 0};
+    if (!czero) {
     fdct_quad(cd, r);
     cdc = cd[0];        // valid in lanes with r == 0
     const int zz = c_zz_row[r];
@@ -377,7 +384,6 @@ __global__ __launch_bounds__(64) void k_pmb2(FrameParams P0)
     }
     cnz += __builtin_amdgcn_mov_dpp(cnz, 0xB1, 0xf, 0xf, false);
     cnz += __builtin_amdgcn_mov_dpp(cnz, 0x4E, 0xf, 0xf, false);
-    int any_dc[2] = {0, 0};
     {   // chroma DC: block DCs sit in lanes h*32 + pl*16 + blk*4 (r == 0); the 2x2 transforms run on the scalar unit
         int mydeq = 0;
 #pragma unroll
@@ -397,6 +403,10 @@ __global__ __launch_bounds__(64) void k_pmb2(FrameParams P0)
         if (r == 0) cd[0] = mydeq;
     }
     idct_quad(cd, r);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++) cd[k] = 0;
+    }
     if (cact)
         *(uint32_t*)((cpl ? P.rec[2] : P.rec[1]) + (size_t)(8 * cmy + cy) * cs + 8 * cmx + cx) =
             pack4(clip255(byte_of(cpred4, 0) + cd[0]), clip255(byte_of(cpred4, 1) + cd[1]), clip255(byte_of(cpred4, 2) + cd[2]), clip255(byte_of(cpred4, 3) + cd[3]));
