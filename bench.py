@@ -110,7 +110,7 @@ def main():
                     help="layout of the resident pictures; nv12 + --profile main --fps 60 is BASELINE.json configs[2]")
     ap.add_argument("--profile", default="baseline", choices=["baseline", "main", "high"])
     ap.add_argument("--fps", type=int, default=30, choices=[30, 60])
-    ap.add_argument("--content", default="s1", choices=["s1", "s2", "s3"],
+    ap.add_argument("--content", default="s1", choices=["s1", "s2", "s3", "scroll"],
                     help="synthetic input of SURVEY.md 8(d); s1 pan+noise is the headline workload")
     args = ap.parse_args()
 

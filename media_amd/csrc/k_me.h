@@ -125,29 +125,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
     __syncthreads();
     const uint8_t* winb = (const uint8_t*)s_win;
 
-    // ---- 1. zero-motion test: does the residual at mv = 0 quantise to nothing?  lane = (4x4 block, row); luma rides
-    // in the low and chroma (lanes 0..31) in the high 16 bits of every register, so one packed forward transform
-    // (row pass in the lane, column pass over the DPP quad) serves both ----
+    // ---- 1. "nothing left to code" tests: does the residual against a given prediction quantise to nothing?
+    // lane = (4x4 block, row); luma rides in the low and chroma (lanes 0..31) in the high 16 bits of every register,
+    // so one packed forward transform (row pass in the lane, column pass over the DPP quad) serves both.  Tried at
+    // the zero vector (static content) and, when that fails, at the macroblock's previous-picture vector if it is a
+    // non-zero integer-sample vector (scrolling content); a hit fixes the vector and ends the search. ----
     {
         typedef unsigned short pk16 __attribute__((ext_vector_type(2)));
         const int r = lane & 3, b4 = lane >> 2;
+        const int cplz = lane >> 4, cyz = ((lane >> 3) & 1) * 4 + r, cxz = ((lane >> 2) & 1) * 4;   // chroma lane (lanes < 32)
         const uint32_t sy = *(const uint32_t*)(s_src + ((b4 >> 2) * 4 + r) * 16 + (b4 & 3) * 4);
-        const uint32_t ry = s_win[(ME_R + ME_AP + (b4 >> 2) * 4 + r) * ME_WDW + (ME_R + ME_AP) / 4 + (b4 & 3)];
-        uint32_t sc = 0, rc = 0;
-        if (lane < 32) {   // (plane, block, row) = (lane >> 4, (lane >> 2) & 3, r)
-            const int o = (lane >> 4) * 64 + (((lane >> 3) & 1) * 4 + r) * 8 + ((lane >> 2) & 1) * 4;
-            sc = *(const uint32_t*)(s_srcc + o); rc = *(const uint32_t*)(s_refc + o);
-        }
-        pk16 d[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const uint32_t sel = 0x0c040c00u + 0x00010001u * k;   // byte k of the low operand -> bits 0..7, of the high -> 16..23
-            d[k] = __builtin_bit_cast(pk16, __builtin_amdgcn_perm(sc, sy, sel)) - __builtin_bit_cast(pk16, __builtin_amdgcn_perm(rc, ry, sel));
-        }
-        {
-            const pk16 s0 = d[0] + d[3], s1 = d[1] + d[2], d0 = d[0] - d[3], d1 = d[1] - d[2];
-            d[0] = s0 + s1; d[1] = d0 + d0 + d1; d[2] = s0 - s1; d[3] = d0 - d1 - d1;
-        }
+        const uint32_t sc = lane < 32 ? *(const uint32_t*)(s_srcc + cplz * 64 + cyz * 8 + cxz) : 0u;
         const uint32_t one = 0x00010001u;
         const pk16 sA = __builtin_bit_cast(pk16, (r & 1) ? 0xFFFFFFFFu : one);                          // +-1
         const pk16 mA = __builtin_bit_cast(pk16, r == 1 ? 2u * one : one);
@@ -157,41 +145,79 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
         const uint32_t t1 = (uint32_t)(P.qy.thr_inter[1] - 1) | ((uint32_t)(P.qc.thr_inter[1] - 1) << 16);
         const uint32_t t2 = (uint32_t)(P.qy.thr_inter[2] - 1) | ((uint32_t)(P.qc.thr_inter[2] - 1) << 16);
         const pk16 th_even = __builtin_bit_cast(pk16, (r & 1) ? t2 : t0), th_odd = __builtin_bit_cast(pk16, (r & 1) ? t1 : t2);
-        uint32_t over = 0;
-        int dc = 0;
+        // ry / rc: this lane's four predicted luma / chroma samples (rc = 0 in lanes >= 32)
+        auto quantises_to_nothing = [&](uint32_t ry, uint32_t rc) -> bool {
+            pk16 d[4];
 #pragma unroll
-        for (int c = 0; c < 4; c++) {
-            const pk16 q0 = __builtin_bit_cast(pk16, quad_bcast<0>(__builtin_bit_cast(int, d[c])));
-            const pk16 q1 = __builtin_bit_cast(pk16, quad_bcast<1>(__builtin_bit_cast(int, d[c])));
-            const pk16 q2 = __builtin_bit_cast(pk16, quad_bcast<2>(__builtin_bit_cast(int, d[c])));
-            const pk16 q3 = __builtin_bit_cast(pk16, quad_bcast<3>(__builtin_bit_cast(int, d[c])));
-            const pk16 A = q0 + sA * q3, B = q1 + sA * q2;
-            const pk16 w = mA * A + mB * B;                        // row r of the 4x4 core transform, column c
-            if (c == 0) dc = (int)(short)w.y;                     // chroma DC of the block where r == 0
-            typedef short spk16 __attribute__((ext_vector_type(2)));
-            const spk16 ws = __builtin_bit_cast(spk16, w);
-            const pk16 aw = __builtin_bit_cast(pk16, __builtin_elementwise_max(ws, -ws));
-            uint32_t ov = __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(aw, (c & 1) ? th_odd : th_even));   // != 0 <=> |w| >= thr
-            if (c == 0 && r == 0) ov &= 0xFFFFu;                   // the chroma DC goes through the 2x2 Hadamard instead
-            over |= ov;
-        }
-        // chroma DC: block DCs sit in lanes plane * 16 + block * 4
-        bool dcnz = false;
+            for (int k = 0; k < 4; k++) {
+                const uint32_t sel = 0x0c040c00u + 0x00010001u * k;   // byte k of the low operand -> bits 0..7, of the high -> 16..23
+                d[k] = __builtin_bit_cast(pk16, __builtin_amdgcn_perm(sc, sy, sel)) - __builtin_bit_cast(pk16, __builtin_amdgcn_perm(rc, ry, sel));
+            }
+            {
+                const pk16 s0 = d[0] + d[3], s1 = d[1] + d[2], d0 = d[0] - d[3], d1 = d[1] - d[2];
+                d[0] = s0 + s1; d[1] = d0 + d0 + d1; d[2] = s0 - s1; d[3] = d0 - d1 - d1;
+            }
+            uint32_t over = 0;
+            int dc = 0;
 #pragma unroll
-        for (int pl = 0; pl < 2; pl++) {
-            const int d0 = __builtin_amdgcn_readlane(dc, pl * 16), d1 = __builtin_amdgcn_readlane(dc, pl * 16 + 4);
-            const int d2 = __builtin_amdgcn_readlane(dc, pl * 16 + 8), d3 = __builtin_amdgcn_readlane(dc, pl * 16 + 12);
-            const int t = P.qc.thr_dc_inter;
-            dcnz |= iabs(d0 + d1 + d2 + d3) >= t || iabs(d0 - d1 + d2 - d3) >= t || iabs(d0 + d1 - d2 - d3) >= t || iabs(d0 - d1 - d2 + d3) >= t;
-        }
-        if (!dcnz && __ballot(over != 0) == 0ull) {
+            for (int c = 0; c < 4; c++) {
+                const pk16 q0 = __builtin_bit_cast(pk16, quad_bcast<0>(__builtin_bit_cast(int, d[c])));
+                const pk16 q1 = __builtin_bit_cast(pk16, quad_bcast<1>(__builtin_bit_cast(int, d[c])));
+                const pk16 q2 = __builtin_bit_cast(pk16, quad_bcast<2>(__builtin_bit_cast(int, d[c])));
+                const pk16 q3 = __builtin_bit_cast(pk16, quad_bcast<3>(__builtin_bit_cast(int, d[c])));
+                const pk16 A = q0 + sA * q3, B = q1 + sA * q2;
+                const pk16 w = mA * A + mB * B;                        // row r of the 4x4 core transform, column c
+                if (c == 0) dc = (int)(short)w.y;                     // chroma DC of the block where r == 0
+                typedef short spk16 __attribute__((ext_vector_type(2)));
+                const spk16 ws = __builtin_bit_cast(spk16, w);
+                const pk16 aw = __builtin_bit_cast(pk16, __builtin_elementwise_max(ws, -ws));
+                uint32_t ov = __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(aw, (c & 1) ? th_odd : th_even));   // != 0 <=> |w| >= thr
+                if (c == 0 && r == 0) ov &= 0xFFFFu;                   // the chroma DC goes through the 2x2 Hadamard instead
+                over |= ov;
+            }
+            // chroma DC: block DCs sit in lanes plane * 16 + block * 4
+            bool dcnz = false;
+#pragma unroll
+            for (int pl = 0; pl < 2; pl++) {
+                const int d0 = __builtin_amdgcn_readlane(dc, pl * 16), d1 = __builtin_amdgcn_readlane(dc, pl * 16 + 4);
+                const int d2 = __builtin_amdgcn_readlane(dc, pl * 16 + 8), d3 = __builtin_amdgcn_readlane(dc, pl * 16 + 12);
+                const int t = P.qc.thr_dc_inter;
+                dcnz |= iabs(d0 + d1 + d2 + d3) >= t || iabs(d0 - d1 + d2 - d3) >= t || iabs(d0 + d1 - d2 - d3) >= t || iabs(d0 - d1 - d2 + d3) >= t;
+            }
+            return !dcnz && __ballot(over != 0) == 0ull;
+        };
+        auto settle = [&](int vx, int vy) {   // the vector is final and k_pmb2 need not transform this macroblock
             if (lane == 0) {
                 MbInfo* m = P.mb + mbi;
-                m->mvx = 0; m->mvy = 0; m->type = MB_P16;
-                m->i16_mode = 1;   // for k_pmb2: the zero-motion residual quantises to nothing (it resets the field)
+                m->mvx = (int16_t)vx; m->mvy = (int16_t)vy; m->type = MB_P16;
+                m->i16_mode = 1;   // for k_pmb2: prediction = reconstruction (it resets the field)
                 P.me_cost[mbi] = 0;
             }
-            return;
+        };
+        {   // the zero vector: co-located samples
+            const uint32_t ry = s_win[(ME_R + ME_AP + (b4 >> 2) * 4 + r) * ME_WDW + (ME_R + ME_AP) / 4 + (b4 & 3)];
+            const uint32_t rc = lane < 32 ? *(const uint32_t*)(s_refc + cplz * 64 + cyz * 8 + cxz) : 0u;
+            if (quantises_to_nothing(ry, rc)) { settle(0, 0); return; }
+        }
+        if ((pmx | pmy) != 0 && ((pmx | pmy) & 3) == 0) {   // wave-uniform
+            // luma: integer displacement inside the window; chroma: 1/8-sample bilinear (8.4.2.2.2) at fractions 0 or 4,
+            // samples clamped at the picture edge exactly as motion compensation does
+            const uint32_t ry = lds_ld4(winb, (ME_R + ME_AP + (b4 >> 2) * 4 + r + (pmy >> 2)) * ME_WS + ME_R + ME_AP + (b4 & 3) * 4 + (pmx >> 2));
+            uint32_t rc = 0;
+            if (lane < 32) {
+                const uint8_t* cp = cplz ? P.ref[2] : P.ref[1];
+                const int cs2 = P.cw / 2, chh = P.ch / 2;
+                const int x0c = 8 * mx + cxz + (pmx >> 3), y0c = 8 * my + cyz + (pmy >> 3), fxc = pmx & 7, fyc = pmy & 7;
+                const uint8_t* r0 = cp + (size_t)clip3(0, chh - 1, y0c) * cs2;
+                const uint8_t* r1 = cp + (size_t)clip3(0, chh - 1, y0c + 1) * cs2;
+                int a[5], bq[5];
+#pragma unroll
+                for (int k = 0; k < 5; k++) { const int xx = clip3(0, cs2 - 1, x0c + k); a[k] = r0[xx]; bq[k] = r1[xx]; }
+                const int w00 = (8 - fxc) * (8 - fyc), w10 = fxc * (8 - fyc), w01 = (8 - fxc) * fyc, w11 = fxc * fyc;
+#pragma unroll
+                for (int k = 0; k < 4; k++) rc |= (uint32_t)((w00 * a[k] + w10 * a[k + 1] + w01 * bq[k] + w11 * bq[k + 1] + 32) >> 6) << (8 * k);
+            }
+            if (quantises_to_nothing(ry, rc)) { settle(pmx, pmy); return; }
         }
     }
 

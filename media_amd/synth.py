@@ -62,6 +62,12 @@ def frame_s2(width, height, index):
     return frame_s1(width, height, 0)
 
 
+def frame_scroll(width, height, index):
+    """noise-free texture scrolling by (+4, +2) luma samples per picture: the moving-but-predictable case (a list
+    being scrolled on a cloud-phone screen).  Not one of the SURVEY inputs."""
+    return frame_s1(width, height, index, noise=0, motion=(4, 2))
+
+
 def frame_s3(width, height, index):
     n = width * height * 3 // 2
     return (_hash_u32(1 + index, n) & np.uint32(255)).astype(np.uint8)
@@ -75,7 +81,7 @@ def frame_ramp(width, height, index):
 
 
 def sequence(kind, width, height, count, start=0):
-    fn = {"s1": frame_s1, "s2": frame_s2, "s3": frame_s3, "ramp": frame_ramp}[kind]
+    fn = {"s1": frame_s1, "s2": frame_s2, "s3": frame_s3, "ramp": frame_ramp, "scroll": frame_scroll}[kind]
     return [fn(width, height, start + i) for i in range(count)]
 
 

@@ -13,8 +13,9 @@
  * on data that is final before the stage starts (so the GPU can run each stage
  * over all macroblocks at once):
  *   - I pictures: Intra16x16 (4 modes by SATD) + chroma (4 modes by SATD)
- *   - P pictures: per MB a zero-motion "all levels quantise to zero" test,
- *     else full search dx,dy in [-16,15] on SAD + lambda*bits(mv - pmv), then half-
+ *   - P pictures: per MB a zero-motion "all levels quantise to zero" test, then
+ *     the same test at the macroblock's previous-picture vector when that is a
+ *     non-zero integer-sample vector (scrolling content), else full search dx,dy in [-16,15] on SAD + lambda*bits(mv - pmv), then half-
  *     and quarter-pel refinement on SATD + lambda*bits(mv - pmv), pmv = this
  *     macroblock's vector in the previous picture; P_L0_16x16 only;
  *     P_Skip iff mv == skip predictor and no coefficient survives
@@ -498,21 +499,24 @@ static inline int refpx(const uint8_t *ref, int stride, int w, int h, int x, int
     return ref[clip3(0, h - 1, y) * stride + clip3(0, w - 1, x)];
 }
 
-/* does the zero-motion residual of this MB quantise to nothing? */
-static int zero_mv_all_zero(h264o_enc *e, int mx, int my)
+/* does the residual of this MB against the prediction at (mvx, mvy) quantise to nothing? */
+static int mv_all_zero(h264o_enc *e, int mx, int my, int mvx, int mvy)
 {
-    int qp = e->cfg.qp, cw = e->cw, cs = cw / 2, qpc = o_chroma_qp[qp];
+    int qp = e->cfg.qp, cw = e->cw, ch = e->ch, cs = cw / 2, qpc = o_chroma_qp[qp];
     int16_t lvz[16], deq[16];
+    uint8_t py[256], pc[64];
+    h264o_mc_luma(e->ref[0], cw, cw, ch, 16 * mx, 16 * my, mvx, mvy, 16, 16, py, 16);
     for (int b = 0; b < 16; b++) {
         int off = (16 * my + o_blk_y[b] * 4) * cw + 16 * mx + o_blk_x[b] * 4;
-        if (tq_block(e->src[0] + off, cw, e->ref[0] + off, cw, qp, 0, 0, lvz, deq, NULL)) return 0;
+        if (tq_block(e->src[0] + off, cw, py + o_blk_y[b] * 4 * 16 + o_blk_x[b] * 4, 16, qp, 0, 0, lvz, deq, NULL)) return 0;
     }
     int qbits = 15 + qpc / 6, f = (1 << qbits) / 6;
     for (int pl = 0; pl < 2; pl++) {
         int16_t dc[4];
+        h264o_mc_chroma(e->ref[1 + pl], cs, cs, ch / 2, 8 * mx, 8 * my, mvx, mvy, 8, 8, pc, 8);
         for (int b = 0; b < 4; b++) {
             int off = (8 * my + (b >> 1) * 4) * cs + 8 * mx + (b & 1) * 4;
-            if (tq_block(e->src[1 + pl] + off, cs, e->ref[1 + pl] + off, cs, qpc, 0, 1, lvz, deq, &dc[b])) return 0;
+            if (tq_block(e->src[1 + pl] + off, cs, pc + (b >> 1) * 4 * 8 + (b & 1) * 4, 8, qpc, 0, 1, lvz, deq, &dc[b])) return 0;
         }
         int fd[4] = {dc[0] + dc[1] + dc[2] + dc[3], dc[0] - dc[1] + dc[2] - dc[3],
                      dc[0] + dc[1] - dc[2] - dc[3], dc[0] - dc[1] - dc[2] + dc[3]};
@@ -775,7 +779,13 @@ int64_t h264o_enc_encode(h264o_enc *e, const uint8_t *y, int ys, const uint8_t *
                 const mv_t pmv = {mb->mvx, mb->mvy};   /* previous picture's vector here (intra macroblocks carry 0) */
                 memset(mb, 0, sizeof(*mb));
                 mb->type = H264O_MB_P16;
-                if (!zero_mv_all_zero(e, mx, my)) {
+                if (mv_all_zero(e, mx, my, 0, 0)) {
+                    /* static: vector 0, no search */
+                } else if ((pmv.x | pmv.y) != 0 && ((pmv.x | pmv.y) & 3) == 0 && mv_all_zero(e, mx, my, pmv.x, pmv.y)) {
+                    /* scrolling: the previous (integer-sample) vector still predicts the macroblock completely */
+                    mb->mvx = pmv.x;
+                    mb->mvy = pmv.y;
+                } else {
                     int cost = 0;
                     mv_t m = motion_search(e, mx, my, pmv, &cost);
                     e->me_cost += (uint32_t)(cost < 16383 ? cost : 16383);

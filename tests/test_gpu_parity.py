@@ -326,7 +326,7 @@ def test_randomized_configurations():
         nodb = rng.random() < 0.25
         nv12 = rng.random() < 0.5
         G = rng.choice([1, 1, 2, 3])
-        kind = rng.choice(["s1", "s1", "s2", "s3", "ramp"])
+        kind = rng.choice(["s1", "s1", "s2", "s3", "ramp", "scroll", "scroll"])
         frames = synth.sequence(kind, w, h, gop * G if G > 1 else 5)
         tag = "case %d: %dx%d qp %d gop %d profile %d nodeblock %d nv12 %d batch %d %s" % (case, w, h, qp, gop, prof, nodb, nv12, G, kind)
         orc = OracleEncoder(w, h, qp=qp, gop=gop, profile_idc=prof, disable_deblock=int(nodb))
@@ -345,3 +345,21 @@ def test_randomized_configurations():
             for g in range(G):
                 assert out[g * cap: g * cap + int(gb[g])].tobytes() == b"".join(want[g * gop:(g + 1) * gop]), tag + " GOP %d" % g
         enc.close()
+
+
+def test_scrolling_content_takes_the_previous_vector():
+    """noise-free scroll by (+4, +2): within a few pictures the macroblocks lock on the scroll vector, which the
+    previous-picture-vector test then keeps without a search (P_Skip) - and the stream still equals the oracle's"""
+    w, h = 352, 288
+    enc = capi.Encoder(w, h, qp=30, gop=30)
+    orc = OracleEncoder(w, h, qp=30, gop=30)
+    sizes = []
+    for f in synth.sequence("scroll", w, h, 8):
+        bs, _ = enc.encode(f)
+        assert bs == orc.encode(f)[0]
+        sizes.append(len(bs))
+    mb = orc.mbinfo().reshape(-1)
+    moved = (mb["mvx"] == -16) & (mb["mvy"] == -8)    # the content moves by (+4, +2) samples: the reference lies at (-4, -2)
+    assert moved.mean() > 0.8 and (mb["type"] == 2).mean() > 0.6, (moved.mean(), (mb["type"] == 2).mean())
+    assert sizes[-1] < sizes[1]          # later P pictures cost less than the first one (which had to search)
+    enc.close()
