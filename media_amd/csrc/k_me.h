@@ -128,8 +128,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
     // ---- 1. "nothing left to code" tests: does the residual against a given prediction quantise to nothing?
     // lane = (4x4 block, row); luma rides in the low and chroma (lanes 0..31) in the high 16 bits of every register,
     // so one packed forward transform (row pass in the lane, column pass over the DPP quad) serves both.  Tried at
-    // the zero vector (static content) and, when that fails, at the macroblock's previous-picture vector if it is a
-    // non-zero integer-sample vector (scrolling content); a hit fixes the vector and ends the search. ----
+    // the zero vector (static content) and, when that fails, at the macroblock's previous-picture vector rounded to
+    // integer samples, if non-zero (scrolling content); a hit fixes the vector and ends the search. ----
     {
         typedef unsigned short pk16 __attribute__((ext_vector_type(2)));
         const int r = lane & 3, b4 = lane >> 2;
@@ -199,25 +199,30 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
             const uint32_t rc = lane < 32 ? *(const uint32_t*)(s_refc + cplz * 64 + cyz * 8 + cxz) : 0u;
             if (quantises_to_nothing(ry, rc)) { settle(0, 0); return; }
         }
-        if ((pmx | pmy) != 0 && ((pmx | pmy) & 3) == 0) {   // wave-uniform
+        const int rvx = ((pmx + 2) >> 2) * 4, rvy = ((pmy + 2) >> 2) * 4;   // the previous vector rounded to integer samples
+        if ((rvx | rvy) != 0) {   // wave-uniform
             // luma: integer displacement inside the window; chroma: 1/8-sample bilinear (8.4.2.2.2) at fractions 0 or 4,
             // samples clamped at the picture edge exactly as motion compensation does
-            const uint32_t ry = lds_ld4(winb, (ME_R + ME_AP + (b4 >> 2) * 4 + r + (pmy >> 2)) * ME_WS + ME_R + ME_AP + (b4 & 3) * 4 + (pmx >> 2));
+            const uint32_t ry = lds_ld4(winb, (ME_R + ME_AP + (b4 >> 2) * 4 + r + (rvy >> 2)) * ME_WS + ME_R + ME_AP + (b4 & 3) * 4 + (rvx >> 2));
             uint32_t rc = 0;
             if (lane < 32) {
                 const uint8_t* cp = cplz ? P.ref[2] : P.ref[1];
                 const int cs2 = P.cw / 2, chh = P.ch / 2;
-                const int x0c = 8 * mx + cxz + (pmx >> 3), y0c = 8 * my + cyz + (pmy >> 3), fxc = pmx & 7, fyc = pmy & 7;
+                const int x0c = 8 * mx + cxz + (rvx >> 3), y0c = 8 * my + cyz + (rvy >> 3), fxc = rvx & 7, fyc = rvy & 7;
                 const uint8_t* r0 = cp + (size_t)clip3(0, chh - 1, y0c) * cs2;
                 const uint8_t* r1 = cp + (size_t)clip3(0, chh - 1, y0c + 1) * cs2;
-                int a[5], bq[5];
-#pragma unroll
-                for (int k = 0; k < 5; k++) { const int xx = clip3(0, cs2 - 1, x0c + k); a[k] = r0[xx]; bq[k] = r1[xx]; }
                 const int w00 = (8 - fxc) * (8 - fyc), w10 = fxc * (8 - fyc), w01 = (8 - fxc) * fyc, w11 = fxc * fyc;
+                int xx = clip3(0, cs2 - 1, x0c);
+                int pa = r0[xx], pb = r1[xx];
 #pragma unroll
-                for (int k = 0; k < 4; k++) rc |= (uint32_t)((w00 * a[k] + w10 * a[k + 1] + w01 * bq[k] + w11 * bq[k + 1] + 32) >> 6) << (8 * k);
+                for (int k = 0; k < 4; k++) {
+                    xx = clip3(0, cs2 - 1, x0c + k + 1);
+                    const int na = r0[xx], nb = r1[xx];
+                    rc |= (uint32_t)((w00 * pa + w10 * na + w01 * pb + w11 * nb + 32) >> 6) << (8 * k);
+                    pa = na; pb = nb;
+                }
             }
-            if (quantises_to_nothing(ry, rc)) { settle(pmx, pmy); return; }
+            if (quantises_to_nothing(ry, rc)) { settle(rvx, rvy); return; }
         }
     }
 
@@ -236,8 +241,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
         if (bx + 16 <= P.w && by + 16 <= P.h && ((P.w | (int)(uintptr_t)P.src) & 3) == 0) {
 #pragma unroll
             for (int j = 0; j < 16; j++) {
-                const uint4 v = *(const uint4*)(sp0 + (size_t)j * P.w);
-                srow[j][0] = v.x; srow[j][1] = v.y; srow[j][2] = v.z; srow[j][3] = v.w;
+                // constant address space: the source picture is read-only for this kernel, and a uniform load from
+                // it is a scalar load whatever stores the compiler sees elsewhere in the function
+                typedef const __attribute__((address_space(4))) uint32_t* const_u32p;
+                const const_u32p q = (const_u32p)(uintptr_t)(sp0 + (size_t)j * P.w);
+                srow[j][0] = q[0]; srow[j][1] = q[1]; srow[j][2] = q[2]; srow[j][3] = q[3];
             }
         } else {
 #pragma unroll

@@ -14,8 +14,8 @@
  * over all macroblocks at once):
  *   - I pictures: Intra16x16 (4 modes by SATD) + chroma (4 modes by SATD)
  *   - P pictures: per MB a zero-motion "all levels quantise to zero" test, then
- *     the same test at the macroblock's previous-picture vector when that is a
- *     non-zero integer-sample vector (scrolling content), else full search dx,dy in [-16,15] on SAD + lambda*bits(mv - pmv), then half-
+ *     the same test at the macroblock's previous-picture vector rounded to
+ *     integer samples, when non-zero (scrolling content), else full search dx,dy in [-16,15] on SAD + lambda*bits(mv - pmv), then half-
  *     and quarter-pel refinement on SATD + lambda*bits(mv - pmv), pmv = this
  *     macroblock's vector in the previous picture; P_L0_16x16 only;
  *     P_Skip iff mv == skip predictor and no coefficient survives
@@ -777,14 +777,15 @@ int64_t h264o_enc_encode(h264o_enc *e, const uint8_t *y, int ys, const uint8_t *
             for (int mx = 0; mx < e->mbw; mx++) {
                 h264o_mbinfo *mb = &e->mb[my * e->mbw + mx];
                 const mv_t pmv = {mb->mvx, mb->mvy};   /* previous picture's vector here (intra macroblocks carry 0) */
+                const mv_t rmv = {(int16_t)(((pmv.x + 2) >> 2) * 4), (int16_t)(((pmv.y + 2) >> 2) * 4)};   /* nearest integer-sample vector */
                 memset(mb, 0, sizeof(*mb));
                 mb->type = H264O_MB_P16;
                 if (mv_all_zero(e, mx, my, 0, 0)) {
                     /* static: vector 0, no search */
-                } else if ((pmv.x | pmv.y) != 0 && ((pmv.x | pmv.y) & 3) == 0 && mv_all_zero(e, mx, my, pmv.x, pmv.y)) {
-                    /* scrolling: the previous (integer-sample) vector still predicts the macroblock completely */
-                    mb->mvx = pmv.x;
-                    mb->mvy = pmv.y;
+                } else if ((rmv.x | rmv.y) != 0 && mv_all_zero(e, mx, my, rmv.x, rmv.y)) {
+                    /* scrolling: the previous vector, rounded to integer samples, predicts the macroblock completely */
+                    mb->mvx = rmv.x;
+                    mb->mvy = rmv.y;
                 } else {
                     int cost = 0;
                     mv_t m = motion_search(e, mx, my, pmv, &cost);
