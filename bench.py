@@ -257,6 +257,16 @@ def main():
     fence()
     lat_dt = time.perf_counter() - t1
     st1 = (enc1 if enc1 is not None else enc).stats(reset=True)
+    # self-check of the measured path: GOP 0 as the lockstep batch coded it == the same 30 pictures through the
+    # batch-1 encoder (a different launch geometry of the same kernels); both are bit-exact against the CPU oracle
+    # in tests/test_gpu_parity.py at sizes the oracle finishes quickly
+    selfcheck = None
+    if enc1 is not None:
+        calls0 = args.warmup + args.steps + (1 if I > 1 else 0)      # encode_gops_device calls instance 0 has made
+        enc1.set_idr_pic_id(((calls0 - 1) * B) & 255, 1)             # idr_pic_id its GOP 0 carried in the last one
+        n1 = one_gop(0)
+        a = outs[0][:int(gop_bytes[0][0])]
+        selfcheck = bool(int(gop_bytes[0][0]) == n1 and np.array_equal(a, out1[:n1]))
     for e_ in encs:
         e_.close()
 
@@ -291,7 +301,7 @@ def main():
                                    "closed GOPs per step on %d encoder instance(s), each encoding its %d GOPs in lockstep "
                                    "(grid.y) on its own HIP streams; pictures resident in HBM" % (G, I, B),
                        "content": args.content, "width": WIDTH, "height": HEIGHT, "qp": QP, "gop": GOP, "frames_per_step": FRAMES_PER_STEP * G, "gops_in_flight": G, "instances": I, "lockstep_batch": B,
-                       "streams": world, "bytes_per_gop": int(nbytes), "parity": "bit-exact vs CPU oracle "
+                       "streams": world, "bytes_per_gop": int(nbytes), "selfcheck_batch_equals_single": selfcheck, "parity": "bit-exact vs CPU oracle "
                        "(oracle unpinned vs OpenH264: no libopenh264 available)"},
             "roofline": {"kernel": "k_pmb2 (MC + fDCT + quant + dequant + iDCT + recon)", "bound": "hbm",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
