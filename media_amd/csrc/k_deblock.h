@@ -309,6 +309,26 @@ __global__ __launch_bounds__(64) void k_deblock_rows(DbRowParams R)
     uint4 b0 = pf_b0, b1 = pf_b1;
     u64 g = pf_g;
 
+    // 7. the previous macroblock is final with respect to this row once the current one's left edge has been filtered
+    // (the horizontal edges of the current macroblock do not touch it): store / publish it.  Issued right after the
+    // vertical-edge phase, so that the stores' acknowledgements (the agent-scope granule stores go all the way to the
+    // memory side; vmcnt retires in order) have the rest of the iteration to come back before the next wait for loads.
+    auto store_prev = [&](const int mx, const bool have_cur) {
+        if (mx > 0) {
+            const int pmx = mx - 1;
+            const int co = have_cur ? -16 : 0, cco = have_cur ? -8 : 0;  // after the last macroblock there was no shift
+            const int nrow = last_row ? 16 : 12, ncrow = last_row ? 8 : 6;
+            if (yr < nrow) *(uint32_t*)(D.pl[0] + (size_t)(16 * my + yr) * D.cw + 16 * pmx + yc4) = *(const uint32_t*)&SY(yr, co + yc4);
+            if (lane < 32 && cr_l < ncrow)
+                *(uint32_t*)((cpl_l ? D.pl[2] : D.pl[1]) + (size_t)(8 * my + cr_l) * cs + 8 * pmx + cc4) = *(const uint32_t*)&SC(cpl_l, cr_l, cco + cc4);
+            if (!last_row && lane < 24) {
+                uint32_t v;
+                if (lane < 16) v = *(const uint32_t*)&SY(12 + (gk >> 2), co + (gk & 3) * 4);
+                else v = *(const uint32_t*)&SC((gk - 16) >> 2, 6 + (((gk - 16) >> 1) & 1), cco + ((gk - 16) & 1) * 4);
+                AT_STORE(handoff + ((size_t)my * D.mbw + pmx) * 24 + gk, ((u64)R.serial << 32) | v);
+            }
+        }
+    };
     for (int mx = 0; mx <= D.mbw; mx++) {
         const bool have_cur = mx < D.mbw;
         if (have_cur) {
@@ -360,6 +380,7 @@ __global__ __launch_bounds__(64) void k_deblock_rows(DbRowParams R)
                         *(uint32_t*)(vrow + 4 * w) = (uint32_t)px[4 * w] | ((uint32_t)px[4 * w + 1] << 8) | ((uint32_t)px[4 * w + 2] << 16) | ((uint32_t)px[4 * w + 3] << 24);
             }
             wave_sync();
+            store_prev(mx, true);
             // 5. horizontal edges: lane = one column of samples (rows -4..15; chroma uses rows -4..7 of its tile)
             if (any_h && lane < 32) {
                 int px[20];
@@ -389,21 +410,7 @@ __global__ __launch_bounds__(64) void k_deblock_rows(DbRowParams R)
                 }
             }
         }
-        // 7. the previous macroblock is final with respect to this row: store / publish it
-        if (mx > 0) {
-            const int pmx = mx - 1;
-            const int co = have_cur ? -16 : 0, cco = have_cur ? -8 : 0;  // after the last macroblock there was no shift
-            const int nrow = last_row ? 16 : 12, ncrow = last_row ? 8 : 6;
-            if (yr < nrow) *(uint32_t*)(D.pl[0] + (size_t)(16 * my + yr) * D.cw + 16 * pmx + yc4) = *(const uint32_t*)&SY(yr, co + yc4);
-            if (lane < 32 && cr_l < ncrow)
-                *(uint32_t*)((cpl_l ? D.pl[2] : D.pl[1]) + (size_t)(8 * my + cr_l) * cs + 8 * pmx + cc4) = *(const uint32_t*)&SC(cpl_l, cr_l, cco + cc4);
-            if (!last_row && lane < 24) {
-                uint32_t v;
-                if (lane < 16) v = *(const uint32_t*)&SY(12 + (gk >> 2), co + (gk & 3) * 4);
-                else v = *(const uint32_t*)&SC((gk - 16) >> 2, 6 + (((gk - 16) >> 1) & 1), cco + ((gk - 16) & 1) * 4);
-                AT_STORE(handoff + ((size_t)my * D.mbw + pmx) * 24 + gk, ((u64)R.serial << 32) | v);
-            }
-        }
+        if (!have_cur) store_prev(mx, false);   // after the last macroblock of the row
         cur_y = pf_y; cur_c = pf_c; b0 = pf_b0; b1 = pf_b1; g = pf_g;
         wave_sync();
     }
