@@ -222,28 +222,35 @@ template <bool BS4>
 __device__ __forceinline__ void filt_uni(const int p3, int& p2, int& p1, int& p0, int& q0, int& q1, int& q2, const int q3,
                                          int bS, bool chroma, int alpha, int beta, int t1, int t2, int t3)
 {
+    // Every decision is an all-ones / all-zero MASK applied with AND, not a select: hipcc turns chains of selects over
+    // this much arithmetic back into exec-masked regions with branches, and on a wave that runs alone on its SIMD
+    // every s_and_saveexec / s_cbranch pair is dead time in the dependency chain.
     const int tc0 = bS == 1 ? t1 : (bS == 2 ? t2 : t3);
-    const bool f = bS != 0 && iabs(p0 - q0) < alpha && iabs(p1 - p0) < beta && iabs(q1 - q0) < beta;
-    const bool ap = !chroma && iabs(p2 - p0) < beta, aq = !chroma && iabs(q2 - q0) < beta;
-    const int tc = tc0 + (chroma ? 1 : (int)ap + (int)aq);
+    const int fm = -(int)(bS != 0 && iabs(p0 - q0) < alpha && iabs(p1 - p0) < beta && iabs(q1 - q0) < beta);
+    const int lum = chroma ? 0 : -1;
+    const int apm = lum & -(int)(iabs(p2 - p0) < beta), aqm = lum & -(int)(iabs(q2 - q0) < beta);
+    const int tc = tc0 + (chroma ? 1 : 0) - apm - aqm;          // + 1 per true luma condition
     const int d = clip3(-tc, tc, (((q0 - p0) << 2) + (p1 - q1) + 4) >> 3);
     const int avg = (p0 + q0 + 1) >> 1;
-    int np0 = clip255(p0 + d), nq0 = clip255(q0 - d);
-    int np1 = ap ? p1 + clip3(-tc0, tc0, (p2 + avg - (p1 << 1)) >> 1) : p1;
-    int nq1 = aq ? q1 + clip3(-tc0, tc0, (q2 + avg - (q1 << 1)) >> 1) : q1;
-    int np2 = p2, nq2 = q2;
+    int dp0 = clip255(p0 + d) - p0, dq0 = clip255(q0 - d) - q0;                 // changes of the normal filter
+    int dp1 = apm & clip3(-tc0, tc0, (p2 + avg - (p1 << 1)) >> 1);
+    int dq1 = aqm & clip3(-tc0, tc0, (q2 + avg - (q1 << 1)) >> 1);
+    int dp2 = 0, dq2 = 0;
     if (BS4) {
-        const bool s4 = bS == 4;
-        const bool strong = iabs(p0 - q0) < ((alpha >> 2) + 2);
-        const bool sp = ap && strong, sq = aq && strong;
-        const int wp0 = sp ? (p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3 : (2 * p1 + p0 + q1 + 2) >> 2;
-        const int wq0 = sq ? (p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3 : (2 * q1 + q0 + p1 + 2) >> 2;
-        const int wp1 = sp ? (p2 + p1 + p0 + q0 + 2) >> 2 : p1, wq1 = sq ? (p0 + q0 + q1 + q2 + 2) >> 2 : q1;
-        const int wp2 = sp ? (2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3 : p2, wq2 = sq ? (2 * q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3 : q2;
-        np0 = s4 ? wp0 : np0; nq0 = s4 ? wq0 : nq0; np1 = s4 ? wp1 : np1; nq1 = s4 ? wq1 : nq1; np2 = s4 ? wp2 : np2; nq2 = s4 ? wq2 : nq2;
+        const int s4 = -(int)(bS == 4);
+        const int strong = -(int)(iabs(p0 - q0) < ((alpha >> 2) + 2));
+        const int sp = apm & strong, sq = aqm & strong;
+        // strong (8.7.2.4) and weak intra forms as changes; sp / sq pick per side
+        const int wp0 = (sp & (((p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3) - p0)) | (~sp & (((2 * p1 + p0 + q1 + 2) >> 2) - p0));
+        const int wq0 = (sq & (((p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3) - q0)) | (~sq & (((2 * q1 + q0 + p1 + 2) >> 2) - q0));
+        const int wp1 = sp & (((p2 + p1 + p0 + q0 + 2) >> 2) - p1), wq1 = sq & (((p0 + q0 + q1 + q2 + 2) >> 2) - q1);
+        const int wp2 = sp & (((2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3) - p2), wq2 = sq & (((2 * q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3) - q2);
+        dp0 = (s4 & wp0) | (~s4 & dp0); dq0 = (s4 & wq0) | (~s4 & dq0);
+        dp1 = (s4 & wp1) | (~s4 & dp1); dq1 = (s4 & wq1) | (~s4 & dq1);
+        dp2 = s4 & wp2; dq2 = s4 & wq2;
     }
-    p0 = f ? np0 : p0; q0 = f ? nq0 : q0; p1 = f ? np1 : p1; q1 = f ? nq1 : q1;
-    if (BS4) { p2 = f ? np2 : p2; q2 = f ? nq2 : q2; }
+    p0 += fm & dp0; q0 += fm & dq0; p1 += fm & dp1; q1 += fm & dq1;
+    if (BS4) { p2 += fm & dp2; q2 += fm & dq2; }
 }
 
 enum { DR_LP = 40, DR_CP = 24 };  // LDS pitches; luma tile cols -16..15 (+4 pad), rows -4..15; chroma cols -8..7, rows -4..15
