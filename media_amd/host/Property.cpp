@@ -28,21 +28,21 @@ std::string Lookup(const char *key)
 }
 }
 
-int32_t StrToInt(std::string inputValue)
+// stream extraction semantics on purpose (the reference parses its property text this way, Property.cpp:8-14):
+// "42abc" -> 42, "abc" -> 0 (failed extraction writes 0 since C++11), "" -> the initial -1
+int32_t StrToInt(std::string text)
 {
-    std::stringstream strStream;
-    strStream << inputValue;
-    int32_t result = -1;
-    strStream >> result;
-    return result;
+    int32_t number = -1;
+    std::istringstream(text) >> number;
+    return number;
 }
 
-int32_t GetIntEncParam(const char *inputValue) { return StrToInt(Lookup(inputValue)); }
-std::string GetStrEncParam(const char *inputValue) { return Lookup(inputValue); }
+int32_t GetIntEncParam(const char *key) { return StrToInt(Lookup(key)); }
+std::string GetStrEncParam(const char *key) { return Lookup(key); }
 
-void SetEncParam(const char *key, const char *value)
+void SetEncParam(const char *key, const char *text)
 {
-    if (key == nullptr || value == nullptr) return;
+    if (key == nullptr || text == nullptr) return;
     std::lock_guard<std::mutex> g(g_lock);
-    g_props[key] = value;
+    g_props[key] = text;
 }

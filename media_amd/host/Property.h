@@ -11,9 +11,13 @@
 #include <cstdint>
 #include <string>
 
-int32_t GetIntEncParam(const char *inputValue);
-std::string GetStrEncParam(const char *inputValue);
-void SetEncParam(const char *key, const char *value);
-int32_t StrToInt(std::string inputValue);
+// value of an integer-valued key; -1 when the key is unset or its text is not a number
+int32_t GetIntEncParam(const char *key);
+// text of a key; "" when unset
+std::string GetStrEncParam(const char *key);
+// create or overwrite
+void SetEncParam(const char *key, const char *text);
+// the reference's number parse: leading integer of the text, 0 for junk, -1 for an empty string
+int32_t StrToInt(std::string text);
 
 #endif
