@@ -103,12 +103,22 @@ __device__ __forceinline__ void intra_mb_core(const FrameParams& P, int mx, int 
     int best_mode;
     {
         const int mode = lane >> 4, blk = lane & 15, x0 = (blk & 3) * 4, y0 = (blk >> 2) * 4;
+        // this lane's block: four source dwords, the four top and left neighbours, the plane value of its corner -
+        // fetched once instead of per sample
+        int tp[4], lf[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { tp[k] = S.top[1 + x0 + k]; lf[k] = S.left[y0 + k]; }
+        const int pl0 = ip.a + ip.b * (x0 - 7) + ip.c * (y0 - 7) + 16;
         int d[16];
 #pragma unroll
-        for (int y = 0; y < 4; y++)
+        for (int y = 0; y < 4; y++) {
+            const uint32_t sw = *(const uint32_t*)(S.src + (y0 + y) * 16 + x0);
 #pragma unroll
-            for (int x = 0; x < 4; x++)
-                d[4 * y + x] = (int)S.src[(y0 + y) * 16 + x0 + x] - i16_px(mode, x0 + x, y0 + y, S.top, S.left, ip);
+            for (int x = 0; x < 4; x++) {
+                const int pr = mode == 0 ? tp[x] : mode == 1 ? lf[y] : mode == 2 ? ip.dc : clip255((pl0 + ip.b * x + ip.c * y) >> 5);
+                d[4 * y + x] = (int)((sw >> (8 * x)) & 255) - pr;
+            }
+        }
         int sum = group_sum<16>(hadamard_abs(d)) >> 1;
         const bool ok = mode == 0 ? (avail & 2) : mode == 1 ? (avail & 1) : mode == 2 ? true : avail == 7;
         unsigned key = ok ? (((unsigned)sum << 2) | (unsigned)mode) : 0xFFFFFFFFu;
@@ -126,13 +136,22 @@ __device__ __forceinline__ void intra_mb_core(const FrameParams& P, int mx, int 
     C8Params cp[2] = {c8_params(S.ctop[0], S.cleft[0], avail), c8_params(S.ctop[1], S.cleft[1], avail)};
     {
         const int mode = (lane >> 3) & 3, pl = (lane >> 2) & 1, blk = lane & 3, x0 = (blk & 1) * 4, y0 = (blk >> 1) * 4;
+        int tp[4], lf[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { tp[k] = S.ctop[pl][1 + x0 + k]; lf[k] = S.cleft[pl][y0 + k]; }
+        const int ca = pl ? cp[1].a : cp[0].a, cbb = pl ? cp[1].b : cp[0].b, cc = pl ? cp[1].c : cp[0].c;
+        const int cdc = pl ? cp[1].dc[blk] : cp[0].dc[blk];       // blk = (y0 >> 2) * 2 + (x0 >> 2)
+        const int pl0 = ca + cbb * (x0 - 3) + cc * (y0 - 3) + 16;
         int d[16];
 #pragma unroll
-        for (int y = 0; y < 4; y++)
+        for (int y = 0; y < 4; y++) {
+            const uint32_t sw = *(const uint32_t*)(S.srcc + pl * 64 + (y0 + y) * 8 + x0);
 #pragma unroll
-            for (int x = 0; x < 4; x++)
-                d[4 * y + x] = (int)S.srcc[pl * 64 + (y0 + y) * 8 + x0 + x] -
-                               c8_px(mode, x0 + x, y0 + y, S.ctop[pl], S.cleft[pl], pl ? cp[1] : cp[0]);
+            for (int x = 0; x < 4; x++) {
+                const int pr = mode == 0 ? cdc : mode == 1 ? lf[y] : mode == 2 ? tp[x] : clip255((pl0 + cbb * x + cc * y) >> 5);
+                d[4 * y + x] = (int)((sw >> (8 * x)) & 255) - pr;
+            }
+        }
         // per-plane SATD is (sum over 4 blocks) >> 1; cost = Cb + Cr
         int sp = group_sum<4>(hadamard_abs(d)) >> 1;
         int sum = sp + __shfl_xor(sp, 4);
