@@ -16,8 +16,22 @@ namespace h264 {
 
 // Intra16x16 predictor sample (8.3.3); top[0..16] holds p[-1..15,-1], left[y] = p[-1,y]
 struct I16Params { int dc, a, b, c; };
-__device__ __forceinline__ I16Params i16_params(const uint8_t* top, const uint8_t* left, int avail)
+__device__ __forceinline__ I16Params i16_params(const uint8_t* top_, const uint8_t* left_, int avail)
 {
+    // the 17 + 16 neighbour samples as nine dword reads (both arrays are 4-byte aligned in IntraLds)
+    int top[20], left[16];
+#pragma unroll
+    for (int w = 0; w < 5; w++) {
+        const uint32_t v = ((const uint32_t*)top_)[w];
+#pragma unroll
+        for (int k = 0; k < 4; k++) top[4 * w + k] = (int)((v >> (8 * k)) & 255);
+    }
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        const uint32_t v = ((const uint32_t*)left_)[w];
+#pragma unroll
+        for (int k = 0; k < 4; k++) left[4 * w + k] = (int)((v >> (8 * k)) & 255);
+    }
     I16Params q;
     int st = 0, sl = 0;
 #pragma unroll
@@ -27,10 +41,10 @@ __device__ __forceinline__ I16Params i16_params(const uint8_t* top, const uint8_
     int H = 0, V = 0;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-        H += (i + 1) * ((int)top[1 + 8 + i] - (int)top[1 + 6 - i]);
-        V += (i + 1) * ((int)left[8 + i] - (i == 7 ? (int)top[0] : (int)left[6 - i]));
+        H += (i + 1) * (top[1 + 8 + i] - top[1 + 6 - i]);
+        V += (i + 1) * (left[8 + i] - (i == 7 ? top[0] : left[6 - i]));
     }
-    q.a = 16 * ((int)left[15] + (int)top[16]);
+    q.a = 16 * (left[15] + top[16]);
     q.b = (5 * H + 32) >> 6;
     q.c = (5 * V + 32) >> 6;
     return q;
@@ -176,18 +190,21 @@ __device__ __forceinline__ void intra_mb_core(const FrameParams& P, int mx, int 
     if (is_luma) {
         const int x = blk_x(lane) * 4, y = blk_y(lane) * 4;
 #pragma unroll
-        for (int r = 0; r < 4; r++)
+        for (int r = 0; r < 4; r++) {
+            const uint32_t sw = *(const uint32_t*)(S.src + (y + r) * 16 + x), pw = *(const uint32_t*)(S.py + (y + r) * 16 + x);
 #pragma unroll
-            for (int c = 0; c < 4; c++) d[4 * r + c] = (int)S.src[(y + r) * 16 + x + c] - (int)S.py[(y + r) * 16 + x + c];
+            for (int c = 0; c < 4; c++) d[4 * r + c] = (int)((sw >> (8 * c)) & 255) - (int)((pw >> (8 * c)) & 255);
+        }
         nnz = tq4x4(d, P.qy, P.qy.f_intra, 1, S.lv + LV_LUMA + lane * 16, &dcw, 0, false);
         S.dc[blk_y(lane) * 4 + blk_x(lane)] = dcw;
     } else if (is_chroma) {
         const int x = (cb & 1) * 4, y = (cb >> 1) * 4;
 #pragma unroll
-        for (int r = 0; r < 4; r++)
+        for (int r = 0; r < 4; r++) {
+            const uint32_t sw = *(const uint32_t*)(S.srcc + cpl * 64 + (y + r) * 8 + x), pw = *(const uint32_t*)(S.pc + cpl * 64 + (y + r) * 8 + x);
 #pragma unroll
-            for (int c = 0; c < 4; c++)
-                d[4 * r + c] = (int)S.srcc[cpl * 64 + (y + r) * 8 + x + c] - (int)S.pc[cpl * 64 + (y + r) * 8 + x + c];
+            for (int c = 0; c < 4; c++) d[4 * r + c] = (int)((sw >> (8 * c)) & 255) - (int)((pw >> (8 * c)) & 255);
+        }
         nnz = tq4x4(d, P.qc, P.qc.f_intra, 1, S.lv + LV_CHROMA_AC + (cpl * 4 + cb) * 16, &dcw, 0, false);
     }
     __syncthreads();
