@@ -14,6 +14,16 @@
 
 namespace h264 {
 
+// "shift, clamp to 0..255, pack bytes" written plainly makes hipcc (ROCm 7.2, gfx950) select v_ashr_pk_u8_i32 and OR
+// further bytes into its result as if its upper half were zero (it is not: see k_pmb2.h); the clamped plane samples
+// therefore pass through this no-op before they are packed.
+__device__ __forceinline__ int plane_px(int v)
+{
+    int c = clip255(v >> 5);
+    asm volatile("" : "+v"(c));
+    return c;
+}
+
 // Intra16x16 predictor sample (8.3.3); top[0..16] holds p[-1..15,-1], left[y] = p[-1,y]
 struct I16Params { int dc, a, b, c; };
 __device__ __forceinline__ I16Params i16_params(const uint8_t* top_, const uint8_t* left_, int avail)
@@ -56,8 +66,21 @@ __device__ __forceinline__ int i16_px(int mode, int x, int y, const uint8_t* top
 
 // chroma 8x8 predictor (8.3.4): 0 DC, 1 horizontal, 2 vertical, 3 plane
 struct C8Params { int dc[4], a, b, c; };
-__device__ __forceinline__ C8Params c8_params(const uint8_t* top, const uint8_t* left, int avail)
+__device__ __forceinline__ C8Params c8_params(const uint8_t* top_, const uint8_t* left_, int avail)
 {
+    int top[12], left[8];      // 9 + 8 neighbour samples as five dword reads (both arrays 4-byte aligned in IntraLds)
+#pragma unroll
+    for (int w = 0; w < 3; w++) {
+        const uint32_t v = ((const uint32_t*)top_)[w];
+#pragma unroll
+        for (int k = 0; k < 4; k++) top[4 * w + k] = (int)((v >> (8 * k)) & 255);
+    }
+#pragma unroll
+    for (int w = 0; w < 2; w++) {
+        const uint32_t v = ((const uint32_t*)left_)[w];
+#pragma unroll
+        for (int k = 0; k < 4; k++) left[4 * w + k] = (int)((v >> (8 * k)) & 255);
+    }
     C8Params q;
     const bool t = avail & 2, l = avail & 1;
     int st[2] = {0, 0}, sl[2] = {0, 0};
@@ -75,10 +98,10 @@ __device__ __forceinline__ C8Params c8_params(const uint8_t* top, const uint8_t*
     int H = 0, V = 0;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        H += (i + 1) * ((int)top[1 + 4 + i] - (int)top[1 + 2 - i]);
-        V += (i + 1) * ((int)left[4 + i] - (i == 3 ? (int)top[0] : (int)left[2 - i]));
+        H += (i + 1) * (top[1 + 4 + i] - top[1 + 2 - i]);
+        V += (i + 1) * (left[4 + i] - (i == 3 ? top[0] : left[2 - i]));
     }
-    q.a = 16 * ((int)left[7] + (int)top[8]);
+    q.a = 16 * (left[7] + top[8]);
     q.b = (34 * H + 32) >> 6;
     q.c = (34 * V + 32) >> 6;
     return q;
@@ -141,8 +164,16 @@ __device__ __forceinline__ void intra_mb_core(const FrameParams& P, int mx, int 
     {
         const int y = lane >> 2, xs = (lane & 3) * 4;
         uint32_t o = 0;
+        if (best_mode == 0) {          // vertical: the four samples above (best_mode is wave-uniform)
 #pragma unroll
-        for (int k = 0; k < 4; k++) o |= (uint32_t)i16_px(best_mode, xs + k, y, S.top, S.left, ip) << (8 * k);
+            for (int k = 0; k < 4; k++) o |= (uint32_t)S.top[1 + xs + k] << (8 * k);
+        } else if (best_mode == 1) o = 0x01010101u * (uint32_t)S.left[y];
+        else if (best_mode == 2) o = 0x01010101u * (uint32_t)ip.dc;
+        else {
+            const int pl0 = ip.a + ip.b * (xs - 7) + ip.c * (y - 7) + 16;
+#pragma unroll
+            for (int k = 0; k < 4; k++) o |= (uint32_t)plane_px(pl0 + ip.b * k) << (8 * k);
+        }
         *(uint32_t*)(S.py + y * 16 + xs) = o;
     }
     // ---- chroma mode decision: lane<32 = (mode, plane, block) ----
@@ -176,8 +207,17 @@ __device__ __forceinline__ void intra_mb_core(const FrameParams& P, int mx, int 
     if (lane < 32) {
         const int pl = lane >> 4, y = (lane >> 1) & 7, xs = (lane & 1) * 4;
         uint32_t o = 0;
+        if (best_cmode == 0) o = 0x01010101u * (uint32_t)(pl ? cp[1].dc[(y >> 2) * 2 + (xs >> 2)] : cp[0].dc[(y >> 2) * 2 + (xs >> 2)]);
+        else if (best_cmode == 1) o = 0x01010101u * (uint32_t)S.cleft[pl][y];
+        else if (best_cmode == 2) {
 #pragma unroll
-        for (int k = 0; k < 4; k++) o |= (uint32_t)c8_px(best_cmode, xs + k, y, S.ctop[pl], S.cleft[pl], pl ? cp[1] : cp[0]) << (8 * k);
+            for (int k = 0; k < 4; k++) o |= (uint32_t)S.ctop[pl][1 + xs + k] << (8 * k);
+        } else {
+            const int ca = pl ? cp[1].a : cp[0].a, cbb = pl ? cp[1].b : cp[0].b, cc = pl ? cp[1].c : cp[0].c;
+            const int pl0 = ca + cbb * (xs - 3) + cc * (y - 3) + 16;
+#pragma unroll
+            for (int k = 0; k < 4; k++) o |= (uint32_t)plane_px(pl0 + cbb * k) << (8 * k);
+        }
         *(uint32_t*)(S.pc + pl * 64 + y * 8 + xs) = o;
     }
     __syncthreads();
