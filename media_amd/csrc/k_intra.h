@@ -156,10 +156,10 @@ __device__ __forceinline__ void intra_mb_core(const FrameParams& P, int mx, int 
                 d[4 * y + x] = (int)((sw >> (8 * x)) & 255) - pr;
             }
         }
-        int sum = group_sum<16>(hadamard_abs(d)) >> 1;
+        int sum = row_sum16_dpp(hadamard_abs(d)) >> 1;
         const bool ok = mode == 0 ? (avail & 2) : mode == 1 ? (avail & 1) : mode == 2 ? true : avail == 7;
         unsigned key = ok ? (((unsigned)sum << 2) | (unsigned)mode) : 0xFFFFFFFFu;
-        best_mode = (int)(wave_min_u32(key) & 3);
+        best_mode = (int)(wave_min_u32_dpp(key) & 3);
     }
     {
         const int y = lane >> 2, xs = (lane & 3) * 4;
@@ -198,11 +198,14 @@ __device__ __forceinline__ void intra_mb_core(const FrameParams& P, int mx, int 
             }
         }
         // per-plane SATD is (sum over 4 blocks) >> 1; cost = Cb + Cr
-        int sp = group_sum<4>(hadamard_abs(d)) >> 1;
-        int sum = sp + __shfl_xor(sp, 4);
+        int sp = hadamard_abs(d);
+        sp += __builtin_amdgcn_mov_dpp(sp, 0xB1, 0xf, 0xf, false);     // the four blocks of the plane (a quad)
+        sp += __builtin_amdgcn_mov_dpp(sp, 0x4E, 0xf, 0xf, false);
+        sp >>= 1;
+        int sum = sp + __builtin_amdgcn_mov_dpp(sp, 0x141, 0xf, 0xf, false);   // + the other plane: lanes l ^ 4 = half-row mirror partner's quad (same sum in all four)
         const bool ok = mode == 0 ? true : mode == 1 ? (avail & 1) : mode == 2 ? (avail & 2) : avail == 7;
         unsigned key = (ok && lane < 32) ? (((unsigned)sum << 2) | (unsigned)mode) : 0xFFFFFFFFu;
-        best_cmode = (int)(wave_min_u32(key) & 3);
+        best_cmode = (int)(wave_min_u32_dpp(key) & 3);
     }
     if (lane < 32) {
         const int pl = lane >> 4, y = (lane >> 1) & 7, xs = (lane & 1) * 4;
