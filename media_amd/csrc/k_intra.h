@@ -223,7 +223,7 @@ __device__ __forceinline__ void intra_mb_core(const FrameParams& P, int mx, int 
         }
         *(uint32_t*)(S.pc + pl * 64 + y * 8 + xs) = o;
     }
-    __syncthreads();
+    wave_sync();
 
     // ---- transform / quant: lanes 0..15 luma AC (+DC via Hadamard), 16..23 chroma ----
     int nnz = 0, dcw = 0;
@@ -250,7 +250,7 @@ __device__ __forceinline__ void intra_mb_core(const FrameParams& P, int mx, int 
         }
         nnz = tq4x4(d, P.qc, P.qc.f_intra, 1, S.lv + LV_CHROMA_AC + (cpl * 4 + cb) * 16, &dcw, 0, false);
     }
-    __syncthreads();
+    wave_sync();
     {   // luma DC: forward Hadamard, quantise at qbits+2, inverse Hadamard, 8.5.10 scaling
         int h[16];
 #pragma unroll
@@ -314,7 +314,7 @@ __device__ __forceinline__ void intra_mb_core(const FrameParams& P, int mx, int 
             *(uint32_t*)(ldst + r * ppitch) = o;
         }
     }
-    __syncthreads();
+    wave_sync();
     MbInfo* m = P.mb + mbi;
     const int tcv = (lane < 16 ? cbp_luma != 0 : cbp_chroma == 2) ? nnz : 0;
     if (lane < 24) m->tc[lane] = (uint8_t)tcv;
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(64) void k_intra_diag(FrameParams P0, int s)
             S.cleft[pl][i] = mx > 0 ? (pl ? P.rec[2] : P.rec[1])[(size_t)(8 * my + i) * cs + 8 * mx - 1] : 0;
         }
     }
-    __syncthreads();
+    wave_sync();
     intra_mb_core(P, mx, my, S, lane);
 }
 
@@ -421,7 +421,7 @@ __global__ __launch_bounds__(64) void k_intra_rows(IntraRowParams R)
         }
         *(uint32_t*)(S.src + (lane >> 2) * 16 + (lane & 3) * 4) = cur_y;
         if (lane < 32) *(uint32_t*)(S.srcc + (lane >> 4) * 64 + ((lane >> 1) & 7) * 8 + (lane & 1) * 4) = cur_c;
-        __syncthreads();   // corner moved before the top row is overwritten
+        wave_sync();   // corner moved before the top row is overwritten
         if (my > 0) {
             unsigned spins = 0;
             while (!timed_out) {
@@ -439,7 +439,7 @@ __global__ __launch_bounds__(64) void k_intra_rows(IntraRowParams R)
                 for (int k = 0; k < 4; k++) dst[k] = (uint8_t)(v >> (8 * k));
             }
         }
-        __syncthreads();
+        wave_sync();
         intra_mb_core(P, mx, my, S, lane);
         // publish this macroblock's bottom sample row for the row below
         if (my + 1 < P.mbh && lane < 8) {
@@ -449,7 +449,7 @@ __global__ __launch_bounds__(64) void k_intra_rows(IntraRowParams R)
             __hip_atomic_store(handoff + ((size_t)my * P.mbw + mx) * 8 + lane, ((unsigned long long)R.serial << 32) | v,
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        __syncthreads();
+        wave_sync();
     }
     if (timed_out && lane == 0) *R.err = 2u;
 }
