@@ -200,15 +200,22 @@ __device__ __forceinline__ int group_sum(int v)
     return v;
 }
 
-// The same reductions for a wave that runs ALONE on its SIMD (the row-wavefront kernels): DPP moves instead of
-// ds_bpermute round trips (~8 cycles instead of ~120 per step).  Mirrors are as good as xor exchanges for a
-// commutative reduction.
+// The same reductions with DPP moves instead of ds_bpermute round trips: ~8 cycles instead of ~120 per step for a
+// wave that runs alone on its SIMD (the row-wavefront kernels), and no address arithmetic for the VALU-bound ones.
+// Mirrors are as good as xor exchanges for a commutative reduction.
 __device__ __forceinline__ int row_sum16_dpp(int v)   // sum over aligned groups of 16 lanes, in every lane
 {
     v += __builtin_amdgcn_mov_dpp(v, 0xB1, 0xf, 0xf, false);    // quad_perm [1,0,3,2]
     v += __builtin_amdgcn_mov_dpp(v, 0x4E, 0xf, 0xf, false);    // quad_perm [2,3,0,1]
     v += __builtin_amdgcn_mov_dpp(v, 0x141, 0xf, 0xf, false);   // row_half_mirror
     v += __builtin_amdgcn_mov_dpp(v, 0x140, 0xf, 0xf, false);   // row_mirror
+    return v;
+}
+__device__ __forceinline__ int group_sum8_dpp(int v)   // sum over aligned groups of 8 lanes, in every lane
+{
+    v += __builtin_amdgcn_mov_dpp(v, 0xB1, 0xf, 0xf, false);    // quad_perm [1,0,3,2]
+    v += __builtin_amdgcn_mov_dpp(v, 0x4E, 0xf, 0xf, false);    // quad_perm [2,3,0,1]
+    v += __builtin_amdgcn_mov_dpp(v, 0x141, 0xf, 0xf, false);   // row_half_mirror
     return v;
 }
 __device__ __forceinline__ unsigned wave_min_u32_dpp(unsigned v)   // minimum over the 64 lanes, wave-uniform result

@@ -299,7 +299,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
             lbk[4 * q + 2] = (acc[4 * q + 2] << 10) + (t.z + kbase); lbk[4 * q + 3] = (acc[4 * q + 3] << 10) + (t.w + kbase);
             bestlb = min(min(bestlb, lbk[4 * q]), min(lbk[4 * q + 1], min(lbk[4 * q + 2], lbk[4 * q + 3])));
         }
-        bestlb = wave_min_u32(bestlb);
+        bestlb = wave_min_u32_dpp(bestlb);
         // the other half of a candidate's SAD (columns 4..7, 12..15), candidate given by its key's index bits
         auto rest_of_sad = [&](uint32_t key) -> uint32_t {
             const int ccol = (int)(key & 31) + ME_AP, csh = ccol & 3;
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
                 best = tk <= bound && key < best ? key : best;
             }
         }
-        best = wave_min_u32(best);
+        best = wave_min_u32_dpp(best);
         __syncthreads();   // the list's memory becomes the half-sample planes
     }
     const int ix = (int)(best & 31) - ME_R, iy = (int)((best >> 5) & 31) - ME_R;
@@ -464,12 +464,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
             sum = __builtin_amdgcn_sad_u16(__builtin_bit_cast(uint32_t, s0 - s1), 0x80008000u, sum);
             sum = __builtin_amdgcn_sad_u16(__builtin_bit_cast(uint32_t, d0 - d1), 0x80008000u, sum);
         }
-        const int s = group_sum<8>((int)sum);
+        const int s = group_sum8_dpp((int)sum);
         const unsigned cost = (unsigned)(s >> 1) + (unsigned)(P.lambda * (se_len(qx - pmx) + se_len(qy - pmy)));
         const unsigned key = live ? ((cost << 4) | (unsigned)ord) : 0xFFFFFFFFu;
         bestk = key < bestk ? key : bestk;               // per-lane running minimum; reduced once per pass
         if (round == 0) continue;
-        bestk = wave_min_u32(bestk);
+        bestk = wave_min_u32_dpp(bestk);
         const int w = (int)(bestk & 15);
         best_cost = bestk >> 4;
         if (w) {
