@@ -363,3 +363,32 @@ def test_scrolling_content_takes_the_previous_vector():
     assert moved.mean() > 0.8 and (mb["type"] == 2).mean() > 0.6, (moved.mean(), (mb["type"] == 2).mean())
     assert sizes[-1] < sizes[1]          # later P pictures cost less than the first one (which had to search)
     enc.close()
+
+
+def test_large_global_motion_and_noise_pictures():
+    """seeded sweep aimed at the motion path's corners: global motion up to +-20 samples per picture (beyond the
+    +-16 search range, so vectors pile up at the window edge and previous-picture vectors point outside the picture),
+    pure-noise pictures (nothing ever quantises to zero, every search runs to the end, worst-case bit counts), very
+    low and very high QP, GOPs that restart mid-sequence"""
+    import random
+    rng = random.Random(11)
+    for case in range(120):
+        w, h = 2 * rng.randint(8, 200), 2 * rng.randint(8, 150)
+        qp = rng.choice([12, 18, 24, 28, 33, 40, 48])
+        mot = (rng.randint(-20, 20), rng.randint(-20, 20))
+        noise = rng.choice([0, 0, 1, 3, 8])
+        gop = rng.choice([3, 5, 30])
+        kind = rng.choice(["s1", "s1", "scroll", "rand"])
+        if kind == "s1":
+            frames = [synth.frame_s1(w, h, i, noise=noise, motion=mot) for i in range(8)]
+        elif kind == "scroll":
+            frames = [synth.frame_scroll(w, h, i) for i in range(8)]
+        else:
+            r = np.random.default_rng(case)
+            frames = [r.integers(0, 256, w * h * 3 // 2, dtype=np.uint8) for _ in range(8)]
+        enc = capi.Encoder(w, h, qp=qp, gop=gop)
+        orc = OracleEncoder(w, h, qp=qp, gop=gop)
+        for i, f in enumerate(frames):
+            assert enc.encode(f)[0] == orc.encode(f)[0], "case %d: %dx%d qp %d motion %s noise %d gop %d %s picture %d" % (
+                case, w, h, qp, mot, noise, gop, kind, i)
+        enc.close()
