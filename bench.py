@@ -112,6 +112,8 @@ def main():
     ap.add_argument("--fps", type=int, default=30, choices=[30, 60])
     ap.add_argument("--content", default="s1", choices=["s1", "s2", "s3", "scroll"],
                     help="synthetic input of SURVEY.md 8(d); s1 pan+noise is the headline workload")
+    ap.add_argument("--slices", type=int, default=0,
+                    help="slices per picture (bands of macroblock rows, SURVEY.md 8e-3); 0/1 = one slice, the reference preset and the headline")
     args = ap.parse_args()
 
     import numpy as np
@@ -158,7 +160,7 @@ def main():
         del uv
     torch.cuda.synchronize()
     profile_idc = {"baseline": 66, "main": 77, "high": 100}[args.profile]
-    enc_kw = dict(qp=QP, gop=GOP, device=local_rank, fps=args.fps, profile_idc=profile_idc, input_format=1 if args.input == "nv12" else 0)
+    enc_kw = dict(qp=QP, gop=GOP, device=local_rank, fps=args.fps, profile_idc=profile_idc, input_format=1 if args.input == "nv12" else 0, slices=args.slices)
 
     # I encoder instances (own HIP stream each), each encoding G/I GOPs in lockstep: every kernel launch of an
     # instance covers all its pictures of one time step (grid.y = G/I); instances overlap each other's
@@ -297,9 +299,9 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "1080p%d %s synthetic S1 pan+noise, %s profile, fixed QP 26, closed GOPs of 30 " % (args.fps, args.input.upper(), args.profile) +
-                                   "(1 IDR + 29 P), single slice, 1 ref, deblock on, CAVLC; per GPU one stream, %d of its "
+                                   "(1 IDR + 29 P), %s, 1 ref, deblock on, CAVLC; per GPU one stream, %d of its "
                                    "closed GOPs per step on %d encoder instance(s), each encoding its %d GOPs in lockstep "
-                                   "(grid.y) on its own HIP streams; pictures resident in HBM" % (G, I, B),
+                                   "(grid.y) on its own HIP streams; pictures resident in HBM" % ("single slice" if args.slices < 2 else "%d slice bands (filter idc 2)" % args.slices, G, I, B),
                        "content": args.content, "width": WIDTH, "height": HEIGHT, "qp": QP, "gop": GOP, "frames_per_step": FRAMES_PER_STEP * G, "gops_in_flight": G, "instances": I, "lockstep_batch": B,
                        "streams": world, "bytes_per_gop": int(nbytes), "selfcheck_batch_equals_single": selfcheck, "parity": "bit-exact vs CPU oracle "
                        "(oracle unpinned vs OpenH264: no libopenh264 available)"},

@@ -75,7 +75,11 @@ typedef struct mi355x_h264_config {
                               * 1..64; > 1 is driven through mi355x_h264_encode_gops_device only      */
     int32_t input_format;    /* layout of pictures handed over in DEVICE memory (encode_device, encode_batch_device,
                               * encode_gops_device): MI355X_H264_INPUT_I420 (default) or MI355X_H264_INPUT_NV12     */
-    int32_t reserved[3];
+    int32_t slices;          /* 0 / 1: one slice per picture (the reference preset, SM_SINGLE_SLICE, ref :247).  n > 1:
+                              * n bands of ceil(rows / n) macroblock rows (at least two rows each), one slice NAL
+                              * unit per band, disable_deblocking_filter_idc = 2: the bands of a picture
+                              * do not depend on one another, their row wavefronts run side by side                  */
+    int32_t reserved[2];
 } mi355x_h264_config;
 
 typedef struct mi355x_h264_encoder mi355x_h264_encoder;

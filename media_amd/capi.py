@@ -32,7 +32,7 @@ class Config(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("width", C.c_int32), ("height", C.c_int32), ("fps", C.c_int32),
                 ("bitrate", C.c_int32), ("gop", C.c_int32), ("profile_idc", C.c_int32), ("rc_mode", C.c_int32),
                 ("qp", C.c_int32), ("device", C.c_int32), ("disable_deblock", C.c_int32),
-                ("batch", C.c_int32), ("input_format", C.c_int32), ("reserved", C.c_int32 * 3)]
+                ("batch", C.c_int32), ("input_format", C.c_int32), ("slices", C.c_int32), ("reserved", C.c_int32 * 2)]
 
 
 class Stats(C.Structure):
@@ -88,7 +88,7 @@ class Encoder:
     """thin object wrapper; argument meaning follows mi355x_h264_config"""
 
     def __init__(self, width, height, qp=26, gop=30, fps=30, profile_idc=66, device=0, disable_deblock=0,
-                 bitrate=5000000, rc_mode=0, batch=1, input_format=0):
+                 bitrate=5000000, rc_mode=0, batch=1, input_format=0, slices=0):
         L = lib()
         cfg = Config()
         L.mi355x_h264_default_config(C.byref(cfg))
@@ -96,6 +96,7 @@ class Encoder:
         cfg.profile_idc, cfg.device, cfg.disable_deblock = profile_idc, device, disable_deblock
         cfg.bitrate, cfg.rc_mode, cfg.batch = bitrate, rc_mode, batch
         cfg.input_format = input_format   # 0 I420, 1 NV12: layout of pictures handed over in device memory
+        cfg.slices = slices               # > 1: that many bands of macroblock rows, one slice NAL unit each
         self.batch = batch
         self.h = C.c_void_p()
         rc = L.mi355x_h264_create(C.byref(cfg), C.byref(self.h))

@@ -34,6 +34,17 @@ struct Quant {
     int qp;
 };
 
+// Slices are bands of `rows` whole macroblock rows (the last band may be shorter); with one slice rows = mbh.
+// row_in_slice() is my % rows through a 32-bit reciprocal (inv = floor(2^32 / rows) + 1, exact for my < 65536):
+// two scalar multiplies where a runtime modulo would be a float division sequence.
+struct SliceRows {
+    int rows;
+    unsigned inv;
+    __device__ __forceinline__ int row_in_slice(int my) const { return my - (int)__umulhi((unsigned)my, inv) * rows; }
+    // 6.4.4: the macroblocks above belong to another slice (or lie outside the picture) on a slice's first row
+    __device__ __forceinline__ bool has_top(int my) const { return row_in_slice(my) != 0; }
+};
+
 struct FrameParams {
     const uint8_t* src;  // tight picture in HBM: Y (w*h), then U, V planes (I420) or one interleaved UV plane (NV12)
     int src_nv12;        // 1: chroma is read straight from the interleaved plane (no conversion pass)
@@ -52,6 +63,7 @@ struct FrameParams {
     size_t st_src;       // bytes between the source pictures of two batch items
     size_t st_y, st_c;   // bytes between reconstruction planes (luma, chroma)
     int st_mb;           // macroblocks per batch item (MbInfo / levels / mvd arrays)
+    SliceRows sl;        // slices of the picture: bands of sl.rows macroblock rows (sl.rows = mbh: one slice)
 };
 
 // the parameter block of batch item g (pointers advanced by g strides)
@@ -302,7 +314,7 @@ __device__ __forceinline__ int xcd_mb_index(int b, int n)
 
 // 8.4.1.3 motion vector prediction for a 16x16 partition with one reference
 // frame.  All macroblocks of the picture already carry their final vectors, so
-// any neighbour inside the picture is "available" (single slice).
+// a neighbour is "available" when it lies inside the picture and in the same slice (P.sl).
 struct Mv { int x, y; };
 __device__ __forceinline__ int med3(int a, int b, int c)
 {
@@ -315,7 +327,8 @@ __device__ __forceinline__ int med3(int a, int b, int c)
 // this build, but the general rule is kept.
 __device__ __forceinline__ Mv predict_mv(const FrameParams& P, int mx, int my, Mv& skip)
 {
-    const bool avA = mx > 0, avB = my > 0, avC0 = my > 0 && mx + 1 < P.mbw, avD = mx > 0 && my > 0;
+    const bool top = P.sl.has_top(my);   // neighbours above exist and lie in the same slice
+    const bool avA = mx > 0, avB = top, avC0 = top && mx + 1 < P.mbw, avD = mx > 0 && top;
     const MbInfo* base = P.mb + (size_t)my * P.mbw + mx;
     // every lane loads the same words: hand them to the scalar unit, which then does the whole prediction
     auto uni = [](const uint2 v) { return make_uint2((uint32_t)__builtin_amdgcn_readfirstlane((int)v.x), (uint32_t)__builtin_amdgcn_readfirstlane((int)v.y)); };

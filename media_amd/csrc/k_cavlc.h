@@ -237,24 +237,25 @@ __device__ __forceinline__ void cavlc_block(S& s, const int16_t* lv, int maxc, i
 }
 
 // nC of a luma 4x4 block (bx4,by4 in 0..3) / chroma block (2x2 grid), 9.2.1
-__device__ __forceinline__ int nc_luma(const MbInfo* m, int mx, int my, int mbw, int x, int y)
+// (top: the macroblock above is in this slice)
+__device__ __forceinline__ int nc_luma(const MbInfo* m, int mx, bool top, int mbw, int x, int y)
 {
     int nA = -1, nB = -1;
     if (x > 0) nA = m->tc[xy2blk(x - 1, y)];
     else if (mx > 0) nA = (m - 1)->tc[xy2blk(3, y)];
     if (y > 0) nB = m->tc[xy2blk(x, y - 1)];
-    else if (my > 0) nB = (m - mbw)->tc[xy2blk(x, 3)];
+    else if (top) nB = (m - mbw)->tc[xy2blk(x, 3)];
     if (nA >= 0 && nB >= 0) return (nA + nB + 1) >> 1;
     return nA >= 0 ? nA : (nB >= 0 ? nB : 0);
 }
-__device__ __forceinline__ int nc_chroma(const MbInfo* m, int mx, int my, int mbw, int pl, int x, int y)
+__device__ __forceinline__ int nc_chroma(const MbInfo* m, int mx, bool top, int mbw, int pl, int x, int y)
 {
     const int base = 16 + pl * 4;
     int nA = -1, nB = -1;
     if (x > 0) nA = m->tc[base + 2 * y];
     else if (mx > 0) nA = (m - 1)->tc[base + 2 * y + 1];
     if (y > 0) nB = m->tc[base + x];
-    else if (my > 0) nB = (m - mbw)->tc[base + 2 + x];
+    else if (top) nB = (m - mbw)->tc[base + 2 + x];
     if (nA >= 0 && nB >= 0) return (nA + nB + 1) >> 1;
     return nA >= 0 ? nA : (nB >= 0 ? nB : 0);
 }
@@ -264,6 +265,7 @@ struct CavlcParams {
     const int16_t* levels;
     const int16_t* mvd;
     int mbw, nmb, p_slice;
+    SliceRows sl;         // slices of the picture (bands of sl.rows macroblock rows)
     uint16_t* slotbits;   // 32 per macroblock
     unsigned long long* slotcode;   // 32 per macroblock: the slot's bits, left aligned, when slotbits <= 64
     uint32_t* mbbits;     // per macroblock, then (after the scan) bit offsets
@@ -282,13 +284,15 @@ __device__ __forceinline__ CavlcParams batch_view(CavlcParams C, int g)
     return C;
 }
 enum { MAX_BATCH = 64 };
-struct HdrBatch { unsigned long long bits[MAX_BATCH]; unsigned char len[MAX_BATCH]; };  // slice header of every batch item
+struct HdrBatch { unsigned long long bits[MAX_BATCH]; unsigned char len[MAX_BATCH]; };  // slice header of every batch item, from slice_type on
 
 // 8.7.2.1 boundary strength of one 4-sample edge segment; l = (dir, edge, segment) within the macroblock.
-__device__ __forceinline__ int mb_edge_strength(const MbInfo* q, int mx, int my, int mbw, int l)
+// top: the macroblock above is in this slice; with several slices the stream says disable_deblocking_filter_idc 2
+// and the edge between two slices is not filtered.
+__device__ __forceinline__ int mb_edge_strength(const MbInfo* q, int mx, bool top, int mbw, int l)
 {
     const int dir = l >> 4, e = (l >> 2) & 3, k = l & 3;
-    if (e == 0 && (dir == 0 ? mx == 0 : my == 0)) return 0;
+    if (e == 0 && (dir == 0 ? mx == 0 : !top)) return 0;
     const MbInfo* p = e == 0 ? (dir == 0 ? q - 1 : q - mbw) : q;
     const int bq = dir == 0 ? xy2blk(e, k) : xy2blk(k, e);
     const int bp = dir == 0 ? (e == 0 ? xy2blk(3, k) : xy2blk(e - 1, k)) : (e == 0 ? xy2blk(k, 3) : xy2blk(k, e - 1));
@@ -305,12 +309,15 @@ __device__ __forceinline__ void code_slot(S& s, const CavlcParams& C, int mbi, i
     const MbInfo* m = C.mb + mbi;
     if (m->type == MB_PSKIP) return;
     const int mx = mbi % C.mbw, my = mbi / C.mbw;
+    const int srow = C.sl.row_in_slice(my);
+    const bool top = srow != 0;
     const int16_t* lv = C.levels + (size_t)mbi * LV_STRIDE;
     const int cbpl = m->cbp & 15, cbpc = m->cbp >> 4;
     const bool i16 = m->type == MB_I16;
     if (slot == 0) {
         if (C.p_slice) {
-            put_ue(s, (unsigned)(mbi - 1 - C.prevcoded[mbi]));   // mb_skip_run: the P_Skip macroblocks right before this one
+            // mb_skip_run: the P_Skip macroblocks right before this one, counted from the slice's first macroblock
+            put_ue(s, (unsigned)(mbi - 1 - max(C.prevcoded[mbi], (my - srow) * C.mbw - 1)));
         }
         if (i16) {
             const unsigned t = 1u + m->i16_mode + 4u * (unsigned)cbpc + (cbpl ? 12u : 0u);
@@ -325,11 +332,11 @@ __device__ __forceinline__ void code_slot(S& s, const CavlcParams& C, int mbi, i
             if (m->cbp) put_se(s, 0);
         }
     } else if (slot == 1) {
-        if (i16) cavlc_block(s, lv + LV_LUMA_DC, 16, nc_luma(m, mx, my, C.mbw, 0, 0));
+        if (i16) cavlc_block(s, lv + LV_LUMA_DC, 16, nc_luma(m, mx, top, C.mbw, 0, 0));
     } else if (slot < 18) {
         const int b = slot - 2;
         if (cbpl & (1 << (b >> 2))) {
-            const int nC = nc_luma(m, mx, my, C.mbw, blk_x(b), blk_y(b));
+            const int nC = nc_luma(m, mx, top, C.mbw, blk_x(b), blk_y(b));
             if (i16) cavlc_block(s, lv + LV_LUMA + b * 16 + 1, 15, nC);
             else cavlc_block(s, lv + LV_LUMA + b * 16, 16, nC);
         }
@@ -337,7 +344,7 @@ __device__ __forceinline__ void code_slot(S& s, const CavlcParams& C, int mbi, i
         if (cbpc) cavlc_block(s, lv + LV_CHROMA_DC + (slot - 18) * 4, 4, -1);
     } else if (slot < 28) {
         const int k = slot - 20, pl = k >> 2, b = k & 3;
-        if (cbpc == 2) cavlc_block(s, lv + LV_CHROMA_AC + k * 16 + 1, 15, nc_chroma(m, mx, my, C.mbw, pl, b & 1, b >> 1));
+        if (cbpc == 2) cavlc_block(s, lv + LV_CHROMA_AC + k * 16 + 1, 15, nc_chroma(m, mx, top, C.mbw, pl, b & 1, b >> 1));
     }
 }
 
@@ -353,7 +360,7 @@ __global__ __launch_bounds__(64) void k_bs(CavlcParams C0, unsigned* anybs, unsi
     const int mbi = blockIdx.x * 2 + (lane >> 5);
     int bs = 0;
     if (mbi < C.nmb) {
-        bs = mb_edge_strength(C.mb + mbi, mbi % C.mbw, mbi / C.mbw, C.mbw, slot);
+        bs = mb_edge_strength(C.mb + mbi, mbi % C.mbw, C.sl.has_top(mbi / C.mbw), C.mbw, slot);
         C.bs[(size_t)mbi * 32 + slot] = (uint8_t)bs;
     }
     if (__ballot(bs != 0) != 0ull && lane == 0) anybs[blockIdx.y] = serial;   // same value from every writer: a plain store
@@ -443,29 +450,38 @@ struct SliceInfo {       // lives in pinned host memory, written by the device
     uint32_t pad[3];
 };
 
-// one workgroup of SCAN_NT threads per picture: exclusive scan of mbbits (in place -> offsets), header, tail.
+// one workgroup of SCAN_NT threads per slice (item = picture * nsl + slice): exclusive scan of mbbits over the
+// slice's macroblocks (in place -> bit offsets inside the picture's payload buffer, where slice s starts at byte
+// s * slice_cap), slice header, tail.
 // Kept small (4 waves): a workgroup is dispatched only when one CU has room for all of its waves, and beside
 // another instance's motion search a 16-wave workgroup waits long for that.
 enum { SCAN_NT = 256 };
-__global__ __launch_bounds__(SCAN_NT) void k_bit_scan(CavlcParams C0, HdrBatch H, SliceInfo* info0, const uint16_t* me_cost0)
+__global__ __launch_bounds__(SCAN_NT) void k_bit_scan(CavlcParams C0, HdrBatch H, SliceInfo* info0, const uint16_t* me_cost0, int nsl, unsigned slice_cap)
 {
     __builtin_amdgcn_s_setprio(1);
-    const CavlcParams C = batch_view(C0, blockIdx.x);
-    const unsigned long long hdr_bits = H.bits[blockIdx.x];
-    const int hdr_len = H.len[blockIdx.x];
-    SliceInfo* info = info0 + blockIdx.x;
+    const int item = blockIdx.x, pic = item / nsl, sl = item - pic * nsl;
+    const CavlcParams C = batch_view(C0, pic);
+    const int mb0 = sl * C.sl.rows * C.mbw, mb1 = min(C.nmb, mb0 + C.sl.rows * C.mbw), cnt = mb1 - mb0;
+    // slice_header(): first_mb_in_slice is written here, the rest (the same for every slice of the picture) comes from the host
+    const unsigned long long hdr_bits = H.bits[pic];
+    const int hdr_rest = H.len[pic];
+    BitCount fl;
+    fl.init(0);
+    put_ue(fl, (unsigned)mb0);
+    const unsigned base = (unsigned)sl * slice_cap * 8u, hdr_len = fl.n + (unsigned)hdr_rest;
+    SliceInfo* info = info0 + item;
     __shared__ unsigned s_part[SCAN_NT];
     __shared__ unsigned s_cost;
     const int t = threadIdx.x;
     if (t == 0) s_cost = 0;
-    const int per = (C.nmb + SCAN_NT - 1) / SCAN_NT;
-    const int b0 = t * per, b1 = min(C.nmb, b0 + per);
+    const int per = (cnt + SCAN_NT - 1) / SCAN_NT;
+    const int b0 = min(mb1, mb0 + t * per), b1 = min(mb1, b0 + per);
     unsigned sum = 0;
     for (int i = b0; i < b1; i++) sum += C.mbbits[i];
     s_part[t] = sum;
     __syncthreads();
     if (C.p_slice) {   // scene-change statistic: sum of the per-macroblock motion costs k_me left
-        const uint16_t* mc = me_cost0 + (size_t)blockIdx.x * C.st_mb;
+        const uint16_t* mc = me_cost0 + (size_t)pic * C.st_mb;
         unsigned cs = 0;
         for (int i = b0; i < b1; i++) cs += mc[i];
         if (cs) atomicAdd(&s_cost, cs);
@@ -476,7 +492,7 @@ __global__ __launch_bounds__(SCAN_NT) void k_bit_scan(CavlcParams C0, HdrBatch H
         s_part[t] += v;
         __syncthreads();
     }
-    unsigned run = (unsigned)hdr_len + s_part[t] - sum;
+    unsigned run = base + hdr_len + s_part[t] - sum;
     for (int i = b0; i < b1; i++) {
         const unsigned n = C.mbbits[i];
         C.mbbits[i] = run;
@@ -485,16 +501,18 @@ __global__ __launch_bounds__(SCAN_NT) void k_bit_scan(CavlcParams C0, HdrBatch H
     if (t == 0) {
         BitWrite s;
         s.buf = C.bitbuf;
-        s.init(0);
-        if (hdr_len > 32) { s.put(hdr_len - 32, (unsigned)(hdr_bits >> 32)); s.put(32, (unsigned)hdr_bits); }
-        else s.put(hdr_len, (unsigned)hdr_bits);
+        s.init(base);
+        put_ue(s, (unsigned)mb0);
+        if (hdr_rest > 32) { s.put(hdr_rest - 32, (unsigned)(hdr_bits >> 32)); s.put(32, (unsigned)hdr_bits); }
+        else s.put(hdr_rest, (unsigned)hdr_bits);
         s.flush();
-        unsigned total = (unsigned)hdr_len + s_part[SCAN_NT - 1];
-        s.init(total);
+        unsigned total = hdr_len + s_part[SCAN_NT - 1];
+        s.init(base + total);
         BitCount c;
         c.init(0);
         if (C.p_slice) {
-            const unsigned skips = (unsigned)(C.nmb - 1 - C.prevcoded[C.nmb]);   // P_Skip macroblocks that end the slice
+            // P_Skip macroblocks that end the slice
+            const unsigned skips = (unsigned)(mb1 - 1 - max(C.prevcoded[mb1], mb0 - 1));
             if (skips) { put_ue(s, skips); put_ue(c, skips); }
         }
         s.put(1, 1);  // rbsp_stop_one_bit
@@ -503,24 +521,25 @@ __global__ __launch_bounds__(SCAN_NT) void k_bit_scan(CavlcParams C0, HdrBatch H
         info->total_bits = total;
         info->total_bytes = (total + 7) >> 3;
         info->epb_count = 0;
-        info->error = 0;
+        info->error = ((total + 7) >> 3) + 32u > slice_cap ? 1u : 0u;   // the slice outgrew its share of the payload buffer
         info->me_cost = s_cost;   // complete: every thread passed the scan's barriers after its atomicAdd
     }
 }
 
-// Copy the payload to the pinned access unit, count emulation-prevention sites, publish SliceInfo to
-// pinned host memory and leave the device bit buffer zeroed for its next use (one workgroup).
+// Copy the payload of one slice to the pinned access unit buffer, count emulation-prevention sites, publish
+// SliceInfo to pinned host memory and leave the device bit buffer zeroed for its next use (one workgroup per slice).
 __global__ __launch_bounds__(SCAN_NT) void k_pack(uint8_t* bitbuf0, size_t st_bitbuf_bytes, uint8_t* dst0, size_t st_dst, const SliceInfo* info0,
-                                               SliceInfo* host_info0)
+                                               SliceInfo* host_info0, int nsl, unsigned slice_cap)
 {
-    uint8_t* bitbuf = bitbuf0 + (size_t)blockIdx.x * st_bitbuf_bytes;
-    uint8_t* dst = dst0 + (size_t)blockIdx.x * st_dst;
-    const SliceInfo* info = info0 + blockIdx.x;
-    SliceInfo* host_info = host_info0 + blockIdx.x;
+    const int item = blockIdx.x, pic = item / nsl, sl = item - pic * nsl;
+    uint8_t* bitbuf = bitbuf0 + (size_t)pic * st_bitbuf_bytes + (size_t)sl * slice_cap;
+    uint8_t* dst = dst0 + (size_t)pic * st_dst + (size_t)sl * slice_cap;
+    const SliceInfo* info = info0 + item;
+    SliceInfo* host_info = host_info0 + item;
     __shared__ unsigned s_cnt;
     if (threadIdx.x == 0) s_cnt = 0;
     __syncthreads();
-    const unsigned nbytes = info->total_bytes;
+    const unsigned nbytes = min(info->total_bytes, slice_cap - 32u);   // (an overflowing slice is reported through info->error)
     unsigned cnt = 0;
     for (unsigned i = threadIdx.x * 16u; i < nbytes; i += blockDim.x * 16u) {
         const uint4 v = *(const uint4*)(bitbuf + i);  // buffer is padded and zeroed past the end

@@ -37,6 +37,7 @@ struct DbParams {
     int cw, ch, mbw, mbh;
     int alpha_y, beta_y, alpha_c, beta_c;
     int tc0_y[3], tc0_c[3];  // by bS-1
+    SliceRows sl;        // several slices: disable_deblocking_filter_idc 2, the edge between two slices is left alone
 };
 
 // filter one line across an edge; p points at q0 inside LDS, xs = distance between samples across the edge
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(64) void k_deblock_diag(DbParams D, int s)
                 bS = edge_bs(p, e == 0 ? xy2blk(3, k) : xy2blk(e - 1, k), q, xy2blk(e, k), e == 0);
             }
         } else {
-            if (!(e == 0 && my == 0)) {
+            if (!(e == 0 && !D.sl.has_top(my))) {
                 const MbInfo* p = e == 0 ? q - D.mbw : q;
                 bS = edge_bs(p, e == 0 ? xy2blk(k, 3) : xy2blk(k, e - 1), q, xy2blk(k, e), e == 0);
             }
@@ -269,7 +270,10 @@ __global__ __launch_bounds__(64) void k_deblock_rows(DbRowParams R)
     u64* const handoff = R.handoff + (size_t)blockIdx.y * R.st_handoff;
     const uint32_t* const bsw = R.bs + (size_t)blockIdx.y * R.st_mb * 8;
     const int lane = threadIdx.x, my = blockIdx.x, cs = D.cw / 2;
-    const bool last_row = my == D.mbh - 1;
+    // a slice's rows form a wavefront of their own: its first row waits for nobody (no edge to the slice above is
+    // filtered), its last row stores all sixteen sample rows itself
+    const bool first_row = !D.sl.has_top(my);
+    const bool last_row = my == D.mbh - 1 || !D.sl.has_top(my + 1);
     __shared__ __attribute__((aligned(16))) uint8_t s_y[20 * DR_LP];     // [row+4][col+16]
     __shared__ __attribute__((aligned(16))) uint8_t s_c[2][20 * DR_CP];  // [row+4][col+8] (rows 8.. unused padding)
 #define SY(r, c) s_y[((r) + 4) * DR_LP + (c) + 16]
@@ -296,7 +300,7 @@ __global__ __launch_bounds__(64) void k_deblock_rows(DbRowParams R)
     uint32_t pf_y = 0, pf_c = 0;
     uint4 pf_b0 = {0, 0, 0, 0}, pf_b1 = pf_b0;
     u64 pf_g = 0;
-    const int grow = my > 0 ? my - 1 : 0;          // row 0 reads (and ignores) its own slots
+    const int grow = first_row ? my : my - 1;      // a first row reads (and ignores) its own slots
     const int glane = lane < 24 ? lane : lane - 24 < 24 ? lane - 24 : lane - 48;
     auto prefetch = [&](int mx) {
         pf_y = *(const uint32_t*)(D.pl[0] + (size_t)(16 * my + yr) * D.cw + 16 * mx + yc4);
@@ -349,7 +353,7 @@ __global__ __launch_bounds__(64) void k_deblock_rows(DbRowParams R)
             *(uint32_t*)&SY(yr, yc4) = cur_y;
             if (lane < 32) *(uint32_t*)&SC(cpl_l, cr_l, cc4) = cur_c;
             // 3. top apron: wait until every granule carries this picture's tag
-            if (my > 0) {
+            if (!first_row) {
                 unsigned spins = 0;
                 while (!timed_out) {
                     const bool bad = lane < 24 && (unsigned)(g >> 32) != R.serial;
@@ -409,7 +413,7 @@ __global__ __launch_bounds__(64) void k_deblock_rows(DbRowParams R)
             wave_sync();
             consume();   // the next macroblock's data has arrived; nothing below waits for memory any more
             // 6. the top apron (rows 12..15 / 6..7 of the macroblock above) is final: store it
-            if (my > 0) {
+            if (!first_row) {
                 if (lane < 16) *(uint32_t*)(D.pl[0] + (size_t)(16 * my - 4 + (gk >> 2)) * D.cw + 16 * mx + (gk & 3) * 4) = *(const uint32_t*)&SY(-4 + (gk >> 2), (gk & 3) * 4);
                 else if (lane < 24) {
                     const int k = gk - 16, pl = k >> 2, r = (k >> 1) & 1, c4 = (k & 1) * 4;

@@ -132,7 +132,8 @@ struct IntraLds {
 __device__ __forceinline__ void intra_mb_core(const FrameParams& P, int mx, int my, IntraLds& S, int lane)
 {
     const int mbi = my * P.mbw + mx, bx = 16 * mx, by = 16 * my, cs = P.cw / 2;
-    const int avail = (mx > 0 ? 1 : 0) | (my > 0 ? 2 : 0) | ((mx > 0 && my > 0) ? 4 : 0);
+    const bool top = P.sl.has_top(my);   // the row above belongs to this slice
+    const int avail = (mx > 0 ? 1 : 0) | (top ? 2 : 0) | ((mx > 0 && top) ? 4 : 0);
     for (int i = lane; i < LV_STRIDE / 2; i += 64) ((uint32_t*)S.lv)[i] = 0;
 
     // ---- luma mode decision: lane = (mode, 4x4 block), SATD per mode ----
@@ -344,11 +345,12 @@ __global__ __launch_bounds__(64) void k_intra_diag(FrameParams P0, int s)
     load_src_mb(P, mx, my, S.src, S.srcc, lane);
     {
         const uint8_t* R = P.rec[0];
-        if (lane < 17) S.top[lane] = (my > 0 && (lane > 0 || mx > 0)) ? R[(size_t)(by - 1) * P.cw + bx - 1 + lane] : 0;
+        const bool top = P.sl.has_top(my);
+        if (lane < 17) S.top[lane] = (top && (lane > 0 || mx > 0)) ? R[(size_t)(by - 1) * P.cw + bx - 1 + lane] : 0;
         else if (lane < 33) S.left[lane - 17] = mx > 0 ? R[(size_t)(by + lane - 17) * P.cw + bx - 1] : 0;
         else if (lane < 33 + 18) {
             const int k = lane - 33, pl = k / 9, i = k % 9;
-            S.ctop[pl][i] = (my > 0 && (i > 0 || mx > 0)) ? (pl ? P.rec[2] : P.rec[1])[(size_t)(8 * my - 1) * cs + 8 * mx - 1 + i] : 0;
+            S.ctop[pl][i] = (P.sl.has_top(my) && (i > 0 || mx > 0)) ? (pl ? P.rec[2] : P.rec[1])[(size_t)(8 * my - 1) * cs + 8 * mx - 1 + i] : 0;
         }
         if (lane < 16) {
             const int pl = lane >> 3, i = lane & 7;
@@ -382,6 +384,7 @@ __global__ __launch_bounds__(64) void k_intra_rows(IntraRowParams R)
     const FrameParams P = batch_view(R.p, blockIdx.y);
     unsigned long long* const handoff = R.handoff + (size_t)blockIdx.y * R.st_handoff;
     const int lane = threadIdx.x, my = blockIdx.x;
+    const bool top = P.sl.has_top(my);   // first row of a slice: nothing above to wait for, the slices' wavefronts run side by side
     __shared__ IntraLds S;
     bool timed_out = false;
     const uint8_t* Y = P.src;
@@ -404,7 +407,7 @@ __global__ __launch_bounds__(64) void k_intra_rows(IntraRowParams R)
             const int pl = lane >> 4, row = (lane >> 1) & 7, xs = (lane & 1) * 4;
             pf_c = src_chroma4(P, pl, 8 * mx + xs, 8 * my + row);
         }
-        if (my > 0 && lane < 8) pf_g = __hip_atomic_load(handoff + ((size_t)(my - 1) * P.mbw + mx) * 8 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (top && lane < 8) pf_g = __hip_atomic_load(handoff + ((size_t)(my - 1) * P.mbw + mx) * 8 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
     prefetch(0);
     for (int mx = 0; mx < P.mbw; mx++) {
@@ -422,7 +425,7 @@ __global__ __launch_bounds__(64) void k_intra_rows(IntraRowParams R)
         *(uint32_t*)(S.src + (lane >> 2) * 16 + (lane & 3) * 4) = cur_y;
         if (lane < 32) *(uint32_t*)(S.srcc + (lane >> 4) * 64 + ((lane >> 1) & 7) * 8 + (lane & 1) * 4) = cur_c;
         wave_sync();   // corner moved before the top row is overwritten
-        if (my > 0) {
+        if (top) {
             unsigned spins = 0;
             while (!timed_out) {
                 const bool bad = lane < 8 && (unsigned)(g >> 32) != R.serial;

@@ -146,6 +146,9 @@ struct mi355x_h264_encoder {
     int mbw = 0, mbh = 0, cw = 0, ch = 0, nmb = 0, level_idc = 0;
     int device = 0;
     int G = 1;                               // lockstep batch: closed GOPs / streams encoded together
+    int nsl = 1;                             // slices per picture: bands of sl.rows macroblock rows
+    SliceRows sl{};
+    size_t slice_cap = 0;                    // bytes of payload buffer per slice (multiple of 16)
     size_t st_y = 0, st_c = 0, st_bitbuf_bytes = 0, st_au = 0, st_handoff = 0;  // per-item strides
     hipStream_t stream = nullptr;
     hipStream_t stream_ec = nullptr;         // entropy coding runs here, beside the deblocking wavefront
@@ -240,11 +243,11 @@ void build_parameter_sets(mi355x_h264_encoder* e)
     append_nal(e->sps_pps, 3, 8, p);
 }
 
-// slice_header() of 7.3.3 for this build's fixed choices; returns bit count (< 64)
+// slice_header() of 7.3.3 for this build's fixed choices, from slice_type on (first_mb_in_slice differs per slice and
+// is written by k_bit_scan); returns bit count (< 64)
 int build_slice_header(const mi355x_h264_encoder* e, bool idr, int idr_id, uint64_t* bits)
 {
     HostBits h;
-    h.ue(0);
     h.ue(idr ? 7 : 5);
     h.ue(0);
     h.put(8, (uint32_t)e->frame_num);
@@ -252,7 +255,7 @@ int build_slice_header(const mi355x_h264_encoder* e, bool idr, int idr_id, uint6
     if (!idr) { h.put(1, 0); h.put(1, 0); }
     if (idr) { h.put(1, 0); h.put(1, 0); } else h.put(1, 0);
     h.se(e->qp - 26);
-    h.ue(e->cfg.disable_deblock ? 1 : 0);
+    h.ue(e->cfg.disable_deblock ? 1 : e->nsl > 1 ? 2 : 0);   // several slices: no filtering across slice edges, the bands stay independent
     if (!e->cfg.disable_deblock) { h.se(0); h.se(0); }
     uint64_t v = 0;
     for (uint64_t i = 0; i < h.nbits; i++) v = (v << 1) | ((h.bytes[i >> 3] >> (7 - (i & 7))) & 1);
@@ -294,7 +297,7 @@ int submit(mi355x_h264_encoder* e, const uint8_t* d_src, size_t src_item_stride,
     P.cw = e->cw; P.ch = e->ch; P.mbw = e->mbw; P.mbh = e->mbh;
     for (int p = 0; p < 3; p++) { P.rec[p] = e->d_planes[cur][p]; P.ref[p] = e->d_planes[prev][p]; }
     P.mb = e->d_mb; P.levels = e->d_levels; P.mvd = e->d_mvd; P.me_cost = e->d_me_cost;
-    P.st_src = src_item_stride; P.st_y = e->st_y; P.st_c = e->st_c; P.st_mb = e->nmb;
+    P.st_src = src_item_stride; P.st_y = e->st_y; P.st_c = e->st_c; P.st_mb = e->nmb; P.sl = e->sl;
     const unsigned G = (unsigned)e->G;
     fill_quant(P.qy, e->qp);
     fill_quant(P.qc, h_chroma_qp[e->qp]);
@@ -335,7 +338,7 @@ int submit(mi355x_h264_encoder* e, const uint8_t* d_src, size_t src_item_stride,
     // (a small launch of its own on this stream): the two run side by side and the filter never waits for the coder
     hipStream_t ec = e->stream_ec;
     CavlcParams C{};
-    C.mb = e->d_mb; C.levels = e->d_levels; C.mvd = e->d_mvd; C.mbw = e->mbw; C.nmb = e->nmb; C.p_slice = idr ? 0 : 1;
+    C.mb = e->d_mb; C.levels = e->d_levels; C.mvd = e->d_mvd; C.mbw = e->mbw; C.nmb = e->nmb; C.p_slice = idr ? 0 : 1; C.sl = e->sl;
     C.slotbits = e->d_slotbits; C.slotcode = e->d_slotcode; C.mbbits = e->d_mbbits; C.bitbuf = S.d_bitbuf;
     C.bs = (uint8_t*)e->d_bs; C.prevcoded = e->d_prevcoded;
     C.st_mb = e->nmb; C.st_bitbuf = e->st_bitbuf_bytes / 4;
@@ -353,17 +356,18 @@ int submit(mi355x_h264_encoder* e, const uint8_t* d_src, size_t src_item_stride,
         const int grid = cavlc_grid;
         if (!idr) hipLaunchKernelGGL(k_skip_scan, dim3(G), dim3(256), 0, ec, C);
         hipLaunchKernelGGL(k_cavlc<false>, dim3(grid, G), dim3(64), 0, ec, C);
-        hipLaunchKernelGGL(k_bit_scan, dim3(G), dim3(SCAN_NT), 0, ec, C, H, S.d_info, e->d_me_cost);
+        hipLaunchKernelGGL(k_bit_scan, dim3(G * (unsigned)e->nsl), dim3(SCAN_NT), 0, ec, C, H, S.d_info, e->d_me_cost, e->nsl, (unsigned)e->slice_cap);
         hipLaunchKernelGGL(k_cavlc<true>, dim3(grid, G), dim3(64), 0, ec, C);
-        // access unit layout in the pinned buffer: [pad][SPS PPS (IDR only)][00 00 00 01 hdr][payload...]
+        // access unit layout in the pinned buffer: [pad][SPS PPS (IDR only)][00 00 00 01 hdr][payload...];
+        // with several slices: the payload of slice s at s * slice_cap, the access unit is put together by finish_item
         const size_t pre = (idr ? e->sps_pps.size() : 0) + 5;
         const size_t pad = (16 - (pre & 15)) & 15;
         S.au_start = pad;
-        S.payload_off = pad + pre;
+        S.payload_off = e->nsl > 1 ? 0 : pad + pre;
         S.idr = idr;
         S.nal_hdr = idr ? ((3 << 5) | 5) : ((2 << 5) | 1);
-        hipLaunchKernelGGL(k_pack, dim3(G), dim3(SCAN_NT), 0, ec, (uint8_t*)S.d_bitbuf, e->st_bitbuf_bytes, S.h_au + S.payload_off, e->st_au,
-                           (const SliceInfo*)S.d_info, S.h_info);
+        hipLaunchKernelGGL(k_pack, dim3(G * (unsigned)e->nsl), dim3(SCAN_NT), 0, ec, (uint8_t*)S.d_bitbuf, e->st_bitbuf_bytes, S.h_au + S.payload_off, e->st_au,
+                           (const SliceInfo*)S.d_info, S.h_info, e->nsl, (unsigned)e->slice_cap);
     }
     HIPCHK(e, hipEventRecord(S.entropy_done, ec));
     if (e->keep_pre)
@@ -374,7 +378,7 @@ int submit(mi355x_h264_encoder* e, const uint8_t* d_src, size_t src_item_stride,
         StatScope sc(e, &S, MI355X_H264_K_DEBLOCK, (uint32_t)(e->diag_mode ? steps : 1), (uint32_t)(e->nmb * e->G));
         DbParams D{};
         for (int p = 0; p < 3; p++) D.pl[p] = e->d_planes[cur][p];
-        D.mb = e->d_mb; D.cw = e->cw; D.ch = e->ch; D.mbw = e->mbw; D.mbh = e->mbh;
+        D.mb = e->d_mb; D.cw = e->cw; D.ch = e->ch; D.mbw = e->mbw; D.mbh = e->mbh; D.sl = e->sl;
         const int qp = e->qp, qpc = h_chroma_qp[qp];
         D.alpha_y = h_alpha[qp]; D.beta_y = h_beta[qp]; D.alpha_c = h_alpha[qpc]; D.beta_c = h_beta[qpc];
         for (int i = 0; i < 3; i++) { D.tc0_y[i] = h_tc0[qp][i]; D.tc0_c[i] = h_tc0[qpc][i]; }
@@ -431,11 +435,40 @@ int wait_slot(mi355x_h264_encoder* e, int slot_idx)
 int finish_item(mi355x_h264_encoder* e, int slot_idx, int g, uint8_t** out, uint32_t* out_len, int* frame_type)
 {
     Slot& S = e->slots[slot_idx];
+    uint8_t* base = S.h_au + (size_t)g * e->st_au;
+    if (e->nsl > 1) {
+        // several slices: one NAL unit each, put together here (the payloads lie slice_cap apart in the pinned buffer)
+        std::vector<uint8_t>& eb = e->esc_buf[g];
+        size_t need = e->sps_pps.size() + 16;
+        uint32_t cost = 0;
+        for (int sl = 0; sl < e->nsl; sl++) {
+            const SliceInfo& si = S.h_info[(size_t)g * e->nsl + sl];
+            if (si.error) return fail(e, si.error == 1 ? MI355X_H264_E_OVERFLOW : MI355X_H264_E_INTERNAL, "device reported error %u (slice %d)", si.error, sl);
+            need += 5 + (size_t)si.total_bytes * 3 / 2 + 16;
+            cost += si.me_cost;
+        }
+        e->last_me_cost[g] = cost;
+        eb.resize(need);
+        size_t pos = 0;
+        if (S.idr) { memcpy(eb.data(), e->sps_pps.data(), e->sps_pps.size()); pos = e->sps_pps.size(); }
+        for (int sl = 0; sl < e->nsl; sl++) {
+            const SliceInfo& si = S.h_info[(size_t)g * e->nsl + sl];
+            const uint8_t* pay = base + (size_t)sl * e->slice_cap;
+            uint8_t* o = eb.data() + pos;
+            o[0] = 0; o[1] = 0; o[2] = 0; o[3] = 1; o[4] = (uint8_t)S.nal_hdr;
+            pos += 5;
+            if (si.epb_count == 0) { memcpy(eb.data() + pos, pay, si.total_bytes); pos += si.total_bytes; }
+            else pos += nal_escape(pay, si.total_bytes, eb.data() + pos);
+        }
+        *out = eb.data();
+        *out_len = (uint32_t)pos;
+        if (frame_type) *frame_type = S.idr ? MI355X_H264_FRAME_IDR : MI355X_H264_FRAME_P;
+        return MI355X_H264_OK;
+    }
     const SliceInfo info = S.h_info[g];
     e->last_me_cost[g] = info.me_cost;
-    if (info.error) return fail(e, MI355X_H264_E_INTERNAL, "device reported error %u", info.error);
+    if (info.error) return fail(e, info.error == 1 ? MI355X_H264_E_OVERFLOW : MI355X_H264_E_INTERNAL, "device reported error %u", info.error);
     if ((size_t)info.total_bytes + 64 > e->bitbuf_cap) return fail(e, MI355X_H264_E_OVERFLOW, "slice of %u bytes exceeds buffer", info.total_bytes);
-    uint8_t* base = S.h_au + (size_t)g * e->st_au;
     uint8_t* au = base + S.au_start;
     size_t pos = 0;
     if (S.idr) { memcpy(au, e->sps_pps.data(), e->sps_pps.size()); pos = e->sps_pps.size(); }
@@ -494,6 +527,7 @@ int mi355x_h264_create(const mi355x_h264_config* cfg, mi355x_h264_encoder** out)
     if (cfg->qp < 10 || cfg->qp > 51 || cfg->gop < 1) return MI355X_H264_E_ARG;
     if (cfg->profile_idc != 66 && cfg->profile_idc != 77 && cfg->profile_idc != 100) return MI355X_H264_E_ARG;
     if (cfg->input_format != MI355X_H264_INPUT_I420 && cfg->input_format != MI355X_H264_INPUT_NV12) return MI355X_H264_E_ARG;
+    if (cfg->slices < 0 || cfg->slices > 64) return MI355X_H264_E_ARG;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev) return MI355X_H264_E_NODEVICE;
     mi355x_h264_encoder* e = new (std::nothrow) mi355x_h264_encoder();
@@ -504,6 +538,12 @@ int mi355x_h264_create(const mi355x_h264_config* cfg, mi355x_h264_encoder** out)
     e->mbw = (cfg->width + 15) / 16; e->mbh = (cfg->height + 15) / 16;
     e->cw = e->mbw * 16; e->ch = e->mbh * 16; e->nmb = e->mbw * e->mbh;
     e->level_idc = std::max(32, pick_level(e->nmb, cfg->fps > 0 ? cfg->fps : 30));
+    {   // slices: bands of ceil(rows / slices) macroblock rows, at least two rows each
+        const int n = std::min(std::max(cfg->slices, 1), std::max(1, e->mbh / 2));
+        e->sl.rows = (e->mbh + n - 1) / n;
+        e->sl.inv = e->sl.rows > 1 ? (unsigned)(0x100000000ull / (unsigned)e->sl.rows) + 1u : 0u;   // (one row: my is always 0)
+        e->nsl = (e->mbh + e->sl.rows - 1) / e->sl.rows;
+    }
     e->G = cfg->batch > 1 ? cfg->batch : 1;
     if (e->G > MAX_BATCH) { delete e; return MI355X_H264_E_ARG; }
     e->esc_buf.resize((size_t)e->G);
@@ -552,14 +592,19 @@ int mi355x_h264_create(const mi355x_h264_config* cfg, mi355x_h264_encoder** out)
     CK(hipMalloc((void**)&e->d_stage, e->frame_bytes + 256));
     CK(hipHostMalloc((void**)&e->h_stage, e->frame_bytes + 256, hipHostMallocDefault));
     e->bitbuf_cap = ysz * 2 + (1 << 16);
+    e->slice_cap = e->bitbuf_cap;
+    if (e->nsl > 1) {   // every slice gets room for twice its luma bytes (CAVLC's worst case is about 1.6 times)
+        e->slice_cap = ((size_t)e->sl.rows * 256 * e->mbw * 2 + 4096 + 15) & ~(size_t)15;
+        e->bitbuf_cap = e->slice_cap * e->nsl;
+    }
     e->st_bitbuf_bytes = (e->bitbuf_cap + 256 + 255) & ~(size_t)255;
     e->au_cap = e->bitbuf_cap + e->sps_pps.size() + 64;
     e->st_au = (e->au_cap + 256 + 255) & ~(size_t)255;
     for (auto& S : e->slots) {
         CK(hipMalloc((void**)&S.d_bitbuf, e->st_bitbuf_bytes * Gn));
         CK(hipMemset(S.d_bitbuf, 0, e->st_bitbuf_bytes * Gn));
-        CK(hipMalloc((void**)&S.d_info, sizeof(SliceInfo) * Gn));
-        CK(hipHostMalloc((void**)&S.h_info, sizeof(SliceInfo) * Gn, hipHostMallocDefault));
+        CK(hipMalloc((void**)&S.d_info, sizeof(SliceInfo) * Gn * e->nsl));
+        CK(hipHostMalloc((void**)&S.h_info, sizeof(SliceInfo) * Gn * e->nsl, hipHostMallocDefault));
         CK(hipHostMalloc((void**)&S.h_err, sizeof(unsigned), hipHostMallocDefault));
         *S.h_err = 0;
         CK(hipHostMalloc((void**)&S.h_au, e->st_au * Gn, hipHostMallocDefault));

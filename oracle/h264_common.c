@@ -403,7 +403,7 @@ static int edge_bs(const h264o_mbinfo *p, int bp, const h264o_mbinfo *q, int bq,
 static const uint8_t xy2blk[16] = {0, 1, 4, 5, 2, 3, 6, 7, 8, 9, 12, 13, 10, 11, 14, 15};
 
 void h264o_deblock_picture(uint8_t *Y, uint8_t *U, uint8_t *V, int cw, int ch,
-                           const h264o_mbinfo *mbs, int qp)
+                           const h264o_mbinfo *mbs, int qp, const int16_t *slice_of)
 {
     int mbw = cw / 16, mbh = ch / 16;
     int qpc = o_chroma_qp[clip3(0, 51, qp)];
@@ -415,6 +415,8 @@ void h264o_deblock_picture(uint8_t *Y, uint8_t *U, uint8_t *V, int cw, int ch,
             /* vertical edges, left to right */
             for (int e = 0; e < 4; e++) {
                 if (e == 0 && mx == 0) continue;
+                /* disable_deblocking_filter_idc 2: edges between slices stay unfiltered (slice_of given) */
+                if (e == 0 && slice_of && slice_of[my * mbw + mx] != slice_of[my * mbw + mx - 1]) continue;
                 const h264o_mbinfo *p = e == 0 ? q - 1 : q;
                 for (int r = 0; r < 4; r++) { /* four rows of 4x4 blocks */
                     int bq = xy2blk[4 * r + e], bp = e == 0 ? xy2blk[4 * r + 3] : xy2blk[4 * r + e - 1];
@@ -434,6 +436,7 @@ void h264o_deblock_picture(uint8_t *Y, uint8_t *U, uint8_t *V, int cw, int ch,
             /* horizontal edges, top to bottom */
             for (int e = 0; e < 4; e++) {
                 if (e == 0 && my == 0) continue;
+                if (e == 0 && slice_of && slice_of[my * mbw + mx] != slice_of[(my - 1) * mbw + mx]) continue;
                 const h264o_mbinfo *p = e == 0 ? q - mbw : q;
                 for (int c = 0; c < 4; c++) {
                     int bq = xy2blk[4 * e + c], bp = e == 0 ? xy2blk[12 + c] : xy2blk[4 * (e - 1) + c];

@@ -148,9 +148,11 @@ int h264o_cavlc_block(const int16_t *lv, int max_coeff, int nC, uint8_t *buf)
 struct h264o_enc {
     h264o_config cfg;
     int mbw, mbh, cw, ch, level_idc;
+    int slice_rows;   /* macroblock rows per slice (mbh for one slice); a slice is a band of whole rows */
     uint8_t *src[3], *rec[3], *cur[3], *ref[3]; /* coded size; pitch cw / cw/2 */
     h264o_mbinfo *mb;
     int16_t *levels;
+    int16_t *slice_of;   /* slice index of every macroblock */
     int frame_in_gop, frame_num, idr_id, idr_step;
     long frames;
     uint8_t *rbsp;
@@ -180,6 +182,11 @@ h264o_enc *h264o_enc_create(const h264o_config *cfg)
     e->mbh = (cfg->height + 15) / 16;
     e->cw = e->mbw * 16;
     e->ch = e->mbh * 16;
+    {   /* slices: bands of ceil(mbh / slices) macroblock rows (the last one may be shorter), at least two rows each */
+        int most = e->mbh / 2 > 1 ? e->mbh / 2 : 1;
+        int n = cfg->slices < 1 ? 1 : cfg->slices > most ? most : cfg->slices;
+        e->slice_rows = (e->mbh + n - 1) / n;
+    }
     int lvl = pick_level(e->mbw * e->mbh, cfg->fps > 0 ? cfg->fps : 30);
     e->level_idc = lvl < 32 ? 32 : lvl; /* the reference asks for LEVEL_3_2 (ref :255) */
     size_t ysz = (size_t)e->cw * e->ch, csz = ysz / 4;
@@ -192,6 +199,8 @@ h264o_enc *h264o_enc_create(const h264o_config *cfg)
     }
     e->mb = (h264o_mbinfo *)calloc((size_t)e->mbw * e->mbh, sizeof(h264o_mbinfo));
     e->levels = (int16_t *)calloc((size_t)e->mbw * e->mbh * H264O_LV_STRIDE, sizeof(int16_t));
+    e->slice_of = (int16_t *)calloc((size_t)e->mbw * e->mbh, sizeof(int16_t));
+    for (int i = 0; i < e->mbw * e->mbh; i++) e->slice_of[i] = (int16_t)(i / e->mbw / e->slice_rows);
     e->rbsp_cap = ysz * 4 + 65536;
     e->rbsp = (uint8_t *)malloc(e->rbsp_cap);
     return e;
@@ -203,6 +212,7 @@ void h264o_enc_destroy(h264o_enc *e)
     for (int p = 0; p < 3; p++) { free(e->src[p]); free(e->rec[p]); free(e->cur[p]); free(e->ref[p]); }
     free(e->mb);
     free(e->levels);
+    free(e->slice_of);
     free(e->rbsp);
     free(e);
 }
@@ -292,9 +302,9 @@ static void write_pps(h264o_enc *e, bitw *b)
     bw_trailing(b);
 }
 
-static void write_slice_header(h264o_enc *e, bitw *b, int idr)
+static void write_slice_header(h264o_enc *e, bitw *b, int idr, int first_mb)
 {
-    bw_ue(b, 0);              /* first_mb_in_slice */
+    bw_ue(b, (uint32_t)first_mb); /* first_mb_in_slice */
     bw_ue(b, idr ? 7 : 5);    /* slice_type: all slices of the picture I / P */
     bw_ue(b, 0);              /* pic_parameter_set_id */
     bw_put(b, 8, (uint32_t)e->frame_num);
@@ -310,7 +320,8 @@ static void write_slice_header(h264o_enc *e, bitw *b, int idr)
         bw_put(b, 1, 0); /* adaptive_ref_pic_marking_mode_flag */
     }
     bw_se(b, e->cfg.qp - 26); /* slice_qp_delta */
-    bw_ue(b, e->cfg.disable_deblock ? 1 : 0);
+    /* several slices: 2 = no filtering across slice edges, so that the bands stay independent of one another */
+    bw_ue(b, e->cfg.disable_deblock ? 1 : e->slice_rows < e->mbh ? 2 : 0);
     if (!e->cfg.disable_deblock) {
         bw_se(b, 0); /* slice_alpha_c0_offset_div2 */
         bw_se(b, 0); /* slice_beta_offset_div2 */
@@ -397,6 +408,10 @@ static int code_chroma(h264o_enc *e, int mx, int my, uint8_t predc[2][64], int i
     return cbp;
 }
 
+/* 6.4.4: a neighbour in another slice is not available; slices are bands of whole rows here, so only
+ * the neighbours above are affected */
+static int top_in_slice(const h264o_enc *e, int my) { return my % e->slice_rows != 0; }
+
 /* ------------------------------------------------------------ intra picture */
 static void encode_intra_mb(h264o_enc *e, int mx, int my)
 {
@@ -406,7 +421,8 @@ static void encode_intra_mb(h264o_enc *e, int mx, int my)
     memset(lv, 0, H264O_LV_STRIDE * sizeof(int16_t));
     memset(mb, 0, sizeof(*mb));
     mb->type = H264O_MB_I16;
-    int avail = (mx > 0 ? 1 : 0) | (my > 0 ? 2 : 0) | ((mx > 0 && my > 0) ? 4 : 0);
+    int top = top_in_slice(e, my);
+    int avail = (mx > 0 ? 1 : 0) | (top ? 2 : 0) | ((mx > 0 && top) ? 4 : 0);
     const uint8_t *s = e->src[0] + (16 * my) * cw + 16 * mx;
     uint8_t *r = e->rec[0] + (16 * my) * cw + 16 * mx;
     uint8_t pred[256], best_pred[256];
@@ -597,9 +613,9 @@ static mv_t motion_search(h264o_enc *e, int mx, int my, mv_t pmv, int *final_cos
 }
 
 /* 8.4.1.3 median prediction for a 16x16 partition, single reference */
-static void neighbour(const h264o_enc *e, int mx, int my, int *avail, int *ref, mv_t *mv)
+static void neighbour(const h264o_enc *e, int mx, int my, int cur_my, int *avail, int *ref, mv_t *mv)
 {
-    *avail = mx >= 0 && my >= 0 && mx < e->mbw;
+    *avail = mx >= 0 && mx < e->mbw && my >= cur_my - cur_my % e->slice_rows;   /* inside the picture and the current slice */
     *ref = -1;
     mv->x = mv->y = 0;
     if (!*avail) return;
@@ -612,10 +628,10 @@ static mv_t predict_mv(const h264o_enc *e, int mx, int my, mv_t *skip_mv)
 {
     int aA, aB, aC, rA, rB, rC;
     mv_t A, B, C;
-    neighbour(e, mx - 1, my, &aA, &rA, &A);
-    neighbour(e, mx, my - 1, &aB, &rB, &B);
-    neighbour(e, mx + 1, my - 1, &aC, &rC, &C);
-    if (!aC) neighbour(e, mx - 1, my - 1, &aC, &rC, &C);
+    neighbour(e, mx - 1, my, my, &aA, &rA, &A);
+    neighbour(e, mx, my - 1, my, &aB, &rB, &B);
+    neighbour(e, mx + 1, my - 1, my, &aC, &rC, &C);
+    if (!aC) neighbour(e, mx - 1, my - 1, my, &aC, &rC, &C);
     if (!aB && !aC && aA) { B = A; C = A; rB = rA; rC = rA; }
     mv_t p;
     int n = (rA == 0) + (rB == 0) + (rC == 0);
@@ -624,9 +640,9 @@ static mv_t predict_mv(const h264o_enc *e, int mx, int my, mv_t *skip_mv)
     if (skip_mv) {
         int uA, uB, t;
         mv_t tA, tB;
-        neighbour(e, mx - 1, my, &uA, &t, &tA);
+        neighbour(e, mx - 1, my, my, &uA, &t, &tA);
         int refA = t;
-        neighbour(e, mx, my - 1, &uB, &t, &tB);
+        neighbour(e, mx, my - 1, my, &uB, &t, &tB);
         int refB = t;
         if (!uA || !uB || (refA == 0 && tA.x == 0 && tA.y == 0) || (refB == 0 && tB.x == 0 && tB.y == 0)) skip_mv->x = skip_mv->y = 0;
         else *skip_mv = p;
@@ -674,7 +690,7 @@ static int nc_luma(const h264o_enc *e, int mx, int my, int b)
     if (x > 0) nA = m->tc[xy2blk[4 * y + x - 1]];
     else if (mx > 0) nA = (m - 1)->tc[xy2blk[4 * y + 3]];
     if (y > 0) nB = m->tc[xy2blk[4 * (y - 1) + x]];
-    else if (my > 0) nB = (m - e->mbw)->tc[xy2blk[12 + x]];
+    else if (top_in_slice(e, my)) nB = (m - e->mbw)->tc[xy2blk[12 + x]];
     if (nA >= 0 && nB >= 0) return (nA + nB + 1) >> 1;
     return nA >= 0 ? nA : nB >= 0 ? nB : 0;
 }
@@ -685,7 +701,7 @@ static int nc_chroma(const h264o_enc *e, int mx, int my, int pl, int b)
     if (x > 0) nA = m->tc[base + 2 * y];
     else if (mx > 0) nA = (m - 1)->tc[base + 2 * y + 1];
     if (y > 0) nB = m->tc[base + x];
-    else if (my > 0) nB = (m - e->mbw)->tc[base + 2 + x];
+    else if (top_in_slice(e, my)) nB = (m - e->mbw)->tc[base + 2 + x];
     if (nA >= 0 && nB >= 0) return (nA + nB + 1) >> 1;
     return nA >= 0 ? nA : nB >= 0 ? nB : 0;
 }
@@ -797,34 +813,40 @@ int64_t h264o_enc_encode(h264o_enc *e, const uint8_t *y, int ys, const uint8_t *
         for (int my = 0; my < e->mbh; my++)
             for (int mx = 0; mx < e->mbw; mx++) encode_inter_mb(e, mx, my);
     }
-    /* stage 2: entropy coding */
+    /* stage 2: entropy coding, one NAL unit per slice */
+    e->last_slice_bits = 0;
     memset(e->rbsp, 0, e->rbsp_cap);
-    b = (bitw){e->rbsp, e->rbsp_cap, 0};
-    write_slice_header(e, &b, idr);
-    uint64_t hdr_bits = b.bits;
-    int skip_run = 0;
-    for (int my = 0; my < e->mbh; my++)
-        for (int mx = 0; mx < e->mbw; mx++) {
-            const h264o_mbinfo *mb = &e->mb[my * e->mbw + mx];
-            if (!idr) {
-                if (mb->type == H264O_MB_PSKIP) { skip_run++; continue; }
-                bw_ue(&b, (uint32_t)skip_run);
-                skip_run = 0;
+    for (int row0 = 0; row0 < e->mbh; row0 += e->slice_rows) {
+        int row1 = row0 + e->slice_rows < e->mbh ? row0 + e->slice_rows : e->mbh;
+        b = (bitw){e->rbsp, e->rbsp_cap, 0};
+        write_slice_header(e, &b, idr, row0 * e->mbw);
+        uint64_t hdr_bits = b.bits;
+        int skip_run = 0;
+        for (int my = row0; my < row1; my++)
+            for (int mx = 0; mx < e->mbw; mx++) {
+                const h264o_mbinfo *mb = &e->mb[my * e->mbw + mx];
+                if (!idr) {
+                    if (mb->type == H264O_MB_PSKIP) { skip_run++; continue; }
+                    bw_ue(&b, (uint32_t)skip_run);
+                    skip_run = 0;
+                }
+                write_mb(e, &b, mx, my, !idr);
             }
-            write_mb(e, &b, mx, my, !idr);
-        }
-    if (skip_run) bw_ue(&b, (uint32_t)skip_run);
-    e->last_slice_bits = (int64_t)(b.bits - hdr_bits);
-    bw_trailing(&b);
-    if ((b.bits >> 3) > e->rbsp_cap) return -3;
-    pos = emit_nal(out, out_cap, pos, idr ? 3 : 2, idr ? 5 : 1, e->rbsp, (size_t)(b.bits >> 3));
-    if (pos == (size_t)-1) return -2;
+        if (skip_run) bw_ue(&b, (uint32_t)skip_run);
+        e->last_slice_bits += (int64_t)(b.bits - hdr_bits);
+        bw_trailing(&b);
+        if ((b.bits >> 3) > e->rbsp_cap) return -3;
+        pos = emit_nal(out, out_cap, pos, idr ? 3 : 2, idr ? 5 : 1, e->rbsp, (size_t)(b.bits >> 3));
+        if (pos == (size_t)-1) return -2;
+        memset(e->rbsp, 0, (size_t)(b.bits >> 3) + 8);   /* the bit writer ORs into zeroed bytes */
+    }
     /* stage 3: in-loop filter into the next reference */
     size_t ysz = (size_t)e->cw * e->ch;
     memcpy(e->cur[0], e->rec[0], ysz);
     memcpy(e->cur[1], e->rec[1], ysz / 4);
     memcpy(e->cur[2], e->rec[2], ysz / 4);
-    if (!e->cfg.disable_deblock) h264o_deblock_picture(e->cur[0], e->cur[1], e->cur[2], e->cw, e->ch, e->mb, e->cfg.qp);
+    if (!e->cfg.disable_deblock)
+        h264o_deblock_picture(e->cur[0], e->cur[1], e->cur[2], e->cw, e->ch, e->mb, e->cfg.qp, e->slice_rows < e->mbh ? e->slice_of : NULL);
     for (int p = 0; p < 3; p++) { uint8_t *t = e->ref[p]; e->ref[p] = e->cur[p]; e->cur[p] = t; }
     if (idr) e->idr_id = (e->idr_id + e->idr_step) & 0xFF;
     e->frame_num = (e->frame_num + 1) & 255;

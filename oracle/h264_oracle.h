@@ -43,6 +43,8 @@ typedef struct {
     int32_t gop;            /* IDR period in frames (uiIntraPeriod, ref :242)        */
     int32_t profile_idc;    /* 66 baseline, 77 main (CAVLC), 100 high (no 8x8)       */
     int32_t disable_deblock;/* 0: in-loop filter on (ref :295 iLoopFilterDisableIdc) */
+    int32_t slices;         /* 0/1: one slice per picture (the reference preset, SM_SINGLE_SLICE :247); n > 1: n bands of
+                             * ceil(rows / n) macroblock rows, one slice NAL each, no loop filtering across them      */
 } h264o_config;
 
 typedef struct h264o_enc h264o_enc;
@@ -104,9 +106,10 @@ int h264o_satd8x8(const uint8_t *a, int as, const uint8_t *b, int bs);
 /* intra predictors; avail bit0 = left, bit1 = top, bit2 = top-left */
 void h264o_pred16x16(const uint8_t *rec, int stride, int mode, int avail, uint8_t pred[256]);
 void h264o_pred_chroma8x8(const uint8_t *rec, int stride, int mode, int avail, uint8_t pred[64]);
-/* deblock a whole picture in place given per-MB info (8.7) */
+/* deblock a whole picture in place given per-MB info (8.7); slice_of (slice index per macroblock) non-NULL =
+ * disable_deblocking_filter_idc 2, edges between different slices are left alone */
 void h264o_deblock_picture(uint8_t *y, uint8_t *u, uint8_t *v, int cw, int ch,
-                           const h264o_mbinfo *mbs, int qp);
+                           const h264o_mbinfo *mbs, int qp, const int16_t *slice_of);
 /* Exp-Golomb / CAVLC helpers for known-answer tests */
 int h264o_ue_bits(uint32_t v, uint32_t *code); /* returns length, *code = bit pattern */
 int h264o_se_bits(int32_t v, uint32_t *code);
