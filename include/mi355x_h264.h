@@ -79,7 +79,9 @@ typedef struct mi355x_h264_config {
                               * n bands of ceil(rows / n) macroblock rows (at least two rows each), one slice NAL
                               * unit per band, disable_deblocking_filter_idc = 2: the bands of a picture
                               * do not depend on one another, their row wavefronts run side by side                  */
-    int32_t reserved[2];
+    int32_t band_index;      /* slice bands of ONE picture over several GPUs (BASELINE.json configs[4]): */
+    int32_t band_count;      /* with band_count > 1 this instance codes only its share of the `slices` slices (a contiguous
+                              * run of whole slices, index band_index of band_count); see mi355x_h264_band_*              */
 } mi355x_h264_config;
 
 typedef struct mi355x_h264_encoder mi355x_h264_encoder;
@@ -127,6 +129,20 @@ int mi355x_h264_encode_batch_device(mi355x_h264_encoder *enc, const void *d_fram
 int mi355x_h264_encode_gops_device(mi355x_h264_encoder *enc, const void *d_frames, size_t frame_stride,
                                    size_t gop_stride, int frames_per_gop, uint8_t *host_out,
                                    size_t out_cap_per_gop, uint32_t *sizes, size_t *gop_bytes);
+
+/* ---- slice bands of one picture on several encoder instances / GPUs (config.band_count > 1) ----
+ * Every instance is created with the full picture geometry and the same `slices`, and is handed the full source picture
+ * (only its band's rows are read).  mi355x_h264_encode* then returns this band's slice NAL units only (SPS/PPS with
+ * band 0); the access unit is the concatenation over band_index.  Motion search and compensation of the next picture
+ * reach up to 19 sample rows beyond the band, so after every picture the neighbours swap two macroblock rows of
+ * reconstruction (the host class does it with one RCCL send/recv pair per neighbour over xGMI):
+ *     export(enc, 0, buf) -> send to band_index-1;  export(enc, 1, buf) -> send to band_index+1
+ *     import(enc, 0, buf) <- received from band_index-1 (its bottom rows);  import(enc, 1, buf) <- from band_index+1
+ * buf: device memory of halo_bytes (band_info).  The result equals the stream ONE instance with the same `slices` makes. */
+int mi355x_h264_band_info(const mi355x_h264_encoder *enc, int *first_row, int *rows, int *first_slice, int *slices,
+                          size_t *halo_bytes);
+int mi355x_h264_band_halo_export(mi355x_h264_encoder *enc, int edge, void *d_dst);
+int mi355x_h264_band_halo_import(mi355x_h264_encoder *enc, int edge, const void *d_src);
 
 int mi355x_h264_force_idr(mi355x_h264_encoder *enc);
 /* picture QP (10..51) for the pictures that follow; the hook the rate controller

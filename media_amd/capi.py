@@ -32,7 +32,7 @@ class Config(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("width", C.c_int32), ("height", C.c_int32), ("fps", C.c_int32),
                 ("bitrate", C.c_int32), ("gop", C.c_int32), ("profile_idc", C.c_int32), ("rc_mode", C.c_int32),
                 ("qp", C.c_int32), ("device", C.c_int32), ("disable_deblock", C.c_int32),
-                ("batch", C.c_int32), ("input_format", C.c_int32), ("slices", C.c_int32), ("reserved", C.c_int32 * 2)]
+                ("batch", C.c_int32), ("input_format", C.c_int32), ("slices", C.c_int32), ("band_index", C.c_int32), ("band_count", C.c_int32)]
 
 
 class Stats(C.Structure):
@@ -67,6 +67,9 @@ def lib():
         L.mi355x_h264_force_idr.argtypes = [vp]
         L.mi355x_h264_set_qp.argtypes = [vp, C.c_int]
         L.mi355x_h264_set_idr_pic_id.argtypes = [vp, C.c_int, C.c_int]
+        L.mi355x_h264_band_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_size_t)]
+        L.mi355x_h264_band_halo_export.argtypes = [vp, C.c_int, vp]
+        L.mi355x_h264_band_halo_import.argtypes = [vp, C.c_int, vp]
         L.mi355x_h264_last_error.argtypes = [vp]
         L.mi355x_h264_last_error.restype = C.c_char_p
         L.mi355x_h264_coded_width.argtypes = [vp]
@@ -88,7 +91,7 @@ class Encoder:
     """thin object wrapper; argument meaning follows mi355x_h264_config"""
 
     def __init__(self, width, height, qp=26, gop=30, fps=30, profile_idc=66, device=0, disable_deblock=0,
-                 bitrate=5000000, rc_mode=0, batch=1, input_format=0, slices=0):
+                 bitrate=5000000, rc_mode=0, batch=1, input_format=0, slices=0, band_index=0, band_count=0):
         L = lib()
         cfg = Config()
         L.mi355x_h264_default_config(C.byref(cfg))
@@ -97,6 +100,7 @@ class Encoder:
         cfg.bitrate, cfg.rc_mode, cfg.batch = bitrate, rc_mode, batch
         cfg.input_format = input_format   # 0 I420, 1 NV12: layout of pictures handed over in device memory
         cfg.slices = slices               # > 1: that many bands of macroblock rows, one slice NAL unit each
+        cfg.band_index, cfg.band_count = band_index, band_count   # band_count > 1: this instance codes its share of the slices
         self.batch = batch
         self.h = C.c_void_p()
         rc = L.mi355x_h264_create(C.byref(cfg), C.byref(self.h))
@@ -163,6 +167,20 @@ class Encoder:
 
     def set_idr_pic_id(self, nxt, step=1):
         self._check(lib().mi355x_h264_set_idr_pic_id(self.h, nxt, step))
+
+    def band_info(self):
+        """(first macroblock row, rows, first slice, slices, halo bytes) of the band this instance codes"""
+        r0, rows, s0, ns, hb = C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_size_t()
+        self._check(lib().mi355x_h264_band_info(self.h, C.byref(r0), C.byref(rows), C.byref(s0), C.byref(ns), C.byref(hb)))
+        return r0.value, rows.value, s0.value, ns.value, hb.value
+
+    def halo_export(self, edge, d_dst):
+        """edge 0: this band's top rows, 1: its bottom rows, of the newest reconstruction -> device buffer"""
+        self._check(lib().mi355x_h264_band_halo_export(self.h, edge, d_dst))
+
+    def halo_import(self, edge, d_src):
+        """edge 0: rows right above the band (the upper neighbour's bottom rows), 1: rows right below"""
+        self._check(lib().mi355x_h264_band_halo_import(self.h, edge, d_src))
 
     def keep_pre(self, on=True):
         self._check(lib().mi355x_h264_debug_keep_pre(self.h, int(on)))

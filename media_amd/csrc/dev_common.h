@@ -45,6 +45,10 @@ struct SliceRows {
     __device__ __forceinline__ bool has_top(int my) const { return row_in_slice(my) != 0; }
 };
 
+// Band of the picture this encoder instance works on (slice bands of one picture on several GPUs):
+// macroblock rows row0 .. row0 + rows - 1, always whole slices.  One instance alone: row0 = 0, rows = mbh.
+struct Band { int row0, rows; };
+
 struct FrameParams {
     const uint8_t* src;  // tight picture in HBM: Y (w*h), then U, V planes (I420) or one interleaved UV plane (NV12)
     int src_nv12;        // 1: chroma is read straight from the interleaved plane (no conversion pass)
@@ -64,6 +68,7 @@ struct FrameParams {
     size_t st_y, st_c;   // bytes between reconstruction planes (luma, chroma)
     int st_mb;           // macroblocks per batch item (MbInfo / levels / mvd arrays)
     SliceRows sl;        // slices of the picture: bands of sl.rows macroblock rows (sl.rows = mbh: one slice)
+    Band band;           // the rows this instance encodes; grids cover the band, coordinates stay those of the picture
 };
 
 // the parameter block of batch item g (pointers advanced by g strides)

@@ -266,6 +266,7 @@ struct CavlcParams {
     const int16_t* mvd;
     int mbw, nmb, p_slice;
     SliceRows sl;         // slices of the picture (bands of sl.rows macroblock rows)
+    int mb_first, mb_end; // the macroblocks this instance codes (its band of whole slices; 0 .. nmb alone)
     uint16_t* slotbits;   // 32 per macroblock
     unsigned long long* slotcode;   // 32 per macroblock: the slot's bits, left aligned, when slotbits <= 64
     uint32_t* mbbits;     // per macroblock, then (after the scan) bit offsets
@@ -357,9 +358,9 @@ __global__ __launch_bounds__(64) void k_bs(CavlcParams C0, unsigned* anybs, unsi
     __builtin_amdgcn_s_setprio(2);
     const CavlcParams C = batch_view(C0, blockIdx.y);
     const int lane = threadIdx.x, slot = lane & 31;
-    const int mbi = blockIdx.x * 2 + (lane >> 5);
+    const int mbi = C.mb_first + blockIdx.x * 2 + (lane >> 5);
     int bs = 0;
-    if (mbi < C.nmb) {
+    if (mbi < C.mb_end) {
         bs = mb_edge_strength(C.mb + mbi, mbi % C.mbw, C.sl.has_top(mbi / C.mbw), C.mbw, slot);
         C.bs[(size_t)mbi * 32 + slot] = (uint8_t)bs;
     }
@@ -374,8 +375,8 @@ __global__ __launch_bounds__(256) void k_skip_scan(CavlcParams C0)
     const CavlcParams C = batch_view(C0, blockIdx.x);
     __shared__ int s_last[256];
     const int t = threadIdx.x;
-    const int per = (C.nmb + 255) / 256;
-    const int b0 = min(C.nmb, t * per), b1 = min(C.nmb, b0 + per);
+    const int per = (C.mb_end - C.mb_first + 255) / 256;
+    const int b0 = min(C.mb_end, C.mb_first + t * per), b1 = min(C.mb_end, b0 + per);
     int last = -1;
     for (int i = b0; i < b1; i++)
         if (C.mb[i].type != MB_PSKIP) last = i;
@@ -392,7 +393,7 @@ __global__ __launch_bounds__(256) void k_skip_scan(CavlcParams C0)
         C.prevcoded[i] = run;
         if (C.mb[i].type != MB_PSKIP) run = i;
     }
-    if (t == 255) C.prevcoded[C.nmb] = s_last[255];
+    if (t == 255) C.prevcoded[C.mb_end] = s_last[255];
 }
 
 template <bool WRITE>
@@ -401,8 +402,8 @@ __global__ __launch_bounds__(64) void k_cavlc(CavlcParams C0)
     __builtin_amdgcn_s_setprio(1);
     const CavlcParams C = batch_view(C0, blockIdx.y);
     const int lane = threadIdx.x, slot = lane & 31;
-    const int mbi = blockIdx.x * 2 + (lane >> 5);
-    const bool live = mbi < C.nmb;
+    const int mbi = C.mb_first + blockIdx.x * 2 + (lane >> 5);
+    const bool live = mbi < C.mb_end;
     if (!WRITE) {
         BitPack s;
         s.init(0);
@@ -456,10 +457,10 @@ struct SliceInfo {       // lives in pinned host memory, written by the device
 // Kept small (4 waves): a workgroup is dispatched only when one CU has room for all of its waves, and beside
 // another instance's motion search a 16-wave workgroup waits long for that.
 enum { SCAN_NT = 256 };
-__global__ __launch_bounds__(SCAN_NT) void k_bit_scan(CavlcParams C0, HdrBatch H, SliceInfo* info0, const uint16_t* me_cost0, int nsl, unsigned slice_cap)
-{
+__global__ __launch_bounds__(SCAN_NT) void k_bit_scan(CavlcParams C0, HdrBatch H, SliceInfo* info0, const uint16_t* me_cost0, int nsl, int sl0, unsigned slice_cap)
+{   // nsl slices of this instance's band per picture, the first of them is slice sl0 of the picture
     __builtin_amdgcn_s_setprio(1);
-    const int item = blockIdx.x, pic = item / nsl, sl = item - pic * nsl;
+    const int item = blockIdx.x, pic = item / nsl, sl = sl0 + item - pic * nsl;
     const CavlcParams C = batch_view(C0, pic);
     const int mb0 = sl * C.sl.rows * C.mbw, mb1 = min(C.nmb, mb0 + C.sl.rows * C.mbw), cnt = mb1 - mb0;
     // slice_header(): first_mb_in_slice is written here, the rest (the same for every slice of the picture) comes from the host
@@ -529,9 +530,9 @@ __global__ __launch_bounds__(SCAN_NT) void k_bit_scan(CavlcParams C0, HdrBatch H
 // Copy the payload of one slice to the pinned access unit buffer, count emulation-prevention sites, publish
 // SliceInfo to pinned host memory and leave the device bit buffer zeroed for its next use (one workgroup per slice).
 __global__ __launch_bounds__(SCAN_NT) void k_pack(uint8_t* bitbuf0, size_t st_bitbuf_bytes, uint8_t* dst0, size_t st_dst, const SliceInfo* info0,
-                                               SliceInfo* host_info0, int nsl, unsigned slice_cap)
+                                               SliceInfo* host_info0, int nsl, int sl0, unsigned slice_cap)
 {
-    const int item = blockIdx.x, pic = item / nsl, sl = item - pic * nsl;
+    const int item = blockIdx.x, pic = item / nsl, sl = sl0 + item - pic * nsl;
     uint8_t* bitbuf = bitbuf0 + (size_t)pic * st_bitbuf_bytes + (size_t)sl * slice_cap;
     uint8_t* dst = dst0 + (size_t)pic * st_dst + (size_t)sl * slice_cap;
     const SliceInfo* info = info0 + item;

@@ -214,6 +214,7 @@ struct DbRowParams {
     // lockstep batch strides (gridDim.y items)
     size_t st_y, st_c, st_handoff;   // bytes, bytes, u64 words
     int st_mb;
+    int row0;            // first macroblock row of this instance's band (blockIdx.x counts from it)
 };
 
 // One edge, one line of samples held in registers, branch-free so that luma and
@@ -269,7 +270,7 @@ __global__ __launch_bounds__(64) void k_deblock_rows(DbRowParams R)
     }
     u64* const handoff = R.handoff + (size_t)blockIdx.y * R.st_handoff;
     const uint32_t* const bsw = R.bs + (size_t)blockIdx.y * R.st_mb * 8;
-    const int lane = threadIdx.x, my = blockIdx.x, cs = D.cw / 2;
+    const int lane = threadIdx.x, my = R.row0 + blockIdx.x, cs = D.cw / 2;   // (row0: first row of this instance's band)
     // a slice's rows form a wavefront of their own: its first row waits for nobody (no edge to the slice above is
     // filtered), its last row stores all sixteen sample rows itself
     const bool first_row = !D.sl.has_top(my);

@@ -383,7 +383,7 @@ __global__ __launch_bounds__(64) void k_intra_rows(IntraRowParams R)
     __builtin_amdgcn_s_setprio(3);   // dependency-bound row wavefront: issue ahead of co-resident throughput kernels
     const FrameParams P = batch_view(R.p, blockIdx.y);
     unsigned long long* const handoff = R.handoff + (size_t)blockIdx.y * R.st_handoff;
-    const int lane = threadIdx.x, my = blockIdx.x;
+    const int lane = threadIdx.x, my = P.band.row0 + blockIdx.x;
     const bool top = P.sl.has_top(my);   // first row of a slice: nothing above to wait for, the slices' wavefronts run side by side
     __shared__ IntraLds S;
     bool timed_out = false;

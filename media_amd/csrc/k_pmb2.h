@@ -168,7 +168,7 @@ __global__ __launch_bounds__(64) void k_pmb2(FrameParams P0)
     __builtin_amdgcn_s_setprio(2);   // short and on the way to the loop filter: ahead of another stream's motion search
     const FrameParams P = batch_view(P0, blockIdx.y);
     const int lane = threadIdx.x;
-    const int nmb = P.mbw * P.mbh;
+    const int nmb = P.mbw * P.band.rows, mb0 = P.band.row0 * P.mbw;   // (pairs are formed inside this instance's band)
     const int q = xcd_mb_index(blockIdx.x, (nmb + 1) >> 1);
     const int cs = P.cw / 2;
     const bool two = 2 * q + 1 < nmb;   // the last pair of an odd macroblock count has one member
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(64) void k_pmb2(FrameParams P0)
     MbInfo* m[2];
 #pragma unroll
     for (int h = 0; h < 2; h++) {
-        mbi[h] = 2 * q + ((h && two) ? 1 : 0);
+        mbi[h] = mb0 + 2 * q + ((h && two) ? 1 : 0);
         mx[h] = mbi[h] % P.mbw; my[h] = mbi[h] / P.mbw;
         m[h] = P.mb + mbi[h];
         const int mvw = __builtin_amdgcn_readfirstlane(*(const int*)m[h]);   // mvx | mvy << 16
@@ -435,7 +435,7 @@ __global__ __launch_bounds__(64) void k_pmb2(FrameParams P0)
     __syncthreads();
     // the two level blocks are consecutive in HBM (macroblocks 2q, 2q+1)
     const int nv = (two ? 2 : 1) * (LV_STRIDE * 2 / 16);
-    for (int i = lane; i < nv; i += 64) ((uint4*)(P.levels + (size_t)(2 * q) * LV_STRIDE))[i] = ((const uint4*)&s_lv[0][0])[i];
+    for (int i = lane; i < nv; i += 64) ((uint4*)(P.levels + (size_t)(mb0 + 2 * q) * LV_STRIDE))[i] = ((const uint4*)&s_lv[0][0])[i];
 }
 
 }  // namespace h264

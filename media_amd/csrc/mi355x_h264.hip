@@ -149,6 +149,8 @@ struct mi355x_h264_encoder {
     int nsl = 1;                             // slices per picture: bands of sl.rows macroblock rows
     SliceRows sl{};
     size_t slice_cap = 0;                    // bytes of payload buffer per slice (multiple of 16)
+    // slice bands over several GPUs: this instance codes slices b_sl0 .. b_sl0 + b_nsl - 1 = rows b_row0 .. b_row0 + b_rows - 1
+    int b_sl0 = 0, b_nsl = 1, b_row0 = 0, b_rows = 0, b_nmb = 0;
     size_t st_y = 0, st_c = 0, st_bitbuf_bytes = 0, st_au = 0, st_handoff = 0;  // per-item strides
     hipStream_t stream = nullptr;
     hipStream_t stream_ec = nullptr;         // entropy coding runs here, beside the deblocking wavefront
@@ -298,6 +300,7 @@ int submit(mi355x_h264_encoder* e, const uint8_t* d_src, size_t src_item_stride,
     for (int p = 0; p < 3; p++) { P.rec[p] = e->d_planes[cur][p]; P.ref[p] = e->d_planes[prev][p]; }
     P.mb = e->d_mb; P.levels = e->d_levels; P.mvd = e->d_mvd; P.me_cost = e->d_me_cost;
     P.st_src = src_item_stride; P.st_y = e->st_y; P.st_c = e->st_c; P.st_mb = e->nmb; P.sl = e->sl;
+    P.band.row0 = e->b_row0; P.band.rows = e->b_rows;
     const unsigned G = (unsigned)e->G;
     fill_quant(P.qy, e->qp);
     fill_quant(P.qc, h_chroma_qp[e->qp]);
@@ -307,7 +310,7 @@ int submit(mi355x_h264_encoder* e, const uint8_t* d_src, size_t src_item_stride,
     // (the payload buffer of this slot was left zeroed by the k_pack of its previous use)
 
     if (idr) {
-        StatScope sc(e, &S, MI355X_H264_K_INTRA, (uint32_t)(e->diag_mode ? e->mbw + e->mbh - 1 : 1), (uint32_t)(e->nmb * e->G));
+        StatScope sc(e, &S, MI355X_H264_K_INTRA, (uint32_t)(e->diag_mode ? e->mbw + e->mbh - 1 : 1), (uint32_t)(e->b_nmb * e->G));
         if (e->diag_mode) {
             for (int s = 0; s < e->mbw + e->mbh - 1; s++) {
                 const int ymin = std::max(0, s - e->mbw + 1), ymax = std::min(e->mbh - 1, s);
@@ -318,14 +321,14 @@ int submit(mi355x_h264_encoder* e, const uint8_t* d_src, size_t src_item_stride,
             R.p = P; R.handoff = e->d_handoff; R.st_handoff = e->st_handoff; R.err = S.h_err;
             e->serial = e->serial == 0xFFFFFFFFu ? 1 : e->serial + 1;
             R.serial = e->serial;
-            hipLaunchKernelGGL(k_intra_rows, dim3(e->mbh, G), dim3(64), 0, st, R);
+            hipLaunchKernelGGL(k_intra_rows, dim3(e->b_rows, G), dim3(64), 0, st, R);
         }
     } else {
-        { StatScope sc(e, &S, MI355X_H264_K_ME, 1, (uint32_t)(e->nmb * e->G));
-          hipLaunchKernelGGL(k_me, dim3(e->nmb, G), dim3(64), 0, st, P); }
-        { StatScope sc(e, &S, MI355X_H264_K_PMB, 1, (uint32_t)(e->nmb * e->G));
-          if (e->pmb_v1) hipLaunchKernelGGL(k_pmb, dim3(e->nmb, G), dim3(64), 0, st, P);
-          else hipLaunchKernelGGL(k_pmb2, dim3((e->nmb + 1) / 2, G), dim3(64), 0, st, P); }   // one wave per macroblock pair
+        { StatScope sc(e, &S, MI355X_H264_K_ME, 1, (uint32_t)(e->b_nmb * e->G));
+          hipLaunchKernelGGL(k_me, dim3(e->b_nmb, G), dim3(64), 0, st, P); }
+        { StatScope sc(e, &S, MI355X_H264_K_PMB, 1, (uint32_t)(e->b_nmb * e->G));
+          if (e->pmb_v1) hipLaunchKernelGGL(k_pmb, dim3(e->b_nmb, G), dim3(64), 0, st, P);
+          else hipLaunchKernelGGL(k_pmb2, dim3((e->b_nmb + 1) / 2, G), dim3(64), 0, st, P); }   // one wave per macroblock pair
     }
     // entropy coding
     HdrBatch H{};
@@ -339,10 +342,11 @@ int submit(mi355x_h264_encoder* e, const uint8_t* d_src, size_t src_item_stride,
     hipStream_t ec = e->stream_ec;
     CavlcParams C{};
     C.mb = e->d_mb; C.levels = e->d_levels; C.mvd = e->d_mvd; C.mbw = e->mbw; C.nmb = e->nmb; C.p_slice = idr ? 0 : 1; C.sl = e->sl;
+    C.mb_first = e->b_row0 * e->mbw; C.mb_end = C.mb_first + e->b_nmb;
     C.slotbits = e->d_slotbits; C.slotcode = e->d_slotcode; C.mbbits = e->d_mbbits; C.bitbuf = S.d_bitbuf;
     C.bs = (uint8_t*)e->d_bs; C.prevcoded = e->d_prevcoded;
     C.st_mb = e->nmb; C.st_bitbuf = e->st_bitbuf_bytes / 4;
-    const int cavlc_grid = (e->nmb + 1) / 2;
+    const int cavlc_grid = (e->b_nmb + 1) / 2;
     unsigned db_serial = 0;
     if (!e->cfg.disable_deblock && !e->diag_mode) {
         e->serial = e->serial == 0xFFFFFFFFu ? 1 : e->serial + 1;   // the serial the loop filter of this picture will run under
@@ -352,11 +356,11 @@ int submit(mi355x_h264_encoder* e, const uint8_t* d_src, size_t src_item_stride,
     HIPCHK(e, hipEventRecord(S.recon_ready, st));
     HIPCHK(e, hipStreamWaitEvent(ec, S.recon_ready, 0));
     {
-        StatScope sc(e, &S, MI355X_H264_K_CAVLC, 4, (uint32_t)(e->nmb * e->G), ec);
+        StatScope sc(e, &S, MI355X_H264_K_CAVLC, 4, (uint32_t)(e->b_nmb * e->G), ec);
         const int grid = cavlc_grid;
         if (!idr) hipLaunchKernelGGL(k_skip_scan, dim3(G), dim3(256), 0, ec, C);
         hipLaunchKernelGGL(k_cavlc<false>, dim3(grid, G), dim3(64), 0, ec, C);
-        hipLaunchKernelGGL(k_bit_scan, dim3(G * (unsigned)e->nsl), dim3(SCAN_NT), 0, ec, C, H, S.d_info, e->d_me_cost, e->nsl, (unsigned)e->slice_cap);
+        hipLaunchKernelGGL(k_bit_scan, dim3(G * (unsigned)e->b_nsl), dim3(SCAN_NT), 0, ec, C, H, S.d_info, e->d_me_cost, e->b_nsl, e->b_sl0, (unsigned)e->slice_cap);
         hipLaunchKernelGGL(k_cavlc<true>, dim3(grid, G), dim3(64), 0, ec, C);
         // access unit layout in the pinned buffer: [pad][SPS PPS (IDR only)][00 00 00 01 hdr][payload...];
         // with several slices: the payload of slice s at s * slice_cap, the access unit is put together by finish_item
@@ -366,8 +370,8 @@ int submit(mi355x_h264_encoder* e, const uint8_t* d_src, size_t src_item_stride,
         S.payload_off = e->nsl > 1 ? 0 : pad + pre;
         S.idr = idr;
         S.nal_hdr = idr ? ((3 << 5) | 5) : ((2 << 5) | 1);
-        hipLaunchKernelGGL(k_pack, dim3(G * (unsigned)e->nsl), dim3(SCAN_NT), 0, ec, (uint8_t*)S.d_bitbuf, e->st_bitbuf_bytes, S.h_au + S.payload_off, e->st_au,
-                           (const SliceInfo*)S.d_info, S.h_info, e->nsl, (unsigned)e->slice_cap);
+        hipLaunchKernelGGL(k_pack, dim3(G * (unsigned)e->b_nsl), dim3(SCAN_NT), 0, ec, (uint8_t*)S.d_bitbuf, e->st_bitbuf_bytes, S.h_au + S.payload_off, e->st_au,
+                           (const SliceInfo*)S.d_info, S.h_info, e->b_nsl, e->b_sl0, (unsigned)e->slice_cap);
     }
     HIPCHK(e, hipEventRecord(S.entropy_done, ec));
     if (e->keep_pre)
@@ -375,7 +379,7 @@ int submit(mi355x_h264_encoder* e, const uint8_t* d_src, size_t src_item_stride,
             HIPCHK(e, hipMemcpyAsync(e->d_pre[p], e->d_planes[cur][p], (p ? e->st_c : e->st_y) * e->G, hipMemcpyDeviceToDevice, st));
     if (!e->cfg.disable_deblock) {
         const int steps = e->mbw + 2 * (e->mbh - 1);
-        StatScope sc(e, &S, MI355X_H264_K_DEBLOCK, (uint32_t)(e->diag_mode ? steps : 1), (uint32_t)(e->nmb * e->G));
+        StatScope sc(e, &S, MI355X_H264_K_DEBLOCK, (uint32_t)(e->diag_mode ? steps : 1), (uint32_t)(e->b_nmb * e->G));
         DbParams D{};
         for (int p = 0; p < 3; p++) D.pl[p] = e->d_planes[cur][p];
         D.mb = e->d_mb; D.cw = e->cw; D.ch = e->ch; D.mbw = e->mbw; D.mbh = e->mbh; D.sl = e->sl;
@@ -392,10 +396,10 @@ int submit(mi355x_h264_encoder* e, const uint8_t* d_src, size_t src_item_stride,
             DbRowParams R{};
             R.d = D; R.handoff = e->d_handoff; R.err = S.h_err;
             R.st_y = e->st_y; R.st_c = e->st_c; R.st_handoff = e->st_handoff; R.st_mb = e->nmb;
-            R.serial = db_serial;
+            R.serial = db_serial; R.row0 = e->b_row0;
             R.bs = e->d_bs; R.anybs = e->d_anybs;
-            if (idr) hipLaunchKernelGGL(k_deblock_rows<true>, dim3(e->mbh, G), dim3(64), 0, st, R);
-            else hipLaunchKernelGGL(k_deblock_rows<false>, dim3(e->mbh, G), dim3(64), 0, st, R);
+            if (idr) hipLaunchKernelGGL(k_deblock_rows<true>, dim3(e->b_rows, G), dim3(64), 0, st, R);
+            else hipLaunchKernelGGL(k_deblock_rows<false>, dim3(e->b_rows, G), dim3(64), 0, st, R);
         }
     }
     HIPCHK(e, hipStreamWaitEvent(st, S.entropy_done, 0));   // join: the next picture rewrites MbInfo / levels
@@ -441,8 +445,8 @@ int finish_item(mi355x_h264_encoder* e, int slot_idx, int g, uint8_t** out, uint
         std::vector<uint8_t>& eb = e->esc_buf[g];
         size_t need = e->sps_pps.size() + 16;
         uint32_t cost = 0;
-        for (int sl = 0; sl < e->nsl; sl++) {
-            const SliceInfo& si = S.h_info[(size_t)g * e->nsl + sl];
+        for (int sl = 0; sl < e->b_nsl; sl++) {
+            const SliceInfo& si = S.h_info[(size_t)g * e->b_nsl + sl];
             if (si.error) return fail(e, si.error == 1 ? MI355X_H264_E_OVERFLOW : MI355X_H264_E_INTERNAL, "device reported error %u (slice %d)", si.error, sl);
             need += 5 + (size_t)si.total_bytes * 3 / 2 + 16;
             cost += si.me_cost;
@@ -450,10 +454,10 @@ int finish_item(mi355x_h264_encoder* e, int slot_idx, int g, uint8_t** out, uint
         e->last_me_cost[g] = cost;
         eb.resize(need);
         size_t pos = 0;
-        if (S.idr) { memcpy(eb.data(), e->sps_pps.data(), e->sps_pps.size()); pos = e->sps_pps.size(); }
-        for (int sl = 0; sl < e->nsl; sl++) {
-            const SliceInfo& si = S.h_info[(size_t)g * e->nsl + sl];
-            const uint8_t* pay = base + (size_t)sl * e->slice_cap;
+        if (S.idr && e->b_sl0 == 0) { memcpy(eb.data(), e->sps_pps.data(), e->sps_pps.size()); pos = e->sps_pps.size(); }   // parameter sets go with the first band
+        for (int sl = 0; sl < e->b_nsl; sl++) {
+            const SliceInfo& si = S.h_info[(size_t)g * e->b_nsl + sl];
+            const uint8_t* pay = base + (size_t)(e->b_sl0 + sl) * e->slice_cap;
             uint8_t* o = eb.data() + pos;
             o[0] = 0; o[1] = 0; o[2] = 0; o[3] = 1; o[4] = (uint8_t)S.nal_hdr;
             pos += 5;
@@ -528,6 +532,7 @@ int mi355x_h264_create(const mi355x_h264_config* cfg, mi355x_h264_encoder** out)
     if (cfg->profile_idc != 66 && cfg->profile_idc != 77 && cfg->profile_idc != 100) return MI355X_H264_E_ARG;
     if (cfg->input_format != MI355X_H264_INPUT_I420 && cfg->input_format != MI355X_H264_INPUT_NV12) return MI355X_H264_E_ARG;
     if (cfg->slices < 0 || cfg->slices > 64) return MI355X_H264_E_ARG;
+    if (cfg->band_count < 0 || cfg->band_index < 0 || (cfg->band_count > 1 && (cfg->band_index >= cfg->band_count || cfg->batch > 1))) return MI355X_H264_E_ARG;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev) return MI355X_H264_E_NODEVICE;
     mi355x_h264_encoder* e = new (std::nothrow) mi355x_h264_encoder();
@@ -544,6 +549,15 @@ int mi355x_h264_create(const mi355x_h264_config* cfg, mi355x_h264_encoder** out)
         e->sl.inv = e->sl.rows > 1 ? (unsigned)(0x100000000ull / (unsigned)e->sl.rows) + 1u : 0u;   // (one row: my is always 0)
         e->nsl = (e->mbh + e->sl.rows - 1) / e->sl.rows;
     }
+    e->b_sl0 = 0; e->b_nsl = e->nsl;
+    if (cfg->band_count > 1) {   // this instance codes its share of the slices; the others belong to the neighbours
+        if (cfg->band_count > e->nsl) { delete e; return MI355X_H264_E_ARG; }
+        e->b_sl0 = (int)((long)cfg->band_index * e->nsl / cfg->band_count);
+        e->b_nsl = (int)((long)(cfg->band_index + 1) * e->nsl / cfg->band_count) - e->b_sl0;
+    }
+    e->b_row0 = e->b_sl0 * e->sl.rows;
+    e->b_rows = std::min(e->mbh, (e->b_sl0 + e->b_nsl) * e->sl.rows) - e->b_row0;
+    e->b_nmb = e->b_rows * e->mbw;
     e->G = cfg->batch > 1 ? cfg->batch : 1;
     if (e->G > MAX_BATCH) { delete e; return MI355X_H264_E_ARG; }
     e->esc_buf.resize((size_t)e->G);
@@ -586,7 +600,7 @@ int mi355x_h264_create(const mi355x_h264_config* cfg, mi355x_h264_encoder** out)
     CK(hipMalloc((void**)&e->d_me_cost, Gn * e->nmb * sizeof(uint16_t)));
     CK(hipMemset(e->d_me_cost, 0, Gn * e->nmb * sizeof(uint16_t)));
     e->last_me_cost.assign(Gn, 0);
-    e->diag_mode = getenv("MI355X_H264_DIAG") != nullptr && e->G == 1;
+    e->diag_mode = getenv("MI355X_H264_DIAG") != nullptr && e->G == 1 && e->b_nsl == e->nsl;
     e->pmb_v1 = getenv("MI355X_H264_PMB_V1") != nullptr;
     e->frame_bytes = (size_t)cfg->width * cfg->height * 3 / 2;
     CK(hipMalloc((void**)&e->d_stage, e->frame_bytes + 256));
@@ -802,6 +816,58 @@ int mi355x_h264_set_idr_pic_id(mi355x_h264_encoder* e, int next, int step)
     e->idr_id = next & 0xFF;
     e->idr_step = step;
     return MI355X_H264_OK;
+}
+
+// ---- slice bands over several GPUs: the rows next to a band in the reference picture come from the neighbours ----
+namespace {
+enum { HALO_MB_ROWS = 2 };   // 32 luma rows: the search reaches 16 rows + 0.75 + the 6-tap filter's 3, chroma half of that
+// rows [r0, r1) of the newest reconstruction <-> a packed block (Y rows, then U rows, then V rows)
+int halo_copy(mi355x_h264_encoder* e, int r0, int r1, void* d_blk, bool to_block)
+{
+    const int last = e->cur ^ 1;
+    uint8_t* blk = (uint8_t*)d_blk;
+    for (int p = 0; p < 3; p++) {
+        const size_t pitch = p ? e->cw / 2 : e->cw, rows_per_mb = p ? 8 : 16;
+        const size_t off = (size_t)r0 * rows_per_mb * pitch, n = (size_t)(r1 - r0) * rows_per_mb * pitch;
+        uint8_t* pl = e->d_planes[last][p] + off;
+        if (n) HIPCHK(e, hipMemcpyAsync(to_block ? (void*)blk : (void*)pl, to_block ? (const void*)pl : (const void*)blk, n, hipMemcpyDeviceToDevice, e->stream));
+        blk += (size_t)HALO_MB_ROWS * rows_per_mb * pitch;   // fixed layout, whatever the number of rows present
+    }
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    return MI355X_H264_OK;
+}
+}  // namespace
+
+int mi355x_h264_band_info(const mi355x_h264_encoder* e, int* first_row, int* rows, int* first_slice, int* slices, size_t* halo_bytes)
+{
+    if (!e) return MI355X_H264_E_ARG;
+    if (first_row) *first_row = e->b_row0;
+    if (rows) *rows = e->b_rows;
+    if (first_slice) *first_slice = e->b_sl0;
+    if (slices) *slices = e->b_nsl;
+    if (halo_bytes) *halo_bytes = (size_t)HALO_MB_ROWS * 16 * e->cw * 3 / 2;
+    return MI355X_H264_OK;
+}
+
+int mi355x_h264_band_halo_export(mi355x_h264_encoder* e, int edge, void* d_dst)
+{
+    if (!e || !d_dst || (edge != 0 && edge != 1)) return fail(e, MI355X_H264_E_ARG, "bad argument");
+    HIPCHK(e, hipSetDevice(e->device));
+    const int n = std::min((int)HALO_MB_ROWS, e->b_rows);
+    const int r0 = edge == 0 ? e->b_row0 : e->b_row0 + e->b_rows - n;
+    return halo_copy(e, r0, r0 + n, d_dst, true);
+}
+
+int mi355x_h264_band_halo_import(mi355x_h264_encoder* e, int edge, const void* d_src)
+{
+    if (!e || !d_src || (edge != 0 && edge != 1)) return fail(e, MI355X_H264_E_ARG, "bad argument");
+    HIPCHK(e, hipSetDevice(e->device));
+    // above: the neighbour's LAST rows end right above this band; below: its FIRST rows start right below
+    int r0, r1;
+    if (edge == 0) { r1 = e->b_row0; r0 = std::max(0, r1 - (int)HALO_MB_ROWS); if (r1 - r0 < (int)HALO_MB_ROWS && r1 > 0) return fail(e, MI355X_H264_E_INTERNAL, "band above is shorter than the halo"); }
+    else { r0 = e->b_row0 + e->b_rows; r1 = std::min(e->mbh, r0 + (int)HALO_MB_ROWS); }
+    if (r1 <= r0) return MI355X_H264_OK;   // picture edge: nothing beyond
+    return halo_copy(e, r0, r1, const_cast<void*>(d_src), false);
 }
 
 const char* mi355x_h264_last_error(const mi355x_h264_encoder* e) { return e ? e->err : "null encoder"; }

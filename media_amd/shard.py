@@ -59,3 +59,71 @@ def encode_gops_bitrate(encode_gop, n_gops, rank, world, rc, dist=None, device=N
         last = min(n_gops, (j + 1) * world) - 1          # last GOP of this round in stream order
         broadcast_rc_state(rc, last - j * world, dist, device)
     return mine
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Slice bands of ONE picture over the ranks (BASELINE.json configs[4]).  Every rank holds an
+# encoder created with the full picture geometry, the same `slices` and band_index = rank, band_count = world:
+# it codes its run of whole slices.  Slices do not depend on one another inside a picture (no prediction and, with
+# disable_deblocking_filter_idc 2, no loop filtering across them); BETWEEN pictures motion search and compensation
+# reach up to 19 sample rows beyond the band, so after every picture each rank swaps two macroblock rows of
+# reconstruction with each neighbour: one send/recv pair per neighbour, point to point (on GPUs: RCCL over the direct
+# xGMI link of the two devices - no ring, no collective), then the slice NAL units are gathered on rank 0.
+# ---------------------------------------------------------------------------------------------------------
+class BandHalo:
+    """the four exchange buffers of one rank (torch uint8 tensors on `device`: cuda for nccl, cpu for gloo)"""
+
+    def __init__(self, halo_bytes, device=None):
+        import torch
+        mk = lambda: torch.zeros(halo_bytes, dtype=torch.uint8, device=device)
+        self.send_up, self.send_down, self.recv_up, self.recv_down = mk(), mk(), mk(), mk()
+
+
+def exchange_band_halos(engine, rank, world, dist, halo):
+    """engine: .halo_export(edge, ptr) / .halo_import(edge, ptr) (capi.Encoder on a GPU, the oracle in the CPU test).
+    After the call the reference rows right above and below this rank's band are the neighbours' newest rows."""
+    if world == 1:
+        return
+    ops = []
+    if rank > 0:
+        engine.halo_export(0, halo.send_up.data_ptr())
+        ops += [dist.P2POp(dist.isend, halo.send_up, rank - 1), dist.P2POp(dist.irecv, halo.recv_up, rank - 1)]
+    if rank < world - 1:
+        engine.halo_export(1, halo.send_down.data_ptr())
+        ops += [dist.P2POp(dist.isend, halo.send_down, rank + 1), dist.P2POp(dist.irecv, halo.recv_down, rank + 1)]
+    for req in dist.batch_isend_irecv(ops):
+        req.wait()
+    if halo.recv_up.is_cuda:
+        import torch
+        torch.cuda.current_stream().synchronize()     # the received rows are copied on the encoder's own stream next
+    if rank > 0:
+        engine.halo_import(0, halo.recv_up.data_ptr())
+    if rank < world - 1:
+        engine.halo_import(1, halo.recv_down.data_ptr())
+
+
+def gather_access_unit(part, rank, world, dist, device=None, cap=None):
+    """slice NAL units of every band -> the access unit on rank 0 (b'' elsewhere): sizes by all_gather, then the
+    payloads as equally sized uint8 tensors (cap = upper bound of one band's bytes, default: the largest size)"""
+    if world == 1:
+        return part
+    import torch
+    n = torch.tensor([len(part)], dtype=torch.int64, device=device)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n)
+    sizes = [int(s.item()) for s in sizes]
+    cap = max(sizes) if cap is None else cap
+    mine = torch.zeros(cap, dtype=torch.uint8, device=device)
+    mine[:len(part)] = torch.frombuffer(bytearray(part), dtype=torch.uint8).to(mine.device)
+    parts = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine)
+    if rank != 0:
+        return b""
+    return b"".join(parts[r][:sizes[r]].cpu().numpy().tobytes() for r in range(world))
+
+
+def encode_picture_bands(engine, frame, rank, world, dist, halo, device=None):
+    """one picture of a band-sharded stream: code this rank's slices, swap halos, gather the access unit on rank 0"""
+    part = engine.encode(frame)[0]
+    exchange_band_halos(engine, rank, world, dist, halo)
+    return gather_access_unit(part, rank, world, dist, device)

@@ -403,13 +403,14 @@ static int edge_bs(const h264o_mbinfo *p, int bp, const h264o_mbinfo *q, int bq,
 static const uint8_t xy2blk[16] = {0, 1, 4, 5, 2, 3, 6, 7, 8, 9, 12, 13, 10, 11, 14, 15};
 
 void h264o_deblock_picture(uint8_t *Y, uint8_t *U, uint8_t *V, int cw, int ch,
-                           const h264o_mbinfo *mbs, int qp, const int16_t *slice_of)
+                           const h264o_mbinfo *mbs, int qp, const int16_t *slice_of, int row0, int row1)
 {
     int mbw = cw / 16, mbh = ch / 16;
     int qpc = o_chroma_qp[clip3(0, 51, qp)];
     /* all macroblocks share one QP in this encoder; indexA = indexB = qPav (offsets 0) */
     int aY = o_alpha[qp], bY = o_beta[qp], aC = o_alpha[qpc], bC = o_beta[qpc];
-    for (int my = 0; my < mbh; my++)
+    if (row1 > mbh) row1 = mbh;
+    for (int my = row0; my < row1; my++)
         for (int mx = 0; mx < mbw; mx++) {
             const h264o_mbinfo *q = &mbs[my * mbw + mx];
             /* vertical edges, left to right */

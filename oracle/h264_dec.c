@@ -499,7 +499,7 @@ static int decode_slice(h264o_dec *d, bitr *b, int nal_type, int nal_ref_idc)
     if (addr < nmb) return 0; /* more slices follow */
     /* (all slices of a picture carry the same filter idc and QP in the streams this test decoder reads) */
     if (disable_dbf != 1)
-        h264o_deblock_picture(d->cur[0], d->cur[1], d->cur[2], d->cw, d->ch, d->mb, slice_qp, disable_dbf == 2 ? d->slice_of : NULL);
+        h264o_deblock_picture(d->cur[0], d->cur[1], d->cur[2], d->cw, d->ch, d->mb, slice_qp, disable_dbf == 2 ? d->slice_of : NULL, 0, d->mbh);
     for (int p = 0; p < 3; p++) { uint8_t *t = d->ref[p]; d->ref[p] = d->cur[p]; d->cur[p] = t; }
     return 1;
 }

@@ -149,6 +149,7 @@ struct h264o_enc {
     h264o_config cfg;
     int mbw, mbh, cw, ch, level_idc;
     int slice_rows;   /* macroblock rows per slice (mbh for one slice); a slice is a band of whole rows */
+    int band_row0, band_row1;   /* rows this instance codes (band_count > 1: its share of the slices), else 0..mbh */
     uint8_t *src[3], *rec[3], *cur[3], *ref[3]; /* coded size; pitch cw / cw/2 */
     h264o_mbinfo *mb;
     int16_t *levels;
@@ -186,6 +187,15 @@ h264o_enc *h264o_enc_create(const h264o_config *cfg)
         int most = e->mbh / 2 > 1 ? e->mbh / 2 : 1;
         int n = cfg->slices < 1 ? 1 : cfg->slices > most ? most : cfg->slices;
         e->slice_rows = (e->mbh + n - 1) / n;
+        int nsl = (e->mbh + e->slice_rows - 1) / e->slice_rows;
+        e->band_row0 = 0;
+        e->band_row1 = e->mbh;
+        if (cfg->band_count > 1 && cfg->band_count <= nsl && cfg->band_index >= 0 && cfg->band_index < cfg->band_count) {
+            /* slice bands of one picture on several instances: slices [i*nsl/c, (i+1)*nsl/c) (mirrors mi355x_h264_create) */
+            int s0 = (int)((long)cfg->band_index * nsl / cfg->band_count), s1 = (int)((long)(cfg->band_index + 1) * nsl / cfg->band_count);
+            e->band_row0 = s0 * e->slice_rows;
+            e->band_row1 = s1 * e->slice_rows < e->mbh ? s1 * e->slice_rows : e->mbh;
+        }
     }
     int lvl = pick_level(e->mbw * e->mbh, cfg->fps > 0 ? cfg->fps : 30);
     e->level_idc = lvl < 32 ? 32 : lvl; /* the reference asks for LEVEL_3_2 (ref :255) */
@@ -229,6 +239,33 @@ int h264o_enc_set_idr_id(h264o_enc *e, int next, int step)
     e->idr_id = next & 0xFF;
     e->idr_step = step;
     return 0;
+}
+/* slice bands on several instances: rows next to the band in the reference picture come from the neighbours
+ * (same block layout as mi355x_h264_band_halo_*: 2 macroblock rows of Y, then U, then V) */
+enum { HALO_MB_ROWS = 2 };
+size_t h264o_enc_halo_bytes(const h264o_enc *e) { return (size_t)HALO_MB_ROWS * 16 * e->cw * 3 / 2; }
+static void halo_copy(h264o_enc *e, int r0, int r1, uint8_t *blk, int to_block)
+{
+    for (int p = 0; p < 3; p++) {
+        size_t pitch = p ? e->cw / 2 : e->cw, rpm = p ? 8 : 16;
+        uint8_t *pl = e->ref[p] + (size_t)r0 * rpm * pitch;
+        size_t n = (size_t)(r1 - r0) * rpm * pitch;
+        if (to_block) memcpy(blk, pl, n); else memcpy(pl, blk, n);
+        blk += (size_t)HALO_MB_ROWS * rpm * pitch;
+    }
+}
+void h264o_enc_halo_export(h264o_enc *e, int edge, uint8_t *dst)
+{
+    int rows = e->band_row1 - e->band_row0, n = rows < HALO_MB_ROWS ? rows : HALO_MB_ROWS;
+    int r0 = edge == 0 ? e->band_row0 : e->band_row1 - n;
+    halo_copy(e, r0, r0 + n, dst, 1);
+}
+void h264o_enc_halo_import(h264o_enc *e, int edge, const uint8_t *src)
+{
+    int r0, r1;
+    if (edge == 0) { r1 = e->band_row0; r0 = r1 - HALO_MB_ROWS < 0 ? 0 : r1 - HALO_MB_ROWS; }
+    else { r0 = e->band_row1; r1 = r0 + HALO_MB_ROWS > e->mbh ? e->mbh : r0 + HALO_MB_ROWS; }
+    if (r1 > r0) halo_copy(e, r0, r1, (uint8_t *)src, 0);
 }
 int h264o_enc_coded_width(const h264o_enc *e) { return e->cw; }
 int h264o_enc_coded_height(const h264o_enc *e) { return e->ch; }
@@ -772,7 +809,7 @@ int64_t h264o_enc_encode(h264o_enc *e, const uint8_t *y, int ys, const uint8_t *
     e->me_cost = 0;
     size_t pos = 0;
     bitw b;
-    if (idr) {
+    if (idr && e->band_row0 == 0) {   /* parameter sets go with the first band */
         memset(e->rbsp, 0, 256);
         b = (bitw){e->rbsp, e->rbsp_cap, 0};
         write_sps(e, &b);
@@ -786,10 +823,10 @@ int64_t h264o_enc_encode(h264o_enc *e, const uint8_t *y, int ys, const uint8_t *
     }
     /* stage 1: decisions + reconstruction (pre-deblock) */
     if (idr) {
-        for (int my = 0; my < e->mbh; my++)
+        for (int my = e->band_row0; my < e->band_row1; my++)
             for (int mx = 0; mx < e->mbw; mx++) encode_intra_mb(e, mx, my);
     } else {
-        for (int my = 0; my < e->mbh; my++)
+        for (int my = e->band_row0; my < e->band_row1; my++)
             for (int mx = 0; mx < e->mbw; mx++) {
                 h264o_mbinfo *mb = &e->mb[my * e->mbw + mx];
                 const mv_t pmv = {mb->mvx, mb->mvy};   /* previous picture's vector here (intra macroblocks carry 0) */
@@ -810,13 +847,13 @@ int64_t h264o_enc_encode(h264o_enc *e, const uint8_t *y, int ys, const uint8_t *
                     mb->mvy = m.y;
                 }
             }
-        for (int my = 0; my < e->mbh; my++)
+        for (int my = e->band_row0; my < e->band_row1; my++)
             for (int mx = 0; mx < e->mbw; mx++) encode_inter_mb(e, mx, my);
     }
     /* stage 2: entropy coding, one NAL unit per slice */
     e->last_slice_bits = 0;
     memset(e->rbsp, 0, e->rbsp_cap);
-    for (int row0 = 0; row0 < e->mbh; row0 += e->slice_rows) {
+    for (int row0 = e->band_row0; row0 < e->band_row1; row0 += e->slice_rows) {
         int row1 = row0 + e->slice_rows < e->mbh ? row0 + e->slice_rows : e->mbh;
         b = (bitw){e->rbsp, e->rbsp_cap, 0};
         write_slice_header(e, &b, idr, row0 * e->mbw);
@@ -846,7 +883,8 @@ int64_t h264o_enc_encode(h264o_enc *e, const uint8_t *y, int ys, const uint8_t *
     memcpy(e->cur[1], e->rec[1], ysz / 4);
     memcpy(e->cur[2], e->rec[2], ysz / 4);
     if (!e->cfg.disable_deblock)
-        h264o_deblock_picture(e->cur[0], e->cur[1], e->cur[2], e->cw, e->ch, e->mb, e->cfg.qp, e->slice_rows < e->mbh ? e->slice_of : NULL);
+        h264o_deblock_picture(e->cur[0], e->cur[1], e->cur[2], e->cw, e->ch, e->mb, e->cfg.qp, e->slice_rows < e->mbh ? e->slice_of : NULL,
+                              e->band_row0, e->band_row1);
     for (int p = 0; p < 3; p++) { uint8_t *t = e->ref[p]; e->ref[p] = e->cur[p]; e->cur[p] = t; }
     if (idr) e->idr_id = (e->idr_id + e->idr_step) & 0xFF;
     e->frame_num = (e->frame_num + 1) & 255;

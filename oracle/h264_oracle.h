@@ -45,6 +45,8 @@ typedef struct {
     int32_t disable_deblock;/* 0: in-loop filter on (ref :295 iLoopFilterDisableIdc) */
     int32_t slices;         /* 0/1: one slice per picture (the reference preset, SM_SINGLE_SLICE :247); n > 1: n bands of
                              * ceil(rows / n) macroblock rows, one slice NAL each, no loop filtering across them      */
+    int32_t band_index;     /* band_count > 1: this instance codes only its share of the slices (slice bands of one   */
+    int32_t band_count;     /* picture on several instances / GPUs, mirrors mi355x_h264_config)                       */
 } h264o_config;
 
 typedef struct h264o_enc h264o_enc;
@@ -72,6 +74,10 @@ int h264o_enc_set_qp(h264o_enc *e, int qp);
 /* idr_pic_id of the next IDR and its increment per IDR (mod 256): lets closed GOPs of one
  * stream be encoded by different instances and still concatenate to the serial stream */
 int h264o_enc_set_idr_id(h264o_enc *e, int next, int step);
+/* band mode: reference rows next to the band, exchanged with the neighbours (mirrors mi355x_h264_band_halo_*) */
+size_t h264o_enc_halo_bytes(const h264o_enc *e);
+void h264o_enc_halo_export(h264o_enc *e, int edge, uint8_t *dst);
+void h264o_enc_halo_import(h264o_enc *e, int edge, const uint8_t *src);
 /* Accessors valid until the next encode call.  Planes are coded size
  * (multiples of 16), pitch == coded width (chroma: half). */
 int h264o_enc_coded_width(const h264o_enc *e);
@@ -107,9 +113,9 @@ int h264o_satd8x8(const uint8_t *a, int as, const uint8_t *b, int bs);
 void h264o_pred16x16(const uint8_t *rec, int stride, int mode, int avail, uint8_t pred[256]);
 void h264o_pred_chroma8x8(const uint8_t *rec, int stride, int mode, int avail, uint8_t pred[64]);
 /* deblock a whole picture in place given per-MB info (8.7); slice_of (slice index per macroblock) non-NULL =
- * disable_deblocking_filter_idc 2, edges between different slices are left alone */
+ * disable_deblocking_filter_idc 2, edges between different slices are left alone; macroblock rows row0..row1-1 */
 void h264o_deblock_picture(uint8_t *y, uint8_t *u, uint8_t *v, int cw, int ch,
-                           const h264o_mbinfo *mbs, int qp, const int16_t *slice_of);
+                           const h264o_mbinfo *mbs, int qp, const int16_t *slice_of, int row0, int row1);
 /* Exp-Golomb / CAVLC helpers for known-answer tests */
 int h264o_ue_bits(uint32_t v, uint32_t *code); /* returns length, *code = bit pattern */
 int h264o_se_bits(int32_t v, uint32_t *code);

@@ -14,7 +14,7 @@ LV_LUMA_DC, LV_LUMA, LV_CHROMA_DC, LV_CHROMA_AC = 0, 16, 272, 280
 
 class Config(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("fps", C.c_int32), ("qp", C.c_int32),
-                ("gop", C.c_int32), ("profile_idc", C.c_int32), ("disable_deblock", C.c_int32), ("slices", C.c_int32)]
+                ("gop", C.c_int32), ("profile_idc", C.c_int32), ("disable_deblock", C.c_int32), ("slices", C.c_int32), ("band_index", C.c_int32), ("band_count", C.c_int32)]
 
 
 MBINFO_DTYPE = np.dtype([("mvx", "<i2"), ("mvy", "<i2"), ("type", "u1"), ("i16_mode", "u1"),
@@ -56,6 +56,12 @@ def lib():
         L.h264o_enc_last_me_cost.argtypes = [vp]
         L.h264o_enc_last_me_cost.restype = C.c_uint32
         L.h264o_enc_set_idr_id.argtypes = [vp, C.c_int, C.c_int]
+        L.h264o_enc_halo_bytes.argtypes = [vp]
+        L.h264o_enc_halo_bytes.restype = C.c_size_t
+        L.h264o_enc_halo_export.argtypes = [vp, C.c_int, vp]
+        L.h264o_enc_halo_export.restype = None
+        L.h264o_enc_halo_import.argtypes = [vp, C.c_int, vp]
+        L.h264o_enc_halo_import.restype = None
         L.h264o_enc_last_slice_bits.restype = C.c_int64
         L.h264o_enc_last_slice_bits.argtypes = [vp]
         L.h264o_dec_create.restype = vp
@@ -79,7 +85,7 @@ def lib():
             getattr(L, n).argtypes = [vp, C.c_int, vp, C.c_int]
         L.h264o_pred16x16.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp]
         L.h264o_pred_chroma8x8.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp]
-        L.h264o_deblock_picture.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, C.c_int, vp]
+        L.h264o_deblock_picture.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int]
         L.h264o_ue_bits.argtypes = [C.c_uint32, C.POINTER(C.c_uint32)]
         L.h264o_se_bits.argtypes = [C.c_int32, C.POINTER(C.c_uint32)]
         L.h264o_cavlc_block.argtypes = [vp, C.c_int, C.c_int, vp]
@@ -94,8 +100,8 @@ def _ptr(a):
 
 
 class OracleEncoder:
-    def __init__(self, width, height, qp=26, gop=30, fps=30, profile_idc=66, disable_deblock=0, slices=0):
-        self.cfg = Config(width, height, fps, qp, gop, profile_idc, disable_deblock, slices)
+    def __init__(self, width, height, qp=26, gop=30, fps=30, profile_idc=66, disable_deblock=0, slices=0, band_index=0, band_count=0):
+        self.cfg = Config(width, height, fps, qp, gop, profile_idc, disable_deblock, slices, band_index, band_count)
         self.h = lib().h264o_enc_create(C.byref(self.cfg))
         if not self.h:
             raise ValueError("oracle rejected config")
@@ -140,6 +146,15 @@ class OracleEncoder:
     def set_qp(self, qp):
         if lib().h264o_enc_set_qp(self.h, qp) != 0:
             raise ValueError("bad qp")
+
+    def halo_bytes(self):
+        return lib().h264o_enc_halo_bytes(self.h)
+
+    def halo_export(self, edge, ptr):
+        lib().h264o_enc_halo_export(self.h, edge, ptr)
+
+    def halo_import(self, edge, ptr):
+        lib().h264o_enc_halo_import(self.h, edge, ptr)
 
     def set_idr_id(self, nxt, step=1):
         lib().h264o_enc_set_idr_id(self.h, nxt, step)

@@ -424,3 +424,35 @@ def test_slice_bands_bit_exact_and_decodable():
             for p in range(3):
                 assert np.array_equal(dec.plane(p), enc.debug_read(capi.DBG_RECON_Y + p)), tag + " plane %d" % p
         enc.close()
+
+
+def test_slice_bands_on_several_instances_equal_one_instance():
+    """SURVEY.md 8e-3 / BASELINE.json configs[4] (slice-parallel): W encoder instances, each coding its band of whole
+    slices of the SAME picture and swapping two macroblock rows of reconstruction with its neighbours after every
+    picture (mi355x_h264_band_halo_export / _import; across GPUs the swap is one send/recv pair per neighbour), must
+    produce byte for byte the access units ONE instance with the same number of slices makes.  Here the W instances
+    share one GPU; tests/test_shard_gloo.py runs the exchange schedule over torch.distributed"""
+    import torch
+    cases = [(320, 240, 4, 2, "s1"), (352, 288, 6, 3, "scroll"), (178, 98, 3, 3, "s1"), (1920, 1080, 8, 4, "s1"), (640, 368, 8, 8, "s3"),
+             (96, 112, 3, 2, "s1")]
+    for w, h, slices, W, kind in cases:
+        n = 4 if w * h > 500000 else 7
+        one = capi.Encoder(w, h, qp=27, gop=5, slices=slices)
+        parts = [capi.Encoder(w, h, qp=27, gop=5, slices=slices, band_index=r, band_count=W) for r in range(W)]
+        info = [p.band_info() for p in parts]
+        assert info[0][0] == 0 and sum(i[1] for i in info) == (h + 15) // 16 and all(info[r][0] + info[r][1] == info[r + 1][0] for r in range(W - 1))
+        hb = info[0][4]
+        buf = torch.empty(hb, dtype=torch.uint8, device="cuda")
+        for i, f in enumerate(synth.sequence(kind, w, h, n)):
+            want = one.encode(f)[0]
+            got = b"".join(p.encode(f)[0] for p in parts)
+            assert got == want, "%dx%d slices %d on %d instances, picture %d" % (w, h, slices, W, i)
+            for r in range(W):
+                if r > 0:            # my top rows become the rows below my upper neighbour
+                    parts[r].halo_export(0, buf.data_ptr())
+                    parts[r - 1].halo_import(1, buf.data_ptr())
+                if r < W - 1:        # my bottom rows become the rows above my lower neighbour
+                    parts[r].halo_export(1, buf.data_ptr())
+                    parts[r + 1].halo_import(0, buf.data_ptr())
+        for p in parts + [one]:
+            p.close()

@@ -139,3 +139,47 @@ def test_bitrate_mode_gop_sharding_broadcasts_rc_state():
     assert shard.reassemble(parts) == stream
     assert states[0] == state
     assert state != RateControl(bitrate, fps).state()   # the controller actually moved
+
+
+def _band_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    from media_amd import shard, synth
+    from oracle_lib import OracleEncoder
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    w, h, slices, n = 176, 144, 4, 6
+    eng = OracleEncoder(w, h, qp=27, gop=4, slices=slices, band_index=rank, band_count=world)
+    halo = shard.BandHalo(eng.halo_bytes())
+    aus = [shard.encode_picture_bands(eng, f, rank, world, dist, halo) for f in synth.sequence("s1", w, h, n)]
+    if rank == 0:
+        q.put(aus)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_slice_band_sharding_of_one_picture_swaps_halos():
+    """SURVEY.md 8e-3 / BASELINE.json configs[4]: the slices of every picture are split over two ranks; after each
+    picture the ranks swap two macroblock rows of reconstruction point to point (gloo here, RCCL send/recv over xGMI
+    on GPUs) and rank 0 gathers the slice NAL units.  The result must be the stream one encoder with the same number
+    of slices makes.  (Engine: the CPU oracle's band mode; tests/test_gpu_parity.py checks that the HIP encoder's band
+    mode equals the oracle's through the same export/import calls.)"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from media_amd import synth
+    from oracle_lib import OracleEncoder
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_band_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    aus = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    w, h, slices, n = 176, 144, 4, 6
+    one = OracleEncoder(w, h, qp=27, gop=4, slices=slices)
+    for i, f in enumerate(synth.sequence("s1", w, h, n)):
+        assert aus[i] == one.encode(f)[0], "picture %d" % i
