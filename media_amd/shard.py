@@ -102,16 +102,21 @@ def exchange_band_halos(engine, rank, world, dist, halo):
         engine.halo_import(1, halo.recv_down.data_ptr())
 
 
-def gather_access_unit(part, rank, world, dist, device=None, cap=None):
+def gather_access_unit(part, rank, world, dist, device=None, cap=None, sizes_out=None):
     """slice NAL units of every band -> the access unit on rank 0 (b'' elsewhere): sizes by all_gather, then the
-    payloads as equally sized uint8 tensors (cap = upper bound of one band's bytes, default: the largest size)"""
+    payloads as equally sized uint8 tensors (cap = upper bound of one band's bytes, default: the largest size).
+    sizes_out (a list) receives every band's byte count on EVERY rank - what a rate controller needs."""
     if world == 1:
+        if sizes_out is not None:
+            sizes_out[:] = [len(part)]
         return part
     import torch
     n = torch.tensor([len(part)], dtype=torch.int64, device=device)
     sizes = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(sizes, n)
     sizes = [int(s.item()) for s in sizes]
+    if sizes_out is not None:
+        sizes_out[:] = sizes
     cap = max(sizes) if cap is None else cap
     mine = torch.zeros(cap, dtype=torch.uint8, device=device)
     mine[:len(part)] = torch.frombuffer(bytearray(part), dtype=torch.uint8).to(mine.device)
@@ -122,8 +127,17 @@ def gather_access_unit(part, rank, world, dist, device=None, cap=None):
     return b"".join(parts[r][:sizes[r]].cpu().numpy().tobytes() for r in range(world))
 
 
-def encode_picture_bands(engine, frame, rank, world, dist, halo, device=None):
-    """one picture of a band-sharded stream: code this rank's slices, swap halos, gather the access unit on rank 0"""
-    part = engine.encode(frame)[0]
+def encode_picture_bands(engine, frame, rank, world, dist, halo, device=None, rc=None):
+    """one picture of a band-sharded stream: code this rank's slices, swap halos, gather the access unit on rank 0.
+    rc (media_amd.ratecontrol.RateControl, the same initial state on every rank): bitrate mode.  Every rank sets the
+    picture QP from its own copy of the controller and feeds it the picture's TOTAL size, which the gather's size
+    exchange already delivers to every rank - the copies stay identical without any further message."""
+    if rc is not None:
+        engine.set_qp(rc.qp)
+    part, idr = engine.encode(frame)[:2]
     exchange_band_halos(engine, rank, world, dist, halo)
-    return gather_access_unit(part, rank, world, dist, device)
+    sizes = []
+    au = gather_access_unit(part, rank, world, dist, device, sizes_out=sizes)
+    if rc is not None:
+        rc.update(sum(sizes), idr == 1)      # (capi: frame type 1 = IDR; the oracle engine: True)
+    return au

@@ -150,12 +150,17 @@ def _band_worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    from media_amd.ratecontrol import RateControl
     w, h, slices, n = 176, 144, 4, 6
     eng = OracleEncoder(w, h, qp=27, gop=4, slices=slices, band_index=rank, band_count=world)
     halo = shard.BandHalo(eng.halo_bytes())
     aus = [shard.encode_picture_bands(eng, f, rank, world, dist, halo) for f in synth.sequence("s1", w, h, n)]
+    # bitrate mode: every rank runs its own copy of the controller on the gathered picture sizes
+    eng2 = OracleEncoder(w, h, qp=27, gop=4, slices=slices, band_index=rank, band_count=world)
+    rc = RateControl(300000, 30)
+    aus_rc = [shard.encode_picture_bands(eng2, f, rank, world, dist, halo, rc=rc) for f in synth.sequence("s1", w, h, n)]
     if rank == 0:
-        q.put(aus)
+        q.put((aus, aus_rc, rc.state()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -175,11 +180,23 @@ def test_slice_band_sharding_of_one_picture_swaps_halos():
     procs = [ctx.Process(target=_band_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    aus = q.get(timeout=120)
+    aus, aus_rc, rc_state = q.get(timeout=120)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
+    from media_amd.ratecontrol import RateControl
     w, h, slices, n = 176, 144, 4, 6
     one = OracleEncoder(w, h, qp=27, gop=4, slices=slices)
     for i, f in enumerate(synth.sequence("s1", w, h, n)):
         assert aus[i] == one.encode(f)[0], "picture %d" % i
+    # bitrate mode: the same controller driving ONE encoder makes the same stream and ends in the same state
+    one = OracleEncoder(w, h, qp=27, gop=4, slices=slices)
+    rc = RateControl(300000, 30)
+    qps = set()
+    for i, f in enumerate(synth.sequence("s1", w, h, n)):
+        one.set_qp(rc.qp)
+        qps.add(rc.qp)
+        bs, idr = one.encode(f)
+        rc.update(len(bs), idr)
+        assert aus_rc[i] == bs, "bitrate mode, picture %d" % i
+    assert rc.state() == tuple(rc_state) and len(qps) > 1      # (the controller did move the QP)
