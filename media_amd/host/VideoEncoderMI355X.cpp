@@ -42,6 +42,10 @@ bool VideoEncoderMI355X::EngineOpen(const Settings &s)
     m_qp = cfg.qp;
     m_bufferBits = 0;
     m_sceneDetect = GetStrEncParam("persist.vmi.video.encode.scenedetect") != "0";
+    // extension: 2..64 slice bands per picture for a shorter per-picture latency; anything else keeps the preset's
+    // single slice (SM_SINGLE_SLICE, ref :247)
+    const int32_t slices = GetIntEncParam("persist.vmi.video.encode.slices");
+    cfg.slices = Within(slices, 2, 64) ? slices : 0;
     const int rc = mi355x_h264_create(&cfg, &m_engine);
     if (rc != MI355X_H264_OK) {
         ERR("mi355x_h264_create returned %d", rc);

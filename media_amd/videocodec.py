@@ -51,7 +51,7 @@ def prop_get(key):
     return buf.value.decode()
 
 
-def set_video_mode(width, height, fps=30, bitrate=5000000, gop=30, profile="baseline", fmt=3, qp=None):
+def set_video_mode(width, height, fps=30, bitrate=5000000, gop=30, profile="baseline", fmt=3, qp=None, slices=None):
     """fill the property store the way a 'video' mode cloud phone would"""
     prop_set("ro.vmi.demo.video.encode.format", fmt)
     prop_set("ro.sys.vmi.cloudphone", "video")
@@ -65,6 +65,7 @@ def set_video_mode(width, height, fps=30, bitrate=5000000, gop=30, profile="base
     prop_set("persist.vmi.video.encode.keyframe", "0")
     prop_set("persist.vmi.video.encode.qp", "" if qp is None else qp)
     prop_set("persist.vmi.video.encode.scenedetect", "1")
+    prop_set("persist.vmi.video.encode.slices", "" if slices is None else slices)
 
 
 class VideoEncoder:

@@ -110,3 +110,20 @@ def test_bitrate_mode_tracks_target_and_replays_on_oracle():
     assert 0.6 * bitrate < achieved < 1.5 * bitrate, (achieved, qps)
     assert min(qps) >= 12 and max(qps) <= 48
     e.delete()
+
+
+def test_slices_extension_key():
+    """persist.vmi.video.encode.slices = 4: every access unit carries four slice NAL units and equals the oracle's
+    four-slice stream; without the key the preset's single slice is used (covered by the tests above)"""
+    w, h = 320, 240
+    e = _new(w, h, qp=28, gop=30, slices=4)
+    orc = OracleEncoder(w, h, qp=28, gop=30, slices=4)
+    dec = OracleDecoder()
+    for f in synth.sequence("s1", w, h, 4):
+        rc, bs = e.encode(f)
+        assert rc == vc.SUCCESS and bs == orc.encode(f)[0]
+        assert sum(1 for k in range(len(bs) - 4) if bs[k:k + 4] == b"\x00\x00\x00\x01" and (bs[k + 4] & 31) in (1, 5)) == 4
+        assert dec.decode(bs) == 1
+    e.destroy()
+    assert e.delete() == vc.SUCCESS
+    vc.prop_set("persist.vmi.video.encode.slices", "")
