@@ -456,3 +456,39 @@ def test_slice_bands_on_several_instances_equal_one_instance():
                     parts[r + 1].halo_import(0, buf.data_ptr())
         for p in parts + [one]:
             p.close()
+
+
+def test_slice_bands_with_other_options():
+    """slices combined with the rest of the configuration surface: profiles, loop filter off (idc 1 instead of 2),
+    NV12 device pictures, lockstep batches of GOPs - every access unit / GOP against the oracle"""
+    import random
+    import torch
+    rng = random.Random(77)
+    for case in range(24):
+        w, h = 2 * rng.randint(16, 180), 2 * rng.randint(24, 140)
+        sl = rng.randint(2, 7)
+        qp = rng.choice([20, 27, 35])
+        gop = rng.choice([2, 3, 4])
+        prof = rng.choice([66, 77, 100])
+        nodb = rng.random() < 0.3
+        nv12 = rng.random() < 0.5
+        G = rng.choice([1, 2, 3])
+        kind = rng.choice(["s1", "scroll", "s3"])
+        frames = synth.sequence(kind, w, h, gop * G if G > 1 else 5)
+        tag = "case %d: %dx%d slices %d qp %d gop %d profile %d nodeblock %d nv12 %d batch %d %s" % (case, w, h, sl, qp, gop, prof, nodb, nv12, G, kind)
+        orc = OracleEncoder(w, h, qp=qp, gop=gop, profile_idc=prof, disable_deblock=int(nodb), slices=sl)
+        want = [orc.encode(f)[0] for f in frames]
+        pics = [(_to_nv12(f, w, h) if nv12 else f) for f in frames]
+        dev = torch.from_numpy(np.stack(pics)).cuda()
+        fbytes = w * h * 3 // 2
+        enc = capi.Encoder(w, h, qp=qp, gop=gop, profile_idc=prof, disable_deblock=int(nodb), batch=G, input_format=int(nv12), slices=sl)
+        if G == 1:
+            for i in range(len(frames)):
+                assert enc.encode_device(dev[i].data_ptr())[0] == want[i], tag + " picture %d" % i
+        else:
+            cap = max(8192, gop * fbytes * 2)
+            out, szs, gb = np.zeros(G * cap, np.uint8), np.zeros(G * gop, np.uint32), np.zeros(G, np.uint64)
+            enc.encode_gops_device(dev.data_ptr(), fbytes, gop * fbytes, gop, out, cap, szs, gb)
+            for g in range(G):
+                assert out[g * cap: g * cap + int(gb[g])].tobytes() == b"".join(want[g * gop:(g + 1) * gop]), tag + " GOP %d" % g
+        enc.close()
