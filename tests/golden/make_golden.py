@@ -17,7 +17,7 @@ from media_amd import synth  # noqa: E402
 from oracle_lib import OracleEncoder  # noqa: E402
 
 CASES = [
-    # name, width, height, kind, qp, gop, frames, profile_idc
+    # name, width, height, kind, qp, gop, frames, profile_idc[, slices]
     ("qcif_s1_qp26", 176, 144, "s1", 26, 30, 6, 66),
     ("qvga_s1_gop4", 320, 240, "s1", 26, 4, 6, 66),
     ("tiny_s2_static", 64, 48, "s2", 26, 30, 4, 66),
@@ -29,18 +29,20 @@ CASES = [
     ("qcif_s1_main", 176, 144, "s1", 26, 30, 3, 77),
     ("qcif_s1_high", 176, 144, "s1", 26, 30, 3, 100),
     ("portrait_720x1280_s1", 720, 1280, "s1", 26, 30, 3, 66),
+    ("qvga_s1_4slices", 320, 240, "s1", 26, 4, 6, 66, 4),
+    ("cif_scroll_6slices_main", 352, 288, "scroll", 30, 30, 5, 77, 6),
 ]
 
 
-def run_case(name, w, h, kind, qp, gop, n, prof):
-    enc = OracleEncoder(w, h, qp=qp, gop=gop, profile_idc=prof)
+def run_case(name, w, h, kind, qp, gop, n, prof, slices=0):
+    enc = OracleEncoder(w, h, qp=qp, gop=gop, profile_idc=prof, slices=slices)
     frames = []
     for f in synth.sequence(kind, w, h, n):
         bs, idr = enc.encode(f)
         rec = hashlib.sha256(b"".join(enc.recon(p).tobytes() for p in range(3))).hexdigest()
         frames.append({"idr": bool(idr), "bytes": len(bs), "sha256": hashlib.sha256(bs).hexdigest(), "recon_sha256": rec})
     enc.close()
-    return {"name": name, "width": w, "height": h, "kind": kind, "qp": qp, "gop": gop, "profile_idc": prof, "frames": frames}
+    return {"name": name, "width": w, "height": h, "kind": kind, "qp": qp, "gop": gop, "profile_idc": prof, "slices": slices, "frames": frames}
 
 
 if __name__ == "__main__":
