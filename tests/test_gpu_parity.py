@@ -492,3 +492,36 @@ def test_slice_bands_with_other_options():
             for g in range(G):
                 assert out[g * cap: g * cap + int(gb[g])].tobytes() == b"".join(want[g * gop:(g + 1) * gop]), tag + " GOP %d" % g
         enc.close()
+
+
+def test_long_gop_frame_num_wrap_and_gop_boundary_1080p():
+    """(a) the longest GOP the reference accepts (gopsize 3000, VideoEncoderOpenH264.cpp:16-23): 300 P pictures in a
+    row, frame_num (8 bits here) wraps past 255; (b) 1080p across a GOP boundary: pictures 28..33 of a 34-picture
+    run (IDR at 30) - every access unit against the oracle, the stream decodable"""
+    w, h = 64, 48
+    enc = capi.Encoder(w, h, qp=30, gop=3000)
+    orc = OracleEncoder(w, h, qp=30, gop=3000)
+    dec = OracleDecoder()
+    idrs = 0
+    for i in range(300):
+        f = synth.frame_s1(w, h, i)
+        bs, ft = enc.encode(f)
+        idrs += ft == capi.FRAME_IDR
+        assert bs == orc.encode(f)[0], "picture %d" % i
+        assert dec.decode(bs) == 1
+    assert idrs == 1
+    for p in range(3):
+        assert np.array_equal(dec.plane(p), enc.debug_read(capi.DBG_RECON_Y + p))
+    enc.close()
+    w, h = 1920, 1080
+    enc = capi.Encoder(w, h, qp=26, gop=30)
+    orc = OracleEncoder(w, h, qp=26, gop=30)
+    for i in range(34):
+        f = synth.frame_s1(w, h, i)
+        bs, ft = enc.encode(f)
+        assert (ft == capi.FRAME_IDR) == (i % 30 == 0)
+        if i >= 28 or i < 2:
+            assert bs == orc.encode(f)[0], "1080p picture %d" % i
+        else:
+            orc.encode(f)      # (keeps the oracle's reference in step; ~0.1 s per picture)
+    enc.close()
