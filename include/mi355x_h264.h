@@ -51,7 +51,9 @@ enum {
     MI355X_H264_E_NODEVICE = -2, /* no usable HIP device (never a silent CPU path)  */
     MI355X_H264_E_HIP = -3,      /* a HIP runtime call failed (see last_error)      */
     MI355X_H264_E_NOMEM = -4,
-    MI355X_H264_E_OVERFLOW = -5, /* bitstream exceeded the output buffer            */
+    MI355X_H264_E_OVERFLOW = -5, /* a slice coded to more than its payload buffer (twice its luma bytes; only synthetic
+                                  * noise at the lowest QPs does): the picture is refused, nothing is written past the
+                                  * buffer, the encoder state stays valid for the next picture                        */
     MI355X_H264_E_INTERNAL = -6
 };
 

@@ -267,6 +267,7 @@ struct CavlcParams {
     int mbw, nmb, p_slice;
     SliceRows sl;         // slices of the picture (bands of sl.rows macroblock rows)
     int mb_first, mb_end; // the macroblocks this instance codes (its band of whole slices; 0 .. nmb alone)
+    unsigned slice_cap;   // bytes of payload buffer per slice: slice s owns bytes [s * slice_cap, (s + 1) * slice_cap)
     uint16_t* slotbits;   // 32 per macroblock
     unsigned long long* slotcode;   // 32 per macroblock: the slot's bits, left aligned, when slotbits <= 64
     uint32_t* mbbits;     // per macroblock, then (after the scan) bit offsets
@@ -420,8 +421,11 @@ __global__ __launch_bounds__(64) void k_cavlc(CavlcParams C0)
             const unsigned t = (unsigned)__shfl_up((int)incl, o, 32);
             if (slot >= o) incl += t;
         }
-        if (live && n) {
-            const unsigned pos = C.mbbits[mbi] + incl - n;
+        // A slice that outgrows its share of the payload buffer (twice its luma bytes: only noise at the lowest QPs
+        // codes to that) is reported by k_bit_scan and refused by the host; nothing may be written past the share.
+        const unsigned pos = live ? C.mbbits[mbi] + incl - n : 0u;
+        const unsigned lim = (__umulhi((unsigned)(mbi / C.mbw), C.sl.inv) + 1u) * C.slice_cap * 8u - 1024u;
+        if (live && n && pos + n <= lim) {
             if (n <= 64u) {   // coded by the count pass: OR the stored word in at its final bit position
                 const unsigned long long code = C.slotcode[(size_t)mbi * 32 + slot];
                 const unsigned off = pos & 31;
@@ -508,21 +512,21 @@ __global__ __launch_bounds__(SCAN_NT) void k_bit_scan(CavlcParams C0, HdrBatch H
         else s.put(hdr_rest, (unsigned)hdr_bits);
         s.flush();
         unsigned total = hdr_len + s_part[SCAN_NT - 1];
-        s.init(base + total);
+        const bool fits = (total >> 3) + 64u <= slice_cap;
+        s.init(base + (fits ? total : hdr_len));
         BitCount c;
         c.init(0);
         if (C.p_slice) {
             // P_Skip macroblocks that end the slice
             const unsigned skips = (unsigned)(mb1 - 1 - max(C.prevcoded[mb1], mb0 - 1));
-            if (skips) { put_ue(s, skips); put_ue(c, skips); }
+            if (skips) { if (fits) put_ue(s, skips); put_ue(c, skips); }
         }
-        s.put(1, 1);  // rbsp_stop_one_bit
-        s.flush();
+        if (fits) { s.put(1, 1); s.flush(); }  // rbsp_stop_one_bit
         total += c.n + 1;
         info->total_bits = total;
         info->total_bytes = (total + 7) >> 3;
         info->epb_count = 0;
-        info->error = ((total + 7) >> 3) + 32u > slice_cap ? 1u : 0u;   // the slice outgrew its share of the payload buffer
+        info->error = fits ? 0u : 1u;   // 1: the slice outgrew its share of the payload buffer (k_cavlc<true> writes nothing past it)
         info->me_cost = s_cost;   // complete: every thread passed the scan's barriers after its atomicAdd
     }
 }

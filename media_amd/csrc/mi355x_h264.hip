@@ -343,6 +343,7 @@ int submit(mi355x_h264_encoder* e, const uint8_t* d_src, size_t src_item_stride,
     CavlcParams C{};
     C.mb = e->d_mb; C.levels = e->d_levels; C.mvd = e->d_mvd; C.mbw = e->mbw; C.nmb = e->nmb; C.p_slice = idr ? 0 : 1; C.sl = e->sl;
     C.mb_first = e->b_row0 * e->mbw; C.mb_end = C.mb_first + e->b_nmb;
+    C.slice_cap = (unsigned)e->slice_cap;
     C.slotbits = e->d_slotbits; C.slotcode = e->d_slotcode; C.mbbits = e->d_mbbits; C.bitbuf = S.d_bitbuf;
     C.bs = (uint8_t*)e->d_bs; C.prevcoded = e->d_prevcoded;
     C.st_mb = e->nmb; C.st_bitbuf = e->st_bitbuf_bytes / 4;

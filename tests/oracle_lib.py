@@ -108,7 +108,7 @@ class OracleEncoder:
         self.width, self.height = width, height
         self.cw = lib().h264o_enc_coded_width(self.h)
         self.ch = lib().h264o_enc_coded_height(self.h)
-        self.out = np.zeros(width * height * 3 + (1 << 16), dtype=np.uint8)
+        self.out = np.zeros(width * height * 8 + (1 << 16), dtype=np.uint8)
 
     def encode(self, i420, force_idr=False):
         w, h = self.width, self.height

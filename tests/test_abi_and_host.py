@@ -64,7 +64,8 @@ def test_create_rejects_bad_config():
     from media_amd import capi
     L = capi.lib()
     h = C.c_void_p()
-    for field, val in (("width", 15), ("height", 4098), ("width", 641), ("qp", 9), ("qp", 52), ("gop", 0), ("profile_idc", 88)):
+    for field, val in (("width", 15), ("height", 4098), ("width", 641), ("qp", 9), ("qp", 52), ("gop", 0), ("profile_idc", 88),
+                       ("input_format", 2), ("slices", -1), ("slices", 65), ("band_index", -1), ("band_count", -2)):
         cfg = capi.Config()
         L.mi355x_h264_default_config(C.byref(cfg))
         setattr(cfg, field, val)

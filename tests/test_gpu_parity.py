@@ -525,3 +525,25 @@ def test_long_gop_frame_num_wrap_and_gop_boundary_1080p():
         else:
             orc.encode(f)      # (keeps the oracle's reference in step; ~0.1 s per picture)
     enc.close()
+
+
+def test_payload_buffer_overflow_is_refused_not_written():
+    """black-and-white noise at the lowest QP codes to more than twice the luma bytes, the size of the payload buffer (a
+    conforming encoder would switch such macroblocks to I_PCM, which this build does not have): the picture must be
+    refused with MI355X_H264_E_OVERFLOW - nothing written past the buffer - and the encoder must carry on with the
+    next picture as if nothing had happened (the reconstruction of the refused picture is complete)"""
+    w, h = 640, 480
+    rng = np.random.default_rng(3)
+    noise = [(rng.integers(0, 2, w * h * 3 // 2, dtype=np.uint8) * 255).astype(np.uint8) for _ in range(3)]   # black / white noise
+    for slices in (0, 4):
+        enc = capi.Encoder(w, h, qp=10, gop=30, slices=slices)
+        orc = OracleEncoder(w, h, qp=10, gop=30, slices=slices)
+        want = orc.encode(noise[0])[0]
+        assert len(want) > 2 * w * h + 65536   # the premise: this picture does not fit (uniform noise still does: 1.95 x)
+        with pytest.raises(RuntimeError, match="-5"):
+            enc.encode(noise[0])
+        for f in noise[1:]:                    # P pictures at a QP where they fit again
+            enc.set_qp(36)
+            orc.set_qp(36)
+            assert enc.encode(f)[0] == orc.encode(f)[0]
+        enc.close()
