@@ -738,16 +738,24 @@ int mi355x_h264_encode_batch_device(mi355x_h264_encoder* e, const void* d_frames
         pos += n;
         return 0;
     };
+    // on an error the pictures still in flight are waited for (and dropped) before returning: no slot stays busy
+    auto bail = [&](int rc) -> int {
+        char first[sizeof(e->err)];
+        memcpy(first, e->err, sizeof(first));
+        for (; npend > 0; head++, npend--) (void)wait_slot(e, pending[head % NSLOT]);
+        memcpy(e->err, first, sizeof(first));
+        return rc;
+    };
     for (int i = 0; i < count; i++) {
-        if (npend == NSLOT - 1) { int rc = drain_one(); if (rc) return rc; }
+        if (npend == NSLOT - 1) { int rc = drain_one(); if (rc) return bail(rc); }
         const int slot = e->next_slot;
         e->next_slot = (e->next_slot + 1) % NSLOT;
         pending[i % NSLOT] = slot;
         int rc = submit(e, (const uint8_t*)d_frames + (size_t)i * stride, 0, slot, e->cfg.input_format == MI355X_H264_INPUT_NV12);
-        if (rc) return rc;
+        if (rc) return bail(rc);
         npend++;
     }
-    while (npend) { int rc = drain_one(); if (rc) return rc; }
+    while (npend) { int rc = drain_one(); if (rc) return bail(rc); }
     if (total_len) *total_len = pos;
     return MI355X_H264_OK;
 }
@@ -777,16 +785,23 @@ int mi355x_h264_encode_gops_device(mi355x_h264_encoder* e, const void* d_frames,
         head++; npend--;
         return 0;
     };
+    auto bail = [&](int rc) -> int {   // as in mi355x_h264_encode_batch_device
+        char first[sizeof(e->err)];
+        memcpy(first, e->err, sizeof(first));
+        for (; npend > 0; head++, npend--) (void)wait_slot(e, pending[head % NSLOT]);
+        memcpy(e->err, first, sizeof(first));
+        return rc;
+    };
     for (int i = 0; i < frames_per_gop; i++) {
-        if (npend == NSLOT - 1) { int rc = drain_one(); if (rc) return rc; }
+        if (npend == NSLOT - 1) { int rc = drain_one(); if (rc) return bail(rc); }
         const int slot = e->next_slot;
         e->next_slot = (e->next_slot + 1) % NSLOT;
         pending[i % NSLOT] = slot;
         int rc = submit(e, (const uint8_t*)d_frames + (size_t)i * frame_stride, gop_stride, slot, e->cfg.input_format == MI355X_H264_INPUT_NV12);
-        if (rc) return rc;
+        if (rc) return bail(rc);
         npend++;
     }
-    while (npend) { int rc = drain_one(); if (rc) return rc; }
+    while (npend) { int rc = drain_one(); if (rc) return bail(rc); }
     return MI355X_H264_OK;
 }
 

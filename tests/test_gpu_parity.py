@@ -547,3 +547,18 @@ def test_payload_buffer_overflow_is_refused_not_written():
             orc.set_qp(36)
             assert enc.encode(f)[0] == orc.encode(f)[0]
         enc.close()
+    # the pipelined lockstep path: the failing call waits for its pictures in flight, the next call is clean
+    import torch
+    G, gop, fbytes = 2, 3, w * h * 3 // 2
+    dev = torch.from_numpy(np.stack(noise * G)).cuda()
+    enc = capi.Encoder(w, h, qp=10, gop=gop, batch=G)
+    cap = 4 * gop * fbytes
+    out, szs, gb = np.zeros(G * cap, np.uint8), np.zeros(G * gop, np.uint32), np.zeros(G, np.uint64)
+    with pytest.raises(RuntimeError, match="-5"):
+        enc.encode_gops_device(dev.data_ptr(), fbytes, gop * fbytes, gop, out, cap, szs, gb)
+    enc.set_qp(36)
+    enc.encode_gops_device(dev.data_ptr(), fbytes, gop * fbytes, gop, out, cap, szs, gb)
+    orc = OracleEncoder(w, h, qp=36, gop=gop)
+    orc.set_idr_id(G, 1)                       # the refused call used up idr_pic_id 0 .. G-1
+    assert out[:int(gb[0])].tobytes() == b"".join(orc.encode(f)[0] for f in noise)
+    enc.close()
