@@ -86,3 +86,26 @@ def test_decoder_rejects_garbage():
     dec = OracleDecoder()
     with pytest.raises(RuntimeError):
         dec.decode(b"\x00\x00\x00\x01\x65\x88\x84\x00\x10")  # slice before parameter sets
+
+
+def test_access_units_walk_like_the_reference_decoder_adapter_expects():
+    """the reference's decoder adapter caches the SPS / PPS in front of a key picture by walking the
+    leading non-VCL NAL units (tests/annexb.py restates that walk).  IDR access units must yield exactly [SPS, PPS]
+    and then slices only, P access units no parameter sets; one slice NAL per slice band."""
+    import annexb
+    assert annexb.find_nal_start_code(b"\x11\x00\x00\x01\x65") == 1 and annexb.find_nal_start_code(b"\x00\x00\x00\x01\x67") == 0
+    assert annexb.find_nal_start_code(b"\x00\x00\x02\x00\x01") == -1
+    assert annexb.find_next_non_vcl_nalu(b"\x00\x00\x00\x01\x65\x88") == (0, 5)
+    assert annexb.find_next_non_vcl_nalu(b"\x00\x00\x00\x01\x67\x42\x00\x00\x00\x01\x68") == (6, 7)
+    assert annexb.find_next_non_vcl_nalu(b"\x00\x00\x01\x68\xce") == (5, 8)          # last unit: the whole buffer
+    for slices in (0, 3):
+        w, h = 176, 144
+        enc = OracleEncoder(w, h, qp=28, gop=3, slices=slices)
+        for i, f in enumerate(synth.sequence("s1", w, h, 5)):
+            au, idr = enc.encode(f)
+            sets, rest = annexb.leading_parameter_sets(au)
+            assert [t for t, _ in sets] == ([7, 8] if idr else []), "picture %d" % i
+            units = annexb.split_nal_units(rest)
+            assert len(units) == max(slices, 1) and all(t == (5 if idr else 1) for _, t, _ in units)
+            assert all(ref == (3 if idr else 2) for ref, _, _ in units)
+            assert b"".join(b for _, b in sets) + rest == au
