@@ -62,6 +62,7 @@ struct FrameParams {
     uint16_t* me_cost;   // per macroblock: min(final motion cost, 16383), 0 where the zero-motion test hit (summed by k_bit_scan)
     Quant qy, qc;        // luma / chroma quantisers
     int lambda;
+    int sad_nz;          // a luma SAD of this much or more cannot quantise to nothing (fill in submit(): exact bound)
     // lockstep batch (gridDim.y = number of independent closed GOPs / streams encoded together):
     // element strides between consecutive batch items
     size_t st_src;       // bytes between the source pictures of two batch items

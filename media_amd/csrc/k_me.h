@@ -161,6 +161,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
             int dc = 0;
 #pragma unroll
             for (int c = 0; c < 4; c++) {
+                // a residual that does not vanish shows in the first coefficient column (the DC column) nearly always:
+                // ask once after it and spare the other three
+                if (c == 1 && __ballot(over != 0) != 0ull) return false;
                 const pk16 q0 = __builtin_bit_cast(pk16, quad_bcast<0>(__builtin_bit_cast(int, d[c])));
                 const pk16 q1 = __builtin_bit_cast(pk16, quad_bcast<1>(__builtin_bit_cast(int, d[c])));
                 const pk16 q2 = __builtin_bit_cast(pk16, quad_bcast<2>(__builtin_bit_cast(int, d[c])));
@@ -186,6 +189,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
             }
             return !dcnz && __ballot(over != 0) == 0ull;
         };
+        // Exact shortcut: if every luma coefficient stays below its threshold t_ij, then (the core transform's rows are
+        // orthogonal with squared norms 4, 10, 4, 10) the residual energy of a 4x4 block is below E = sum t_ij^2 / (n_i n_j),
+        // and by Cauchy-Schwarz the macroblock's SAD below 64 sqrt(E) = P.sad_nz.  A SAD at or above that (a moving
+        // macroblock tested at the zero vector) needs no transform to be turned down.
+        auto luma_sad = [&](uint32_t ry) -> unsigned {
+            const int s = row_sum16_dpp((int)__builtin_amdgcn_sad_u8(sy, ry, 0u));
+            return (unsigned)(__builtin_amdgcn_readlane(s, 0) + __builtin_amdgcn_readlane(s, 16) + __builtin_amdgcn_readlane(s, 32) + __builtin_amdgcn_readlane(s, 48));
+        };
         auto settle = [&](int vx, int vy) {   // the vector is final and k_pmb2 need not transform this macroblock
             if (lane == 0) {
                 MbInfo* m = P.mb + mbi;
@@ -197,7 +208,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
         {   // the zero vector: co-located samples
             const uint32_t ry = s_win[(ME_R + ME_AP + (b4 >> 2) * 4 + r) * ME_WDW + (ME_R + ME_AP) / 4 + (b4 & 3)];
             const uint32_t rc = lane < 32 ? *(const uint32_t*)(s_refc + cplz * 64 + cyz * 8 + cxz) : 0u;
-            if (quantises_to_nothing(ry, rc)) { settle(0, 0); return; }
+            if (luma_sad(ry) < (unsigned)P.sad_nz && quantises_to_nothing(ry, rc)) { settle(0, 0); return; }
         }
         const int rvx = ((pmx + 2) >> 2) * 4, rvy = ((pmy + 2) >> 2) * 4;   // the previous vector rounded to integer samples
         if ((rvx | rvy) != 0) {   // wave-uniform
@@ -222,7 +233,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
                     pa = na; pb = nb;
                 }
             }
-            if (quantises_to_nothing(ry, rc)) { settle(rvx, rvy); return; }
+            if (luma_sad(ry) < (unsigned)P.sad_nz && quantises_to_nothing(ry, rc)) { settle(rvx, rvy); return; }
         }
     }
 

@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdarg>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -305,6 +306,10 @@ int submit(mi355x_h264_encoder* e, const uint8_t* d_src, size_t src_item_stride,
     fill_quant(P.qy, e->qp);
     fill_quant(P.qc, h_chroma_qp[e->qp]);
     P.lambda = h_lambda[e->qp];
+    {   // k_me's shortcut for the "quantises to nothing" test: 64 sqrt(sum over the 16 positions of t^2 / (n_i n_j)), rounded up
+        const double t0 = P.qy.thr_inter[0], t1 = P.qy.thr_inter[1], t2 = P.qy.thr_inter[2];
+        P.sad_nz = (int)std::ceil(64.0 * std::sqrt(4 * t0 * t0 / 16.0 + 4 * t1 * t1 / 100.0 + 8 * t2 * t2 / 40.0)) + 1;
+    }
     hipStream_t st = e->stream;
 
     // (the payload buffer of this slot was left zeroed by the k_pack of its previous use)
