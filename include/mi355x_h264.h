@@ -53,7 +53,8 @@ enum {
     MI355X_H264_E_NOMEM = -4,
     MI355X_H264_E_OVERFLOW = -5, /* a slice coded to more than its payload buffer (twice its luma bytes; only synthetic
                                   * noise at the lowest QPs does): the picture is refused, nothing is written past the
-                                  * buffer, the encoder state stays valid for the next picture                        */
+                                  * buffer, and the next picture is coded as an IDR (the refused one is missing from
+                                  * the stream and must not be referred to)                                            */
     MI355X_H264_E_INTERNAL = -6
 };
 

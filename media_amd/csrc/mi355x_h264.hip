@@ -453,7 +453,10 @@ int finish_item(mi355x_h264_encoder* e, int slot_idx, int g, uint8_t** out, uint
         uint32_t cost = 0;
         for (int sl = 0; sl < e->b_nsl; sl++) {
             const SliceInfo& si = S.h_info[(size_t)g * e->b_nsl + sl];
-            if (si.error) return fail(e, si.error == 1 ? MI355X_H264_E_OVERFLOW : MI355X_H264_E_INTERNAL, "device reported error %u (slice %d)", si.error, sl);
+            if (si.error) {
+                e->force_idr = 1;   // the refused picture is missing from the stream: the next one must not refer to it
+                return fail(e, si.error == 1 ? MI355X_H264_E_OVERFLOW : MI355X_H264_E_INTERNAL, "device reported error %u (slice %d)", si.error, sl);
+            }
             need += 5 + (size_t)si.total_bytes * 3 / 2 + 16;
             cost += si.me_cost;
         }
@@ -477,7 +480,10 @@ int finish_item(mi355x_h264_encoder* e, int slot_idx, int g, uint8_t** out, uint
     }
     const SliceInfo info = S.h_info[g];
     e->last_me_cost[g] = info.me_cost;
-    if (info.error) return fail(e, info.error == 1 ? MI355X_H264_E_OVERFLOW : MI355X_H264_E_INTERNAL, "device reported error %u", info.error);
+    if (info.error) {
+        e->force_idr = 1;   // the refused picture is missing from the stream: the next one must not refer to it
+        return fail(e, info.error == 1 ? MI355X_H264_E_OVERFLOW : MI355X_H264_E_INTERNAL, "device reported error %u", info.error);
+    }
     if ((size_t)info.total_bytes + 64 > e->bitbuf_cap) return fail(e, MI355X_H264_E_OVERFLOW, "slice of %u bytes exceeds buffer", info.total_bytes);
     uint8_t* au = base + S.au_start;
     size_t pos = 0;

@@ -531,7 +531,7 @@ def test_payload_buffer_overflow_is_refused_not_written():
     """black-and-white noise at the lowest QP codes to more than twice the luma bytes, the size of the payload buffer (a
     conforming encoder would switch such macroblocks to I_PCM, which this build does not have): the picture must be
     refused with MI355X_H264_E_OVERFLOW - nothing written past the buffer - and the encoder must carry on with the
-    next picture as if nothing had happened (the reconstruction of the refused picture is complete)"""
+    next picture, coded as an IDR because the refused one is missing from the stream"""
     w, h = 640, 480
     rng = np.random.default_rng(3)
     noise = [(rng.integers(0, 2, w * h * 3 // 2, dtype=np.uint8) * 255).astype(np.uint8) for _ in range(3)]   # black / white noise
@@ -542,10 +542,16 @@ def test_payload_buffer_overflow_is_refused_not_written():
         assert len(want) > 2 * w * h + 65536   # the premise: this picture does not fit (uniform noise still does: 1.95 x)
         with pytest.raises(RuntimeError, match="-5"):
             enc.encode(noise[0])
-        for f in noise[1:]:                    # P pictures at a QP where they fit again
-            enc.set_qp(36)
+        dec = OracleDecoder()
+        for k, f in enumerate(noise[1:]):      # at a QP where the pictures fit again: an IDR first (the refused picture is
+            enc.set_qp(36)                     # missing from the stream), then P; what was delivered decodes
             orc.set_qp(36)
-            assert enc.encode(f)[0] == orc.encode(f)[0]
+            bs, ft = enc.encode(f)
+            assert (ft == capi.FRAME_IDR) == (k == 0)
+            assert bs == orc.encode(f, force_idr=(k == 0))[0]
+            assert dec.decode(bs) == 1
+        for p in range(3):
+            assert np.array_equal(dec.plane(p), enc.debug_read(capi.DBG_RECON_Y + p))
         enc.close()
     # the pipelined lockstep path: the failing call waits for its pictures in flight, the next call is clean
     import torch

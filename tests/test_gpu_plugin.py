@@ -127,3 +127,25 @@ def test_slices_extension_key():
     e.destroy()
     assert e.delete() == vc.SUCCESS
     vc.prop_set("persist.vmi.video.encode.slices", "")
+
+
+def test_picture_that_does_not_fit_is_an_encode_fail_and_the_stream_recovers():
+    """black/white noise at QP 10 codes to more than the payload buffer holds: EncodeOneFrame returns ENCODE_FAIL
+    (the C ABI's E_OVERFLOW), the caller drops the picture, and the next picture is an IDR - the delivered stream
+    stays decodable"""
+    w, h = 640, 480
+    e = _new(w, h, qp=10, gop=30)
+    dec = OracleDecoder()
+    frames = synth.sequence("s1", w, h, 3)
+    rc, bs = e.encode(frames[0])
+    assert rc == vc.SUCCESS and dec.decode(bs) == 1
+    rng = np.random.default_rng(3)
+    bad = (rng.integers(0, 2, w * h * 3 // 2, dtype=np.uint8) * 255).astype(np.uint8)
+    assert e.encode(bad)[0] == vc.ENCODE_FAIL
+    for f in frames[1:]:
+        rc, bs = e.encode(f)
+        assert rc == vc.SUCCESS and dec.decode(bs) == 1
+        if f is frames[1]:
+            assert bs[:5] == b"\x00\x00\x00\x01\x67"       # SPS first: an IDR access unit
+    e.destroy()
+    assert e.delete() == vc.SUCCESS
