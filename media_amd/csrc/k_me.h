@@ -427,16 +427,39 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
     }
     S[0] = __builtin_bit_cast(pk16, __builtin_bit_cast(uint32_t, S[0]) ^ 0x80008000u);
     int cx = 4 * ix, cy = 4 * iy;
+    // The centre (the integer position itself) is the one candidate whose prediction is plain window samples and that
+    // has no seven companions to share a round with: it is costed apart, quad-mapped - lane = (4x4 block, row), the
+    // Hadamard's rows in the lane, its columns as two butterflies over the DPP quad - for a third of a round's price.
+    unsigned centre_key;
+    {
+        const int r = lane & 3, b4 = lane >> 2;
+        const uint32_t sy = *(const uint32_t*)(s_src + ((b4 >> 2) * 4 + r) * 16 + (b4 & 3) * 4);
+        const uint32_t ry = lds_ld4(winb, (ME_R + ME_AP + (b4 >> 2) * 4 + r + iy) * ME_WS + ME_R + ME_AP + (b4 & 3) * 4 + ix);
+        const int d0 = (int)(sy & 255u) - (int)(ry & 255u), d1 = (int)((sy >> 8) & 255u) - (int)((ry >> 8) & 255u);
+        const int d2 = (int)((sy >> 16) & 255u) - (int)((ry >> 16) & 255u), d3 = (int)(sy >> 24) - (int)(ry >> 24);
+        const int s0 = d0 + d3, s1 = d1 + d2, u0 = d0 - d3, u1 = d1 - d2;
+        const int hr[4] = {s0 + s1, u0 + u1, s0 - s1, u0 - u1};
+        const int sg1 = (lane & 1) ? -1 : 1, sg2 = (lane & 2) ? -1 : 1;
+        int acc = 0;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const int y = __builtin_amdgcn_mov_dpp(hr[c], 0xB1, 0xf, 0xf, false) + sg1 * hr[c];   // rows r, r^1: sum / difference
+            const int z = __builtin_amdgcn_mov_dpp(y, 0x4E, 0xf, 0xf, false) + sg2 * y;           // rows r, r^2
+            acc += z < 0 ? -z : z;
+        }
+        const int s16 = row_sum16_dpp(acc);
+        const int tot = __builtin_amdgcn_readlane(s16, 0) + __builtin_amdgcn_readlane(s16, 16) + __builtin_amdgcn_readlane(s16, 32) + __builtin_amdgcn_readlane(s16, 48);
+        centre_key = ((unsigned)(tot >> 1) + (unsigned)(P.lambda * (se_len(cx - pmx) + se_len(cy - pmy)))) << 4;   // order 0
+    }
     unsigned best_cost = 0, bestk = 0xFFFFFFFFu;
 #pragma unroll 1
-    for (int round = 0; round < 3; round++) {
-        // round 0: the 8 half-sample neighbours; round 1: the centre itself; round 2: the 8 quarter-sample neighbours
-        const int step = round == 2 ? 1 : 2;
-        const int ord = round == 1 ? 0 : cand + 1;        // 0 = centre
-        const bool live = round != 1 || cand == 0;
+    for (int round = 0; round < 2; round++) {
+        // round 0: the 8 half-sample neighbours (then the centre joins the comparison); round 1: the 8 quarter-sample neighbours
+        const int step = round == 1 ? 1 : 2;
+        const int ord = cand + 1;                         // 0 = centre
         // neighbour order (-1,-1)(0,-1)(1,-1)(-1,0)(1,0)(-1,1)(0,1)(1,1)
         const int nn = cand >= 4 ? cand + 1 : cand;
-        const int ddx = ord == 0 ? 0 : (nn % 3) - 1, ddy = ord == 0 ? 0 : (nn / 3) - 1;
+        const int ddx = (nn % 3) - 1, ddy = (nn / 3) - 1;
         const int qx = cx + step * ddx, qy = cy + step * ddy;
         const int ox = qx - 4 * ix, oy = qy - 4 * iy;
         const int gx = 1 + (ox >> 2), gy = 1 + (oy >> 2);
@@ -477,9 +500,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
         }
         const int s = group_sum8_dpp((int)sum);
         const unsigned cost = (unsigned)(s >> 1) + (unsigned)(P.lambda * (se_len(qx - pmx) + se_len(qy - pmy)));
-        const unsigned key = live ? ((cost << 4) | (unsigned)ord) : 0xFFFFFFFFu;
-        bestk = key < bestk ? key : bestk;               // per-lane running minimum; reduced once per pass
-        if (round == 0) continue;
+        const unsigned key = (cost << 4) | (unsigned)ord;
+        bestk = key < bestk ? key : bestk;
+        if (round == 0) bestk = centre_key < bestk ? centre_key : bestk;
         bestk = wave_min_u32_dpp(bestk);
         const int w = (int)(bestk & 15);
         best_cost = bestk >> 4;
