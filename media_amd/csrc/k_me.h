@@ -336,8 +336,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
             }
             return sum;
         };
-        // the candidate with the smallest bound, completed: its true key bounds the optimum from above
-        const uint32_t bound = bestlb + (rest_of_sad(bestlb) << 10);
+        // the candidate with the smallest bound, completed: its true key bounds the optimum from above.  One candidate
+        // for the whole wave: lane = (source row, column group) takes one dword of it, the wave adds up
+        uint32_t bound;
+        {
+            const int j = lane & 15, g = (lane >> 4) & 1;                // columns 4..7 (g = 0) or 12..15 (g = 1)
+            const int ccol = (int)(bestlb & 31) + ME_AP + 4 + 8 * g, crow = ME_AP + (int)((bestlb >> 5) & 31) + j;
+            const uint32_t rv = lds_ld4(winb, crow * ME_WS + ccol), sv = *(const uint32_t*)(s_src + 16 * j + 4 + 8 * g);
+            const int part = row_sum16_dpp(lane < 32 ? (int)__builtin_amdgcn_sad_u8(rv, sv, 0u) : 0);
+            bound = bestlb + ((uint32_t)(__builtin_amdgcn_readlane(part, 0) + __builtin_amdgcn_readlane(part, 16)) << 10);
+        }
         // Pass 2 - only candidates whose bound does not exceed that key can still win (exact: true key >= bound key);
         // they are compacted into one list and completed 64 at a time
         {
