@@ -145,28 +145,26 @@ __device__ __forceinline__ void put_se(S& s, int v)
     put_ue(s, v > 0 ? (unsigned)(2 * v - 1) : (unsigned)(-2 * v));
 }
 
-// 9.2.2.1 level_prefix / level_suffix for one levelCode
+// 9.2.2.1 level_prefix / level_suffix for one levelCode.  Prefix (zeros, then the one) and suffix leave as ONE
+// put of at most 28 bits: the sink's 64-bit shift-and-or is the expensive part of a level.
 template <class S>
 __device__ __forceinline__ void put_level(S& s, int code, int suffix_len)
 {
     if (suffix_len == 0) {
         if (code < 14) { s.put(code + 1, 1); return; }
-        if (code < 30) { s.put(15, 1); s.put(4, (unsigned)(code - 14)); return; }
+        if (code < 30) { s.put(19, 16u | (unsigned)(code - 14)); return; }
         int c = code - 30, prefix = 15;
         while (c >= (1 << (prefix - 3))) { c -= 1 << (prefix - 3); prefix++; }
-        s.put(prefix + 1, 1);
-        s.put(prefix - 3, (unsigned)c);
+        s.put(2 * prefix - 2, (1u << (prefix - 3)) | (unsigned)c);
         return;
     }
     if (code < (15 << suffix_len)) {
-        s.put((code >> suffix_len) + 1, 1);
-        s.put(suffix_len, (unsigned)(code & ((1 << suffix_len) - 1)));
+        s.put((code >> suffix_len) + 1 + suffix_len, (1u << suffix_len) | (unsigned)(code & ((1 << suffix_len) - 1)));
         return;
     }
     int c = code - (15 << suffix_len), prefix = 15;
     while (c >= (1 << (prefix - 3))) { c -= 1 << (prefix - 3); prefix++; }
-    s.put(prefix + 1, 1);
-    s.put(prefix - 3, (unsigned)c);
+    s.put(2 * prefix - 2, (1u << (prefix - 3)) | (unsigned)c);
 }
 
 // residual_block_cavlc(): lv points at scan position 0 of this block's list
@@ -197,10 +195,14 @@ __device__ __forceinline__ void cavlc_block(S& s, const int16_t* lv, int maxc, i
     }
     if (!tc) return;
     unsigned m = nzm;
-    for (int k = 0; k < t1; k++) {
-        const int i = 31 - __clz((int)m);
-        s.put(1, lv[i] < 0 ? 1u : 0u);
-        m &= ~(1u << i);
+    {   // trailing_ones_sign_flag of the (up to three) trailing ones, highest frequency first: one put
+        unsigned signs = 0;
+        for (int k = 0; k < t1; k++) {
+            const int i = 31 - __clz((int)m);
+            signs = (signs << 1) | (lv[i] < 0 ? 1u : 0u);
+            m &= ~(1u << i);
+        }
+        s.put(t1, signs);
     }
     int suffix_len = (tc > 10 && t1 < 3) ? 1 : 0;
     bool first = true;
