@@ -141,7 +141,8 @@ int mi355x_h264_encode_gops_device(mi355x_h264_encoder *enc, const void *d_frame
  * reconstruction (the host class does it with one RCCL send/recv pair per neighbour over xGMI):
  *     export(enc, 0, buf) -> send to band_index-1;  export(enc, 1, buf) -> send to band_index+1
  *     import(enc, 0, buf) <- received from band_index-1 (its bottom rows);  import(enc, 1, buf) <- from band_index+1
- * buf: device memory of halo_bytes (band_info).  The result equals the stream ONE instance with the same `slices` makes. */
+ * buf: halo_bytes (band_info) of device memory - or of host memory, when the transport between the ranks is a host one.
+ * The result equals the stream ONE instance with the same `slices` makes. */
 int mi355x_h264_band_info(const mi355x_h264_encoder *enc, int *first_row, int *rows, int *first_slice, int *slices,
                           size_t *halo_bytes);
 int mi355x_h264_band_halo_export(mi355x_h264_encoder *enc, int edge, void *d_dst);

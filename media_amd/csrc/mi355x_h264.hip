@@ -857,7 +857,7 @@ int halo_copy(mi355x_h264_encoder* e, int r0, int r1, void* d_blk, bool to_block
         const size_t pitch = p ? e->cw / 2 : e->cw, rows_per_mb = p ? 8 : 16;
         const size_t off = (size_t)r0 * rows_per_mb * pitch, n = (size_t)(r1 - r0) * rows_per_mb * pitch;
         uint8_t* pl = e->d_planes[last][p] + off;
-        if (n) HIPCHK(e, hipMemcpyAsync(to_block ? (void*)blk : (void*)pl, to_block ? (const void*)pl : (const void*)blk, n, hipMemcpyDeviceToDevice, e->stream));
+        if (n) HIPCHK(e, hipMemcpyAsync(to_block ? (void*)blk : (void*)pl, to_block ? (const void*)pl : (const void*)blk, n, hipMemcpyDefault, e->stream));   // the block may be device or host memory
         blk += (size_t)HALO_MB_ROWS * rows_per_mb * pitch;   // fixed layout, whatever the number of rows present
     }
     HIPCHK(e, hipStreamSynchronize(e->stream));
