@@ -95,6 +95,35 @@ def openh264_differential(frames, count):
         return {"oracle": "absent", "reason": "differential tool failed: %s" % exc}
 
 
+def valu_issue_bound(nmb):
+    """What actually bounds the pipeline: VALU instruction issue.  From the committed PMC pass
+    (profiles/r01?_summary.json, SQ_INSTS_VALU of the lockstep launches of this same default workload): instructions per
+    macroblock over all kernels of a P picture -> pictures per second 1 024 SIMDs can issue (one VALU instruction per
+    wave per 4 cycles at 2.4 GHz).  Informational; None when no summary is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r01?_summary.json")))
+    if not files:
+        return None
+    try:
+        sq = json.load(open(files[-1])).get("sq", {})
+        per = {}
+        for name, v in sq.items():
+            k = name.split(" grid=")[0]
+            if not k.startswith(("k_me", "k_pmb2", "k_bs", "k_cavlc", "k_deblock_rows<false>")) or not v.get("SQ_WAVES"):
+                continue
+            if k not in per or v["SQ_INSTS_VALU"] > per[k][0]:          # the lockstep (largest) launch of each kernel
+                per[k] = (v["SQ_INSTS_VALU"], name)
+        if len(per) < 5:
+            return None
+        mbs = 32 * nmb                                                   # the profiled launches cover 32 pictures
+        total = sum(v[0] for v in per.values()) / mbs
+        return {"valu_per_macroblock": round(total, 1), "source": os.path.basename(files[-1]),
+                "bound_fps": round(1024 * 2.4e9 / 4 / (total * nmb), 1),
+                "note": "P-picture kernels (k_me, k_pmb2, k_bs, k_cavlc count + write, k_deblock_rows); 256 CUs x 4 SIMDs, one VALU instruction per wave per 4 cycles at 2.4 GHz"}
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -329,6 +358,10 @@ def main():
             res["roofline_isolated"] = {"kernel": "k_pmb2, one GOP in flight (no other kernels on the chip)",
                                         "achieved": round(a1, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                         "frac": round(a1 / HBM_PEAK_GBS, 4), "avg_launch_ms": round(ms1, 5)}
+        ib = valu_issue_bound(nmb)
+        if ib is not None and args.content == "s1" and args.slices < 2:
+            ib["achieved_frac"] = round(fps / world / ib["bound_fps"], 3)
+            res["valu_issue"] = ib
         if world == 1 and not args.no_cpu_baseline:
             cores = min(16, os.cpu_count() or 1)
             ref = openh264_differential(frames, args.cpu_frames * 4)
