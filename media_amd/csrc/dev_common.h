@@ -45,6 +45,14 @@ struct SliceRows {
     __device__ __forceinline__ bool has_top(int my) const { return row_in_slice(my) != 0; }
 };
 
+// macroblock index -> (mx, my) without a runtime division (a float reciprocal sequence of ~20 instructions, per lane in the
+// entropy kernels): q = mulhi(i, inv) with inv = floor(2^32 / mbw) + 1 is exact for i * mbw < 2^32 (i < 65 536, mbw <= 256);
+// mbw = 1 has no 32-bit inv and is flagged by inv = 0.
+struct MbDiv {
+    unsigned inv;
+    __device__ __forceinline__ int row(int i) const { return inv ? (int)__umulhi((unsigned)i, inv) : i; }
+};
+
 // Band of the picture this encoder instance works on (slice bands of one picture on several GPUs):
 // macroblock rows row0 .. row0 + rows - 1, always whole slices.  One instance alone: row0 = 0, rows = mbh.
 struct Band { int row0, rows; };
@@ -70,6 +78,7 @@ struct FrameParams {
     int st_mb;           // macroblocks per batch item (MbInfo / levels / mvd arrays)
     SliceRows sl;        // slices of the picture: bands of sl.rows macroblock rows (sl.rows = mbh: one slice)
     Band band;           // the rows this instance encodes; grids cover the band, coordinates stay those of the picture
+    MbDiv mbdiv;         // macroblock index / mbw
 };
 
 // the parameter block of batch item g (pointers advanced by g strides)

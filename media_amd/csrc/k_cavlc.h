@@ -269,6 +269,7 @@ struct CavlcParams {
     int mbw, nmb, p_slice;
     SliceRows sl;         // slices of the picture (bands of sl.rows macroblock rows)
     int mb_first, mb_end; // the macroblocks this instance codes (its band of whole slices; 0 .. nmb alone)
+    MbDiv mbdiv;          // macroblock index / mbw
     unsigned slice_cap;   // bytes of payload buffer per slice: slice s owns bytes [s * slice_cap, (s + 1) * slice_cap)
     uint16_t* slotbits;   // 32 per macroblock
     unsigned long long* slotcode;   // 32 per macroblock: the slot's bits, left aligned, when slotbits <= 64
@@ -312,7 +313,7 @@ __device__ __forceinline__ void code_slot(S& s, const CavlcParams& C, int mbi, i
 {
     const MbInfo* m = C.mb + mbi;
     if (m->type == MB_PSKIP) return;
-    const int mx = mbi % C.mbw, my = mbi / C.mbw;
+    const int my = C.mbdiv.row(mbi), mx = mbi - my * C.mbw;
     const int srow = C.sl.row_in_slice(my);
     const bool top = srow != 0;
     const int16_t* lv = C.levels + (size_t)mbi * LV_STRIDE;
@@ -364,7 +365,8 @@ __global__ __launch_bounds__(64) void k_bs(CavlcParams C0, unsigned* anybs, unsi
     const int mbi = C.mb_first + blockIdx.x * 2 + (lane >> 5);
     int bs = 0;
     if (mbi < C.mb_end) {
-        bs = mb_edge_strength(C.mb + mbi, mbi % C.mbw, C.sl.has_top(mbi / C.mbw), C.mbw, slot);
+        const int my = C.mbdiv.row(mbi);
+        bs = mb_edge_strength(C.mb + mbi, mbi - my * C.mbw, C.sl.has_top(my), C.mbw, slot);
         C.bs[(size_t)mbi * 32 + slot] = (uint8_t)bs;
     }
     if (__ballot(bs != 0) != 0ull && lane == 0) anybs[blockIdx.y] = serial;   // same value from every writer: a plain store
@@ -426,7 +428,7 @@ __global__ __launch_bounds__(64) void k_cavlc(CavlcParams C0)
         // A slice that outgrows its share of the payload buffer (twice its luma bytes: only noise at the lowest QPs
         // codes to that) is reported by k_bit_scan and refused by the host; nothing may be written past the share.
         const unsigned pos = live ? C.mbbits[mbi] + incl - n : 0u;
-        const unsigned lim = (__umulhi((unsigned)(mbi / C.mbw), C.sl.inv) + 1u) * C.slice_cap * 8u - 1024u;
+        const unsigned lim = (__umulhi((unsigned)C.mbdiv.row(mbi), C.sl.inv) + 1u) * C.slice_cap * 8u - 1024u;
         if (live && n && pos + n <= lim) {
             if (n <= 64u) {   // coded by the count pass: OR the stored word in at its final bit position
                 const unsigned long long code = C.slotcode[(size_t)mbi * 32 + slot];

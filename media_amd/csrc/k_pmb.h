@@ -58,7 +58,7 @@ __global__ __launch_bounds__(64) void k_pmb(FrameParams P0)
 {
     const FrameParams P = batch_view(P0, blockIdx.y);
     const int lane = threadIdx.x;
-    const int mbi = P.band.row0 * P.mbw + xcd_mb_index(blockIdx.x, P.mbw * P.band.rows), mx = mbi % P.mbw, my = mbi / P.mbw;
+    const int mbi = P.band.row0 * P.mbw + xcd_mb_index(blockIdx.x, P.mbw * P.band.rows), my = P.mbdiv.row(mbi), mx = mbi - my * P.mbw;
     const int bx = 16 * mx, by = 16 * my, cs = P.cw / 2;
 
     __shared__ __attribute__((aligned(16))) uint8_t s_src[256];

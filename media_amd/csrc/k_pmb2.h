@@ -190,7 +190,7 @@ __global__ __launch_bounds__(64) void k_pmb2(FrameParams P0)
 #pragma unroll
     for (int h = 0; h < 2; h++) {
         mbi[h] = mb0 + 2 * q + ((h && two) ? 1 : 0);
-        mx[h] = mbi[h] % P.mbw; my[h] = mbi[h] / P.mbw;
+        my[h] = P.mbdiv.row(mbi[h]); mx[h] = mbi[h] - my[h] * P.mbw;
         m[h] = P.mb + mbi[h];
         const int mvw = __builtin_amdgcn_readfirstlane(*(const int*)m[h]);   // mvx | mvy << 16
         mvx[h] = (int)(int16_t)(mvw & 0xFFFF); mvy[h] = mvw >> 16;

@@ -302,6 +302,7 @@ int submit(mi355x_h264_encoder* e, const uint8_t* d_src, size_t src_item_stride,
     P.mb = e->d_mb; P.levels = e->d_levels; P.mvd = e->d_mvd; P.me_cost = e->d_me_cost;
     P.st_src = src_item_stride; P.st_y = e->st_y; P.st_c = e->st_c; P.st_mb = e->nmb; P.sl = e->sl;
     P.band.row0 = e->b_row0; P.band.rows = e->b_rows;
+    P.mbdiv.inv = e->mbw > 1 ? (unsigned)(0x100000000ull / (unsigned)e->mbw) + 1u : 0u;
     const unsigned G = (unsigned)e->G;
     fill_quant(P.qy, e->qp);
     fill_quant(P.qc, h_chroma_qp[e->qp]);
@@ -349,6 +350,7 @@ int submit(mi355x_h264_encoder* e, const uint8_t* d_src, size_t src_item_stride,
     C.mb = e->d_mb; C.levels = e->d_levels; C.mvd = e->d_mvd; C.mbw = e->mbw; C.nmb = e->nmb; C.p_slice = idr ? 0 : 1; C.sl = e->sl;
     C.mb_first = e->b_row0 * e->mbw; C.mb_end = C.mb_first + e->b_nmb;
     C.slice_cap = (unsigned)e->slice_cap;
+    C.mbdiv = P.mbdiv;
     C.slotbits = e->d_slotbits; C.slotcode = e->d_slotcode; C.mbbits = e->d_mbbits; C.bitbuf = S.d_bitbuf;
     C.bs = (uint8_t*)e->d_bs; C.prevcoded = e->d_prevcoded;
     C.st_mb = e->nmb; C.st_bitbuf = e->st_bitbuf_bytes / 4;
