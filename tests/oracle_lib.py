@@ -74,6 +74,15 @@ def lib():
         L.h264o_dec_plane.argtypes = [vp, C.c_int]
         L.h264o_dec_error.restype = C.c_char_p
         L.h264o_dec_error.argtypes = [vp]
+        for n in ("h264o_dec_max_mb_bits", "h264o_dec_max_level_prefix"):
+            getattr(L, n).argtypes = [vp]
+        L.h264o_dec_mb_kind.argtypes = [vp, C.c_int]
+        L.h264o_dec_mb_mv.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        ip, up = C.POINTER(C.c_int), C.POINTER(C.c_uint)
+        L.h264o_dec_table_coeff_token.argtypes = [C.c_int, C.c_int, C.c_int, ip, up]
+        L.h264o_dec_table_total_zeros.argtypes = [C.c_int, C.c_int, C.c_int, ip, up]
+        L.h264o_dec_table_run_before.argtypes = [C.c_int, C.c_int, ip, up]
+        L.h264o_dec_table_misc.argtypes = [C.c_int, C.c_int, C.c_int]
         L.h264o_fdct4x4.argtypes = [vp, vp]
         L.h264o_idct4x4_add.argtypes = [vp, vp, C.c_int]
         L.h264o_quant4x4.argtypes = [vp, C.c_int, C.c_int, vp]
@@ -195,6 +204,26 @@ class OracleDecoder:
     @property
     def size(self):
         return lib().h264o_dec_width(self.h), lib().h264o_dec_height(self.h)
+
+    # statistics of the last decoded picture
+    KIND_I4, KIND_I16, KIND_IPCM, KIND_INTER, KIND_SKIP = 1, 2, 3, 4, 5
+
+    def mb_kinds(self):
+        n = (lib().h264o_dec_coded_width(self.h) // 16) * (lib().h264o_dec_coded_height(self.h) // 16)
+        return np.array([lib().h264o_dec_mb_kind(self.h, i) for i in range(n)], dtype=np.int32)
+
+    def mb_mv(self, addr, blk4=0):
+        x, y, r = C.c_int(0), C.c_int(0), C.c_int(0)
+        lib().h264o_dec_mb_mv(self.h, addr, blk4, C.byref(x), C.byref(y), C.byref(r))
+        return x.value, y.value, r.value
+
+    @property
+    def max_mb_bits(self):
+        return lib().h264o_dec_max_mb_bits(self.h)
+
+    @property
+    def max_level_prefix(self):
+        return lib().h264o_dec_max_level_prefix(self.h)
 
     def close(self):
         if self.h:
