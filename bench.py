@@ -334,7 +334,7 @@ def main():
                        "content": args.content, "width": WIDTH, "height": HEIGHT, "qp": QP, "gop": GOP, "frames_per_step": FRAMES_PER_STEP * G, "gops_in_flight": G, "instances": I, "lockstep_batch": B,
                        "streams": world, "bytes_per_gop": int(nbytes), "selfcheck_batch_equals_single": selfcheck, "parity": "bit-exact vs CPU oracle "
                        "(oracle unpinned vs OpenH264: no libopenh264 available)"},
-            "roofline": {"kernel": "k_pmb2 (MC + fDCT + quant + dequant + iDCT + recon)", "bound": "hbm",
+            "roofline": {"kernel": "k_tq (residual + fDCT + quant + dequant + iDCT + recon, 8 macroblocks per wave)", "bound": "hbm",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "bytes_per_launch": PMB_BYTES_PER_MB * nmb * B, "macroblocks_per_launch": nmb * B,
@@ -346,7 +346,7 @@ def main():
             pe = st_ex["kernels"]["pmb"]
             ms_e = pe["ms"] / max(1, pe["launches"])
             a_e = PMB_BYTES_PER_MB * nmb * B / (ms_e * 1e-3) / 1e9
-            res["roofline_exclusive"] = {"kernel": "k_pmb2, same launches with one instance running alone (no other stream's kernels "
+            res["roofline_exclusive"] = {"kernel": "k_tq, same launches with one instance running alone (no other stream's kernels "
                                                    "sharing the CUs during the launch)", "achieved": round(a_e, 1), "peak": HBM_PEAK_GBS,
                                          "unit": "GB/s", "frac": round(a_e / HBM_PEAK_GBS, 4), "avg_launch_ms": round(ms_e, 5)}
             res["kernels_exclusive"] = {name: {"ms_per_launch": round(v["ms"] / v["launches"], 4)}
@@ -355,7 +355,7 @@ def main():
         if p1["launches"]:
             ms1 = p1["ms"] / p1["launches"]
             a1 = PMB_BYTES_PER_MB * nmb / (ms1 * 1e-3) / 1e9
-            res["roofline_isolated"] = {"kernel": "k_pmb2, one GOP in flight (no other kernels on the chip)",
+            res["roofline_isolated"] = {"kernel": "k_tq, one GOP in flight (no other kernels on the chip)",
                                         "achieved": round(a1, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                         "frac": round(a1 / HBM_PEAK_GBS, 4), "avg_launch_ms": round(ms1, 5)}
         ib = valu_issue_bound(nmb)

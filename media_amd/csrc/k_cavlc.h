@@ -289,6 +289,10 @@ __device__ __forceinline__ CavlcParams batch_view(CavlcParams C, int g)
     return C;
 }
 enum { MAX_BATCH = 64 };
+// One limit for both halves of the overflow guard: a slice is accepted by k_bit_scan only when header + data +
+// tail end at least SLICE_GUARD_BITS before the end of its share of the payload buffer, and k_cavlc<true> drops a slot
+// only when it would end past that same line - so an accepted slice never has a slot missing.
+enum { SLICE_GUARD_BITS = 1024, SLICE_TAIL_BITS = 64 };   // tail: the final mb_skip_run (<= 33 bits) + rbsp_stop_one_bit
 struct HdrBatch { unsigned long long bits[MAX_BATCH]; unsigned char len[MAX_BATCH]; };  // slice header of every batch item, from slice_type on
 
 // 8.7.2.1 boundary strength of one 4-sample edge segment; l = (dir, edge, segment) within the macroblock.
@@ -428,7 +432,7 @@ __global__ __launch_bounds__(64) void k_cavlc(CavlcParams C0)
         // A slice that outgrows its share of the payload buffer (twice its luma bytes: only noise at the lowest QPs
         // codes to that) is reported by k_bit_scan and refused by the host; nothing may be written past the share.
         const unsigned pos = live ? C.mbbits[mbi] + incl - n : 0u;
-        const unsigned lim = (__umulhi((unsigned)C.mbdiv.row(mbi), C.sl.inv) + 1u) * C.slice_cap * 8u - 1024u;
+        const unsigned lim = (__umulhi((unsigned)C.mbdiv.row(mbi), C.sl.inv) + 1u) * C.slice_cap * 8u - (unsigned)SLICE_GUARD_BITS;
         if (live && n && pos + n <= lim) {
             if (n <= 64u) {   // coded by the count pass: OR the stored word in at its final bit position
                 const unsigned long long code = C.slotcode[(size_t)mbi * 32 + slot];
@@ -516,7 +520,7 @@ __global__ __launch_bounds__(SCAN_NT) void k_bit_scan(CavlcParams C0, HdrBatch H
         else s.put(hdr_rest, (unsigned)hdr_bits);
         s.flush();
         unsigned total = hdr_len + s_part[SCAN_NT - 1];
-        const bool fits = (total >> 3) + 64u <= slice_cap;
+        const bool fits = total + (unsigned)SLICE_TAIL_BITS + (unsigned)SLICE_GUARD_BITS <= slice_cap * 8u;
         s.init(base + (fits ? total : hdr_len));
         BitCount c;
         c.init(0);

@@ -10,7 +10,7 @@
 // /root/reference/video_codec/VideoEncoderOpenH264.cpp:344).
 #pragma once
 #include "dev_common.h"
-#include "k_pmb.h"
+#include "mc_filters.h"
 
 namespace h264 {
 

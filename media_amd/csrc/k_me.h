@@ -12,11 +12,13 @@
 //      macroblock sits in SGPRs
 //   3. half- then quarter-pel refinement on SATD over half-sample planes built
 //      once in LDS (18x18 grid of G/b/h/j, 8.4.2.2.1)
+//   4. the winning prediction (luma from those planes, chroma by 8.4.2.2.2) is written into the
+//      reconstruction planes; k_tq.h codes the residual against it in place
 // Decisions use only the previous picture and this macroblock's source, so the
 // kernel is one launch over all macroblocks.
 #pragma once
 #include "dev_common.h"
-#include "k_pmb2.h"   // lds_ld4 / avg4 and the packed half-sample filter helpers
+#include "mc_filters.h"   // lds_ld4 / avg4 and the packed half-sample filter helpers
 
 namespace h264 {
 
@@ -48,6 +50,38 @@ __device__ __forceinline__ void qpel_taps(int fx, int fy, int& o0, int& o1)
     }
 }
 
+
+// four chroma prediction samples (8.4.2.2.2) of plane cp (pitch cs2, chh rows): integer position (x0, y0), eighth-sample
+// fraction (fx, fy); samples clamped at the picture edge exactly as motion compensation does.  Inside the picture the two
+// rows are read as aligned dwords and realigned (v_alignbyte), at the edge sample by sample.
+__device__ __forceinline__ uint32_t chroma_pred4(const uint8_t* cp, int cs2, int chh, int x0, int y0, int fx, int fy)
+{
+    const uint8_t* r0 = cp + (size_t)clip3(0, chh - 1, y0) * cs2;
+    const uint8_t* r1 = cp + (size_t)clip3(0, chh - 1, y0 + 1) * cs2;
+    uint32_t A, B, C, D;
+    if (x0 >= 0 && (x0 & ~3) + 8 <= cs2) {
+        const int xa = x0 & ~3, sh = x0 & 3;
+        const uint32_t a0 = *(const uint32_t*)(r0 + xa), a1 = *(const uint32_t*)(r0 + xa + 4);
+        const uint32_t c0 = *(const uint32_t*)(r1 + xa), c1 = *(const uint32_t*)(r1 + xa + 4);
+        A = __builtin_amdgcn_alignbyte(a1, a0, sh); B = sh == 3 ? a1 : __builtin_amdgcn_alignbyte(a1, a0, sh + 1);
+        C = __builtin_amdgcn_alignbyte(c1, c0, sh); D = sh == 3 ? c1 : __builtin_amdgcn_alignbyte(c1, c0, sh + 1);
+    } else {
+        A = B = C = D = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int xa = clip3(0, cs2 - 1, x0 + k), xb = clip3(0, cs2 - 1, x0 + k + 1);
+            A |= (uint32_t)r0[xa] << (8 * k); B |= (uint32_t)r0[xb] << (8 * k);
+            C |= (uint32_t)r1[xa] << (8 * k); D |= (uint32_t)r1[xb] << (8 * k);
+        }
+    }
+    if ((fx | fy) == 0) return A;
+    const int w00 = (8 - fx) * (8 - fy), w10 = fx * (8 - fy), w01 = (8 - fx) * fy, w11 = fx * fy;
+    uint32_t o = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        o |= (uint32_t)((w00 * byte_of(A, k) + w10 * byte_of(B, k) + w01 * byte_of(C, k) + w11 * byte_of(D, k) + 32) >> 6) << (8 * k);
+    return o;
+}
 
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_me(FrameParams P0)
 {
@@ -197,18 +231,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
             const int s = row_sum16_dpp((int)__builtin_amdgcn_sad_u8(sy, ry, 0u));
             return (unsigned)(__builtin_amdgcn_readlane(s, 0) + __builtin_amdgcn_readlane(s, 16) + __builtin_amdgcn_readlane(s, 32) + __builtin_amdgcn_readlane(s, 48));
         };
-        auto settle = [&](int vx, int vy) {   // the vector is final and k_pmb2 need not transform this macroblock
+        // the vector is final and nothing is left to code: the prediction IS the reconstruction.  Every lane stores its
+        // four luma (lanes < 32: and chroma) samples; lane 0 writes the whole side info (k_tq skips this macroblock)
+        auto settle = [&](int vx, int vy, uint32_t ry, uint32_t rc) {
+            *(uint32_t*)(P.rec[0] + (size_t)(by + (b4 >> 2) * 4 + r) * P.cw + bx + (b4 & 3) * 4) = ry;
+            if (lane < 32) *(uint32_t*)((cplz ? P.rec[2] : P.rec[1]) + (size_t)(8 * my + cyz) * (P.cw / 2) + 8 * mx + cxz) = rc;
             if (lane == 0) {
-                MbInfo* m = P.mb + mbi;
-                m->mvx = (int16_t)vx; m->mvy = (int16_t)vy; m->type = MB_P16;
-                m->i16_mode = 1;   // for k_pmb2: prediction = reconstruction (it resets the field)
+                uint4* m = (uint4*)(P.mb + mbi);
+                m[0] = make_uint4(((uint32_t)vx & 0xFFFFu) | ((uint32_t)vy << 16), (uint32_t)MB_P16 | (1u << 8), 0u, 0u);   // i16_mode = 1: mark for k_tq / k_mvpred
+                m[1] = make_uint4(0u, 0u, 0u, 0u);
                 P.me_cost[mbi] = 0;
             }
         };
         {   // the zero vector: co-located samples
             const uint32_t ry = s_win[(ME_R + ME_AP + (b4 >> 2) * 4 + r) * ME_WDW + (ME_R + ME_AP) / 4 + (b4 & 3)];
             const uint32_t rc = lane < 32 ? *(const uint32_t*)(s_refc + cplz * 64 + cyz * 8 + cxz) : 0u;
-            if (luma_sad(ry) < (unsigned)P.sad_nz && quantises_to_nothing(ry, rc)) { settle(0, 0); return; }
+            if (luma_sad(ry) < (unsigned)P.sad_nz && quantises_to_nothing(ry, rc)) { settle(0, 0, ry, rc); return; }
         }
         const int rvx = ((pmx + 2) >> 2) * 4, rvy = ((pmy + 2) >> 2) * 4;   // the previous vector rounded to integer samples
         if ((rvx | rvy) != 0) {   // wave-uniform
@@ -216,24 +254,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
             // samples clamped at the picture edge exactly as motion compensation does
             const uint32_t ry = lds_ld4(winb, (ME_R + ME_AP + (b4 >> 2) * 4 + r + (rvy >> 2)) * ME_WS + ME_R + ME_AP + (b4 & 3) * 4 + (rvx >> 2));
             uint32_t rc = 0;
-            if (lane < 32) {
-                const uint8_t* cp = cplz ? P.ref[2] : P.ref[1];
-                const int cs2 = P.cw / 2, chh = P.ch / 2;
-                const int x0c = 8 * mx + cxz + (rvx >> 3), y0c = 8 * my + cyz + (rvy >> 3), fxc = rvx & 7, fyc = rvy & 7;
-                const uint8_t* r0 = cp + (size_t)clip3(0, chh - 1, y0c) * cs2;
-                const uint8_t* r1 = cp + (size_t)clip3(0, chh - 1, y0c + 1) * cs2;
-                const int w00 = (8 - fxc) * (8 - fyc), w10 = fxc * (8 - fyc), w01 = (8 - fxc) * fyc, w11 = fxc * fyc;
-                int xx = clip3(0, cs2 - 1, x0c);
-                int pa = r0[xx], pb = r1[xx];
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    xx = clip3(0, cs2 - 1, x0c + k + 1);
-                    const int na = r0[xx], nb = r1[xx];
-                    rc |= (uint32_t)((w00 * pa + w10 * na + w01 * pb + w11 * nb + 32) >> 6) << (8 * k);
-                    pa = na; pb = nb;
-                }
-            }
-            if (luma_sad(ry) < (unsigned)P.sad_nz && quantises_to_nothing(ry, rc)) { settle(rvx, rvy); return; }
+            if (lane < 32) rc = chroma_pred4(cplz ? P.ref[2] : P.ref[1], P.cw / 2, P.ch / 2, 8 * mx + cxz + (rvx >> 3), 8 * my + cyz + (rvy >> 3), rvx & 7, rvy & 7);
+            if (luma_sad(ry) < (unsigned)P.sad_nz && quantises_to_nothing(ry, rc)) { settle(rvx, rvy, ry, rc); return; }
         }
     }
 
@@ -521,10 +543,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
         }
         bestk = best_cost << 4;                          // the next pass starts from "stay" (order 0)
     }
+    // ---- 5. the winning prediction goes to the reconstruction planes (k_tq turns it into the reconstruction in place):
+    // luma from the half-sample planes still in LDS, lane = (row, 4-sample segment); chroma by 8.4.2.2.2 ----
+    {
+        const int ox = cx - 4 * ix, oy = cy - 4 * iy;
+        int t0, t1;
+        qpel_taps(ox & 3, oy & 3, t0, t1);
+        const int y = lane >> 2, seg = (lane & 3) * 4;
+        const int gb = (1 + (oy >> 2) + y) * ME_GP + 1 + (ox >> 2) + seg;
+        *(uint32_t*)(P.rec[0] + (size_t)(by + y) * P.cw + bx + seg) = avg4(lds_ld4(s_pl, t0 + gb), lds_ld4(s_pl, t1 + gb));
+        if (lane < 32) {
+            const int pl = lane >> 4, cyy = (lane >> 1) & 7, cxx = (lane & 1) * 4;
+            *(uint32_t*)((pl ? P.rec[2] : P.rec[1]) + (size_t)(8 * my + cyy) * (P.cw / 2) + 8 * mx + cxx) =
+                chroma_pred4(pl ? P.ref[2] : P.ref[1], P.cw / 2, P.ch / 2, 8 * mx + cxx + (cx >> 3), 8 * my + cyy + (cy >> 3), cx & 7, cy & 7);
+        }
+    }
     if (lane == 0) {
-        MbInfo* m = P.mb + mbi;
-        m->mvx = (int16_t)cx; m->mvy = (int16_t)cy; m->type = MB_P16;
-        m->i16_mode = 0;
+        uint4* m = (uint4*)(P.mb + mbi);
+        m[0] = make_uint4(((uint32_t)cx & 0xFFFFu) | ((uint32_t)cy << 16), (uint32_t)MB_P16, 0u, 0u);
+        m[1] = make_uint4(0u, 0u, 0u, 0u);
         P.me_cost[mbi] = (uint16_t)(best_cost < 16383u ? best_cost : 16383u);   // scene-change statistic, summed by k_bit_scan
     }
 }

@@ -22,8 +22,7 @@
 #include "k_deblock.h"
 #include "k_intra.h"
 #include "k_me.h"
-#include "k_pmb.h"
-#include "k_pmb2.h"
+#include "k_tq.h"
 
 using namespace h264;
 
@@ -172,7 +171,6 @@ struct mi355x_h264_encoder {
     std::vector<uint32_t> last_me_cost;      // of the last finished picture, per batch item
     unsigned serial = 0;
     bool diag_mode = false;                  // debug: one launch per wavefront step instead
-    bool pmb_v1 = false;                     // debug: first form of the MC+DCT kernel (k_pmb.h)
     uint8_t* d_stage = nullptr;              // device copy of a host-supplied picture
     uint8_t* h_stage = nullptr;              // pinned staging for strided host input
     size_t frame_bytes = 0, bitbuf_cap = 0, au_cap = 0;
@@ -333,8 +331,7 @@ int submit(mi355x_h264_encoder* e, const uint8_t* d_src, size_t src_item_stride,
         { StatScope sc(e, &S, MI355X_H264_K_ME, 1, (uint32_t)(e->b_nmb * e->G));
           hipLaunchKernelGGL(k_me, dim3(e->b_nmb, G), dim3(64), 0, st, P); }
         { StatScope sc(e, &S, MI355X_H264_K_PMB, 1, (uint32_t)(e->b_nmb * e->G));
-          if (e->pmb_v1) hipLaunchKernelGGL(k_pmb, dim3(e->b_nmb, G), dim3(64), 0, st, P);
-          else hipLaunchKernelGGL(k_pmb2, dim3((e->b_nmb + 1) / 2, G), dim3(64), 0, st, P); }   // one wave per macroblock pair
+          hipLaunchKernelGGL(k_tq, dim3((e->b_nmb + 7) / 8, G), dim3(64), 0, st, P); }   // one wave per eight macroblocks
     }
     // entropy coding
     HdrBatch H{};
@@ -366,7 +363,10 @@ int submit(mi355x_h264_encoder* e, const uint8_t* d_src, size_t src_item_stride,
     {
         StatScope sc(e, &S, MI355X_H264_K_CAVLC, 4, (uint32_t)(e->b_nmb * e->G), ec);
         const int grid = cavlc_grid;
-        if (!idr) hipLaunchKernelGGL(k_skip_scan, dim3(G), dim3(256), 0, ec, C);
+        if (!idr) {
+            hipLaunchKernelGGL(k_mvpred, dim3((e->b_nmb + 63) / 64, G), dim3(64), 0, ec, P);   // vectors + coded_block_pattern are final: mvd, P_Skip
+            hipLaunchKernelGGL(k_skip_scan, dim3(G), dim3(256), 0, ec, C);
+        }
         hipLaunchKernelGGL(k_cavlc<false>, dim3(grid, G), dim3(64), 0, ec, C);
         hipLaunchKernelGGL(k_bit_scan, dim3(G * (unsigned)e->b_nsl), dim3(SCAN_NT), 0, ec, C, H, S.d_info, e->d_me_cost, e->b_nsl, e->b_sl0, (unsigned)e->slice_cap);
         hipLaunchKernelGGL(k_cavlc<true>, dim3(grid, G), dim3(64), 0, ec, C);
@@ -439,7 +439,13 @@ int wait_slot(mi355x_h264_encoder* e, int slot_idx)
     }
     S.evs.clear();
     e->stats.frames += (uint64_t)e->G;
-    if (*S.h_err) return fail(e, MI355X_H264_E_INTERNAL, "wavefront kernel hand-off timed out (flag %u)", *S.h_err);
+    if (*S.h_err) {
+        // the picture's reconstruction is not to be trusted: it must not become a reference, and the flag is per report
+        const unsigned flag = *S.h_err;
+        *S.h_err = 0;
+        e->force_idr = 1;
+        return fail(e, MI355X_H264_E_INTERNAL, "wavefront kernel hand-off timed out (flag %u)", flag);
+    }
     return MI355X_H264_OK;
 }
 
@@ -486,7 +492,6 @@ int finish_item(mi355x_h264_encoder* e, int slot_idx, int g, uint8_t** out, uint
         e->force_idr = 1;   // the refused picture is missing from the stream: the next one must not refer to it
         return fail(e, info.error == 1 ? MI355X_H264_E_OVERFLOW : MI355X_H264_E_INTERNAL, "device reported error %u", info.error);
     }
-    if ((size_t)info.total_bytes + 64 > e->bitbuf_cap) return fail(e, MI355X_H264_E_OVERFLOW, "slice of %u bytes exceeds buffer", info.total_bytes);
     uint8_t* au = base + S.au_start;
     size_t pos = 0;
     if (S.idr) { memcpy(au, e->sps_pps.data(), e->sps_pps.size()); pos = e->sps_pps.size(); }
@@ -615,7 +620,6 @@ int mi355x_h264_create(const mi355x_h264_config* cfg, mi355x_h264_encoder** out)
     CK(hipMemset(e->d_me_cost, 0, Gn * e->nmb * sizeof(uint16_t)));
     e->last_me_cost.assign(Gn, 0);
     e->diag_mode = getenv("MI355X_H264_DIAG") != nullptr && e->G == 1 && e->b_nsl == e->nsl;
-    e->pmb_v1 = getenv("MI355X_H264_PMB_V1") != nullptr;
     e->frame_bytes = (size_t)cfg->width * cfg->height * 3 / 2;
     CK(hipMalloc((void**)&e->d_stage, e->frame_bytes + 256));
     CK(hipHostMalloc((void**)&e->h_stage, e->frame_bytes + 256, hipHostMallocDefault));

@@ -20,7 +20,19 @@ def _compare_all(enc, orc, tag):
     mb, omb = enc.debug_read(capi.DBG_MBINFO), orc.mbinfo()
     for f in ("mvx", "mvy", "type", "i16_mode", "chroma_mode", "cbp", "tc"):
         assert np.array_equal(mb[f], omb[f]), "%s: mbinfo.%s" % (tag, f)
-    assert np.array_equal(enc.debug_read(capi.DBG_LEVELS), orc.levels()), tag + ": levels"
+    # levels: every block the entropy coder reads (by macroblock type and coded_block_pattern, 7.3.5.3) must agree; what it
+    # never reads (blocks of an 8x8 quadrant / chroma parts whose coded_block_pattern bit is clear, skipped macroblocks) is
+    # unspecified: the GPU does not spend HBM writes on it
+    glv, olv = enc.debug_read(capi.DBG_LEVELS), orc.levels()
+    read = np.zeros(olv.shape, dtype=bool)
+    i16 = omb["type"] == 0
+    cbp = omb["cbp"].astype(np.int32)
+    read[i16, 0:16] = True
+    for q in range(4):
+        read[(cbp >> q) & 1 == 1, 16 + 64 * q: 16 + 64 * (q + 1)] = True
+    read[(cbp >> 4) >= 1, 272:280] = True
+    read[(cbp >> 4) == 2, 280:408] = True
+    assert np.array_equal(np.where(read, glv, 0), np.where(read, olv, 0)), tag + ": levels"
     for p in range(3):
         assert np.array_equal(enc.debug_read(capi.DBG_PRE_Y + p), orc.recon_pre(p)), "%s: pre-filter plane %d" % (tag, p)
         assert np.array_equal(enc.debug_read(capi.DBG_RECON_Y + p), orc.recon(p)), "%s: recon plane %d" % (tag, p)
@@ -123,10 +135,9 @@ def test_nv12_device_pictures_in_lockstep_batch():
 
 
 def test_reference_forms_of_the_kernels(monkeypatch):
-    """the simpler first forms (one launch per wavefront step, lane-per-block MC+DCT) stay selectable for
+    """the simpler first forms of the two row-wavefront kernels (one launch per wavefront step) stay selectable for
     debugging and must give the same stream"""
     monkeypatch.setenv("MI355X_H264_DIAG", "1")
-    monkeypatch.setenv("MI355X_H264_PMB_V1", "1")
     w, h = 208, 160
     enc = capi.Encoder(w, h, qp=27, gop=3)
     orc = OracleEncoder(w, h, qp=27, gop=3)

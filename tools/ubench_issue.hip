@@ -102,6 +102,100 @@ DEFK(max_i32, OP_MAXI)
 DEFK(cndmask_b32, OP_CNDMASK)
 DEFK(cvt_pk_u8_f32, OP_CVTPKU8)
 
+
+#define OP_SUBU(i) asm volatile("v_sub_u32 %0, %0, %1" : "+v"(x[i]) : "v"(s));
+#define OP_SUBREV(i) asm volatile("v_subrev_u32 %0, %0, %1" : "+v"(x[i]) : "v"(s));
+#define OP_AND(i) asm volatile("v_and_b32 %0, %0, %1" : "+v"(x[i]) : "v"(s));
+#define OP_OR(i) asm volatile("v_or_b32 %0, %0, %1" : "+v"(x[i]) : "v"(s));
+#define OP_LSHLC(i) asm volatile("v_lshlrev_b32 %0, 1, %0" : "+v"(x[i]));
+#define OP_LSHRC(i) asm volatile("v_lshrrev_b32 %0, 1, %0" : "+v"(x[i]));
+#define OP_ASHRC(i) asm volatile("v_ashrrev_i32 %0, 1, %0" : "+v"(x[i]));
+#define OP_ASHRV(i) asm volatile("v_ashrrev_i32 %0, %1, %0" : "+v"(x[i]) : "v"(s));
+#define OP_MULU24(i) asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(x[i]) : "v"(s));
+#define OP_MULI24(i) asm volatile("v_mul_i32_i24 %0, %0, %1" : "+v"(x[i]) : "v"(s));
+#define OP_MOV(i) asm volatile("v_mov_b32 %0, %1" : "+v"(x[i]) : "v"(s));
+#define OP_ADDINL(i) asm volatile("v_add_u32 %0, 32, %0" : "+v"(x[i]));
+#define OP_ADDLIT(i) asm volatile("v_add_u32 %0, 0x12345, %0" : "+v"(x[i]));
+#define OP_MINU(i) asm volatile("v_min_u32 %0, %0, %1" : "+v"(x[i]) : "v"(s));
+#define OP_MINI(i) asm volatile("v_min_i32 %0, %0, %1" : "+v"(x[i]) : "v"(s));
+#define OP_MULF(i) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(x[i]) : "v"(s));
+#define OP_MAXF(i) asm volatile("v_max_f32 %0, %0, %1" : "+v"(x[i]) : "v"(s));
+#define OP_FMAC(i) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(x[i]) : "v"(s), "v"(t));
+#define OP_CVTFI(i) asm volatile("v_cvt_f32_i32 %0, %0" : "+v"(x[i]));
+#define OP_CVTIF(i) asm volatile("v_cvt_i32_f32 %0, %0" : "+v"(x[i]));
+#define OP_CVTUB0(i) asm volatile("v_cvt_f32_ubyte0 %0, %0" : "+v"(x[i]));
+#define OP_CVTUB3(i) asm volatile("v_cvt_f32_ubyte3 %0, %0" : "+v"(x[i]));
+#define OP_FLOOR(i) asm volatile("v_floor_f32 %0, %0" : "+v"(x[i]));
+#define OP_ANDOR(i) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(x[i]) : "v"(s), "v"(t));
+#define OP_LSHLADD(i) asm volatile("v_lshl_add_u32 %0, %0, 1, %1" : "+v"(x[i]) : "v"(s));
+#define OP_SUBSDWA(i) asm volatile("v_sub_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:BYTE_1" : "+v"(x[i]) : "v"(s), "v"(t));
+#define OP_CMPADDC(i) asm volatile("v_cmp_ne_u32 vcc, %1, %0\n v_addc_co_u32 %0, vcc, 0, %0, vcc" : "+v"(x[i]) : "v"(s) : "vcc");
+#define OP_CMP(i) asm volatile("v_cmp_ne_u32 vcc, %1, %0" : : "v"(x[i]), "v"(s) : "vcc");
+#define OP_CNDS(i) asm volatile("v_cndmask_b32 %0, %0, %1, %2" : "+v"(x[i]) : "v"(s), "s"(m64));
+#define OP_BFI(i) asm volatile("v_bfi_b32 %0, %1, %0, %2" : "+v"(x[i]) : "v"(s), "v"(t));
+#define OP_MULHI24(i) asm volatile("v_mul_hi_u32_u24 %0, %0, %1" : "+v"(x[i]) : "v"(s));
+#define OP_PACK(i) asm volatile("v_pack_b32_f16 %0, %0, %1" : "+v"(x[i]) : "v"(s));
+#define OP_CVTPKI16(i) asm volatile("v_cvt_pk_i16_i32 %0, %0, %1" : "+v"(x[i]) : "v"(s));
+#define OP_MADI24(i) asm volatile("v_mad_i32_i24 %0, %0, %1, %2" : "+v"(x[i]) : "v"(s), "v"(t));
+#define OP_SUBB(i) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(x[i]) : "v"(s));
+#define OP_XNOR(i) asm volatile("v_xnor_b32 %0, %0, %1" : "+v"(x[i]) : "v"(s));
+#define OP_MAXU(i) asm volatile("v_max_u32 %0, %0, %1" : "+v"(x[i]) : "v"(s));
+#define OP_MAXI16(i) asm volatile("v_max_i16 %0, %0, %1" : "+v"(x[i]) : "v"(s));
+#define OP_ADDU16(i) asm volatile("v_add_u16 %0, %0, %1" : "+v"(x[i]) : "v"(s));
+
+DEFK(sub_u32, OP_SUBU)
+DEFK(subrev_u32, OP_SUBREV)
+DEFK(and_b32, OP_AND)
+DEFK(or_b32, OP_OR)
+DEFK(lshlrev_const, OP_LSHLC)
+DEFK(lshrrev_const, OP_LSHRC)
+DEFK(ashrrev_const, OP_ASHRC)
+DEFK(ashrrev_vgpr, OP_ASHRV)
+DEFK(mul_u32_u24, OP_MULU24)
+DEFK(mul_i32_i24, OP_MULI24)
+DEFK(mov_b32, OP_MOV)
+DEFK(add_u32_inline, OP_ADDINL)
+DEFK(add_u32_literal, OP_ADDLIT)
+DEFK(min_u32, OP_MINU)
+DEFK(min_i32, OP_MINI)
+DEFK(mul_f32, OP_MULF)
+DEFK(max_f32, OP_MAXF)
+DEFK(fmac_f32, OP_FMAC)
+DEFK(cvt_f32_i32, OP_CVTFI)
+DEFK(cvt_i32_f32, OP_CVTIF)
+DEFK(cvt_f32_ubyte0, OP_CVTUB0)
+DEFK(cvt_f32_ubyte3, OP_CVTUB3)
+DEFK(floor_f32, OP_FLOOR)
+DEFK(and_or_b32, OP_ANDOR)
+DEFK(lshl_add_u32, OP_LSHLADD)
+DEFK(sub_u32_sdwa_bytes, OP_SUBSDWA)
+DEFK(cmp_addc, OP_CMPADDC)
+DEFK(cmp_ne_u32, OP_CMP)
+DEFK(bfi_b32, OP_BFI)
+DEFK(mul_hi_u32_u24, OP_MULHI24)
+DEFK(pack_b32_f16, OP_PACK)
+DEFK(cvt_pk_i16_i32, OP_CVTPKI16)
+DEFK(mad_i32_i24, OP_MADI24)
+DEFK(sub_f32, OP_SUBB)
+DEFK(xnor_b32, OP_XNOR)
+DEFK(max_u32, OP_MAXU)
+DEFK(max_i16, OP_MAXI16)
+DEFK(add_u16, OP_ADDU16)
+
+__global__ __launch_bounds__(256) void k_cndmask_sgpr(unsigned* out, unsigned a, unsigned b, int iters)
+{
+    unsigned x[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) x[i] = threadIdx.x * a + i;
+    unsigned s = b, t = a ^ 0x01010101u;
+    unsigned long long m64 = __ballot((threadIdx.x * a) & 1);
+    for (int it = 0; it < iters; it++) { REP64(OP_CNDS) }
+    unsigned r = t;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r += x[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+}
+
 __global__ __launch_bounds__(256) void k_pk_fma_f32(unsigned* out, unsigned a, unsigned b, int iters)
 {
     typedef float f2 __attribute__((ext_vector_type(2)));
@@ -155,6 +249,16 @@ int main(int argc, char** argv)
         {"v_dot2_i32_i16", k_dot2_i32_i16}, {"v_dot4_u32_u8", k_dot4_u32_u8}, {"v_mov_b32_dpp quad_perm", k_mov_dpp_quad},
         {"v_add_u32_dpp quad_perm", k_add_u32_dpp_quad}, {"v_add_u32_sdwa", k_add_u32_sdwa}, {"v_sat_pk_u8_i16", k_sat_pk_u8_i16},
         {"v_med3_i32", k_med3_i32}, {"v_max_i32", k_max_i32}, {"v_cndmask_b32", k_cndmask_b32}, {"v_cvt_pk_u8_f32", k_cvt_pk_u8_f32},
+        {"v_sub_u32", k_sub_u32}, {"v_subrev_u32", k_subrev_u32}, {"v_and_b32", k_and_b32}, {"v_or_b32", k_or_b32}, {"v_xnor_b32", k_xnor_b32},
+        {"v_lshlrev_b32 (const)", k_lshlrev_const}, {"v_lshrrev_b32 (const)", k_lshrrev_const}, {"v_ashrrev_i32 (const)", k_ashrrev_const},
+        {"v_ashrrev_i32 (vgpr)", k_ashrrev_vgpr}, {"v_mul_u32_u24", k_mul_u32_u24}, {"v_mul_i32_i24", k_mul_i32_i24}, {"v_mul_hi_u32_u24", k_mul_hi_u32_u24},
+        {"v_mad_i32_i24", k_mad_i32_i24}, {"v_mov_b32", k_mov_b32}, {"v_add_u32 (inline const)", k_add_u32_inline}, {"v_add_u32 (literal)", k_add_u32_literal},
+        {"v_min_u32", k_min_u32}, {"v_max_u32", k_max_u32}, {"v_min_i32", k_min_i32}, {"v_max_i16", k_max_i16}, {"v_add_u16", k_add_u16},
+        {"v_mul_f32", k_mul_f32}, {"v_sub_f32", k_sub_f32}, {"v_max_f32", k_max_f32},
+        {"v_fmac_f32", k_fmac_f32}, {"v_cvt_f32_i32", k_cvt_f32_i32}, {"v_cvt_i32_f32", k_cvt_i32_f32}, {"v_cvt_f32_ubyte0", k_cvt_f32_ubyte0},
+        {"v_cvt_f32_ubyte3", k_cvt_f32_ubyte3}, {"v_floor_f32", k_floor_f32}, {"v_and_or_b32", k_and_or_b32}, {"v_lshl_add_u32", k_lshl_add_u32},
+        {"v_sub_u32_sdwa (byte,byte)", k_sub_u32_sdwa_bytes}, {"v_cmp_ne_u32 + v_addc_co_u32 (pair)", k_cmp_addc}, {"v_cmp_ne_u32", k_cmp_ne_u32},
+        {"v_cndmask_b32 (sgpr mask)", k_cndmask_sgpr}, {"v_bfi_b32", k_bfi_b32}, {"v_pack_b32_f16", k_pack_b32_f16}, {"v_cvt_pk_i16_i32", k_cvt_pk_i16_i32},
     };
     const int only_full = argc > 1 && !strcmp(argv[1], "--full-only");
     for (auto& k : ks) {
