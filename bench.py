@@ -15,8 +15,15 @@ scaling); torch.distributed is used only for the barrier and the max-over-ranks 
 G = 1 is measured too (single_gop_in_flight_fps), and the kernels of one instance running
 alone (roofline_exclusive / kernels_exclusive).
 
-Prints ONE JSON line (rank 0) carrying `roofline` for the MC+DCT kernel (k_pmb) and
-`cpu_baseline` (the CPU oracle timed on this box's host cores, rank 0, N=1 only).
+Prints ONE JSON line (rank 0) carrying `roofline` for the transform kernel (k_tq) and
+`cpu_baseline` (the CPU oracle timed on this box's host cores, rank 0, N=1 only), plus `plugin`:
+the same engine measured through the actual drop-in boundary in the reference's operating mode
+(CreateVideoEncoder -> EncodeOneFrame on HOST I420 pictures, bitrate rate control, one picture at a
+time per stream, S streams side by side; PCIe included) - never the headline, always beside it.
+
+`python bench.py --gpus N` without a launcher (no RANK in the environment) starts N child
+processes itself, one per GPU, BEFORE anything touches a GPU, and relays rank 0's line.
+`python bench.py --mode plugin --streams 1,4,16,64` prints only the plugin measurement.
 """
 import argparse
 import json
@@ -40,24 +47,29 @@ PMB_BYTES_PER_MB = 384 + 384 + 384 + 768 + 32
 HBM_PEAK_GBS = 8000.0
 
 
-def cpu_baseline(frames, cores, per_thread_frames):
-    """time the CPU oracle (kind 'port') on host cores: `cores` independent encoder
-    instances, each encoding the first `per_thread_frames` pictures of the workload"""
+def cpu_baseline(frames, cores, per_thread_frames, repeats=3):
+    """time the CPU oracle (kind 'port') on host cores: `cores` independent encoder instances (threads; the C code
+    runs outside the GIL), each encoding the first `per_thread_frames` pictures of the workload; median of `repeats`
+    runs.  Returns (aggregate fps, single-core fps, [fps of every run])."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle_lib import OracleEncoder
-    encs = [OracleEncoder(WIDTH, HEIGHT, qp=QP, gop=GOP) for _ in range(cores)]
+    runs = []
+    for _ in range(repeats):
+        encs = [OracleEncoder(WIDTH, HEIGHT, qp=QP, gop=GOP) for _ in range(cores)]
 
-    def work(e):
-        for i in range(per_thread_frames):
-            e.encode(frames[i % len(frames)])
+        def work(e):
+            for i in range(per_thread_frames):
+                e.encode(frames[i % len(frames)])
 
-    ths = [threading.Thread(target=work, args=(e,)) for e in encs]
-    t0 = time.perf_counter()
-    for t in ths:
-        t.start()
-    for t in ths:
-        t.join()
-    dt = time.perf_counter() - t0
+        ths = [threading.Thread(target=work, args=(e,)) for e in encs]
+        t0 = time.perf_counter()
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        runs.append(cores * per_thread_frames / (time.perf_counter() - t0))
+        for e in encs:
+            e.close()
     # single-core figure from one more instance
     e1 = OracleEncoder(WIDTH, HEIGHT, qp=QP, gop=GOP)
     t1 = time.perf_counter()
@@ -65,7 +77,68 @@ def cpu_baseline(frames, cores, per_thread_frames):
     for i in range(n1):
         e1.encode(frames[i])
     d1 = time.perf_counter() - t1
-    return cores * per_thread_frames / dt, n1 / d1
+    return sorted(runs)[len(runs) // 2], n1 / d1, runs
+
+
+def plugin_bench(streams, frames_per_stream, bitrate, device=0):
+    """The drop-in boundary in the reference's operating mode: S threads, each
+    CreateVideoEncoder (format 3 = MI355X) -> InitEncoder -> StartEncoder -> EncodeOneFrame x F on HOST I420 pictures
+    (tight layout, as the reference's InitSrcPic expects), bitrate rate control (no fixed-QP key), scene detection on,
+    one picture at a time per stream; H2D and D2H over PCIe are inside every call.  Returns one record per S."""
+    import numpy as np
+    from media_amd import synth
+    from media_amd import videocodec as vc
+    nsrc = 30
+    frames = [np.ascontiguousarray(f) for f in synth.sequence("s1", WIDTH, HEIGHT, nsrc)]
+    out = []
+    for S in streams:
+        vc.set_video_mode(WIDTH, HEIGHT, fps=30, bitrate=bitrate, gop=GOP, profile="baseline", fmt=3, qp=None)
+        vc.prop_set("persist.vmi.video.encode.device", device)
+        encs = []
+        for _ in range(S):
+            e = vc.VideoEncoder()
+            if e.rc_create != vc.SUCCESS or e.init() != vc.SUCCESS or e.start() != vc.SUCCESS:
+                raise SystemExit("plugin bench: encoder %d of %d could not be opened" % (len(encs), S))
+            encs.append(e)
+        lat = [[] for _ in range(S)]
+        nbytes = [0] * S
+        fail = [0] * S
+        psnr = []
+
+        def work(k):
+            e = encs[k]
+            for i in range(frames_per_stream):
+                f = frames[(i + 3 * k) % nsrc]
+                t0 = time.perf_counter()
+                rc, bs = e.encode(f)
+                lat[k].append(time.perf_counter() - t0)
+                if rc != vc.SUCCESS:
+                    fail[k] += 1
+                nbytes[k] += len(bs)
+                if k == 0 and i % 10 == 5:
+                    y = f[:WIDTH * HEIGHT].reshape(HEIGHT, WIDTH)
+                    psnr.append(synth.psnr(y, e.recon_y()[:HEIGHT, :WIDTH]))
+
+        for k in range(S):   # warm-up outside the clock: first IDR, allocations
+            encs[k].encode(frames[0])
+        ths = [threading.Thread(target=work, args=(k,)) for k in range(S)]
+        t0 = time.perf_counter()
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        dt = time.perf_counter() - t0
+        for e in encs:
+            e.stop(); e.destroy(); e.delete()
+        allat = np.sort(np.concatenate([np.asarray(x) for x in lat])) * 1e3
+        n = S * frames_per_stream
+        out.append({"streams": S, "fps_aggregate": round(n / dt, 1), "fps_per_stream": round(n / dt / S, 1),
+                    "latency_ms_p50": round(float(allat[len(allat) // 2]), 3), "latency_ms_p99": round(float(allat[min(len(allat) - 1, int(len(allat) * 0.99))]), 3),
+                    "bytes_per_picture": round(sum(nbytes) / n, 1), "bitrate_target": bitrate, "bitrate_achieved": round(sum(nbytes) * 8 * 30 / n),
+                    "psnr_y_db": round(float(np.mean(psnr)), 2) if psnr else None, "pictures": n, "encode_failures": sum(fail)})
+    return {"what": "VideoCodecApi plugin surface (CreateVideoEncoder / EncodeOneFrame), host I420 pictures over PCIe, bitrate mode, scene detection on, "
+                    "1080p30 S1, GOP 30, baseline; S encoder objects on S host threads of one process",
+            "results": out}
 
 
 def openh264_differential(frames, count):
@@ -143,7 +216,32 @@ def main():
                     help="synthetic input of SURVEY.md 8(d); s1 pan+noise is the headline workload")
     ap.add_argument("--slices", type=int, default=0,
                     help="slices per picture (bands of macroblock rows, SURVEY.md 8e-3); 0/1 = one slice, the reference preset and the headline")
+    ap.add_argument("--mode", default="gops", choices=["gops", "plugin"],
+                    help="gops: the headline (closed GOPs resident in HBM); plugin: only the measurement through the VideoEncoder plugin surface")
+    ap.add_argument("--streams", default="1,4,16", help="plugin measurement: numbers of concurrent streams (encoder objects), comma separated")
+    ap.add_argument("--plugin-frames", type=int, default=60, help="plugin measurement: pictures per stream")
+    ap.add_argument("--bitrate", type=int, default=5000000, help="plugin measurement: target bitrate (the reference accepts 1..10 Mbps)")
+    ap.add_argument("--no-plugin", action="store_true", help="leave the plugin measurement out of the default line")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # no launcher: start one child per GPU ourselves - before this process has touched a GPU (nothing below this
+        # block has run yet, torch is not even imported) - and relay rank 0's line.  Never a re-exec of a GPU process.
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        procs = []
+        for r in range(args.gpus):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                          stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+        line = procs[0].stdout.read().decode()
+        rcs = [p.wait() for p in procs]
+        sys.stdout.write(line)
+        sys.stdout.flush()
+        raise SystemExit(max(rcs))
 
     import numpy as np
     import torch
@@ -157,6 +255,14 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
+    plugin_streams = [int(x) for x in args.streams.split(",") if x.strip()]
+    if args.mode == "plugin":
+        res = plugin_bench(plugin_streams, args.plugin_frames, args.bitrate, local_rank)
+        best = max(res["results"], key=lambda r: r["fps_aggregate"])
+        print(json.dumps({"metric": "encoded fps @1080p I420 baseline-profile through the VideoEncoder plugin surface (host pictures, bitrate mode)",
+                          "value": best["fps_aggregate"], "unit": "frames/s", "n_gpus": 1, "higher_is_better": True, "dtype": "u8", "data": "synthetic",
+                          "config": {"workload": res["what"], "streams_at_value": best["streams"]}, "plugin": res}), flush=True)
+        return
     dist = None
     if world > 1 or os.environ.get("BENCH_FORCE_DIST"):   # the second form rehearses the N>1 path with one rank
         import torch.distributed as dist
@@ -362,18 +468,30 @@ def main():
         if ib is not None and args.content == "s1" and args.slices < 2:
             ib["achieved_frac"] = round(fps / world / ib["bound_fps"], 3)
             res["valu_issue"] = ib
+        if world == 1 and not args.no_plugin and args.content == "s1" and args.slices < 2 and args.input == "i420":
+            try:
+                res["plugin"] = plugin_bench(plugin_streams, args.plugin_frames, args.bitrate, local_rank)
+            except SystemExit as exc:   # never let the side measurement take the headline line down
+                res["plugin"] = {"error": str(exc)}
         if world == 1 and not args.no_cpu_baseline:
-            cores = min(16, os.cpu_count() or 1)
+            # N independent encoder instances on N host threads, N = what this process may run on
+            try:
+                avail = len(os.sched_getaffinity(0))
+            except AttributeError:
+                avail = os.cpu_count() or 1
+            cores = max(1, min(avail, os.cpu_count() or 1))
             ref = openh264_differential(frames, args.cpu_frames * 4)
             sys.stderr.write("oracle: %s\n" % ("absent (no libopenh264.so on this box; own CPU restatement timed instead)"
                                                if ref.get("oracle") != "openh264" else "openh264 found"))
-            agg, single = cpu_baseline(frames, cores, args.cpu_frames)
+            per = max(2, min(args.cpu_frames, 1 + (16 * args.cpu_frames) // cores))   # bound the sample: about the same total work at any core count
+            agg, single, runs = cpu_baseline(frames, cores, per)
             res["cpu_baseline"] = {"value": round(agg, 2), "unit": "frames/s", "cores": cores, "kind": "port",
-                                   "sample": "%d independent CPU-oracle encoder instances (one per core), each "
-                                             "encoding the first %d pictures (1 IDR + %d P) of the same 1080p "
-                                             "S1 workload" % (cores, args.cpu_frames, args.cpu_frames - 1),
+                                   "sample": "%d independent CPU-oracle encoder instances (one thread each; the box reports %d hardware "
+                                             "threads, %d usable by this process), each encoding the first %d pictures (1 IDR + %d P) of "
+                                             "the same 1080p S1 workload; median of %d runs" % (cores, os.cpu_count() or 0, avail, per, per - 1, len(runs)),
+                                   "runs_fps": [round(r, 2) for r in runs],
                                    "single_core_fps": round(single, 2),
-                                   "note": "own scalar CPU restatement (full-search algorithm), not OpenH264",
+                                   "note": "own scalar CPU restatement (exhaustive +-16 search algorithm), not OpenH264: a baseline, not a target",
                                    "openh264": ref}
             if ref.get("oracle") == "openh264" and ref.get("fps"):
                 # a real library on the box: the reference's own single-threaded configuration is the baseline

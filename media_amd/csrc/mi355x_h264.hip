@@ -704,13 +704,25 @@ int mi355x_h264_encode(mi355x_h264_encoder* e, const uint8_t* y, int ys, const u
     if (ys < w || us < w / 2 || vs < w / 2) return fail(e, MI355X_H264_E_ARG, "stride smaller than width");
     HIPCHK(e, hipSetDevice(e->device));
     // the previous picture's use of the staging buffers has completed (encode is synchronous)
-    uint8_t* d = e->h_stage;
-    for (int r = 0; r < h; r++) memcpy(d + (size_t)r * w, y + (size_t)r * ys, (size_t)w);
-    d += (size_t)w * h;
-    for (int r = 0; r < h / 2; r++) memcpy(d + (size_t)r * (w / 2), u + (size_t)r * us, (size_t)(w / 2));
-    d += (size_t)(w / 2) * (h / 2);
-    for (int r = 0; r < h / 2; r++) memcpy(d + (size_t)r * (w / 2), v + (size_t)r * vs, (size_t)(w / 2));
-    HIPCHK(e, hipMemcpyAsync(e->d_stage, e->h_stage, e->frame_bytes, hipMemcpyHostToDevice, e->stream));
+    const size_t ysz = (size_t)w * h;
+    if (ys == w && us == w / 2 && vs == w / 2 && u == y + ysz && v == u + ysz / 4) {
+        // the reference's own layout (InitSrcPic, ref :354-365: one tight I420 buffer): no per-row work.  The picture goes to
+        // pinned memory and on to the device in four pieces, the copy of piece k+1 overlapping the transfer of piece k
+        const size_t n = e->frame_bytes, piece = ((n / 4) + 255) & ~(size_t)255;
+        for (size_t o = 0; o < n; o += piece) {
+            const size_t len = std::min(piece, n - o);
+            memcpy(e->h_stage + o, y + o, len);
+            HIPCHK(e, hipMemcpyAsync(e->d_stage + o, e->h_stage + o, len, hipMemcpyHostToDevice, e->stream));
+        }
+    } else {
+        uint8_t* d = e->h_stage;
+        for (int r = 0; r < h; r++) memcpy(d + (size_t)r * w, y + (size_t)r * ys, (size_t)w);
+        d += ysz;
+        for (int r = 0; r < h / 2; r++) memcpy(d + (size_t)r * (w / 2), u + (size_t)r * us, (size_t)(w / 2));
+        d += ysz / 4;
+        for (int r = 0; r < h / 2; r++) memcpy(d + (size_t)r * (w / 2), v + (size_t)r * vs, (size_t)(w / 2));
+        HIPCHK(e, hipMemcpyAsync(e->d_stage, e->h_stage, e->frame_bytes, hipMemcpyHostToDevice, e->stream));
+    }
     return encode_one_device(e, e->d_stage, false, out, out_len, frame_type);
 }
 

@@ -24,6 +24,7 @@ public:
     // test hooks
     int32_t LastFrameQp() const { return m_lastQp; }
     uint32_t SceneCuts() const { return m_sceneCuts; }
+    mi355x_h264_encoder *Engine() const { return m_engine; }   // measurement hook (bench.py reads the reconstruction for PSNR)
 
 protected:
     const char *BackendName() const override { return "MI355X HIP"; }

@@ -29,6 +29,15 @@ uint32_t vc_scene_cuts(void *enc)
     auto *m = dynamic_cast<VideoEncoderMI355X *>(static_cast<VideoEncoder *>(enc));
     return m != nullptr ? m->SceneCuts() : 0;
 }
+// copies the luma reconstruction of the last picture (coded size) into dst; returns bytes or < 0 (measurement hook: PSNR)
+int64_t vc_debug_recon_y(void *enc, void *dst, uint64_t cap, int32_t *codedWidth, int32_t *codedHeight)
+{
+    auto *m = dynamic_cast<VideoEncoderMI355X *>(static_cast<VideoEncoder *>(enc));
+    if (m == nullptr || m->Engine() == nullptr) return -1;
+    if (codedWidth != nullptr) *codedWidth = mi355x_h264_coded_width(m->Engine());
+    if (codedHeight != nullptr) *codedHeight = mi355x_h264_coded_height(m->Engine());
+    return mi355x_h264_debug_read(m->Engine(), MI355X_H264_DBG_RECON_Y, dst, static_cast<size_t>(cap));
+}
 void vc_prop_set(const char *key, const char *value) { SetEncParam(key, value); }
 int32_t vc_prop_get_int(const char *key) { return GetIntEncParam(key); }
 int32_t vc_prop_get_str(const char *key, char *buf, int32_t cap)

@@ -80,8 +80,21 @@ def frame_ramp(width, height, index):
     return np.concatenate([y, np.full(width * height // 2, 128, np.uint8)])
 
 
+def frame_cut(width, height, index):
+    """S1 for two pictures, then a cut to different content (the same texture mirrored, inverted and offset) that keeps
+    panning: the P picture after the cut finds no match, so macroblocks go intra.  Not one of the SURVEY inputs."""
+    if index < 2:
+        return frame_s1(width, height, index)
+    f = frame_s1(width, height, index + 40)
+    ysz, csz = width * height, width * height // 4
+    y = 255 - f[:ysz].reshape(height, width)[::-1, ::-1]
+    u = f[ysz:ysz + csz].reshape(height // 2, width // 2)[::-1, ::-1]
+    v = 255 - f[ysz + csz:].reshape(height // 2, width // 2)[::-1, ::-1]
+    return np.concatenate([np.ascontiguousarray(y).ravel(), np.ascontiguousarray(u).ravel(), np.ascontiguousarray(v).ravel()])
+
+
 def sequence(kind, width, height, count, start=0):
-    fn = {"s1": frame_s1, "s2": frame_s2, "s3": frame_s3, "ramp": frame_ramp, "scroll": frame_scroll}[kind]
+    fn = {"s1": frame_s1, "s2": frame_s2, "s3": frame_s3, "ramp": frame_ramp, "scroll": frame_scroll, "cut": frame_cut}[kind]
     return [fn(width, height, start + i) for i in range(count)]
 
 

@@ -33,6 +33,8 @@ def lib():
         L.vc_last_qp.argtypes = [vp]
         L.vc_scene_cuts.argtypes = [vp]
         L.vc_scene_cuts.restype = C.c_uint32
+        L.vc_debug_recon_y.argtypes = [vp, vp, C.c_uint64, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        L.vc_debug_recon_y.restype = C.c_int64
         L.vc_prop_set.argtypes = [C.c_char_p, C.c_char_p]
         L.vc_prop_set.restype = None
         L.vc_prop_get_int.argtypes = [C.c_char_p]
@@ -102,6 +104,16 @@ class VideoEncoder:
 
     def scene_cuts(self):
         return lib().vc_scene_cuts(self.h)
+
+    def recon_y(self):
+        """luma reconstruction of the last picture, coded size (measurement hook)"""
+        import numpy as np
+        cw, ch = C.c_int32(0), C.c_int32(0)
+        buf = np.zeros(4096 * 4096, np.uint8)
+        n = lib().vc_debug_recon_y(self.h, buf.ctypes.data, buf.size, C.byref(cw), C.byref(ch))
+        if n < 0:
+            raise RuntimeError("recon read failed")
+        return buf[:n].reshape(ch.value, cw.value)
 
     def delete(self):
         rc = lib().vc_delete(self.h)

@@ -392,7 +392,7 @@ static void filter_line(uint8_t *pix, int xs, int bS, int alpha, int beta, int t
  * (8.7.2.1, frame pictures, single reference, one motion vector per MB) */
 static int edge_bs(const h264o_mbinfo *p, int bp, const h264o_mbinfo *q, int bq, int mb_edge)
 {
-    int pi = p->type == H264O_MB_I16, qi = q->type == H264O_MB_I16;
+    int pi = p->type == H264O_MB_I16 || p->type == H264O_MB_IPCM, qi = q->type == H264O_MB_I16 || q->type == H264O_MB_IPCM;
     if (pi || qi) return mb_edge ? 4 : 3;
     if (p->tc[bp] || q->tc[bq]) return 2;
     if (abs(p->mvx - q->mvx) >= 4 || abs(p->mvy - q->mvy) >= 4) return 1;

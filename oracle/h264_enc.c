@@ -13,6 +13,14 @@
  * on data that is final before the stage starts (so the GPU can run each stage
  * over all macroblocks at once):
  *   - I pictures: Intra16x16 (4 modes by SATD) + chroma (4 modes by SATD)
+ *   - any macroblock whose CAVLC size could exceed the 3200 bits of A.3.1 is coded as I_PCM.  "Could": decided from an
+ *     upper bound on the bits (mb_bits_bound below: sum over the blocks of simple statistics of the levels), not from the
+ *     bits themselves, so the decision is made when the macroblock is coded and nothing coded later depends on a later
+ *     stage.  A picture that holds an I_PCM macroblock is not loop-filtered (disable_deblocking_filter_idc 1).
+ *   - P pictures, macroblocks that went through the motion search and whose motion cost is INTRA_TEST_MIN or more: an
+ *     Intra16x16 cost is estimated from the SOURCE picture's neighbouring samples (vertical / horizontal / DC, SATD); if
+ *     it is lower, the macroblock is coded Intra16x16 after all inter macroblocks, in raster order, predicting from the
+ *     true reconstruction (constrained_intra_pred_flag = 0)
  *   - P pictures: per MB a zero-motion "all levels quantise to zero" test, then
  *     the same test at the macroblock's previous-picture vector rounded to
  *     integer samples, when non-zero (scrolling content), else full search dx,dy in [-16,15] on SAD + lambda*bits(mv - pmv), then half-
@@ -160,6 +168,8 @@ struct h264o_enc {
     size_t rbsp_cap;
     int64_t last_slice_bits;
     uint32_t me_cost; /* scene-change statistic of the last picture */
+    int any_pcm;      /* the picture being coded holds an I_PCM macroblock: it is not loop-filtered */
+    uint8_t *want_intra;   /* P pictures: macroblocks the motion search handed to the intra pass */
 };
 
 static int pick_level(int mbs, int fps)
@@ -210,6 +220,7 @@ h264o_enc *h264o_enc_create(const h264o_config *cfg)
     e->mb = (h264o_mbinfo *)calloc((size_t)e->mbw * e->mbh, sizeof(h264o_mbinfo));
     e->levels = (int16_t *)calloc((size_t)e->mbw * e->mbh * H264O_LV_STRIDE, sizeof(int16_t));
     e->slice_of = (int16_t *)calloc((size_t)e->mbw * e->mbh, sizeof(int16_t));
+    e->want_intra = (uint8_t *)calloc((size_t)e->mbw * e->mbh, 1);
     for (int i = 0; i < e->mbw * e->mbh; i++) e->slice_of[i] = (int16_t)(i / e->mbw / e->slice_rows);
     e->rbsp_cap = ysz * 4 + 65536;
     e->rbsp = (uint8_t *)malloc(e->rbsp_cap);
@@ -223,6 +234,7 @@ void h264o_enc_destroy(h264o_enc *e)
     free(e->mb);
     free(e->levels);
     free(e->slice_of);
+    free(e->want_intra);
     free(e->rbsp);
     free(e);
 }
@@ -358,8 +370,9 @@ static void write_slice_header(h264o_enc *e, bitw *b, int idr, int first_mb)
     }
     bw_se(b, e->cfg.qp - 26); /* slice_qp_delta */
     /* several slices: 2 = no filtering across slice edges, so that the bands stay independent of one another */
-    bw_ue(b, e->cfg.disable_deblock ? 1 : e->slice_rows < e->mbh ? 2 : 0);
-    if (!e->cfg.disable_deblock) {
+    const int no_filter = e->cfg.disable_deblock || e->any_pcm;
+    bw_ue(b, no_filter ? 1 : e->slice_rows < e->mbh ? 2 : 0);
+    if (!no_filter) {
         bw_se(b, 0); /* slice_alpha_c0_offset_div2 */
         bw_se(b, 0); /* slice_beta_offset_div2 */
     }
@@ -376,6 +389,46 @@ static size_t emit_nal(uint8_t *out, size_t cap, size_t pos, int ref_idc, int ty
 
 /* ------------------------------------------------------------ residual coding */
 static const uint8_t xy2blk[16] = {0, 1, 4, 5, 2, 3, 6, 7, 8, 9, 12, 13, 10, 11, 14, 15};
+
+/* ---- I_PCM fallback: an upper bound on the CAVLC bits of one residual block from simple statistics of its levels ----
+ *   coeff_token <= 16 bits; total_zeros + run_before <= min(2 tc + 22, 73 - 4 tc) (Tables 9-7..9-10: total_zeros <= 9 bits,
+ *   a run_before <= 3 bits below 7 zeros left and run - 3 above, at most min(tc - 1, 16 - tc) of them matter);
+ *   levels (9.2.2.1): a level of magnitude a coded at suffixLength s >= 1 costs ((2a - 1) >> s) + 1 + s bits, which is at
+ *   most max(a + 1, smax + 2) for every s in 1..smax, and never more than 28 (the escape) -> max(min(a, 27), smax + 1) + 1;
+ *   smax(largest magnitude m) = 1 for m <= 3, then one more per doubling (the 3 << (s - 1) rule), at most 6 - taken
+ *   from the bitwise OR of the magnitudes (>= m): bits(OR) <= 2 -> 1, else min(bits(OR), 6);
+ *   the first level (s = 0: up to 2a, 19 or 28 bits) and an escape at s = 1 (28 bits for 15 <= a <= 26) can exceed that by
+ *   at most 12, and only one of the two can happen in a block -> + 12.
+ * The macroblock bound adds 64 for mb_type, vectors / prediction modes, coded_block_pattern and mb_qp_delta. */
+static int blk_bits_bound(const int16_t *lv, int n)
+{
+    int tc = 0, orv = 0;
+    for (int i = 0; i < n; i++) {
+        int a = lv[i] < 0 ? -lv[i] : lv[i];
+        tc += a != 0;
+        orv |= a;
+    }
+    if (!tc) return 6;
+    int b = 0;
+    while ((orv >> b) != 0) b++;
+    int smax = b <= 2 ? 1 : (b < 6 ? b : 6), h = smax + 1, sum = 0;
+    for (int i = 0; i < n; i++) {
+        int a = lv[i] < 0 ? -lv[i] : lv[i];
+        if (a) sum += ((a < 27 ? a : 27) > h ? (a < 27 ? a : 27) : h) + 1;
+    }
+    int z = 2 * tc + 22 < 73 - 4 * tc ? 2 * tc + 22 : 73 - 4 * tc;
+    return sum + 12 + 16 + z;
+}
+enum { MB_BITS_LIMIT = 3200, MB_HEADER_BOUND = 64, INTRA_TEST_MIN = 2000 };
+static int mb_bits_bound(const int16_t *lv, int intra16)
+{
+    int b = MB_HEADER_BOUND;
+    if (intra16) b += blk_bits_bound(lv + H264O_LV_LUMA_DC, 16);
+    for (int k = 0; k < 16; k++) b += blk_bits_bound(lv + H264O_LV_LUMA + k * 16, 16);   /* (Intra16x16: level 0 of an AC list is 0) */
+    b += blk_bits_bound(lv + H264O_LV_CHROMA_DC, 4) + blk_bits_bound(lv + H264O_LV_CHROMA_DC + 4, 4);
+    for (int k = 0; k < 8; k++) b += blk_bits_bound(lv + H264O_LV_CHROMA_AC + k * 16, 16);
+    return b;
+}
 
 /* forward transform + quant of one 4x4 of (src - pred); returns nnz over
  * zig-zag positions [first..15]; writes zig-zag levels and raster dequantised
@@ -448,6 +501,21 @@ static int code_chroma(h264o_enc *e, int mx, int my, uint8_t predc[2][64], int i
 /* 6.4.4: a neighbour in another slice is not available; slices are bands of whole rows here, so only
  * the neighbours above are affected */
 static int top_in_slice(const h264o_enc *e, int my) { return my % e->slice_rows != 0; }
+
+/* the macroblock becomes I_PCM (7.3.5, 8.3.5): reconstruction = source samples, TotalCoeff 16 everywhere (9.2.1) */
+static void make_pcm(h264o_enc *e, int mx, int my)
+{
+    int cw = e->cw, cs = cw / 2;
+    h264o_mbinfo *mb = &e->mb[my * e->mbw + mx];
+    memset(mb, 0, sizeof(*mb));
+    mb->type = H264O_MB_IPCM;
+    mb->cbp = 0x2F;
+    memset(mb->tc, 16, 24);
+    for (int y = 0; y < 16; y++) memcpy(e->rec[0] + (16 * my + y) * cw + 16 * mx, e->src[0] + (16 * my + y) * cw + 16 * mx, 16);
+    for (int pl = 1; pl < 3; pl++)
+        for (int y = 0; y < 8; y++) memcpy(e->rec[pl] + (8 * my + y) * cs + 8 * mx, e->src[pl] + (8 * my + y) * cs + 8 * mx, 8);
+    e->any_pcm = 1;
+}
 
 /* ------------------------------------------------------------ intra picture */
 static void encode_intra_mb(h264o_enc *e, int mx, int my)
@@ -542,6 +610,7 @@ static void encode_intra_mb(h264o_enc *e, int mx, int my)
     mb->chroma_mode = (uint8_t)cbest;
     int cbpc = code_chroma(e, mx, my, bestc, 1, lv, mb->tc, 1);
     mb->cbp = (uint8_t)((any_ac ? 15 : 0) | (cbpc << 4));
+    if (mb_bits_bound(lv, 1) > MB_BITS_LIMIT) make_pcm(e, mx, my);
 }
 
 /* ------------------------------------------------------------ motion search */
@@ -649,6 +718,34 @@ static mv_t motion_search(h264o_enc *e, int mx, int my, mv_t pmv, int *final_cos
     return r;
 }
 
+/* Intra16x16 cost estimate of a P macroblock from the SOURCE picture's own neighbouring samples (final before the picture
+ * starts): SATD of the vertical / horizontal / DC prediction built from the source row above and column to the left, the
+ * cheapest of those available (6.4.4 availability, as the real prediction), plus lambda * 8 for the mode bits */
+static int intra_estimate(const h264o_enc *e, int mx, int my)
+{
+    int cw = e->cw, lambda = o_lambda[e->cfg.qp];
+    const uint8_t *s = e->src[0] + (16 * my) * cw + 16 * mx;
+    int top = top_in_slice(e, my), left = mx > 0;
+    uint8_t pred[256];
+    int best = -1;
+    for (int mode = 0; mode < 3; mode++) {
+        if (mode == 0 && !top) continue;
+        if (mode == 1 && !left) continue;
+        if (mode == 0) for (int y = 0; y < 16; y++) memcpy(pred + 16 * y, s - cw, 16);
+        else if (mode == 1) for (int y = 0; y < 16; y++) memset(pred + 16 * y, s[y * cw - 1], 16);
+        else {
+            int sum = 0, dc;
+            if (top) for (int x = 0; x < 16; x++) sum += s[x - cw];
+            if (left) for (int y = 0; y < 16; y++) sum += s[y * cw - 1];
+            dc = (top && left) ? (sum + 16) >> 5 : (top || left) ? (sum + 8) >> 4 : 128;
+            memset(pred, dc, 256);
+        }
+        int c = h264o_satd16x16(s, cw, pred, 16);
+        if (best < 0 || c < best) best = c;
+    }
+    return best + 8 * lambda;
+}
+
 /* 8.4.1.3 median prediction for a 16x16 partition, single reference */
 static void neighbour(const h264o_enc *e, int mx, int my, int cur_my, int *avail, int *ref, mv_t *mv)
 {
@@ -657,7 +754,7 @@ static void neighbour(const h264o_enc *e, int mx, int my, int cur_my, int *avail
     mv->x = mv->y = 0;
     if (!*avail) return;
     const h264o_mbinfo *m = &e->mb[my * e->mbw + mx];
-    if (m->type != H264O_MB_I16) { *ref = 0; mv->x = m->mvx; mv->y = m->mvy; }
+    if (m->type != H264O_MB_I16 && m->type != H264O_MB_IPCM) { *ref = 0; mv->x = m->mvx; mv->y = m->mvy; }
 }
 static int med3(int a, int b, int c) { return a > b ? (b > c ? b : (a > c ? c : a)) : (a > c ? a : (b > c ? c : b)); }
 
@@ -713,10 +810,21 @@ static void encode_inter_mb(h264o_enc *e, int mx, int my)
     }
     int cbpc = code_chroma(e, mx, my, predc, 0, lv, mb->tc, 1);
     mb->cbp = (uint8_t)(cbp | (cbpc << 4));
+    if (mb_bits_bound(lv, 0) > MB_BITS_LIMIT) { make_pcm(e, mx, my); return; }
     mv_t skip;
     predict_mv(e, mx, my, &skip);
     mb->type = (mb->cbp == 0 && skip.x == mb->mvx && skip.y == mb->mvy) ? H264O_MB_PSKIP : H264O_MB_P16;
     mb->i16_mode = mb->chroma_mode = 0;
+}
+/* the part of encode_inter_mb that needs every macroblock's FINAL type (an I_PCM / intra neighbour is not a vector): run
+ * after all macroblocks of the picture are coded */
+static void finish_inter_mb(h264o_enc *e, int mx, int my)
+{
+    h264o_mbinfo *mb = &e->mb[my * e->mbw + mx];
+    if (mb->type != H264O_MB_P16 && mb->type != H264O_MB_PSKIP) return;
+    mv_t skip;
+    predict_mv(e, mx, my, &skip);
+    mb->type = (mb->cbp == 0 && skip.x == mb->mvx && skip.y == mb->mvy) ? H264O_MB_PSKIP : H264O_MB_P16;
 }
 
 /* ------------------------------------------------------------ slice data 7.3.4/7.3.5 */
@@ -748,6 +856,17 @@ static void write_mb(h264o_enc *e, bitw *b, int mx, int my, int p_slice)
     const h264o_mbinfo *mb = &e->mb[my * e->mbw + mx];
     const int16_t *lv = e->levels + (size_t)(my * e->mbw + mx) * H264O_LV_STRIDE;
     int cbpl = mb->cbp & 15, cbpc = mb->cbp >> 4;
+    if (mb->type == H264O_MB_IPCM) {   /* 7.3.5: mb_type I_PCM, alignment, 256 + 2 x 64 samples */
+        int cw = e->cw, cs = cw / 2;
+        bw_ue(b, (uint32_t)(p_slice ? 5 + 25 : 25));
+        while (b->bits & 7) bw_put(b, 1, 0);
+        for (int y = 0; y < 16; y++)
+            for (int x = 0; x < 16; x++) bw_put(b, 8, e->src[0][(16 * my + y) * cw + 16 * mx + x]);
+        for (int pl = 1; pl < 3; pl++)
+            for (int y = 0; y < 8; y++)
+                for (int x = 0; x < 8; x++) bw_put(b, 8, e->src[pl][(8 * my + y) * cs + 8 * mx + x]);
+        return;
+    }
     if (mb->type == H264O_MB_I16) {
         int t = 1 + mb->i16_mode + 4 * cbpc + (cbpl ? 12 : 0);
         bw_ue(b, (uint32_t)(p_slice ? 5 + t : t));
@@ -822,6 +941,7 @@ int64_t h264o_enc_encode(h264o_enc *e, const uint8_t *y, int ys, const uint8_t *
         if (pos == (size_t)-1) return -2;
     }
     /* stage 1: decisions + reconstruction (pre-deblock) */
+    e->any_pcm = 0;
     if (idr) {
         for (int my = e->band_row0; my < e->band_row1; my++)
             for (int mx = 0; mx < e->mbw; mx++) encode_intra_mb(e, mx, my);
@@ -833,6 +953,7 @@ int64_t h264o_enc_encode(h264o_enc *e, const uint8_t *y, int ys, const uint8_t *
                 const mv_t rmv = {(int16_t)(((pmv.x + 2) >> 2) * 4), (int16_t)(((pmv.y + 2) >> 2) * 4)};   /* nearest integer-sample vector */
                 memset(mb, 0, sizeof(*mb));
                 mb->type = H264O_MB_P16;
+                e->want_intra[my * e->mbw + mx] = 0;
                 if (mv_all_zero(e, mx, my, 0, 0)) {
                     /* static: vector 0, no search */
                 } else if ((rmv.x | rmv.y) != 0 && mv_all_zero(e, mx, my, rmv.x, rmv.y)) {
@@ -845,10 +966,23 @@ int64_t h264o_enc_encode(h264o_enc *e, const uint8_t *y, int ys, const uint8_t *
                     e->me_cost += (uint32_t)(cost < 16383 ? cost : 16383);
                     mb->mvx = m.x;
                     mb->mvy = m.y;
+                    /* intra or inter: decided from the source picture and the motion cost alone */
+                    if (cost >= INTRA_TEST_MIN && intra_estimate(e, mx, my) < cost) {
+                        e->want_intra[my * e->mbw + mx] = 1;
+                        mb->mvx = mb->mvy = 0;
+                        mb->type = H264O_MB_I16;
+                    }
                 }
             }
         for (int my = e->band_row0; my < e->band_row1; my++)
-            for (int mx = 0; mx < e->mbw; mx++) encode_inter_mb(e, mx, my);
+            for (int mx = 0; mx < e->mbw; mx++)
+                if (!e->want_intra[my * e->mbw + mx]) encode_inter_mb(e, mx, my);
+        /* intra macroblocks of the P picture: raster order, from the true reconstruction of their neighbours */
+        for (int my = e->band_row0; my < e->band_row1; my++)
+            for (int mx = 0; mx < e->mbw; mx++)
+                if (e->want_intra[my * e->mbw + mx]) encode_intra_mb(e, mx, my);
+        for (int my = e->band_row0; my < e->band_row1; my++)
+            for (int mx = 0; mx < e->mbw; mx++) finish_inter_mb(e, mx, my);
     }
     /* stage 2: entropy coding, one NAL unit per slice */
     e->last_slice_bits = 0;
@@ -882,7 +1016,7 @@ int64_t h264o_enc_encode(h264o_enc *e, const uint8_t *y, int ys, const uint8_t *
     memcpy(e->cur[0], e->rec[0], ysz);
     memcpy(e->cur[1], e->rec[1], ysz / 4);
     memcpy(e->cur[2], e->rec[2], ysz / 4);
-    if (!e->cfg.disable_deblock)
+    if (!e->cfg.disable_deblock && !e->any_pcm)
         h264o_deblock_picture(e->cur[0], e->cur[1], e->cur[2], e->cw, e->ch, e->mb, e->cfg.qp, e->slice_rows < e->mbh ? e->slice_of : NULL,
                               e->band_row0, e->band_row1);
     for (int p = 0; p < 3; p++) { uint8_t *t = e->ref[p]; e->ref[p] = e->cur[p]; e->cur[p] = t; }

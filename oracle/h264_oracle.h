@@ -34,7 +34,7 @@ enum {
     H264O_LV_STRIDE = 416     /* int16 per macroblock (832 B)                       */
 };
 
-enum { H264O_MB_I16 = 0, H264O_MB_P16 = 1, H264O_MB_PSKIP = 2 };
+enum { H264O_MB_I16 = 0, H264O_MB_P16 = 1, H264O_MB_PSKIP = 2, H264O_MB_IPCM = 3 };
 
 typedef struct {
     int32_t width, height;  /* display size, even, 16..4096                          */

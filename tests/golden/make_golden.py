@@ -31,6 +31,9 @@ CASES = [
     ("portrait_720x1280_s1", 720, 1280, "s1", 26, 30, 3, 66),
     ("qvga_s1_4slices", 320, 240, "s1", 26, 4, 6, 66, 4),
     ("cif_scroll_6slices_main", 352, 288, "scroll", 30, 30, 5, 77, 6),
+    ("qcif_cut_qp28", 176, 144, "cut", 28, 30, 5, 66),             # intra macroblocks inside P pictures
+    ("qcif_s3_qp10_pcm", 176, 144, "s3", 10, 30, 3, 66),           # I_PCM fallback (IDR and P)
+    ("qvga_cut_3slices", 320, 240, "cut", 26, 30, 4, 66, 3),
 ]
 
 

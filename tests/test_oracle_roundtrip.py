@@ -33,6 +33,41 @@ def test_golden_and_roundtrip(case):
         assert (bs[4] & 31) == (7 if idr else 1)
 
 
+def test_mode_set_intra_in_p_and_pcm_are_legal_streams():
+    """what the test decoder saw: intra macroblocks inside P pictures after a cut, I_PCM where CAVLC could pass 3200 bits,
+    and never a macroblock_layer() above 3200 bits (A.3.1) or a level_prefix above 15 (A.2, Baseline / Main)"""
+    w, h = 176, 144
+    enc, dec = OracleEncoder(w, h, qp=28, gop=30), OracleDecoder()
+    kinds = []
+    for f in synth.sequence("cut", w, h, 4):
+        bs, _ = enc.encode(f)
+        assert dec.decode(bs) == 1
+        for p in range(3):
+            assert np.array_equal(dec.plane(p), enc.recon(p))
+        kinds.append(dec.mb_kinds())
+        assert dec.max_mb_bits <= 3200 and dec.max_level_prefix <= 15
+    assert (kinds[1] >= dec.KIND_INTER).all()                       # before the cut: inter only
+    n_intra = int((kinds[2] == dec.KIND_I16).sum())
+    # (Intra16x16 predicts this sinusoidal texture poorly, so the exhaustive search still wins most macroblocks)
+    assert n_intra >= 5 and (kinds[2] >= dec.KIND_INTER).any(), "the P picture after the cut should mix intra and inter (%d of %d intra)" % (n_intra, len(kinds[2]))
+    # uniform noise at the lowest QP: every macroblock would pass the limit -> I_PCM, reconstruction == source
+    enc, dec = OracleEncoder(w, h, qp=10, gop=30), OracleDecoder()
+    for i, f in enumerate(synth.sequence("s3", w, h, 3)):
+        bs, _ = enc.encode(f)
+        assert dec.decode(bs) == 1
+        k = dec.mb_kinds()
+        assert (k == dec.KIND_IPCM).all(), "picture %d: %s" % (i, np.bincount(k))
+        assert dec.max_mb_bits <= 3200 and dec.max_level_prefix <= 15
+        assert np.array_equal(dec.plane(0)[:h, :w], f[: w * h].reshape(h, w))
+        for p in range(3):
+            assert np.array_equal(dec.plane(p), enc.recon(p))
+    # in between (noise at QP 30): a mix, still legal
+    enc, dec = OracleEncoder(200, 120, qp=30, gop=30), OracleDecoder()
+    for f in synth.sequence("s3", 200, 120, 2):
+        assert dec.decode(enc.encode(f)[0]) == 1
+        assert dec.max_mb_bits <= 3200 and dec.max_level_prefix <= 15
+
+
 def test_quality_and_skip_behaviour():
     w, h = 320, 240
     enc = OracleEncoder(w, h, qp=26)

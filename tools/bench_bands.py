@@ -28,6 +28,23 @@ def main():
     ap.add_argument("--slices", type=int, default=8)
     ap.add_argument("--size", default="4k", choices=["4k", "1080p"])
     args = ap.parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # no launcher: one child per GPU, started before this process touches a GPU; rank 0's line is relayed
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        procs = []
+        for r in range(args.gpus):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                          stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+        line = procs[0].stdout.read().decode()
+        rcs = [p.wait() for p in procs]
+        sys.stdout.write(line)
+        sys.stdout.flush()
+        raise SystemExit(max(rcs))
     import numpy as np
     import torch
     from media_amd import capi, shard, synth
