@@ -12,7 +12,11 @@
 
 namespace h264 {
 
-enum { MB_I16 = 0, MB_P16 = 1, MB_PSKIP = 2 };
+enum { MB_I16 = 0, MB_P16 = 1, MB_PSKIP = 2, MB_IPCM = 3 };
+__device__ __forceinline__ bool mb_is_intra(int type) { return type == MB_I16 || type == MB_IPCM; }
+// A.3.1: macroblock_layer() of a CAVLC macroblock may not exceed 128 + 3072 bits; a macroblock whose BOUND (below) does
+// is coded as I_PCM.  INTRA_TEST_MIN: motion cost from which a P macroblock is also costed as Intra16x16.
+enum { MB_BITS_LIMIT = 3200, MB_HEADER_BOUND = 64, INTRA_TEST_MIN = 2000 };
 enum { LV_LUMA_DC = 0, LV_LUMA = 16, LV_CHROMA_DC = 272, LV_CHROMA_AC = 280, LV_STRIDE = 416 };
 
 // 32 bytes; identical to the debug layout documented in include/mi355x_h264.h
@@ -76,6 +80,10 @@ struct FrameParams {
     size_t st_src;       // bytes between the source pictures of two batch items
     size_t st_y, st_c;   // bytes between reconstruction planes (luma, chroma)
     int st_mb;           // macroblocks per batch item (MbInfo / levels / mvd arrays)
+    // per batch item, value = pic_serial when raised by a kernel of this picture (never cleared: the serial changes):
+    unsigned* anypcm;    //   the picture holds an I_PCM macroblock (it is then not loop-filtered: slice header idc 1)
+    unsigned* anyintra;  //   P picture: the motion search handed macroblocks to the intra pass (k_pintra_rows, bS 3 / 4 edges)
+    unsigned pic_serial;
     SliceRows sl;        // slices of the picture: bands of sl.rows macroblock rows (sl.rows = mbh: one slice)
     Band band;           // the rows this instance encodes; grids cover the band, coordinates stay those of the picture
     MbDiv mbdiv;         // macroblock index / mbw
@@ -91,6 +99,7 @@ __device__ __forceinline__ FrameParams batch_view(FrameParams P, int g)
     P.levels += (size_t)g * P.st_mb * LV_STRIDE;
     P.mvd += (size_t)g * P.st_mb * 2;
     P.me_cost += (size_t)g * P.st_mb;
+    P.anypcm += g; P.anyintra += g;
     return P;
 }
 
@@ -206,6 +215,52 @@ __device__ __forceinline__ int quant1(int w, int mf, int f, int qbits)
     const int a = iabs(w);
     const int l = (int)(((unsigned)a * (unsigned)mf + (unsigned)f) >> qbits);
     return w < 0 ? -l : l;
+}
+
+// ---- I_PCM fallback: upper bound on the CAVLC bits of one residual block (oracle/h264_enc.c blk_bits_bound states the
+// derivation): tc levels, `sum16` = sum over all 16 positions of max(min(|level|, 27), h) with h = smax + 1, smax from the
+// bitwise OR of the magnitudes ----
+__device__ __forceinline__ int pcm_smax(unsigned orv)
+{
+    const int b = 32 - __clz((int)orv);   // orv > 0
+    return b <= 2 ? 1 : (b < 6 ? b : 6);
+}
+__device__ __forceinline__ int pcm_blk_tail(int tc) { return 12 + 16 + min(2 * tc + 22, 73 - 4 * tc); }
+// plain form over n int16 levels (the intra kernel, one block per lane; not a hot path)
+__device__ __forceinline__ int blk_bits_bound(const int16_t* lv, int n)
+{
+    int tc = 0;
+    unsigned orv = 0;
+    for (int i = 0; i < n; i++) { const int a = iabs((int)lv[i]); tc += a != 0; orv |= (unsigned)a; }
+    if (!tc) return 6;
+    const int h = pcm_smax(orv) + 1;
+    int sum = 0;
+    for (int i = 0; i < n; i++) { const int a = iabs((int)lv[i]); if (a) sum += max(min(a, 27), h) + 1; }
+    return sum + pcm_blk_tail(tc);
+}
+// packed form: lvp[8] = 16 int16 levels (two per word), tc known
+__device__ __forceinline__ int blk_bits_bound_packed(const uint32_t lvp[8], int tc)
+{
+    typedef short s2 __attribute__((ext_vector_type(2)));
+    typedef unsigned short u2 __attribute__((ext_vector_type(2)));
+    uint32_t a[8], orv = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const s2 p = __builtin_bit_cast(s2, lvp[k]);
+        a[k] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(p, -p));
+        orv |= a[k];
+    }
+    orv = (orv | (orv >> 16)) & 0xFFFFu;
+    const int h = pcm_smax(orv | 1u) + 1;
+    const u2 hh = {(unsigned short)h, (unsigned short)h}, c27 = {27, 27};
+    uint32_t sum = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const u2 m = __builtin_elementwise_max(__builtin_elementwise_min(__builtin_bit_cast(u2, a[k]), c27), hh);
+        sum = __builtin_amdgcn_sad_u16(__builtin_bit_cast(uint32_t, m), 0u, sum);
+    }
+    // the 16 - tc zero positions were counted as h each, the non-zero ones lack their + 1
+    return tc ? (int)sum - (16 - tc) * h + tc + pcm_blk_tail(tc) : 6;
 }
 
 // wave-wide reductions over 64 lanes
@@ -354,7 +409,7 @@ __device__ __forceinline__ Mv predict_mv(const FrameParams& P, int mx, int my, M
     auto unpack = [](const uint2 w, bool av, int& ref, Mv& mv) {
         const int type = (int)(w.y & 255);
         ref = -1; mv.x = 0; mv.y = 0;
-        if (av && type != MB_I16) { ref = 0; mv.x = (int)(int16_t)(w.x & 0xFFFF); mv.y = (int)(int16_t)(w.x >> 16); }
+        if (av && !mb_is_intra(type)) { ref = 0; mv.x = (int)(int16_t)(w.x & 0xFFFF); mv.y = (int)(int16_t)(w.x >> 16); }
     };
     int rA, rB, rC;
     Mv A, B, C;

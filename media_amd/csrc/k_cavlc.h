@@ -279,6 +279,10 @@ struct CavlcParams {
     uint8_t* bs;          // boundary strengths for the loop filter, 32 B per macroblock (written by k_bs)
     int st_mb;            // lockstep batch: macroblocks per batch item (all per-MB arrays)
     size_t st_bitbuf;     // 32-bit words between the payload buffers of two batch items
+    // the source picture, for the samples of I_PCM macroblocks (the reconstruction is being loop-filtered meanwhile)
+    const uint8_t* src;
+    int w, h, src_nv12;
+    size_t st_src;
 };
 __device__ __forceinline__ CavlcParams batch_view(CavlcParams C, int g)
 {
@@ -286,6 +290,7 @@ __device__ __forceinline__ CavlcParams batch_view(CavlcParams C, int g)
     C.prevcoded += (size_t)g * (C.st_mb + 1);
     C.slotbits += (size_t)g * C.st_mb * 32; C.slotcode += (size_t)g * C.st_mb * 32; C.mbbits += (size_t)g * C.st_mb; C.bitbuf += (size_t)g * C.st_bitbuf;
     if (C.bs) C.bs += (size_t)g * C.st_mb * 32;
+    C.src += (size_t)g * C.st_src;
     return C;
 }
 enum { MAX_BATCH = 64 };
@@ -305,10 +310,20 @@ __device__ __forceinline__ int mb_edge_strength(const MbInfo* q, int mx, bool to
     const MbInfo* p = e == 0 ? (dir == 0 ? q - 1 : q - mbw) : q;
     const int bq = dir == 0 ? xy2blk(e, k) : xy2blk(k, e);
     const int bp = dir == 0 ? (e == 0 ? xy2blk(3, k) : xy2blk(e - 1, k)) : (e == 0 ? xy2blk(k, 3) : xy2blk(k, e - 1));
-    if (p->type == MB_I16 || q->type == MB_I16) return e == 0 ? 4 : 3;
+    if (mb_is_intra(p->type) || mb_is_intra(q->type)) return e == 0 ? 4 : 3;
     if (p->tc[bp] || q->tc[bq]) return 2;
     if (iabs(p->mvx - q->mvx) >= 4 || iabs(p->mvy - q->mvy) >= 4) return 1;
     return 0;
+}
+
+// one source sample of component comp (0 Y, 1 Cb, 2 Cr), clamped like every other source read
+__device__ __forceinline__ unsigned pcm_sample(const CavlcParams& C, int comp, int x, int y)
+{
+    if (comp == 0) return (unsigned)src_px(C.src, C.w, C.h, x, y);
+    const int pw = C.w / 2, ph = C.h / 2, xx = x < pw ? x : pw - 1, yy = y < ph ? y : ph - 1;
+    const uint8_t* base = C.src + (size_t)C.w * C.h;
+    if (C.src_nv12) return base[(size_t)yy * (2 * pw) + 2 * xx + (comp - 1)];
+    return base[(comp == 2 ? (size_t)pw * ph : 0) + (size_t)yy * pw + xx];
 }
 
 // slot: 0 header, 1 Intra16x16 DC, 2..17 luma blkIdx 0..15, 18/19 chroma DC, 20..27 chroma AC
@@ -323,6 +338,29 @@ __device__ __forceinline__ void code_slot(S& s, const CavlcParams& C, int mbi, i
     const int16_t* lv = C.levels + (size_t)mbi * LV_STRIDE;
     const int cbpl = m->cbp & 15, cbpc = m->cbp >> 4;
     const bool i16 = m->type == MB_I16;
+    if (m->type == MB_IPCM) {
+        // 7.3.5: mb_type I_PCM (slot 0; the alignment zero bits after it are left to the zeroed buffer, k_bit_scan and the
+        // write pass place the samples on the next byte boundary), then 384 samples, 16 per slot: slots 1..16 the luma rows,
+        // 17..20 Cb (two rows each), 21..24 Cr
+        if (slot == 0) {
+            if (C.p_slice) put_ue(s, (unsigned)(mbi - 1 - max(C.prevcoded[mbi], (my - srow) * C.mbw - 1)));
+            put_ue(s, C.p_slice ? 30u : 25u);
+        } else if (slot <= 24) {
+            const int comp = slot <= 16 ? 0 : (slot <= 20 ? 1 : 2);
+#pragma unroll 1
+            for (int j = 0; j < 4; j++) {
+                unsigned v = 0;
+                for (int k = 0; k < 4; k++) {
+                    const int i = 4 * j + k;   // sample index inside the slot
+                    const unsigned smp = comp == 0 ? pcm_sample(C, 0, 16 * mx + i, 16 * my + slot - 1)
+                                                   : pcm_sample(C, comp, 8 * mx + (i & 7), 8 * my + 2 * ((slot - 17) & 3) + (i >> 3));
+                    v = (v << 8) | smp;
+                }
+                s.put(32, v);
+            }
+        }
+        return;
+    }
     if (slot == 0) {
         if (C.p_slice) {
             // mb_skip_run: the P_Skip macroblocks right before this one, counted from the slice's first macroblock
@@ -420,7 +458,7 @@ __global__ __launch_bounds__(64) void k_cavlc(CavlcParams C0)
         if (live) C.slotbits[(size_t)mbi * 32 + slot] = (uint16_t)s.n;
         if (live && s.n && s.n <= 64u) C.slotcode[(size_t)mbi * 32 + slot] = s.acc;
         const int tot = group_sum<32>((int)s.n);
-        if (live && slot == 0) C.mbbits[mbi] = (uint32_t)tot;
+        if (live && slot == 0) C.mbbits[mbi] = (uint32_t)tot | (C.mb[mbi].type == MB_IPCM ? 0x80000000u : 0u);   // bit 31: k_bit_scan aligns the samples
     } else {
         // exclusive prefix over the 32 slots of this macroblock
         unsigned n = live ? C.slotbits[(size_t)mbi * 32 + slot] : 0, incl = n;
@@ -431,7 +469,11 @@ __global__ __launch_bounds__(64) void k_cavlc(CavlcParams C0)
         }
         // A slice that outgrows its share of the payload buffer (twice its luma bytes: only noise at the lowest QPs
         // codes to that) is reported by k_bit_scan and refused by the host; nothing may be written past the share.
-        const unsigned pos = live ? C.mbbits[mbi] + incl - n : 0u;
+        unsigned pos = live ? C.mbbits[mbi] + incl - n : 0u;
+        {   // I_PCM: pcm_alignment_zero_bits between the header (slot 0) and the samples
+            const unsigned hdr = (unsigned)__shfl((int)n, lane & 32);
+            if (live && slot > 0 && C.mb[mbi].type == MB_IPCM) pos += (0u - (C.mbbits[mbi] + hdr)) & 7u;
+        }
         const unsigned lim = (__umulhi((unsigned)C.mbdiv.row(mbi), C.sl.inv) + 1u) * C.slice_cap * 8u - (unsigned)SLICE_GUARD_BITS;
         if (live && n && pos + n <= lim) {
             if (n <= 64u) {   // coded by the count pass: OR the stored word in at its final bit position
@@ -469,15 +511,19 @@ struct SliceInfo {       // lives in pinned host memory, written by the device
 // Kept small (4 waves): a workgroup is dispatched only when one CU has room for all of its waves, and beside
 // another instance's motion search a 16-wave workgroup waits long for that.
 enum { SCAN_NT = 256 };
-__global__ __launch_bounds__(SCAN_NT) void k_bit_scan(CavlcParams C0, HdrBatch H, SliceInfo* info0, const uint16_t* me_cost0, int nsl, int sl0, unsigned slice_cap)
+// H: the picture's slice header; Hpcm: the same with disable_deblocking_filter_idc 1, taken when the picture holds an I_PCM
+// macroblock (anypcm[picture] == pic_serial): such a picture is not loop-filtered.
+__global__ __launch_bounds__(SCAN_NT) void k_bit_scan(CavlcParams C0, HdrBatch H, HdrBatch Hpcm, const unsigned* anypcm, unsigned pic_serial, SliceInfo* info0,
+                                                   const uint16_t* me_cost0, int nsl, int sl0, unsigned slice_cap)
 {   // nsl slices of this instance's band per picture, the first of them is slice sl0 of the picture
     __builtin_amdgcn_s_setprio(1);
     const int item = blockIdx.x, pic = item / nsl, sl = sl0 + item - pic * nsl;
     const CavlcParams C = batch_view(C0, pic);
     const int mb0 = sl * C.sl.rows * C.mbw, mb1 = min(C.nmb, mb0 + C.sl.rows * C.mbw), cnt = mb1 - mb0;
     // slice_header(): first_mb_in_slice is written here, the rest (the same for every slice of the picture) comes from the host
-    const unsigned long long hdr_bits = H.bits[pic];
-    const int hdr_rest = H.len[pic];
+    const bool pcm_pic = anypcm[pic] == pic_serial;
+    const unsigned long long hdr_bits = pcm_pic ? Hpcm.bits[pic] : H.bits[pic];
+    const int hdr_rest = pcm_pic ? Hpcm.len[pic] : H.len[pic];
     BitCount fl;
     fl.init(0);
     put_ue(fl, (unsigned)mb0);
@@ -489,14 +535,17 @@ __global__ __launch_bounds__(SCAN_NT) void k_bit_scan(CavlcParams C0, HdrBatch H
     if (t == 0) s_cost = 0;
     const int per = (cnt + SCAN_NT - 1) / SCAN_NT;
     const int b0 = min(mb1, mb0 + t * per), b1 = min(mb1, b0 + per);
-    unsigned sum = 0;
-    for (int i = b0; i < b1; i++) sum += C.mbbits[i];
+    unsigned sum = 0, flag = 0;
+    for (int i = b0; i < b1; i++) { const unsigned n = C.mbbits[i]; sum += n & 0x7FFFFFFFu; flag |= n >> 31; }
     s_part[t] = sum;
-    __syncthreads();
+    // I_PCM macroblocks (bit 31) need their samples byte aligned, which makes a macroblock's position depend on the exact
+    // position of everything before it: such a slice (rare) is laid out by one thread, in order
+    const bool seq = __syncthreads_or((int)flag) != 0;
+    __shared__ unsigned s_total;
     if (C.p_slice) {   // scene-change statistic: sum of the per-macroblock motion costs k_me left
         const uint16_t* mc = me_cost0 + (size_t)pic * C.st_mb;
         unsigned cs = 0;
-        for (int i = b0; i < b1; i++) cs += mc[i];
+        for (int i = b0; i < b1; i++) cs += mc[i] & 0x7FFFu;   // (bit 15 marks macroblocks of the intra pass)
         if (cs) atomicAdd(&s_cost, cs);
     }
     for (int o = 1; o < SCAN_NT; o <<= 1) {
@@ -505,12 +554,25 @@ __global__ __launch_bounds__(SCAN_NT) void k_bit_scan(CavlcParams C0, HdrBatch H
         s_part[t] += v;
         __syncthreads();
     }
-    unsigned run = base + hdr_len + s_part[t] - sum;
-    for (int i = b0; i < b1; i++) {
-        const unsigned n = C.mbbits[i];
-        C.mbbits[i] = run;
-        run += n;
+    if (!seq) {
+        unsigned run = base + hdr_len + s_part[t] - sum;
+        for (int i = b0; i < b1; i++) {
+            const unsigned n = C.mbbits[i];
+            C.mbbits[i] = run;
+            run += n;
+        }
+        if (t == SCAN_NT - 1) s_total = hdr_len + s_part[SCAN_NT - 1];
+    } else if (t == 0) {
+        unsigned pos = base + hdr_len;   // base is a multiple of 8: positions in the buffer and in the RBSP align alike
+        for (int i = mb0; i < mb1; i++) {
+            const unsigned n = C.mbbits[i];
+            C.mbbits[i] = pos;
+            if (n >> 31) pos = ((pos + ((n & 0x7FFFFFFFu) - 3072u) + 7u) & ~7u) + 3072u;
+            else pos += n;
+        }
+        s_total = pos - base;
     }
+    __syncthreads();
     if (t == 0) {
         BitWrite s;
         s.buf = C.bitbuf;
@@ -519,7 +581,7 @@ __global__ __launch_bounds__(SCAN_NT) void k_bit_scan(CavlcParams C0, HdrBatch H
         if (hdr_rest > 32) { s.put(hdr_rest - 32, (unsigned)(hdr_bits >> 32)); s.put(32, (unsigned)hdr_bits); }
         else s.put(hdr_rest, (unsigned)hdr_bits);
         s.flush();
-        unsigned total = hdr_len + s_part[SCAN_NT - 1];
+        unsigned total = s_total;
         const bool fits = total + (unsigned)SLICE_TAIL_BITS + (unsigned)SLICE_GUARD_BITS <= slice_cap * 8u;
         s.init(base + (fits ? total : hdr_len));
         BitCount c;

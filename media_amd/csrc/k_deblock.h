@@ -85,7 +85,7 @@ __device__ __forceinline__ void filter_line(uint8_t* pix, int xs, int bS, int al
 // 8.7.2.1 boundary strength (frame macroblocks, one reference, one vector per MB)
 __device__ __forceinline__ int edge_bs(const MbInfo* p, int bp, const MbInfo* q, int bq, bool mb_edge)
 {
-    if (p->type == MB_I16 || q->type == MB_I16) return mb_edge ? 4 : 3;
+    if (mb_is_intra(p->type) || mb_is_intra(q->type)) return mb_edge ? 4 : 3;
     if (p->tc[bp] || q->tc[bq]) return 2;
     if (iabs(p->mvx - q->mvx) >= 4 || iabs(p->mvy - q->mvy) >= 4) return 1;
     return 0;
@@ -211,6 +211,11 @@ struct DbRowParams {
     unsigned* err;
     unsigned serial;     // changes every picture, never 0
     const unsigned* anybs;   // [item] == serial when the picture has any non-zero boundary strength (k_bs)
+    const unsigned* anypcm;  // [item] == pic_serial: the picture holds an I_PCM macroblock and is not filtered (slice header idc 1)
+    const unsigned* anyintra;   // [item] == pic_serial: a P picture with intra macroblocks (bS 3 / 4 edges)
+    unsigned pic_serial;
+    int need_intra;          // P pictures are launched in both forms: < 0 this form runs when the picture has no intra
+                             // macroblock, > 0 when it has, 0 = unconditional (IDR)
     // lockstep batch strides (gridDim.y items)
     size_t st_y, st_c, st_handoff;   // bytes, bytes, u64 words
     int st_mb;
@@ -263,6 +268,8 @@ __global__ __launch_bounds__(64) void k_deblock_rows(DbRowParams R)
     // dependency-bound: when a throughput kernel of another stream shares the SIMD, this wave issues first
     __builtin_amdgcn_s_setprio(3);
     if (R.anybs[blockIdx.y] != R.serial) return;   // no edge of this picture is filtered: nothing to do, nobody waits
+    if (R.anypcm[blockIdx.y] == R.pic_serial) return;
+    if (R.need_intra != 0 && (R.anyintra[blockIdx.y] == R.pic_serial) != (R.need_intra > 0)) return;
     DbParams D = R.d;
     {
         const size_t g = blockIdx.y;

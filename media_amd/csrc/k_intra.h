@@ -317,6 +317,39 @@ __device__ __forceinline__ void intra_mb_core(const FrameParams& P, int mx, int 
     }
     wave_sync();
     MbInfo* m = P.mb + mbi;
+    {   // I_PCM fallback (dev_common.h): bit bound of the 27 blocks, one per lane; above the limit of A.3.1 the macroblock is
+        // re-written as I_PCM: reconstruction = source, for the picture and for this row's next prediction alike
+        int bb = 0;
+        if (lane < 16) bb = blk_bits_bound(S.lv + LV_LUMA + lane * 16, 16);
+        else if (lane < 24) bb = blk_bits_bound(S.lv + LV_CHROMA_AC + (lane - 16) * 16, 16);
+        else if (lane == 24) bb = blk_bits_bound(S.lv + LV_LUMA_DC, 16);
+        else if (lane < 27) bb = blk_bits_bound(S.lv + LV_CHROMA_DC + (lane - 25) * 4, 4);
+        const int s16 = row_sum16_dpp(bb);
+        const int tot = MB_HEADER_BOUND + __builtin_amdgcn_readlane(s16, 0) + __builtin_amdgcn_readlane(s16, 16);
+        if (tot > MB_BITS_LIMIT) {   // wave-uniform
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            {
+                const int row = lane >> 2, xs = (lane & 3) * 4;
+                const uint32_t v = *(const uint32_t*)(S.src + row * 16 + xs);
+                *(uint32_t*)(P.rec[0] + (size_t)(by + row) * P.cw + bx + xs) = v;
+                *(uint32_t*)(S.rec_y + row * 16 + xs) = v;
+            }
+            if (lane < 32) {
+                const int pl = lane >> 4, row = (lane >> 1) & 7, xs = (lane & 1) * 4;
+                const uint32_t v = *(const uint32_t*)(S.srcc + pl * 64 + row * 8 + xs);
+                *(uint32_t*)((pl ? P.rec[2] : P.rec[1]) + (size_t)(8 * my + row) * cs + 8 * mx + xs) = v;
+                *(uint32_t*)(S.rec_c + pl * 64 + row * 8 + xs) = v;
+            }
+            if (lane < 6) ((uint32_t*)m)[2 + lane] = 0x10101010u;
+            if (lane == 6) {
+                *(uint2*)m = make_uint2(0u, (uint32_t)MB_IPCM | (0x2Fu << 24));
+                P.mvd[2 * mbi] = 0; P.mvd[2 * mbi + 1] = 0;
+                *P.anypcm = P.pic_serial;
+            }
+            wave_sync();
+            return;
+        }
+    }
     const int tcv = (lane < 16 ? cbp_luma != 0 : cbp_chroma == 2) ? nnz : 0;
     if (lane < 24) m->tc[lane] = (uint8_t)tcv;
     if (lane == 0) {
@@ -455,6 +488,105 @@ __global__ __launch_bounds__(64) void k_intra_rows(IntraRowParams R)
         wave_sync();
     }
     if (timed_out && lane == 0) *R.err = 2u;
+}
+
+// ===========================================================================
+// Intra macroblocks inside P pictures.  k_me marks them (MbInfo.type == MB_I16, no inter prediction written), k_tq has
+// reconstructed every inter macroblock of the picture in an earlier launch; this launch codes the marked macroblocks in
+// raster-order dependency: one persistent wave per macroblock row walks its marked macroblocks left to right.  A
+// neighbour that is an inter macroblock is read from the reconstruction planes (final since the earlier launch); a
+// neighbour that is itself intra is taken from this wave's LDS copy (left) or from the granules the row above
+// publishes (above, above-left) - the same {tag, 4 samples} hand-off as k_intra_rows.  A row waits only for intra
+// macroblocks of the row above, which are coded left to right: no cycle.  Pictures without marked macroblocks return at once.
+// ===========================================================================
+__global__ __launch_bounds__(64) void k_pintra_rows(IntraRowParams R)
+{
+    __builtin_amdgcn_s_setprio(3);
+    const FrameParams P = batch_view(R.p, blockIdx.y);
+    if (*P.anyintra != P.pic_serial) return;
+    unsigned long long* const handoff = R.handoff + (size_t)blockIdx.y * R.st_handoff;
+    const int lane = threadIdx.x, my = P.band.row0 + blockIdx.x, cs = P.cw / 2;
+    const bool top = P.sl.has_top(my);
+    __shared__ IntraLds S;
+    bool timed_out = false;
+    int last_done = -2;   // the macroblock whose reconstruction S.rec_* holds
+    // bit 15 of me_cost = "handed to this pass by k_me": unlike MbInfo.type (an I_PCM conversion changes it, here or in k_tq)
+    // it does not change during the launch, so every row sees the same set of macroblocks to wait for
+    auto marked = [&](int x, int y) { return (P.me_cost[(size_t)y * P.mbw + x] & 0x8000u) != 0; };
+    auto wait_granules = [&](int gx, int nlanes, unsigned long long& g) {   // lanes < nlanes: granule `lane` of macroblock (gx, my - 1)
+        const unsigned long long* src = handoff + ((size_t)(my - 1) * P.mbw + gx) * 8;
+        unsigned spins = 0;
+        g = lane < nlanes ? __hip_atomic_load(src + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+        while (!timed_out) {
+            const bool bad = lane < nlanes && (unsigned)(g >> 32) != R.serial;
+            if (__ballot(bad) == 0ull) break;
+            if (++spins > (1u << 20)) { timed_out = true; break; }
+            __builtin_amdgcn_s_sleep(1);
+            if (lane < nlanes) g = __hip_atomic_load(src + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+    for (int base = 0; base < P.mbw; base += 64) {
+        const int xm = base + lane;
+        unsigned long long todo = __ballot(xm < P.mbw && marked(xm < P.mbw ? xm : 0, my));
+        while (todo) {
+            const int mx = base + __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            load_src_mb(P, mx, my, S.src, S.srcc, lane);
+            // left column + corner sources
+            if (mx > 0) {
+                if (last_done == mx - 1) {
+                    if (lane < 16) S.left[lane] = S.rec_y[lane * 16 + 15];
+                    else if (lane < 32) S.cleft[(lane >> 3) & 1][lane & 7] = S.rec_c[((lane >> 3) & 1) * 64 + (lane & 7) * 8 + 7];
+                } else {
+                    if (lane < 16) S.left[lane] = P.rec[0][(size_t)(16 * my + lane) * P.cw + 16 * mx - 1];
+                    else if (lane < 32) S.cleft[(lane >> 3) & 1][lane & 7] = ((lane & 8) ? P.rec[2] : P.rec[1])[(size_t)(8 * my + (lane & 7)) * cs + 8 * mx - 1];
+                }
+            }
+            wave_sync();
+            if (top) {
+                const bool aI = marked(mx, my - 1), dI = mx > 0 && marked(mx - 1, my - 1);   // wave-uniform
+                if (aI) {
+                    unsigned long long g;
+                    wait_granules(mx, 8, g);
+                    if (lane < 8) {
+                        const uint32_t v = (uint32_t)g;
+                        uint8_t* dst = lane < 4 ? S.top + 1 + 4 * lane : S.ctop[(lane - 4) >> 1] + 1 + 4 * (lane & 1);
+#pragma unroll
+                        for (int k = 0; k < 4; k++) dst[k] = (uint8_t)(v >> (8 * k));
+                    }
+                } else {
+                    if (lane < 16) S.top[1 + lane] = P.rec[0][(size_t)(16 * my - 1) * P.cw + 16 * mx + lane];
+                    else if (lane < 32) S.ctop[(lane >> 3) & 1][1 + (lane & 7)] = ((lane & 8) ? P.rec[2] : P.rec[1])[(size_t)(8 * my - 1) * cs + 8 * mx + (lane & 7)];
+                }
+                if (mx > 0) {
+                    if (dI) {   // last samples of the bottom rows of the macroblock above-left: granules 3 (luma), 5 (Cb), 7 (Cr)
+                        unsigned long long g;
+                        wait_granules(mx - 1, 8, g);
+                        if (lane == 3) S.top[0] = (uint8_t)((uint32_t)g >> 24);
+                        else if (lane == 5) S.ctop[0][0] = (uint8_t)((uint32_t)g >> 24);
+                        else if (lane == 7) S.ctop[1][0] = (uint8_t)((uint32_t)g >> 24);
+                    } else {
+                        if (lane == 0) S.top[0] = P.rec[0][(size_t)(16 * my - 1) * P.cw + 16 * mx - 1];
+                        else if (lane == 1) S.ctop[0][0] = P.rec[1][(size_t)(8 * my - 1) * cs + 8 * mx - 1];
+                        else if (lane == 2) S.ctop[1][0] = P.rec[2][(size_t)(8 * my - 1) * cs + 8 * mx - 1];
+                    }
+                }
+            }
+            wave_sync();
+            intra_mb_core(P, mx, my, S, lane);
+            last_done = mx;
+            // publish the bottom sample row for the row below (it asks only where this macroblock is its neighbour)
+            if (my + 1 < P.mbh && lane < 8) {
+                uint32_t v;
+                if (lane < 4) v = *(const uint32_t*)(S.rec_y + 15 * 16 + 4 * lane);
+                else v = *(const uint32_t*)(S.rec_c + ((lane - 4) >> 1) * 64 + 7 * 8 + 4 * (lane & 1));
+                __hip_atomic_store(handoff + ((size_t)my * P.mbw + mx) * 8 + lane, ((unsigned long long)R.serial << 32) | v,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            wave_sync();
+        }
+    }
+    if (timed_out && lane == 0) *R.err = 3u;
 }
 
 }  // namespace h264

@@ -543,7 +543,47 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
         }
         bestk = best_cost << 4;                          // the next pass starts from "stay" (order 0)
     }
-    // ---- 5. the winning prediction goes to the reconstruction planes (k_tq turns it into the reconstruction in place):
+    // ---- 5. intra or inter: from the motion cost and the SOURCE picture alone (both final before the launch).  A macroblock
+    // whose motion cost is INTRA_TEST_MIN or more is also costed as Intra16x16 with the vertical / horizontal / DC prediction
+    // built from the source samples above and to the left (SATD, lane = (mode, 4x4 block)) + 8 lambda; if that is lower it is
+    // marked for the intra pass (k_pintra_rows predicts from the true reconstruction) and gets no inter prediction ----
+    if (best_cost >= (unsigned)INTRA_TEST_MIN) {   // wave-uniform
+        const bool topav = P.sl.has_top(my), leftav = mx > 0;
+        uint8_t* const s_nb = (uint8_t*)s_ytab;     // the search's table is no longer needed: 16 samples above, 16 to the left
+        int nb = 0;
+        if (lane < 16) nb = topav ? src_px(P.src, P.w, P.h, bx + lane, by - 1) : 0;
+        else if (lane < 32) nb = leftav ? src_px(P.src, P.w, P.h, bx - 1, by + lane - 16) : 0;
+        if (lane < 32) s_nb[lane] = (uint8_t)nb;
+        const int s16 = row_sum16_dpp(lane < 32 ? nb : 0);
+        const int st = __builtin_amdgcn_readlane(s16, 0), sl = __builtin_amdgcn_readlane(s16, 16);
+        const int dc = (topav && leftav) ? (st + sl + 16) >> 5 : topav ? (st + 8) >> 4 : leftav ? (sl + 8) >> 4 : 128;
+        __syncthreads();
+        const int mode = lane >> 4, blk = lane & 15, x0 = (blk & 3) * 4, y0 = (blk >> 2) * 4;
+        int d[16];
+#pragma unroll
+        for (int y = 0; y < 4; y++) {
+            const uint32_t sw = *(const uint32_t*)(s_src + (y0 + y) * 16 + x0);
+#pragma unroll
+            for (int x = 0; x < 4; x++) {
+                const int pr = mode == 0 ? s_nb[x0 + x] : mode == 1 ? s_nb[16 + y0 + y] : dc;
+                d[4 * y + x] = (int)((sw >> (8 * x)) & 255u) - pr;
+            }
+        }
+        const int satd = row_sum16_dpp(lane < 48 ? hadamard_abs(d) : 0) >> 1;
+        const bool ok = mode == 0 ? topav : mode == 1 ? leftav : mode == 2;
+        const unsigned est = wave_min_u32_dpp(ok ? (unsigned)satd : 0xFFFFFFFFu) + 8u * (unsigned)P.lambda;
+        if (est < best_cost) {
+            if (lane == 0) {
+                uint4* m = (uint4*)(P.mb + mbi);
+                m[0] = make_uint4(0u, (uint32_t)MB_I16, 0u, 0u);
+                m[1] = make_uint4(0u, 0u, 0u, 0u);
+                P.me_cost[mbi] = (uint16_t)(0x8000u | (best_cost < 16383u ? best_cost : 16383u));   // bit 15: for k_pintra_rows
+                *P.anyintra = P.pic_serial;
+            }
+            return;
+        }
+    }
+    // ---- 6. the winning prediction goes to the reconstruction planes (k_tq turns it into the reconstruction in place):
     // luma from the half-sample planes still in LDS, lane = (row, 4-sample segment); chroma by 8.4.2.2.2 ----
     {
         const int ox = cx - 4 * ix, oy = cy - 4 * iy;

@@ -20,7 +20,10 @@
 //     sign / magnitude form of the oracle for every w), with its wave-uniform constants pinned in VGPRs;
 //   - TotalCoeff is counted on the packed int16 level pairs (6 fast operations per pair).
 // Macroblocks whose prediction already quantises to nothing (k_me's tests) are not touched at all: k_me has written
-// their side info, and prediction = reconstruction.
+// their side info, and prediction = reconstruction; macroblocks k_me handed to the intra pass are skipped too.
+// I_PCM fallback: every block's levels also give an upper bound on its CAVLC bits (dev_common.h, derivation in
+// oracle/h264_enc.c); a macroblock whose bound passes the 3200 bits of A.3.1 is re-written as I_PCM on the spot
+// (reconstruction = source), so no picture is ever refused for its content and nothing downstream has to change its mind.
 #pragma once
 #include "dev_common.h"
 
@@ -104,6 +107,7 @@ __global__ __launch_bounds__(64) void k_tq(FrameParams P0)
     const bool src_al = ((P.w | (int)(uintptr_t)P.src) & 3) == 0;   // source rows are dword aligned
     const int cwv = vreg(P.cw), wv = vreg(P.w), csv = vreg(cs);
     unsigned long long ymask[2];
+    int ybound[2];   // bit bound of the lane's macroblock, luma part (in all 16 lanes of the macroblock)
 
     // ---- luma: two passes of 4 macroblocks, lane = (macroblock, blkIdx) ----
     {
@@ -112,8 +116,9 @@ __global__ __launch_bounds__(64) void k_tq(FrameParams P0)
         for (int p = 0; p < 2; p++) {
             const int blk = lane & 15, mbi = first + 4 * p + (lane >> 4);
             bool act = mbi < end;
-            if (act) act = *((const uint8_t*)P.mb + (uint32_t)(mbi * 32 + 5)) == 0;   // MbInfo.i16_mode: set by k_me when nothing is left to code
-            int nz = 0;
+            // MbInfo.type == MB_P16 and i16_mode == 0 (k_me sets i16_mode when nothing is left to code, type MB_I16 for the intra pass)
+            if (act) act = *(const uint16_t*)((const uint8_t*)P.mb + (uint32_t)(mbi * 32 + 4)) == (uint16_t)MB_P16;
+            int nz = 0, bb = 0;
             if (act) {
                 const int my = P.mbdiv.row(mbi), mx = mbi - my * P.mbw;
                 const int x = 16 * mx + 4 * blk_x(blk), y = 16 * my + 4 * blk_y(blk);
@@ -143,6 +148,7 @@ __global__ __launch_bounds__(64) void k_tq(FrameParams P0)
                     for (int c = 0; c < 4; c++) d[4 * r + c] = (int)((s4[r] >> (8 * c)) & 255u) - (int)((p4[r] >> (8 * c)) & 255u);
                 uint32_t lvp[8];
                 nz = tq_block<false>(d, K, lvp, [](int) { return 0; });
+                bb = blk_bits_bound_packed(lvp, nz);
                 const uint32_t lo = (uint32_t)__mul24(mbi, LV_STRIDE * 2) + (uint32_t)((LV_LUMA + blk * 16) * 2);
                 *(uint4*)((uint8_t*)P.levels + lo) = make_uint4(lvp[0], lvp[1], lvp[2], lvp[3]);
                 *(uint4*)((uint8_t*)P.levels + lo + 16u) = make_uint4(lvp[4], lvp[5], lvp[6], lvp[7]);
@@ -151,6 +157,7 @@ __global__ __launch_bounds__(64) void k_tq(FrameParams P0)
                 *((uint8_t*)P.mb + (uint32_t)(mbi * 32 + 8 + blk)) = (uint8_t)nz;   // MbInfo.tc[blk]
             }
             ymask[p] = __ballot(nz != 0);
+            ybound[p] = row_sum16_dpp(bb);
         }
     }
 
@@ -159,8 +166,8 @@ __global__ __launch_bounds__(64) void k_tq(FrameParams P0)
         const TqConst K = tq_consts(P.qc);
         const int m8 = lane >> 3, pl = (lane >> 2) & 1, cb = lane & 3, mbi = first + m8;
         bool act = mbi < end;
-        if (act) act = *((const uint8_t*)P.mb + (uint32_t)(mbi * 32 + 5)) == 0;
-        int cnz = 0, ldc = 0;
+        if (act) act = *(const uint16_t*)((const uint8_t*)P.mb + (uint32_t)(mbi * 32 + 4)) == (uint16_t)MB_P16;
+        int cnz = 0, ldc = 0, bb = 0;
         if (act) {
             const int my = P.mbdiv.row(mbi), mx = mbi - my * P.mbw;
             const int x = 8 * mx + 4 * (cb & 1), y = 8 * my + 4 * (cb >> 1);
@@ -190,6 +197,7 @@ __global__ __launch_bounds__(64) void k_tq(FrameParams P0)
                 ldc = quant_signed(fd, K.mf[0], 2 * K.f, 2 * K.c + 1, K.q + 1);   // 2^(q+1) - 1 - 2 (2f) = 2 c + 1
                 return (had2x2(ldc) * 16 * K.dq[0]) >> 5;
             });
+            bb = blk_bits_bound_packed(lvp, cnz);
             const uint32_t lb = (uint32_t)__mul24(mbi, LV_STRIDE * 2), lo = lb + (uint32_t)((LV_CHROMA_AC + (pl * 4 + cb) * 16) * 2);
             *(uint4*)((uint8_t*)P.levels + lo) = make_uint4(lvp[0], lvp[1], lvp[2], lvp[3]);
             *(uint4*)((uint8_t*)P.levels + lo + 16u) = make_uint4(lvp[4], lvp[5], lvp[6], lvp[7]);
@@ -199,11 +207,46 @@ __global__ __launch_bounds__(64) void k_tq(FrameParams P0)
             *((uint8_t*)P.mb + (uint32_t)(mbi * 32 + 24 + pl * 4 + cb)) = (uint8_t)cnz;   // MbInfo.tc[16 + plane * 4 + block]
         }
         const unsigned long long acm = __ballot(cnz != 0), dcm = __ballot(ldc != 0);
+        // bit bound of the macroblock: its 8 chroma AC blocks + the two DC blocks (four lanes of a quad each) + the luma part
+        unsigned long long pcm;
+        {
+            auto quad_red = [](int v, bool orop) {
+                int t = __builtin_amdgcn_mov_dpp(v, 0xB1, 0xf, 0xf, false);
+                v = orop ? (v | t) : (v + t);
+                t = __builtin_amdgcn_mov_dpp(v, 0x4E, 0xf, 0xf, false);
+                return orop ? (v | t) : (v + t);
+            };
+            const int adc = iabs(ldc), tcdc = quad_red(ldc != 0, false), h = pcm_smax((unsigned)quad_red(adc, true) | 1u) + 1;
+            const int dcb = tcdc ? quad_red(adc ? max(min(adc, 27), h) + 1 : 0, false) + pcm_blk_tail(tcdc) : 6;
+            const int csum = group_sum8_dpp(bb + (cb == 0 ? dcb : 0));
+            const int y0 = __shfl(ybound[0], 16 * (m8 & 3)), y1 = __shfl(ybound[1], 16 * (m8 & 3));
+            pcm = __ballot(act && (lane & 7) == 0 && MB_HEADER_BOUND + csum + (m8 < 4 ? y0 : y1) > MB_BITS_LIMIT);
+        }
         if (act && (lane & 7) == 0) {
             const unsigned m16 = (unsigned)(ymask[m8 >> 2] >> (16 * (m8 & 3))) & 0xFFFFu;
             const int cbpl = ((m16 & 0x000Fu) ? 1 : 0) | ((m16 & 0x00F0u) ? 2 : 0) | ((m16 & 0x0F00u) ? 4 : 0) | ((m16 & 0xF000u) ? 8 : 0);
             const int cbpc = ((acm >> (8 * m8)) & 255ull) ? 2 : (((dcm >> (8 * m8)) & 255ull) ? 1 : 0);
             *((uint8_t*)P.mb + (uint32_t)(mbi * 32 + 7)) = (uint8_t)(cbpl | (cbpc << 4));   // MbInfo.cbp
+        }
+        if (pcm) {   // wave-uniform and rare: re-write those macroblocks as I_PCM, the whole wave per macroblock
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's earlier stores to the same samples / bytes have landed
+            while (pcm) {
+                const int pm = first + ((__ffsll((long long)pcm) - 1) >> 3);
+                pcm &= pcm - 1;
+                const int py = P.mbdiv.row(pm), px = pm - py * P.mbw;
+                {
+                    const int row = lane >> 2, xs = (lane & 3) * 4, gx = 16 * px + xs, gy = 16 * py + row;
+                    *(uint32_t*)(P.rec[0] + (size_t)gy * P.cw + gx) = (uint32_t)src_px(P.src, P.w, P.h, gx, gy) | ((uint32_t)src_px(P.src, P.w, P.h, gx + 1, gy) << 8) |
+                                                                     ((uint32_t)src_px(P.src, P.w, P.h, gx + 2, gy) << 16) | ((uint32_t)src_px(P.src, P.w, P.h, gx + 3, gy) << 24);
+                }
+                if (lane < 32) {
+                    const int cp = lane >> 4, row = (lane >> 1) & 7, xs = (lane & 1) * 4;
+                    *(uint32_t*)((cp ? P.rec[2] : P.rec[1]) + (size_t)(8 * py + row) * cs + 8 * px + xs) = src_chroma4(P, cp, 8 * px + xs, 8 * py + row);
+                }
+                if (lane < 6) ((uint32_t*)(P.mb + pm))[2 + lane] = 0x10101010u;                      // TotalCoeff 16 everywhere (9.2.1)
+                if (lane == 6) *(uint2*)(P.mb + pm) = make_uint2(0u, (uint32_t)MB_IPCM | (0x2Fu << 24));   // no vector, type, coded_block_pattern 47
+            }
+            if (lane == 0) *P.anypcm = P.pic_serial;
         }
     }
 }
@@ -222,14 +265,14 @@ __global__ __launch_bounds__(64) void k_mvpred(FrameParams P0)
     const bool avA = mx > 0, avB = top, avC0 = top && mx + 1 < P.mbw, avD = mx > 0 && top;
     const MbInfo* base = P.mb + mbi;
     const uint2 self = *(const uint2*)base;
-    if ((self.y & 255u) == (unsigned)MB_I16) return;   // (intra macroblocks carry no vector)
+    if (mb_is_intra((int)(self.y & 255u))) return;   // (intra macroblocks carry no vector)
     const uint2 wA = *(const uint2*)(avA ? base - 1 : base);
     const uint2 wB = *(const uint2*)(avB ? base - P.mbw : base);
     const uint2 wC = *(const uint2*)(avC0 ? base - P.mbw + 1 : base);
     const uint2 wD = *(const uint2*)(avD ? base - P.mbw - 1 : base);
     auto unpack = [](const uint2 w, bool av, int& ref, Mv& mv) {
         ref = -1; mv.x = 0; mv.y = 0;
-        if (av && (int)(w.y & 255u) != MB_I16) { ref = 0; mv.x = (int)(int16_t)(w.x & 0xFFFFu); mv.y = (int)(int16_t)(w.x >> 16); }
+        if (av && !mb_is_intra((int)(w.y & 255u))) { ref = 0; mv.x = (int)(int16_t)(w.x & 0xFFFFu); mv.y = (int)(int16_t)(w.x >> 16); }
     };
     int rA, rB, rC;
     Mv A, B, C;

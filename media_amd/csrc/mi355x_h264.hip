@@ -164,6 +164,9 @@ struct mi355x_h264_encoder {
     unsigned long long* d_slotcode = nullptr;
     uint32_t* d_mbbits = nullptr;
     unsigned* d_anybs = nullptr;             // [G] picture serial when any boundary strength is non-zero
+    unsigned* d_anypcm = nullptr;            // [G] == pic_serial: the picture holds an I_PCM macroblock (not loop-filtered)
+    unsigned* d_anyintra = nullptr;          // [G] == pic_serial: P picture with macroblocks for the intra pass
+    unsigned pic_serial = 0;                 // changes every picture, never 0
     int32_t* d_prevcoded = nullptr;          // [G][nmb + 1] skip-run helper (k_skip_scan)
     unsigned long long* d_handoff = nullptr; // row-to-row hand-off of the wavefront kernels
     uint32_t* d_bs = nullptr;                // boundary strengths, 32 B per macroblock
@@ -246,7 +249,7 @@ void build_parameter_sets(mi355x_h264_encoder* e)
 
 // slice_header() of 7.3.3 for this build's fixed choices, from slice_type on (first_mb_in_slice differs per slice and
 // is written by k_bit_scan); returns bit count (< 64)
-int build_slice_header(const mi355x_h264_encoder* e, bool idr, int idr_id, uint64_t* bits)
+int build_slice_header(const mi355x_h264_encoder* e, bool idr, int idr_id, bool no_filter, uint64_t* bits)
 {
     HostBits h;
     h.ue(idr ? 7 : 5);
@@ -256,8 +259,9 @@ int build_slice_header(const mi355x_h264_encoder* e, bool idr, int idr_id, uint6
     if (!idr) { h.put(1, 0); h.put(1, 0); }
     if (idr) { h.put(1, 0); h.put(1, 0); } else h.put(1, 0);
     h.se(e->qp - 26);
-    h.ue(e->cfg.disable_deblock ? 1 : e->nsl > 1 ? 2 : 0);   // several slices: no filtering across slice edges, the bands stay independent
-    if (!e->cfg.disable_deblock) { h.se(0); h.se(0); }
+    no_filter = no_filter || e->cfg.disable_deblock;            // (a picture with an I_PCM macroblock is not filtered)
+    h.ue(no_filter ? 1 : e->nsl > 1 ? 2 : 0);   // several slices: no filtering across slice edges, the bands stay independent
+    if (!no_filter) { h.se(0); h.se(0); }
     uint64_t v = 0;
     for (uint64_t i = 0; i < h.nbits; i++) v = (v << 1) | ((h.bytes[i >> 3] >> (7 - (i & 7))) & 1);
     *bits = v;
@@ -301,6 +305,8 @@ int submit(mi355x_h264_encoder* e, const uint8_t* d_src, size_t src_item_stride,
     P.st_src = src_item_stride; P.st_y = e->st_y; P.st_c = e->st_c; P.st_mb = e->nmb; P.sl = e->sl;
     P.band.row0 = e->b_row0; P.band.rows = e->b_rows;
     P.mbdiv.inv = e->mbw > 1 ? (unsigned)(0x100000000ull / (unsigned)e->mbw) + 1u : 0u;
+    e->pic_serial = e->pic_serial == 0xFFFFFFFFu ? 1u : e->pic_serial + 1u;
+    P.anypcm = e->d_anypcm; P.anyintra = e->d_anyintra; P.pic_serial = e->pic_serial;
     const unsigned G = (unsigned)e->G;
     fill_quant(P.qy, e->qp);
     fill_quant(P.qc, h_chroma_qp[e->qp]);
@@ -332,13 +338,22 @@ int submit(mi355x_h264_encoder* e, const uint8_t* d_src, size_t src_item_stride,
           hipLaunchKernelGGL(k_me, dim3(e->b_nmb, G), dim3(64), 0, st, P); }
         { StatScope sc(e, &S, MI355X_H264_K_PMB, 1, (uint32_t)(e->b_nmb * e->G));
           hipLaunchKernelGGL(k_tq, dim3((e->b_nmb + 7) / 8, G), dim3(64), 0, st, P); }   // one wave per eight macroblocks
+        {   // macroblocks the motion search handed to the intra pass (returns at once when there are none)
+            IntraRowParams R{};
+            R.p = P; R.handoff = e->d_handoff; R.st_handoff = e->st_handoff; R.err = S.h_err;
+            e->serial = e->serial == 0xFFFFFFFFu ? 1 : e->serial + 1;
+            R.serial = e->serial;
+            hipLaunchKernelGGL(k_pintra_rows, dim3(e->b_rows, G), dim3(64), 0, st, R);
+        }
     }
     // entropy coding
-    HdrBatch H{};
+    HdrBatch H{}, Hpcm{};
     for (int g = 0; g < e->G; g++) {
         uint64_t hdr = 0;
-        H.len[g] = (unsigned char)build_slice_header(e, idr, (e->idr_id + g * e->idr_step) & 0xFF, &hdr);
+        H.len[g] = (unsigned char)build_slice_header(e, idr, (e->idr_id + g * e->idr_step) & 0xFF, false, &hdr);
         H.bits[g] = hdr;
+        Hpcm.len[g] = (unsigned char)build_slice_header(e, idr, (e->idr_id + g * e->idr_step) & 0xFF, true, &hdr);
+        Hpcm.bits[g] = hdr;
     }
     // entropy coding needs only levels / MbInfo, the loop filter the reconstruction and the boundary strengths
     // (a small launch of its own on this stream): the two run side by side and the filter never waits for the coder
@@ -351,6 +366,7 @@ int submit(mi355x_h264_encoder* e, const uint8_t* d_src, size_t src_item_stride,
     C.slotbits = e->d_slotbits; C.slotcode = e->d_slotcode; C.mbbits = e->d_mbbits; C.bitbuf = S.d_bitbuf;
     C.bs = (uint8_t*)e->d_bs; C.prevcoded = e->d_prevcoded;
     C.st_mb = e->nmb; C.st_bitbuf = e->st_bitbuf_bytes / 4;
+    C.src = d_src; C.w = e->cfg.width; C.h = e->cfg.height; C.src_nv12 = nv12 ? 1 : 0; C.st_src = src_item_stride;
     const int cavlc_grid = (e->b_nmb + 1) / 2;
     unsigned db_serial = 0;
     if (!e->cfg.disable_deblock && !e->diag_mode) {
@@ -368,7 +384,8 @@ int submit(mi355x_h264_encoder* e, const uint8_t* d_src, size_t src_item_stride,
             hipLaunchKernelGGL(k_skip_scan, dim3(G), dim3(256), 0, ec, C);
         }
         hipLaunchKernelGGL(k_cavlc<false>, dim3(grid, G), dim3(64), 0, ec, C);
-        hipLaunchKernelGGL(k_bit_scan, dim3(G * (unsigned)e->b_nsl), dim3(SCAN_NT), 0, ec, C, H, S.d_info, e->d_me_cost, e->b_nsl, e->b_sl0, (unsigned)e->slice_cap);
+        hipLaunchKernelGGL(k_bit_scan, dim3(G * (unsigned)e->b_nsl), dim3(SCAN_NT), 0, ec, C, H, Hpcm, (const unsigned*)e->d_anypcm, e->pic_serial, S.d_info, e->d_me_cost,
+                           e->b_nsl, e->b_sl0, (unsigned)e->slice_cap);
         hipLaunchKernelGGL(k_cavlc<true>, dim3(grid, G), dim3(64), 0, ec, C);
         // access unit layout in the pinned buffer: [pad][SPS PPS (IDR only)][00 00 00 01 hdr][payload...];
         // with several slices: the payload of slice s at s * slice_cap, the access unit is put together by finish_item
@@ -406,8 +423,12 @@ int submit(mi355x_h264_encoder* e, const uint8_t* d_src, size_t src_item_stride,
             R.st_y = e->st_y; R.st_c = e->st_c; R.st_handoff = e->st_handoff; R.st_mb = e->nmb;
             R.serial = db_serial; R.row0 = e->b_row0;
             R.bs = e->d_bs; R.anybs = e->d_anybs;
-            if (idr) hipLaunchKernelGGL(k_deblock_rows<true>, dim3(e->b_rows, G), dim3(64), 0, st, R);
-            else hipLaunchKernelGGL(k_deblock_rows<false>, dim3(e->b_rows, G), dim3(64), 0, st, R);
+            R.anypcm = e->d_anypcm; R.anyintra = e->d_anyintra; R.pic_serial = e->pic_serial;
+            if (idr) { R.need_intra = 0; hipLaunchKernelGGL(k_deblock_rows<true>, dim3(e->b_rows, G), dim3(64), 0, st, R); }
+            else {   // P pictures: the form without the bS 4 filter, or - when the picture has intra macroblocks - the one with it
+                R.need_intra = -1; hipLaunchKernelGGL(k_deblock_rows<false>, dim3(e->b_rows, G), dim3(64), 0, st, R);
+                R.need_intra = 1; hipLaunchKernelGGL(k_deblock_rows<true>, dim3(e->b_rows, G), dim3(64), 0, st, R);
+            }
         }
     }
     HIPCHK(e, hipStreamWaitEvent(st, S.entropy_done, 0));   // join: the next picture rewrites MbInfo / levels
@@ -611,6 +632,10 @@ int mi355x_h264_create(const mi355x_h264_config* cfg, mi355x_h264_encoder** out)
     CK(hipMalloc((void**)&e->d_mbbits, Gn * e->nmb * sizeof(uint32_t)));
     CK(hipMalloc((void**)&e->d_anybs, Gn * sizeof(unsigned)));
     CK(hipMemset(e->d_anybs, 0, Gn * sizeof(unsigned)));
+    CK(hipMalloc((void**)&e->d_anypcm, Gn * sizeof(unsigned)));
+    CK(hipMemset(e->d_anypcm, 0, Gn * sizeof(unsigned)));
+    CK(hipMalloc((void**)&e->d_anyintra, Gn * sizeof(unsigned)));
+    CK(hipMemset(e->d_anyintra, 0, Gn * sizeof(unsigned)));
     CK(hipMalloc((void**)&e->d_prevcoded, Gn * (e->nmb + 1) * sizeof(int32_t)));
     e->st_handoff = (size_t)e->nmb * 24;
     CK(hipMalloc((void**)&e->d_handoff, Gn * e->st_handoff * sizeof(unsigned long long)));
@@ -659,7 +684,7 @@ void mi355x_h264_destroy(mi355x_h264_encoder* e)
         for (int p = 0; p < 3; p++) (void)hipFree(e->d_planes[b][p]);
     for (int p = 0; p < 3; p++) (void)hipFree(e->d_pre[p]);
     (void)hipFree(e->d_mb); (void)hipFree(e->d_levels); (void)hipFree(e->d_mvd);
-    (void)hipFree(e->d_slotbits); (void)hipFree(e->d_slotcode); (void)hipFree(e->d_mbbits); (void)hipFree(e->d_prevcoded); (void)hipFree(e->d_anybs); (void)hipFree(e->d_stage);
+    (void)hipFree(e->d_slotbits); (void)hipFree(e->d_slotcode); (void)hipFree(e->d_mbbits); (void)hipFree(e->d_prevcoded); (void)hipFree(e->d_anybs); (void)hipFree(e->d_anypcm); (void)hipFree(e->d_anyintra); (void)hipFree(e->d_stage);
     (void)hipFree(e->d_handoff); (void)hipFree(e->d_bs); (void)hipFree(e->d_me_cost);
     if (e->h_stage) (void)hipHostFree(e->h_stage);
     for (auto& S : e->slots) {

@@ -32,6 +32,7 @@ def _compare_all(enc, orc, tag):
         read[(cbp >> q) & 1 == 1, 16 + 64 * q: 16 + 64 * (q + 1)] = True
     read[(cbp >> 4) >= 1, 272:280] = True
     read[(cbp >> 4) == 2, 280:408] = True
+    read[omb["type"] == 3, :] = False            # I_PCM: samples, no levels
     assert np.array_equal(np.where(read, glv, 0), np.where(read, olv, 0)), tag + ": levels"
     for p in range(3):
         assert np.array_equal(enc.debug_read(capi.DBG_PRE_Y + p), orc.recon_pre(p)), "%s: pre-filter plane %d" % (tag, p)
@@ -538,44 +539,58 @@ def test_long_gop_frame_num_wrap_and_gop_boundary_1080p():
     enc.close()
 
 
-def test_payload_buffer_overflow_is_refused_not_written():
-    """black-and-white noise at the lowest QP codes to more than twice the luma bytes, the size of the payload buffer (a
-    conforming encoder would switch such macroblocks to I_PCM, which this build does not have): the picture must be
-    refused with MI355X_H264_E_OVERFLOW - nothing written past the buffer - and the encoder must carry on with the
-    next picture, coded as an IDR because the refused one is missing from the stream"""
+def test_content_that_cannot_be_coded_by_cavlc_goes_i_pcm():
+    """black-and-white noise at the lowest QP would code to more than 3200 bits per macroblock (and to more than the payload
+    buffer): round 1 refused such a picture (MI355X_H264_E_OVERFLOW).  Now every such macroblock is coded as I_PCM - in
+    IDR and in P pictures, with one slice and with several - the access units equal the oracle's, and the test decoder
+    finds a legal stream: no macroblock_layer() above 3200 bits (A.3.1), no level_prefix above 15 (A.2)"""
     w, h = 640, 480
     rng = np.random.default_rng(3)
     noise = [(rng.integers(0, 2, w * h * 3 // 2, dtype=np.uint8) * 255).astype(np.uint8) for _ in range(3)]   # black / white noise
     for slices in (0, 4):
         enc = capi.Encoder(w, h, qp=10, gop=30, slices=slices)
+        enc.keep_pre(True)
         orc = OracleEncoder(w, h, qp=10, gop=30, slices=slices)
-        want = orc.encode(noise[0])[0]
-        assert len(want) > 2 * w * h + 65536   # the premise: this picture does not fit (uniform noise still does: 1.95 x)
-        with pytest.raises(RuntimeError, match="-5"):
-            enc.encode(noise[0])
         dec = OracleDecoder()
-        for k, f in enumerate(noise[1:]):      # at a QP where the pictures fit again: an IDR first (the refused picture is
-            enc.set_qp(36)                     # missing from the stream), then P; what was delivered decodes
-            orc.set_qp(36)
+        for k, f in enumerate(noise):
+            if k == 2:                          # and back to a QP where CAVLC fits again: a mix of I_PCM and coded macroblocks
+                enc.set_qp(30)
+                orc.set_qp(30)
             bs, ft = enc.encode(f)
-            assert (ft == capi.FRAME_IDR) == (k == 0)
-            assert bs == orc.encode(f, force_idr=(k == 0))[0]
+            assert bs == orc.encode(f)[0], "picture %d (%d slices)" % (k, slices)
+            _compare_all(enc, orc, "pcm picture %d" % k)
             assert dec.decode(bs) == 1
-        for p in range(3):
-            assert np.array_equal(dec.plane(p), enc.debug_read(capi.DBG_RECON_Y + p))
+            kinds = dec.mb_kinds()
+            assert (kinds == dec.KIND_IPCM).sum() > (len(kinds) // 2 if k < 2 else 0)
+            assert dec.max_mb_bits <= 3200 and dec.max_level_prefix <= 15
+            for p in range(3):
+                assert np.array_equal(dec.plane(p), enc.debug_read(capi.DBG_RECON_Y + p))
         enc.close()
-    # the pipelined lockstep path: the failing call waits for its pictures in flight, the next call is clean
+    # the lockstep batch path
     import torch
     G, gop, fbytes = 2, 3, w * h * 3 // 2
     dev = torch.from_numpy(np.stack(noise * G)).cuda()
     enc = capi.Encoder(w, h, qp=10, gop=gop, batch=G)
     cap = 4 * gop * fbytes
     out, szs, gb = np.zeros(G * cap, np.uint8), np.zeros(G * gop, np.uint32), np.zeros(G, np.uint64)
-    with pytest.raises(RuntimeError, match="-5"):
-        enc.encode_gops_device(dev.data_ptr(), fbytes, gop * fbytes, gop, out, cap, szs, gb)
-    enc.set_qp(36)
     enc.encode_gops_device(dev.data_ptr(), fbytes, gop * fbytes, gop, out, cap, szs, gb)
-    orc = OracleEncoder(w, h, qp=36, gop=gop)
-    orc.set_idr_id(G, 1)                       # the refused call used up idr_pic_id 0 .. G-1
+    orc = OracleEncoder(w, h, qp=10, gop=gop)
     assert out[:int(gb[0])].tobytes() == b"".join(orc.encode(f)[0] for f in noise)
     enc.close()
+
+
+def test_intra_macroblocks_inside_p_pictures():
+    """a cut inside a GOP (no scene-change IDR at the C ABI: that is the plugin class's rule): the P picture after it mixes
+    Intra16x16 and inter macroblocks; every stage equals the oracle, with one slice and with slice bands"""
+    for (w, h, slices) in ((352, 288, 0), (640, 368, 4)):
+        enc = capi.Encoder(w, h, qp=28, gop=30, slices=slices)
+        enc.keep_pre(True)
+        orc = OracleEncoder(w, h, qp=28, gop=30, slices=slices)
+        n_intra = 0
+        for i, f in enumerate(synth.sequence("cut", w, h, 5)):
+            assert enc.encode(f)[0] == orc.encode(f)[0], "picture %d" % i
+            _compare_all(enc, orc, "cut picture %d" % i)
+            if i >= 2:
+                n_intra += int((orc.mbinfo()["type"] == 0).sum())
+        assert n_intra > 0
+        enc.close()

@@ -129,10 +129,10 @@ def test_slices_extension_key():
     vc.prop_set("persist.vmi.video.encode.slices", "")
 
 
-def test_picture_that_does_not_fit_is_an_encode_fail_and_the_stream_recovers():
-    """black/white noise at QP 10 codes to more than the payload buffer holds: EncodeOneFrame returns ENCODE_FAIL
-    (the C ABI's E_OVERFLOW), the caller drops the picture, and the next picture is an IDR - the delivered stream
-    stays decodable"""
+def test_content_no_encoder_setting_can_code_never_fails_the_call():
+    """black/white noise at QP 10: round 1 refused such a picture (EncodeOneFrame -> ENCODE_FAIL, a behaviour the reference
+    does not have: OpenH264 never fails on content).  Now it is coded - as I_PCM where CAVLC could pass the 3200 bits of
+    A.3.1 - and the stream stays decodable without any recovery step"""
     w, h = 640, 480
     e = _new(w, h, qp=10, gop=30)
     dec = OracleDecoder()
@@ -141,11 +141,13 @@ def test_picture_that_does_not_fit_is_an_encode_fail_and_the_stream_recovers():
     assert rc == vc.SUCCESS and dec.decode(bs) == 1
     rng = np.random.default_rng(3)
     bad = (rng.integers(0, 2, w * h * 3 // 2, dtype=np.uint8) * 255).astype(np.uint8)
-    assert e.encode(bad)[0] == vc.ENCODE_FAIL
+    rc, bs = e.encode(bad)
+    assert rc == vc.SUCCESS and dec.decode(bs) == 1
+    assert (dec.mb_kinds() == dec.KIND_IPCM).sum() > 600 and dec.max_mb_bits <= 3200
+    assert np.array_equal(dec.plane(0)[:h, :w][dec.mb_kinds().reshape(h // 16, w // 16).repeat(16, 0).repeat(16, 1) == dec.KIND_IPCM],
+                          bad[: w * h].reshape(h, w)[dec.mb_kinds().reshape(h // 16, w // 16).repeat(16, 0).repeat(16, 1) == dec.KIND_IPCM])
     for f in frames[1:]:
         rc, bs = e.encode(f)
         assert rc == vc.SUCCESS and dec.decode(bs) == 1
-        if f is frames[1]:
-            assert bs[:5] == b"\x00\x00\x00\x01\x67"       # SPS first: an IDR access unit
     e.destroy()
     assert e.delete() == vc.SUCCESS
