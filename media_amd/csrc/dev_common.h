@@ -36,6 +36,7 @@ struct Quant {
     int thr_inter[3];   // smallest |w| whose inter-rounded level is non-zero
     int thr_dc_inter;   // same for the chroma DC path (2x2 Hadamard output)
     int qp;
+    int mf8[6], ls8[6]; // 8x8 transform (High profile): forward multipliers and 16 * normAdjust8x8 by position class (8.5.9)
 };
 
 // Slices are bands of `rows` whole macroblock rows (the last band may be shorter); with one slice rows = mbh.

@@ -267,6 +267,7 @@ struct CavlcParams {
     const int16_t* levels;
     const int16_t* mvd;
     int mbw, nmb, p_slice;
+    int t8x8;             // PPS transform_8x8_mode_flag (High profile)
     SliceRows sl;         // slices of the picture (bands of sl.rows macroblock rows)
     int mb_first, mb_end; // the macroblocks this instance codes (its band of whole slices; 0 .. nmb alone)
     MbDiv mbdiv;          // macroblock index / mbw
@@ -311,7 +312,13 @@ __device__ __forceinline__ int mb_edge_strength(const MbInfo* q, int mx, bool to
     const int bq = dir == 0 ? xy2blk(e, k) : xy2blk(k, e);
     const int bp = dir == 0 ? (e == 0 ? xy2blk(3, k) : xy2blk(e - 1, k)) : (e == 0 ? xy2blk(k, 3) : xy2blk(k, e - 1));
     if (mb_is_intra(p->type) || mb_is_intra(q->type)) return e == 0 ? 4 : 3;
-    if (p->tc[bp] || q->tc[bq]) return 2;
+    // transform_size_8x8_flag (i16_mode of an inter macroblock): no 4x4-internal edges, and "contains non-zero coefficients"
+    // (8.7.2.1) refers to the 8x8 block = the four interleaved lists of the quadrant
+    const bool q8 = q->type == MB_P16 && q->i16_mode == 1, p8 = p->type == MB_P16 && p->i16_mode == 1;
+    if (q8 && (e & 1)) return 0;
+    const bool nzq = q8 ? (*(const uint32_t*)(q->tc + (bq & ~3)) != 0) : q->tc[bq] != 0;
+    const bool nzp = p8 ? (*(const uint32_t*)(p->tc + (bp & ~3)) != 0) : p->tc[bp] != 0;
+    if (nzp || nzq) return 2;
     if (iabs(p->mvx - q->mvx) >= 4 || iabs(p->mvy - q->mvy) >= 4) return 1;
     return 0;
 }
@@ -376,6 +383,7 @@ __device__ __forceinline__ void code_slot(S& s, const CavlcParams& C, int mbi, i
             put_se(s, C.mvd[2 * mbi]);
             put_se(s, C.mvd[2 * mbi + 1]);
             put_ue(s, c_cbp2code_inter[m->cbp]);
+            if (C.t8x8 && cbpl) s.put(1, m->i16_mode & 1u);   // transform_size_8x8_flag (High profile, luma coefficients present)
             if (m->cbp) put_se(s, 0);
         }
     } else if (slot == 1) {

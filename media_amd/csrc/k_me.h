@@ -238,7 +238,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
             if (lane < 32) *(uint32_t*)((cplz ? P.rec[2] : P.rec[1]) + (size_t)(8 * my + cyz) * (P.cw / 2) + 8 * mx + cxz) = rc;
             if (lane == 0) {
                 uint4* m = (uint4*)(P.mb + mbi);
-                m[0] = make_uint4(((uint32_t)vx & 0xFFFFu) | ((uint32_t)vy << 16), (uint32_t)MB_P16 | (1u << 8), 0u, 0u);   // i16_mode = 1: mark for k_tq / k_mvpred
+                m[0] = make_uint4(((uint32_t)vx & 0xFFFFu) | ((uint32_t)vy << 16), (uint32_t)MB_P16 | (0x80u << 8), 0u, 0u);   // i16_mode = 0x80: mark for k_tq / k_mvpred
                 m[1] = make_uint4(0u, 0u, 0u, 0u);
                 P.me_cost[mbi] = 0;
             }

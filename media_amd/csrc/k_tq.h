@@ -96,6 +96,99 @@ __device__ __forceinline__ uint32_t recon4(uint32_t pred, int r0, int r1, int r2
     return (uint32_t)a | ((uint32_t)b << 8) | ((uint32_t)c << 16) | ((uint32_t)e << 24);
 }
 
+// Chroma of 8 macroblocks first8 .. first8 + 7 in one pass, lane = (macroblock, plane, block); the four blocks of a plane are
+// a DPP quad.  cbpl / ybnd: coded_block_pattern bits and bit bound of the luma of THIS lane's macroblock (from the caller's
+// luma passes); t8: the luma went through the 8x8 transform (MbInfo.i16_mode of an inter macroblock = transform_size_8x8_flag).
+// Finishes the macroblock: coded_block_pattern, and the I_PCM fallback when the bit bound passes the limit of A.3.1.
+__device__ __forceinline__ void tq_chroma8(const FrameParams& P, const int first, const int end, const int lane, const int cs, const int csv,
+                                           const int cbpl, const int ybnd, const bool t8)
+{
+
+        const TqConst K = tq_consts(P.qc);
+        const int m8 = lane >> 3, pl = (lane >> 2) & 1, cb = lane & 3, mbi = first + m8;
+        bool act = mbi < end;
+        if (act) act = *(const uint16_t*)((const uint8_t*)P.mb + (uint32_t)(mbi * 32 + 4)) == (uint16_t)MB_P16;
+        int cnz = 0, ldc = 0, bb = 0;
+        if (act) {
+            const int my = P.mbdiv.row(mbi), mx = mbi - my * P.mbw;
+            const int x = 8 * mx + 4 * (cb & 1), y = 8 * my + 4 * (cb >> 1);
+            uint8_t* const cplane = pl ? P.rec[2] : P.rec[1];
+            uint32_t s4[4], p4[4], po[4];
+            po[0] = (uint32_t)__mul24(y, cs) + (uint32_t)x;
+#pragma unroll
+            for (int r = 1; r < 4; r++) po[r] = po[r - 1] + (uint32_t)csv;
+#pragma unroll
+            for (int r = 0; r < 4; r++) { p4[r] = *(const uint32_t*)(cplane + po[r]); s4[r] = src_chroma4(P, pl, x, y + r); }
+            int d[16];
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+#pragma unroll
+                for (int c = 0; c < 4; c++) d[4 * r + c] = (int)((s4[r] >> (8 * c)) & 255u) - (int)((p4[r] >> (8 * c)) & 255u);
+            uint32_t lvp[8];
+            // 8.5.11: the four DC terms of the plane (one per lane of the quad) through the 2x2 Hadamard, quantised at q + 1 with
+            // offset 2f, transformed back and scaled; lane cb keeps output cb of both transforms
+            const int sg1 = (cb & 1) ? -1 : 1, sg2 = (cb & 2) ? -1 : 1;
+            auto had2x2 = [&](int v) {
+                const int a = __builtin_amdgcn_mov_dpp(v, 0x00, 0xf, 0xf, false), b = __builtin_amdgcn_mov_dpp(v, 0x55, 0xf, 0xf, false);
+                const int c = __builtin_amdgcn_mov_dpp(v, 0xAA, 0xf, 0xf, false), e = __builtin_amdgcn_mov_dpp(v, 0xFF, 0xf, 0xf, false);
+                return a + sg1 * b + sg2 * (c + sg1 * e);
+            };
+            cnz = tq_block<true>(d, K, lvp, [&](int w0) {
+                const int fd = had2x2(w0);
+                ldc = quant_signed(fd, K.mf[0], 2 * K.f, 2 * K.c + 1, K.q + 1);   // 2^(q+1) - 1 - 2 (2f) = 2 c + 1
+                return (had2x2(ldc) * 16 * K.dq[0]) >> 5;
+            });
+            bb = blk_bits_bound_packed(lvp, cnz);
+            const uint32_t lb = (uint32_t)__mul24(mbi, LV_STRIDE * 2), lo = lb + (uint32_t)((LV_CHROMA_AC + (pl * 4 + cb) * 16) * 2);
+            *(uint4*)((uint8_t*)P.levels + lo) = make_uint4(lvp[0], lvp[1], lvp[2], lvp[3]);
+            *(uint4*)((uint8_t*)P.levels + lo + 16u) = make_uint4(lvp[4], lvp[5], lvp[6], lvp[7]);
+            *(int16_t*)((uint8_t*)P.levels + lb + (uint32_t)((LV_CHROMA_DC + pl * 4 + cb) * 2)) = (int16_t)ldc;
+#pragma unroll
+            for (int r = 0; r < 4; r++) *(uint32_t*)(cplane + po[r]) = recon4(p4[r], d[4 * r], d[4 * r + 1], d[4 * r + 2], d[4 * r + 3]);
+            *((uint8_t*)P.mb + (uint32_t)(mbi * 32 + 24 + pl * 4 + cb)) = (uint8_t)cnz;   // MbInfo.tc[16 + plane * 4 + block]
+        }
+        const unsigned long long acm = __ballot(cnz != 0), dcm = __ballot(ldc != 0);
+        // bit bound of the macroblock: its 8 chroma AC blocks + the two DC blocks (four lanes of a quad each) + the luma part
+        unsigned long long pcm;
+        {
+            auto quad_red = [](int v, bool orop) {
+                int t = __builtin_amdgcn_mov_dpp(v, 0xB1, 0xf, 0xf, false);
+                v = orop ? (v | t) : (v + t);
+                t = __builtin_amdgcn_mov_dpp(v, 0x4E, 0xf, 0xf, false);
+                return orop ? (v | t) : (v + t);
+            };
+            const int adc = iabs(ldc), tcdc = quad_red(ldc != 0, false), h = pcm_smax((unsigned)quad_red(adc, true) | 1u) + 1;
+            const int dcb = tcdc ? quad_red(adc ? max(min(adc, 27), h) + 1 : 0, false) + pcm_blk_tail(tcdc) : 6;
+            const int csum = group_sum8_dpp(bb + (cb == 0 ? dcb : 0));
+            pcm = __ballot(act && (lane & 7) == 0 && MB_HEADER_BOUND + csum + ybnd > MB_BITS_LIMIT);
+        }
+        if (act && (lane & 7) == 0) {
+            const int cbpc = ((acm >> (8 * m8)) & 255ull) ? 2 : (((dcm >> (8 * m8)) & 255ull) ? 1 : 0);
+            *((uint8_t*)P.mb + (uint32_t)(mbi * 32 + 7)) = (uint8_t)(cbpl | (cbpc << 4));   // MbInfo.cbp
+            if (t8 && cbpl) *((uint8_t*)P.mb + (uint32_t)(mbi * 32 + 5)) = 1;                  // transform_size_8x8_flag
+        }
+        if (pcm) {   // wave-uniform and rare: re-write those macroblocks as I_PCM, the whole wave per macroblock
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's earlier stores to the same samples / bytes have landed
+            while (pcm) {
+                const int pm = first + ((__ffsll((long long)pcm) - 1) >> 3);
+                pcm &= pcm - 1;
+                const int py = P.mbdiv.row(pm), px = pm - py * P.mbw;
+                {
+                    const int row = lane >> 2, xs = (lane & 3) * 4, gx = 16 * px + xs, gy = 16 * py + row;
+                    *(uint32_t*)(P.rec[0] + (size_t)gy * P.cw + gx) = (uint32_t)src_px(P.src, P.w, P.h, gx, gy) | ((uint32_t)src_px(P.src, P.w, P.h, gx + 1, gy) << 8) |
+                                                                     ((uint32_t)src_px(P.src, P.w, P.h, gx + 2, gy) << 16) | ((uint32_t)src_px(P.src, P.w, P.h, gx + 3, gy) << 24);
+                }
+                if (lane < 32) {
+                    const int cp = lane >> 4, row = (lane >> 1) & 7, xs = (lane & 1) * 4;
+                    *(uint32_t*)((cp ? P.rec[2] : P.rec[1]) + (size_t)(8 * py + row) * cs + 8 * px + xs) = src_chroma4(P, cp, 8 * px + xs, 8 * py + row);
+                }
+                if (lane < 6) ((uint32_t*)(P.mb + pm))[2 + lane] = 0x10101010u;                      // TotalCoeff 16 everywhere (9.2.1)
+                if (lane == 6) *(uint2*)(P.mb + pm) = make_uint2(0u, (uint32_t)MB_IPCM | (0x2Fu << 24));   // no vector, type, coded_block_pattern 47
+            }
+            if (lane == 0) *P.anypcm = P.pic_serial;
+        }
+}
+
 __global__ __launch_bounds__(64) void k_tq(FrameParams P0)
 {
     __builtin_amdgcn_s_setprio(2);   // short and on the way to the loop filter: ahead of another stream's motion search
@@ -161,93 +254,168 @@ __global__ __launch_bounds__(64) void k_tq(FrameParams P0)
         }
     }
 
-    // ---- chroma of the 8 macroblocks in one pass, lane = (macroblock, plane, block); the four blocks of a plane are a DPP quad ----
+    // ---- chroma of the 8 macroblocks + coded_block_pattern + I_PCM fallback ----
     {
-        const TqConst K = tq_consts(P.qc);
-        const int m8 = lane >> 3, pl = (lane >> 2) & 1, cb = lane & 3, mbi = first + m8;
+        const int m8 = lane >> 3;
+        const unsigned m16 = (unsigned)(ymask[m8 >> 2] >> (16 * (m8 & 3))) & 0xFFFFu;
+        const int cbpl = ((m16 & 0x000Fu) ? 1 : 0) | ((m16 & 0x00F0u) ? 2 : 0) | ((m16 & 0x0F00u) ? 4 : 0) | ((m16 & 0xF000u) ? 8 : 0);
+        const int y0 = __shfl(ybound[0], 16 * (m8 & 3)), y1 = __shfl(ybound[1], 16 * (m8 & 3));
+        tq_chroma8(P, first, end, lane, cs, csv, cbpl, m8 < 4 ? y0 : y1, false);
+    }
+}
+
+
+// ===========================================================================
+// High profile: the luma residual of inter macroblocks through the 8x8 transform (8.5.13; transform_8x8_mode_flag = 1).
+// lane = ONE 8x8 block with all 64 samples in registers (both passes of the transforms in-lane, as in k_tq); a wave codes
+// SIXTEEN macroblocks: one luma pass (16 macroblocks x 4 blocks) and two chroma passes of 8 macroblocks (4x4 transform,
+// tq_chroma8).  The 64 levels leave as the four interleaved 4x4 lists CAVLC wants (7.3.5.3.2: level i of list k = level
+// 4 i + k of the 8x8 zig-zag scan), stored where the quadrant's 4x4 lists live: TotalCoeff, nC, the bit bound and the entropy
+// coder need no special case.  Oracle: oracle/h264_enc.c encode_inter_mb (profile_idc 100).
+// ===========================================================================
+template <int S>
+__device__ __forceinline__ void fdct8_line(int* d)   // elements d[0], d[S], .. d[7 S], in place (reference-model forward butterfly)
+{
+    const int s07 = d[0] + d[7 * S], s16 = d[S] + d[6 * S], s25 = d[2 * S] + d[5 * S], s34 = d[3 * S] + d[4 * S];
+    const int a0 = s07 + s34, a1 = s16 + s25, a2 = s07 - s34, a3 = s16 - s25;
+    const int d07 = d[0] - d[7 * S], d16 = d[S] - d[6 * S], d25 = d[2 * S] - d[5 * S], d34 = d[3 * S] - d[4 * S];
+    const int a4 = d16 + d25 + (d07 + (d07 >> 1)), a5 = d07 - d34 - (d25 + (d25 >> 1));
+    const int a6 = d07 + d34 - (d16 + (d16 >> 1)), a7 = d16 - d25 + (d34 + (d34 >> 1));
+    d[0] = a0 + a1; d[S] = a4 + (a7 >> 2); d[2 * S] = a2 + (a3 >> 1); d[3 * S] = a5 + (a6 >> 2);
+    d[4 * S] = a0 - a1; d[5 * S] = a6 - (a5 >> 2); d[6 * S] = (a2 >> 1) - a3; d[7 * S] = (a4 >> 2) - a7;
+}
+template <int S>
+__device__ __forceinline__ void idct8_line(int* d)   // 8.5.13, one dimension, in place
+{
+    const int a0 = d[0] + d[4 * S], a2 = d[0] - d[4 * S], a4 = (d[2 * S] >> 1) - d[6 * S], a6 = d[2 * S] + (d[6 * S] >> 1);
+    const int b0 = a0 + a6, b2 = a2 + a4, b4 = a2 - a4, b6 = a0 - a6;
+    const int a1 = -d[3 * S] + d[5 * S] - d[7 * S] - (d[7 * S] >> 1), a3 = d[S] + d[7 * S] - d[3 * S] - (d[3 * S] >> 1);
+    const int a5 = -d[S] + d[7 * S] + d[5 * S] + (d[5 * S] >> 1), a7 = d[3 * S] + d[5 * S] + d[S] + (d[S] >> 1);
+    const int b1 = a1 + (a7 >> 2), b3 = a3 + (a5 >> 2), b5 = (a3 >> 2) - a5, b7 = a7 - (a1 >> 2);
+    d[0] = b0 + b7; d[S] = b2 + b5; d[2 * S] = b4 + b3; d[3 * S] = b6 + b1;
+    d[4 * S] = b6 - b1; d[5 * S] = b4 - b3; d[6 * S] = b2 - b5; d[7 * S] = b0 - b7;
+}
+__device__ constexpr int pos_class8(int pos)
+{
+    const int i = pos >> 3, j = pos & 7;
+    return (i % 4 == 0 && j % 4 == 0) ? 0 : ((i & 1) && (j & 1)) ? 1 : (i % 4 == 2 && j % 4 == 2) ? 2
+         : ((i % 4 == 0 && (j & 1)) || ((i & 1) && j % 4 == 0)) ? 3 : ((i % 4 == 0 && j % 4 == 2) || (i % 4 == 2 && j % 4 == 0)) ? 4 : 5;
+}
+
+__global__ __launch_bounds__(64) void k_tq8(FrameParams P0)
+{
+    __builtin_amdgcn_s_setprio(2);
+    const FrameParams P = batch_view(P0, blockIdx.y);
+    const int lane = threadIdx.x;
+    const int nmb = P.mbw * P.band.rows, mb0 = P.band.row0 * P.mbw, end = mb0 + nmb;
+    const int first = mb0 + 16 * xcd_mb_index(blockIdx.x, (nmb + 15) >> 4);
+    const int cs = P.cw >> 1;
+    const bool src_al = ((P.w | (int)(uintptr_t)P.src) & 3) == 0;
+    const int cwv = vreg(P.cw), wv = vreg(P.w), csv = vreg(cs);
+    unsigned long long ymask;
+    int ybound;
+    {
+        constexpr int ZZ8[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6,  7,  14, 21, 28,
+                                 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+        int mf[6], ls[6];
+#pragma unroll
+        for (int c = 0; c < 6; c++) { mf[c] = vreg(P.qy.mf8[c]); ls[c] = vreg(P.qy.ls8[c]); }
+        const int q8 = P.qy.qbits + 1;                                   // 16 + qp / 6
+        const int f8 = vreg((1 << q8) / 6), c8 = vreg((1 << q8) - 1 - 2 * ((1 << q8) / 6)), q8v = vreg(q8);
+        const int qp6 = P.qy.qp / 6;
+        const int b8 = lane & 3, mbi = first + (lane >> 2);
         bool act = mbi < end;
         if (act) act = *(const uint16_t*)((const uint8_t*)P.mb + (uint32_t)(mbi * 32 + 4)) == (uint16_t)MB_P16;
-        int cnz = 0, ldc = 0, bb = 0;
+        int nzany = 0, bb = 0;
         if (act) {
             const int my = P.mbdiv.row(mbi), mx = mbi - my * P.mbw;
-            const int x = 8 * mx + 4 * (cb & 1), y = 8 * my + 4 * (cb >> 1);
-            uint8_t* const cplane = pl ? P.rec[2] : P.rec[1];
-            uint32_t s4[4], p4[4], po[4];
-            po[0] = (uint32_t)__mul24(y, cs) + (uint32_t)x;
+            const int x = 16 * mx + 8 * (b8 & 1), y = 16 * my + 8 * (b8 >> 1);
+            uint32_t po[8], p8[16], s8[16];
+            po[0] = (uint32_t)__mul24(y, P.cw) + (uint32_t)x;
 #pragma unroll
-            for (int r = 1; r < 4; r++) po[r] = po[r - 1] + (uint32_t)csv;
+            for (int r = 1; r < 8; r++) po[r] = po[r - 1] + (uint32_t)cwv;
 #pragma unroll
-            for (int r = 0; r < 4; r++) { p4[r] = *(const uint32_t*)(cplane + po[r]); s4[r] = src_chroma4(P, pl, x, y + r); }
-            int d[16];
+            for (int r = 0; r < 8; r++) { p8[2 * r] = *(const uint32_t*)(P.rec[0] + po[r]); p8[2 * r + 1] = *(const uint32_t*)(P.rec[0] + po[r] + 4u); }
+            if (src_al && x + 7 < P.w) {
+                const uint32_t omax = (uint32_t)__mul24(P.h - 1, P.w) + (uint32_t)x;
+                uint32_t o = (uint32_t)__mul24(y, P.w) + (uint32_t)x;
 #pragma unroll
-            for (int r = 0; r < 4; r++)
-#pragma unroll
-                for (int c = 0; c < 4; c++) d[4 * r + c] = (int)((s4[r] >> (8 * c)) & 255u) - (int)((p4[r] >> (8 * c)) & 255u);
-            uint32_t lvp[8];
-            // 8.5.11: the four DC terms of the plane (one per lane of the quad) through the 2x2 Hadamard, quantised at q + 1 with
-            // offset 2f, transformed back and scaled; lane cb keeps output cb of both transforms
-            const int sg1 = (cb & 1) ? -1 : 1, sg2 = (cb & 2) ? -1 : 1;
-            auto had2x2 = [&](int v) {
-                const int a = __builtin_amdgcn_mov_dpp(v, 0x00, 0xf, 0xf, false), b = __builtin_amdgcn_mov_dpp(v, 0x55, 0xf, 0xf, false);
-                const int c = __builtin_amdgcn_mov_dpp(v, 0xAA, 0xf, 0xf, false), e = __builtin_amdgcn_mov_dpp(v, 0xFF, 0xf, 0xf, false);
-                return a + sg1 * b + sg2 * (c + sg1 * e);
-            };
-            cnz = tq_block<true>(d, K, lvp, [&](int w0) {
-                const int fd = had2x2(w0);
-                ldc = quant_signed(fd, K.mf[0], 2 * K.f, 2 * K.c + 1, K.q + 1);   // 2^(q+1) - 1 - 2 (2f) = 2 c + 1
-                return (had2x2(ldc) * 16 * K.dq[0]) >> 5;
-            });
-            bb = blk_bits_bound_packed(lvp, cnz);
-            const uint32_t lb = (uint32_t)__mul24(mbi, LV_STRIDE * 2), lo = lb + (uint32_t)((LV_CHROMA_AC + (pl * 4 + cb) * 16) * 2);
-            *(uint4*)((uint8_t*)P.levels + lo) = make_uint4(lvp[0], lvp[1], lvp[2], lvp[3]);
-            *(uint4*)((uint8_t*)P.levels + lo + 16u) = make_uint4(lvp[4], lvp[5], lvp[6], lvp[7]);
-            *(int16_t*)((uint8_t*)P.levels + lb + (uint32_t)((LV_CHROMA_DC + pl * 4 + cb) * 2)) = (int16_t)ldc;
-#pragma unroll
-            for (int r = 0; r < 4; r++) *(uint32_t*)(cplane + po[r]) = recon4(p4[r], d[4 * r], d[4 * r + 1], d[4 * r + 2], d[4 * r + 3]);
-            *((uint8_t*)P.mb + (uint32_t)(mbi * 32 + 24 + pl * 4 + cb)) = (uint8_t)cnz;   // MbInfo.tc[16 + plane * 4 + block]
-        }
-        const unsigned long long acm = __ballot(cnz != 0), dcm = __ballot(ldc != 0);
-        // bit bound of the macroblock: its 8 chroma AC blocks + the two DC blocks (four lanes of a quad each) + the luma part
-        unsigned long long pcm;
-        {
-            auto quad_red = [](int v, bool orop) {
-                int t = __builtin_amdgcn_mov_dpp(v, 0xB1, 0xf, 0xf, false);
-                v = orop ? (v | t) : (v + t);
-                t = __builtin_amdgcn_mov_dpp(v, 0x4E, 0xf, 0xf, false);
-                return orop ? (v | t) : (v + t);
-            };
-            const int adc = iabs(ldc), tcdc = quad_red(ldc != 0, false), h = pcm_smax((unsigned)quad_red(adc, true) | 1u) + 1;
-            const int dcb = tcdc ? quad_red(adc ? max(min(adc, 27), h) + 1 : 0, false) + pcm_blk_tail(tcdc) : 6;
-            const int csum = group_sum8_dpp(bb + (cb == 0 ? dcb : 0));
-            const int y0 = __shfl(ybound[0], 16 * (m8 & 3)), y1 = __shfl(ybound[1], 16 * (m8 & 3));
-            pcm = __ballot(act && (lane & 7) == 0 && MB_HEADER_BOUND + csum + (m8 < 4 ? y0 : y1) > MB_BITS_LIMIT);
-        }
-        if (act && (lane & 7) == 0) {
-            const unsigned m16 = (unsigned)(ymask[m8 >> 2] >> (16 * (m8 & 3))) & 0xFFFFu;
-            const int cbpl = ((m16 & 0x000Fu) ? 1 : 0) | ((m16 & 0x00F0u) ? 2 : 0) | ((m16 & 0x0F00u) ? 4 : 0) | ((m16 & 0xF000u) ? 8 : 0);
-            const int cbpc = ((acm >> (8 * m8)) & 255ull) ? 2 : (((dcm >> (8 * m8)) & 255ull) ? 1 : 0);
-            *((uint8_t*)P.mb + (uint32_t)(mbi * 32 + 7)) = (uint8_t)(cbpl | (cbpc << 4));   // MbInfo.cbp
-        }
-        if (pcm) {   // wave-uniform and rare: re-write those macroblocks as I_PCM, the whole wave per macroblock
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's earlier stores to the same samples / bytes have landed
-            while (pcm) {
-                const int pm = first + ((__ffsll((long long)pcm) - 1) >> 3);
-                pcm &= pcm - 1;
-                const int py = P.mbdiv.row(pm), px = pm - py * P.mbw;
-                {
-                    const int row = lane >> 2, xs = (lane & 3) * 4, gx = 16 * px + xs, gy = 16 * py + row;
-                    *(uint32_t*)(P.rec[0] + (size_t)gy * P.cw + gx) = (uint32_t)src_px(P.src, P.w, P.h, gx, gy) | ((uint32_t)src_px(P.src, P.w, P.h, gx + 1, gy) << 8) |
-                                                                     ((uint32_t)src_px(P.src, P.w, P.h, gx + 2, gy) << 16) | ((uint32_t)src_px(P.src, P.w, P.h, gx + 3, gy) << 24);
+                for (int r = 0; r < 8; r++) {
+                    const uint32_t oo = min(o, omax);
+                    s8[2 * r] = *(const uint32_t*)(P.src + oo); s8[2 * r + 1] = *(const uint32_t*)(P.src + oo + 4u);
+                    o += (uint32_t)wv;
                 }
-                if (lane < 32) {
-                    const int cp = lane >> 4, row = (lane >> 1) & 7, xs = (lane & 1) * 4;
-                    *(uint32_t*)((cp ? P.rec[2] : P.rec[1]) + (size_t)(8 * py + row) * cs + 8 * px + xs) = src_chroma4(P, cp, 8 * px + xs, 8 * py + row);
-                }
-                if (lane < 6) ((uint32_t*)(P.mb + pm))[2 + lane] = 0x10101010u;                      // TotalCoeff 16 everywhere (9.2.1)
-                if (lane == 6) *(uint2*)(P.mb + pm) = make_uint2(0u, (uint32_t)MB_IPCM | (0x2Fu << 24));   // no vector, type, coded_block_pattern 47
+            } else {
+#pragma unroll
+                for (int r = 0; r < 8; r++)
+#pragma unroll
+                    for (int hh = 0; hh < 2; hh++)
+                        s8[2 * r + hh] = (uint32_t)src_px(P.src, P.w, P.h, x + 4 * hh, y + r) | ((uint32_t)src_px(P.src, P.w, P.h, x + 4 * hh + 1, y + r) << 8) |
+                                         ((uint32_t)src_px(P.src, P.w, P.h, x + 4 * hh + 2, y + r) << 16) | ((uint32_t)src_px(P.src, P.w, P.h, x + 4 * hh + 3, y + r) << 24);
             }
-            if (lane == 0) *P.anypcm = P.pic_serial;
+            int d[64];
+#pragma unroll
+            for (int i = 0; i < 64; i++) d[i] = (int)((s8[i >> 2] >> (8 * (i & 3))) & 255u) - (int)((p8[i >> 2] >> (8 * (i & 3))) & 255u);
+#pragma unroll
+            for (int r = 0; r < 8; r++) fdct8_line<1>(d + 8 * r);
+#pragma unroll
+            for (int c = 0; c < 8; c++) fdct8_line<8>(d + c);
+            // quantise (signed form, see quant_signed) and scale (8.5.13) in place; l[] keeps the levels for the lists
+            int l[64];
+#pragma unroll
+            for (int i = 0; i < 64; i++) {
+                constexpr int dummy = 0; (void)dummy;
+                const int cls = pos_class8(i);
+                const int w = d[i], sg = w >> 31;
+                l[i] = (w * mf[cls] + (f8 + (sg & c8))) >> q8v;
+                const int t = l[i] * ls[cls];
+                d[i] = qp6 >= 6 ? t << (qp6 - 6) : (t + (1 << (5 - qp6))) >> (6 - qp6);
+            }
+            uint32_t lvp[32];
+            int tcs[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                uint32_t cnt2 = 0;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const uint32_t pk = ((uint32_t)l[ZZ8[4 * (2 * j) + k]] & 0xFFFFu) | ((uint32_t)l[ZZ8[4 * (2 * j + 1) + k]] << 16);
+                    lvp[8 * k + j] = pk;
+                    const uint32_t t = pk | ((pk & 0x7FFF7FFFu) + 0x7FFF7FFFu);
+                    cnt2 += (t >> 15) & 0x00010001u;
+                }
+                tcs[k] = (int)((cnt2 & 0xFFFFu) + (cnt2 >> 16));
+                bb += blk_bits_bound_packed(lvp + 8 * k, tcs[k]);
+                nzany |= tcs[k];
+            }
+            const uint32_t lo = (uint32_t)__mul24(mbi, LV_STRIDE * 2) + (uint32_t)((LV_LUMA + b8 * 64) * 2);
+#pragma unroll
+            for (int j = 0; j < 8; j++) *(uint4*)((uint8_t*)P.levels + lo + 16u * j) = make_uint4(lvp[4 * j], lvp[4 * j + 1], lvp[4 * j + 2], lvp[4 * j + 3]);
+            *(uint32_t*)((uint8_t*)P.mb + (uint32_t)(mbi * 32 + 8 + 4 * b8)) = (uint32_t)tcs[0] | ((uint32_t)tcs[1] << 8) | ((uint32_t)tcs[2] << 16) | ((uint32_t)tcs[3] << 24);   // MbInfo.tc[4 b8 ..]
+            if (nzany) {   // (an 8x8 block without levels reconstructs to the prediction: nothing to store)
+#pragma unroll
+                for (int r = 0; r < 8; r++) idct8_line<1>(d + 8 * r);
+#pragma unroll
+                for (int c = 0; c < 8; c++) idct8_line<8>(d + c);
+#pragma unroll
+                for (int r = 0; r < 8; r++) {
+                    int* e = d + 8 * r;
+                    *(uint32_t*)(P.rec[0] + po[r]) = recon4(p8[2 * r], (e[0] + 32) >> 6, (e[1] + 32) >> 6, (e[2] + 32) >> 6, (e[3] + 32) >> 6);
+                    *(uint32_t*)(P.rec[0] + po[r] + 4u) = recon4(p8[2 * r + 1], (e[4] + 32) >> 6, (e[5] + 32) >> 6, (e[6] + 32) >> 6, (e[7] + 32) >> 6);
+                }
+            }
         }
+        ymask = __ballot(nzany != 0);
+        int t = bb;   // bit bound of the macroblock's luma = sum over its quad
+        t += __builtin_amdgcn_mov_dpp(t, 0xB1, 0xf, 0xf, false);
+        t += __builtin_amdgcn_mov_dpp(t, 0x4E, 0xf, 0xf, false);
+        ybound = t;
+    }
+#pragma unroll 1
+    for (int c = 0; c < 2; c++) {
+        const int m = 8 * c + (lane >> 3);
+        const int cbpl = (int)((ymask >> (4 * m)) & 15ull);
+        const int yb = __shfl(ybound, 4 * m);
+        tq_chroma8(P, first + 8 * c, end, lane, cs, csv, cbpl, yb, true);
     }
 }
 
@@ -290,7 +458,8 @@ __global__ __launch_bounds__(64) void k_mvpred(FrameParams P0)
     const Mv skip = zero_skip ? Mv{0, 0} : p;
     const int mvx = (int)(int16_t)(self.x & 0xFFFFu), mvy = (int)(int16_t)(self.x >> 16), cbp = (int)(self.y >> 24);
     const int type = (cbp == 0 && skip.x == mvx && skip.y == mvy) ? MB_PSKIP : MB_P16;
-    *(uint16_t*)((uint8_t*)(P.mb + mbi) + 4) = (uint16_t)type;   // type, i16_mode = 0
+    // type; i16_mode keeps transform_size_8x8_flag (bit 0, k_tq8), k_me's "nothing to code" mark (0x80) goes
+    *(uint16_t*)((uint8_t*)(P.mb + mbi) + 4) = (uint16_t)((unsigned)type | (type == MB_P16 ? ((self.y >> 8) & 1u) << 8 : 0u));
     *(uint32_t*)(P.mvd + 2 * mbi) = (uint32_t)((mvx - p.x) & 0xFFFF) | ((uint32_t)(mvy - p.y) << 16);
 }
 

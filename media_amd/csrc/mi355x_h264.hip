@@ -117,6 +117,12 @@ void fill_quant(Quant& q, int qp)
         q.thr_inter[c] = (int)((((int64_t)1 << q.qbits) - q.f_inter + q.mf[c] - 1) / q.mf[c]);
     }
     q.thr_dc_inter = (int)((((int64_t)1 << (q.qbits + 1)) - 2 * (int64_t)q.f_inter + q.mf[0] - 1) / q.mf[0]);
+    static const uint8_t v8[6][6] = {{20, 18, 32, 19, 25, 24}, {22, 19, 35, 21, 28, 26}, {26, 23, 42, 24, 33, 31},
+                                     {28, 25, 45, 26, 35, 33}, {32, 28, 51, 30, 40, 38}, {36, 32, 58, 34, 46, 43}};
+    static const uint16_t m8[6][6] = {{13107, 11428, 20972, 12222, 16777, 15481}, {11916, 10826, 19174, 11058, 14980, 14290},
+                                      {10082, 8943, 15978, 9675, 12710, 11985},   {9362, 8228, 14913, 8931, 11984, 11259},
+                                      {8192, 7346, 13159, 7740, 10486, 9777},     {7282, 6428, 11570, 6830, 9118, 8640}};
+    for (int c = 0; c < 6; c++) { q.mf8[c] = m8[qp % 6][c]; q.ls8[c] = 16 * v8[qp % 6][c]; }
 }
 
 constexpr int NSLOT = 3;          // access-unit slots in flight
@@ -240,7 +246,7 @@ void build_parameter_sets(mi355x_h264_encoder* e)
     p.se(0); p.se(0); p.se(0);
     p.put(1, 1);  // deblocking_filter_control_present_flag
     p.put(1, 0); p.put(1, 0);
-    if (prof == 100) { p.put(1, 0); p.put(1, 0); p.se(0); }
+    if (prof == 100) { p.put(1, 1); p.put(1, 0); p.se(0); }   // transform_8x8_mode_flag = 1: inter macroblocks use the 8x8 transform (k_tq8)
     p.trailing();
     e->sps_pps.clear();
     append_nal(e->sps_pps, 3, 7, s);
@@ -337,7 +343,8 @@ int submit(mi355x_h264_encoder* e, const uint8_t* d_src, size_t src_item_stride,
         { StatScope sc(e, &S, MI355X_H264_K_ME, 1, (uint32_t)(e->b_nmb * e->G));
           hipLaunchKernelGGL(k_me, dim3(e->b_nmb, G), dim3(64), 0, st, P); }
         { StatScope sc(e, &S, MI355X_H264_K_PMB, 1, (uint32_t)(e->b_nmb * e->G));
-          hipLaunchKernelGGL(k_tq, dim3((e->b_nmb + 7) / 8, G), dim3(64), 0, st, P); }   // one wave per eight macroblocks
+          if (e->cfg.profile_idc == 100) hipLaunchKernelGGL(k_tq8, dim3((e->b_nmb + 15) / 16, G), dim3(64), 0, st, P);   // High: 8x8 transform, sixteen macroblocks per wave
+          else hipLaunchKernelGGL(k_tq, dim3((e->b_nmb + 7) / 8, G), dim3(64), 0, st, P); }   // one wave per eight macroblocks
         {   // macroblocks the motion search handed to the intra pass (returns at once when there are none)
             IntraRowParams R{};
             R.p = P; R.handoff = e->d_handoff; R.st_handoff = e->st_handoff; R.err = S.h_err;
@@ -359,7 +366,7 @@ int submit(mi355x_h264_encoder* e, const uint8_t* d_src, size_t src_item_stride,
     // (a small launch of its own on this stream): the two run side by side and the filter never waits for the coder
     hipStream_t ec = e->stream_ec;
     CavlcParams C{};
-    C.mb = e->d_mb; C.levels = e->d_levels; C.mvd = e->d_mvd; C.mbw = e->mbw; C.nmb = e->nmb; C.p_slice = idr ? 0 : 1; C.sl = e->sl;
+    C.mb = e->d_mb; C.levels = e->d_levels; C.mvd = e->d_mvd; C.mbw = e->mbw; C.nmb = e->nmb; C.p_slice = idr ? 0 : 1; C.t8x8 = e->cfg.profile_idc == 100 ? 1 : 0; C.sl = e->sl;
     C.mb_first = e->b_row0 * e->mbw; C.mb_end = C.mb_first + e->b_nmb;
     C.slice_cap = (unsigned)e->slice_cap;
     C.mbdiv = P.mbdiv;

@@ -92,6 +92,79 @@ void h264o_dequant4x4(const int16_t lv[16], int qp, int16_t out[16])
     for (int i = 0; i < 16; i++) out[i] = (int16_t)((lv[i] * o_dequant_v[qp % 6][o_pos_class(i)]) << (qp / 6));
 }
 
+/* ---------------------------------------------------------------- 8x8 transform (High profile) */
+/* forward 8x8 integer transform (the reference model's butterfly, the transpose of 8.5.13's inverse up to scaling) */
+static void fdct8_1d(const int in[8], int out[8])
+{
+    const int s07 = in[0] + in[7], s16 = in[1] + in[6], s25 = in[2] + in[5], s34 = in[3] + in[4];
+    const int a0 = s07 + s34, a1 = s16 + s25, a2 = s07 - s34, a3 = s16 - s25;
+    const int d07 = in[0] - in[7], d16 = in[1] - in[6], d25 = in[2] - in[5], d34 = in[3] - in[4];
+    const int a4 = d16 + d25 + (d07 + (d07 >> 1)), a5 = d07 - d34 - (d25 + (d25 >> 1));
+    const int a6 = d07 + d34 - (d16 + (d16 >> 1)), a7 = d16 - d25 + (d34 + (d34 >> 1));
+    out[0] = a0 + a1; out[1] = a4 + (a7 >> 2); out[2] = a2 + (a3 >> 1); out[3] = a5 + (a6 >> 2);
+    out[4] = a0 - a1; out[5] = a6 - (a5 >> 2); out[6] = (a2 >> 1) - a3; out[7] = (a4 >> 2) - a7;
+}
+void h264o_fdct8x8(const int16_t in[64], int32_t out[64])
+{
+    int t[64];
+    for (int i = 0; i < 8; i++) {
+        int r[8], o[8];
+        for (int j = 0; j < 8; j++) r[j] = in[8 * i + j];
+        fdct8_1d(r, o);
+        for (int j = 0; j < 8; j++) t[8 * i + j] = o[j];
+    }
+    for (int j = 0; j < 8; j++) {
+        int c[8], o[8];
+        for (int i = 0; i < 8; i++) c[i] = t[8 * i + j];
+        fdct8_1d(c, o);
+        for (int i = 0; i < 8; i++) out[8 * i + j] = o[i];
+    }
+}
+void h264o_quant8x8(const int32_t w[64], int qp, int intra, int16_t lv[64])
+{
+    int qbits = 16 + qp / 6;
+    int f = (1 << qbits) / (intra ? 3 : 6);
+    for (int i = 0; i < 64; i++) {
+        int64_t a = w[i] < 0 ? -w[i] : w[i];
+        int l = (int)((a * o_quant8_mf[qp % 6][o_pos_class8(i)] + f) >> qbits);
+        lv[i] = (int16_t)(w[i] < 0 ? -l : l);
+    }
+}
+/* 8.5.13 scaling with flat weights 16 */
+void h264o_dequant8x8(const int16_t lv[64], int qp, int32_t out[64])
+{
+    for (int i = 0; i < 64; i++) {
+        int ls = 16 * o_dequant8_v[qp % 6][o_pos_class8(i)];
+        out[i] = qp >= 36 ? (lv[i] * ls) << (qp / 6 - 6) : (lv[i] * ls + (1 << (5 - qp / 6))) >> (6 - qp / 6);
+    }
+}
+static void idct8_1d(const int in[8], int out[8])
+{
+    const int a0 = in[0] + in[4], a2 = in[0] - in[4], a4 = (in[2] >> 1) - in[6], a6 = in[2] + (in[6] >> 1);
+    const int b0 = a0 + a6, b2 = a2 + a4, b4 = a2 - a4, b6 = a0 - a6;
+    const int a1 = -in[3] + in[5] - in[7] - (in[7] >> 1), a3 = in[1] + in[7] - in[3] - (in[3] >> 1);
+    const int a5 = -in[1] + in[7] + in[5] + (in[5] >> 1), a7 = in[3] + in[5] + in[1] + (in[1] >> 1);
+    const int b1 = a1 + (a7 >> 2), b3 = a3 + (a5 >> 2), b5 = (a3 >> 2) - a5, b7 = a7 - (a1 >> 2);
+    out[0] = b0 + b7; out[1] = b2 + b5; out[2] = b4 + b3; out[3] = b6 + b1;
+    out[4] = b6 - b1; out[5] = b4 - b3; out[6] = b2 - b5; out[7] = b0 - b7;
+}
+void h264o_idct8x8_add(const int32_t coef[64], uint8_t *dst, int stride)
+{
+    int t[64];
+    for (int i = 0; i < 8; i++) {
+        int r[8], o[8];
+        for (int j = 0; j < 8; j++) r[j] = coef[8 * i + j];
+        idct8_1d(r, o);
+        for (int j = 0; j < 8; j++) t[8 * i + j] = o[j];
+    }
+    for (int j = 0; j < 8; j++) {
+        int c[8], o[8];
+        for (int i = 0; i < 8; i++) c[i] = t[8 * i + j];
+        idct8_1d(c, o);
+        for (int i = 0; i < 8; i++) dst[i * stride + j] = clip1(dst[i * stride + j] + ((o[i] + 32) >> 6));
+    }
+}
+
 /* ---------------------------------------------------------------- SAD / SATD */
 int h264o_sad16x16(const uint8_t *a, int as, const uint8_t *b, int bs)
 {
@@ -390,11 +463,20 @@ static void filter_line(uint8_t *pix, int xs, int bS, int alpha, int beta, int t
 
 /* boundary strength between 4x4 block bq of macroblock q and bp of macroblock p
  * (8.7.2.1, frame pictures, single reference, one motion vector per MB) */
+/* transform_size_8x8_flag of an inter macroblock rides in i16_mode (unused there); its residual blocks are 8x8: "contains
+ * non-zero coefficients" (8.7.2.1) then refers to the 8x8 block, i.e. to the four interleaved 4x4 lists of the quadrant */
+static int mb_t8x8(const h264o_mbinfo *m) { return m->type == H264O_MB_P16 && m->i16_mode == 1; }
+static int blk_nonzero(const h264o_mbinfo *m, int blk)
+{
+    if (!mb_t8x8(m)) return m->tc[blk] != 0;
+    int q = blk & ~3;
+    return (m->tc[q] | m->tc[q + 1] | m->tc[q + 2] | m->tc[q + 3]) != 0;
+}
 static int edge_bs(const h264o_mbinfo *p, int bp, const h264o_mbinfo *q, int bq, int mb_edge)
 {
     int pi = p->type == H264O_MB_I16 || p->type == H264O_MB_IPCM, qi = q->type == H264O_MB_I16 || q->type == H264O_MB_IPCM;
     if (pi || qi) return mb_edge ? 4 : 3;
-    if (p->tc[bp] || q->tc[bq]) return 2;
+    if (blk_nonzero(p, bp) || blk_nonzero(q, bq)) return 2;
     if (abs(p->mvx - q->mvx) >= 4 || abs(p->mvy - q->mvy) >= 4) return 1;
     return 0;
 }
@@ -416,6 +498,7 @@ void h264o_deblock_picture(uint8_t *Y, uint8_t *U, uint8_t *V, int cw, int ch,
             /* vertical edges, left to right */
             for (int e = 0; e < 4; e++) {
                 if (e == 0 && mx == 0) continue;
+                if ((e & 1) && mb_t8x8(q)) continue;   /* 8x8 transform: no 4x4-internal edges */
                 /* disable_deblocking_filter_idc 2: edges between slices stay unfiltered (slice_of given) */
                 if (e == 0 && slice_of && slice_of[my * mbw + mx] != slice_of[my * mbw + mx - 1]) continue;
                 const h264o_mbinfo *p = e == 0 ? q - 1 : q;
@@ -437,6 +520,7 @@ void h264o_deblock_picture(uint8_t *Y, uint8_t *U, uint8_t *V, int cw, int ch,
             /* horizontal edges, top to bottom */
             for (int e = 0; e < 4; e++) {
                 if (e == 0 && my == 0) continue;
+                if ((e & 1) && mb_t8x8(q)) continue;
                 if (e == 0 && slice_of && slice_of[my * mbw + mx] != slice_of[(my - 1) * mbw + mx]) continue;
                 const h264o_mbinfo *p = e == 0 ? q - mbw : q;
                 for (int c = 0; c < 4; c++) {

@@ -169,7 +169,9 @@ struct h264o_enc {
     int64_t last_slice_bits;
     uint32_t me_cost; /* scene-change statistic of the last picture */
     int any_pcm;      /* the picture being coded holds an I_PCM macroblock: it is not loop-filtered */
-    uint8_t *want_intra;   /* P pictures: macroblocks the motion search handed to the intra pass */
+    uint8_t *want_intra;   /* P pictures: 1 = the motion search handed the macroblock to the intra pass; 2 = one of the "nothing
+                            * left to code" tests hit: the prediction is the reconstruction, no transform is run (the tests use
+                            * the 4x4 transform whatever transform the profile codes with) */
 };
 
 static int pick_level(int mbs, int fps)
@@ -344,7 +346,7 @@ static void write_pps(h264o_enc *e, bitw *b)
     bw_put(b, 1, 0); /* constrained_intra_pred_flag */
     bw_put(b, 1, 0); /* redundant_pic_cnt_present_flag */
     if (e->cfg.profile_idc == 100) {
-        bw_put(b, 1, 0); /* transform_8x8_mode_flag */
+        bw_put(b, 1, 1); /* transform_8x8_mode_flag: inter macroblocks use the 8x8 transform */
         bw_put(b, 1, 0); /* pic_scaling_matrix_present_flag */
         bw_se(b, 0);     /* second_chroma_qp_index_offset */
     }
@@ -798,6 +800,46 @@ static void encode_inter_mb(h264o_enc *e, int mx, int my)
     uint8_t *r = e->rec[0] + (16 * my) * cw + 16 * mx;
     int cbp = 0;
     for (int y = 0; y < 16; y++) memcpy(r + y * cw, pred + 16 * y, 16);
+    if (e->want_intra[my * e->mbw + mx] == 2) {   /* nothing left to code: prediction = reconstruction */
+        for (int pl = 0; pl < 2; pl++)
+            for (int y = 0; y < 8; y++) memcpy(e->rec[1 + pl] + (8 * my + y) * cs + 8 * mx, predc[pl] + 8 * y, 8);
+        mb->cbp = 0;
+        mv_t skip0;
+        predict_mv(e, mx, my, &skip0);
+        mb->type = (skip0.x == mb->mvx && skip0.y == mb->mvy) ? H264O_MB_PSKIP : H264O_MB_P16;
+        mb->i16_mode = mb->chroma_mode = 0;
+        return;
+    }
+    if (e->cfg.profile_idc == 100) {
+        /* High profile: the luma residual of an inter macroblock goes through the 8x8 transform.  CAVLC carries an 8x8 block
+         * as four interleaved 4x4 lists (7.3.5.3.2): level i of list k = level 4 i + k of the 8x8 zig-zag scan, stored here
+         * where the 4x4 lists of the quadrant live, so that TotalCoeff / nC and the entropy coder need no special case */
+        for (int b8 = 0; b8 < 4; b8++) {
+            int bx = (b8 & 1) * 8, by = (b8 >> 1) * 8;
+            int16_t d[64], l8[64];
+            int32_t w8[64], dq8[64];
+            for (int y = 0; y < 8; y++)
+                for (int x = 0; x < 8; x++) d[8 * y + x] = (int16_t)(s[(by + y) * cw + bx + x] - pred[(by + y) * 16 + bx + x]);
+            h264o_fdct8x8(d, w8);
+            h264o_quant8x8(w8, qp, 0, l8);
+            int any = 0;
+            for (int k = 0; k < 4; k++) {
+                int nnz = 0;
+                for (int i = 0; i < 16; i++) {
+                    int16_t v = l8[o_zigzag8x8[4 * i + k]];
+                    lv[H264O_LV_LUMA + (4 * b8 + k) * 16 + i] = v;
+                    nnz += v != 0;
+                }
+                mb->tc[4 * b8 + k] = (uint8_t)nnz;
+                any |= nnz;
+            }
+            if (any) {
+                cbp |= 1 << b8;
+                h264o_dequant8x8(l8, qp, dq8);
+                h264o_idct8x8_add(dq8, r + by * cw + bx, cw);
+            }
+        }
+    } else
     for (int b = 0; b < 16; b++) {
         int bx = o_blk_x[b] * 4, by = o_blk_y[b] * 4;
         int16_t deq[16];
@@ -814,7 +856,8 @@ static void encode_inter_mb(h264o_enc *e, int mx, int my)
     mv_t skip;
     predict_mv(e, mx, my, &skip);
     mb->type = (mb->cbp == 0 && skip.x == mb->mvx && skip.y == mb->mvy) ? H264O_MB_PSKIP : H264O_MB_P16;
-    mb->i16_mode = mb->chroma_mode = 0;
+    mb->chroma_mode = 0;
+    mb->i16_mode = (e->cfg.profile_idc == 100 && (mb->cbp & 15)) ? 1 : 0;   /* transform_size_8x8_flag (sent only with luma coefficients) */
 }
 /* the part of encode_inter_mb that needs every macroblock's FINAL type (an I_PCM / intra neighbour is not a vector): run
  * after all macroblocks of the picture are coded */
@@ -881,6 +924,7 @@ static void write_mb(h264o_enc *e, bitw *b, int mx, int my, int p_slice)
         int code = 0;
         while (o_cbp_code2inter[code] != mb->cbp) code++;
         bw_ue(b, (uint32_t)code);
+        if (e->cfg.profile_idc == 100 && (mb->cbp & 15)) bw_put(b, 1, mb->i16_mode); /* transform_size_8x8_flag */
         if (mb->cbp) bw_se(b, 0); /* mb_qp_delta */
     }
     for (int b8 = 0; b8 < 4; b8++)
@@ -956,10 +1000,12 @@ int64_t h264o_enc_encode(h264o_enc *e, const uint8_t *y, int ys, const uint8_t *
                 e->want_intra[my * e->mbw + mx] = 0;
                 if (mv_all_zero(e, mx, my, 0, 0)) {
                     /* static: vector 0, no search */
+                    e->want_intra[my * e->mbw + mx] = 2;
                 } else if ((rmv.x | rmv.y) != 0 && mv_all_zero(e, mx, my, rmv.x, rmv.y)) {
                     /* scrolling: the previous vector, rounded to integer samples, predicts the macroblock completely */
                     mb->mvx = rmv.x;
                     mb->mvy = rmv.y;
+                    e->want_intra[my * e->mbw + mx] = 2;
                 } else {
                     int cost = 0;
                     mv_t m = motion_search(e, mx, my, pmv, &cost);
@@ -976,11 +1022,11 @@ int64_t h264o_enc_encode(h264o_enc *e, const uint8_t *y, int ys, const uint8_t *
             }
         for (int my = e->band_row0; my < e->band_row1; my++)
             for (int mx = 0; mx < e->mbw; mx++)
-                if (!e->want_intra[my * e->mbw + mx]) encode_inter_mb(e, mx, my);
+                if (e->want_intra[my * e->mbw + mx] != 1) encode_inter_mb(e, mx, my);
         /* intra macroblocks of the P picture: raster order, from the true reconstruction of their neighbours */
         for (int my = e->band_row0; my < e->band_row1; my++)
             for (int mx = 0; mx < e->mbw; mx++)
-                if (e->want_intra[my * e->mbw + mx]) encode_intra_mb(e, mx, my);
+                if (e->want_intra[my * e->mbw + mx] == 1) encode_intra_mb(e, mx, my);
         for (int my = e->band_row0; my < e->band_row1; my++)
             for (int mx = 0; mx < e->mbw; mx++) finish_inter_mb(e, mx, my);
     }

@@ -56,7 +56,7 @@ typedef struct h264o_dec h264o_dec;
 typedef struct {
     int16_t mvx, mvy;      /* quarter-pel motion vector (0 for intra)              */
     uint8_t type;          /* H264O_MB_*                                            */
-    uint8_t i16_mode;      /* Intra16x16PredMode 0..3                               */
+    uint8_t i16_mode;      /* Intra16x16PredMode 0..3; inter: transform_size_8x8_flag */
     uint8_t chroma_mode;   /* intra_chroma_pred_mode 0..3                           */
     uint8_t cbp;           /* coded_block_pattern (luma | chroma<<4)                */
     uint8_t tc[24];        /* TotalCoeff per 4x4: 16 luma (blkIdx), 4 Cb, 4 Cr      */
@@ -98,6 +98,11 @@ void h264o_idct4x4_add(const int16_t coef[16], uint8_t *dst, int stride);
  * rounding offset; returns levels in raster order */
 void h264o_quant4x4(const int16_t w[16], int qp, int intra, int16_t lv[16]);
 void h264o_dequant4x4(const int16_t lv[16], int qp, int16_t out[16]);
+/* High profile 8x8 transform: forward (non-normative), quantiser, 8.5.13 scaling and inverse transform */
+void h264o_fdct8x8(const int16_t in[64], int32_t out[64]);
+void h264o_quant8x8(const int32_t w[64], int qp, int intra, int16_t lv[64]);
+void h264o_dequant8x8(const int16_t lv[64], int qp, int32_t out[64]);
+void h264o_idct8x8_add(const int32_t coef[64], uint8_t *dst, int stride);
 /* luma quarter-pel and chroma eighth-pel motion compensation (8.4.2.2) on a
  * w x h plane with edge clamping */
 void h264o_mc_luma(const uint8_t *ref, int stride, int w, int h, int x, int y, int mvx, int mvy,

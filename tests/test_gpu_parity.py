@@ -67,6 +67,29 @@ def test_more_content_and_qps(kind, qp):
     enc.close()
 
 
+@pytest.mark.parametrize("kind,qp,w,h", [("s1", 22, 352, 288), ("s1", 34, 320, 240), ("cut", 27, 352, 288), ("s3", 16, 208, 160), ("scroll", 30, 130, 98)])
+def test_high_profile_8x8_transform(kind, qp, w, h):
+    """profile_idc 100: transform_8x8_mode_flag = 1, inter macroblocks go through the 8x8 transform (k_tq8: 64 samples per lane,
+    CAVLC as four interleaved lists, no 4x4-internal deblocking edges): every stage equals the oracle, whose stream the
+    independent decoder reconstructs byte for byte (tests/test_oracle_roundtrip.py)"""
+    enc = capi.Encoder(w, h, qp=qp, gop=30, profile_idc=100)
+    enc.keep_pre(True)
+    orc = OracleEncoder(w, h, qp=qp, gop=30, profile_idc=100)
+    dec = OracleDecoder()
+    n8 = 0
+    for i, f in enumerate(synth.sequence(kind, w, h, 5)):
+        bs = enc.encode(f)[0]
+        assert bs == orc.encode(f)[0], "picture %d" % i
+        _compare_all(enc, orc, "high picture %d" % i)
+        assert dec.decode(bs) == 1
+        for p in range(3):
+            assert np.array_equal(dec.plane(p), enc.debug_read(capi.DBG_RECON_Y + p))
+        mb = orc.mbinfo()
+        n8 += int(((mb["type"] == 1) & (mb["i16_mode"] == 1)).sum())
+    assert n8 > 0 or kind == "s3"
+    enc.close()
+
+
 def test_forced_idr_qp_change_and_strided_input():
     w, h = 176, 144
     enc = capi.Encoder(w, h, qp=30, gop=100)
