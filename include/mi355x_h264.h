@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define MI355X_H264_ABI_VERSION 1
+#define MI355X_H264_ABI_VERSION 2
 
 enum {
     MI355X_H264_OK = 0,
@@ -85,6 +85,8 @@ typedef struct mi355x_h264_config {
     int32_t band_index;      /* slice bands of ONE picture over several GPUs (BASELINE.json configs[4]): */
     int32_t band_count;      /* with band_count > 1 this instance codes only its share of the `slices` slices (a contiguous
                               * run of whole slices, index band_index of band_count); see mi355x_h264_band_*              */
+    int32_t refs;            /* iNumRefFrame (ref :290: 1).  0 / 1: one reference frame; 2, 3: the motion search covers the last
+                              * `refs` pictures and ref_idx_l0 is coded (BASELINE.json configs[4] asks for 3)                  */
 } mi355x_h264_config;
 
 typedef struct mi355x_h264_encoder mi355x_h264_encoder;

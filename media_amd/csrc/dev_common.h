@@ -68,7 +68,9 @@ struct FrameParams {
     int w, h;            // display size
     int cw, ch, mbw, mbh;
     uint8_t* rec[3];        // current picture reconstruction (pitch cw, cw/2, cw/2)
-    const uint8_t* ref[3];  // previous deblocked picture
+    const uint8_t* ref[3];  // previous deblocked picture (= refs[0])
+    const uint8_t* refs[3][3];   // the reference pictures, ref_idx_l0 order (newest first); entries >= nref are not read
+    int nref;               // reference pictures available to this picture (1 .. config.refs)
     MbInfo* mb;
     int16_t* levels;     // LV_STRIDE int16 per macroblock
     int16_t* mvd;        // 2 int16 per macroblock (mv - predictor)
@@ -96,6 +98,8 @@ __device__ __forceinline__ FrameParams batch_view(FrameParams P, int g)
     P.src += (size_t)g * P.st_src;
     P.rec[0] += (size_t)g * P.st_y; P.rec[1] += (size_t)g * P.st_c; P.rec[2] += (size_t)g * P.st_c;
     P.ref[0] += (size_t)g * P.st_y; P.ref[1] += (size_t)g * P.st_c; P.ref[2] += (size_t)g * P.st_c;
+#pragma unroll
+    for (int r = 0; r < 3; r++) { P.refs[r][0] += (size_t)g * P.st_y; P.refs[r][1] += (size_t)g * P.st_c; P.refs[r][2] += (size_t)g * P.st_c; }
     P.mb += (size_t)g * P.st_mb;
     P.levels += (size_t)g * P.st_mb * LV_STRIDE;
     P.mvd += (size_t)g * P.st_mb * 2;

@@ -268,6 +268,7 @@ struct CavlcParams {
     const int16_t* mvd;
     int mbw, nmb, p_slice;
     int t8x8;             // PPS transform_8x8_mode_flag (High profile)
+    int nref;             // num_ref_idx_l0_active of the slice (ref_idx_l0 is coded when > 1)
     SliceRows sl;         // slices of the picture (bands of sl.rows macroblock rows)
     int mb_first, mb_end; // the macroblocks this instance codes (its band of whole slices; 0 .. nmb alone)
     MbDiv mbdiv;          // macroblock index / mbw
@@ -319,6 +320,7 @@ __device__ __forceinline__ int mb_edge_strength(const MbInfo* q, int mx, bool to
     const bool nzq = q8 ? (*(const uint32_t*)(q->tc + (bq & ~3)) != 0) : q->tc[bq] != 0;
     const bool nzp = p8 ? (*(const uint32_t*)(p->tc + (bp & ~3)) != 0) : p->tc[bp] != 0;
     if (nzp || nzq) return 2;
+    if (p->chroma_mode != q->chroma_mode) return 1;   // different reference pictures (ref_idx_l0 rides in chroma_mode; one list, never reordered)
     if (iabs(p->mvx - q->mvx) >= 4 || iabs(p->mvy - q->mvy) >= 4) return 1;
     return 0;
 }
@@ -380,6 +382,8 @@ __device__ __forceinline__ void code_slot(S& s, const CavlcParams& C, int mbi, i
             put_se(s, 0);
         } else {
             put_ue(s, 0);
+            if (C.nref == 2) s.put(1, m->chroma_mode ? 0u : 1u);   // ref_idx_l0, te(v): with two pictures the inverted bit (9.1)
+            else if (C.nref > 2) put_ue(s, m->chroma_mode);
             put_se(s, C.mvd[2 * mbi]);
             put_se(s, C.mvd[2 * mbi + 1]);
             put_ue(s, c_cbp2code_inter[m->cbp]);

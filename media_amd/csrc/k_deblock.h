@@ -87,6 +87,7 @@ __device__ __forceinline__ int edge_bs(const MbInfo* p, int bp, const MbInfo* q,
 {
     if (mb_is_intra(p->type) || mb_is_intra(q->type)) return mb_edge ? 4 : 3;
     if (p->tc[bp] || q->tc[bq]) return 2;
+    if (p->chroma_mode != q->chroma_mode) return 1;
     if (iabs(p->mvx - q->mvx) >= 4 || iabs(p->mvy - q->mvy) >= 4) return 1;
     return 0;
 }

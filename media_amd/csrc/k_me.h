@@ -110,6 +110,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
     const int pmw = __builtin_amdgcn_readfirstlane(*(const int*)(P.mb + mbi));
     const int pmx = (int)(int16_t)(pmw & 0xFFFF), pmy = pmw >> 16;
     load_src_mb(P, mx, my, s_src, s_srcc, lane);
+    // One pass per reference picture (config.refs, BASELINE.json configs[4]: 3): window, integer search, half-sample planes,
+    // sub-pel refinement; the cheapest of them (motion cost + lambda * bits(ref_idx_l0), the lower index on a tie) leaves its
+    // prediction in the reconstruction planes.  With one reference picture (the reference preset, iNumRefFrame = 1) this is
+    // one trip through the same code.
+    unsigned best_total = 0xFFFFFFFFu;
+    int bcx = 0, bcy = 0, bref = 0;
+#pragma unroll 1
+    for (int rf = 0; rf < P.nref; rf++) {
+    const uint8_t* const RY = P.refs[rf][0];
     // reference window, clamped at the picture edge (unrestricted motion vectors); all requests of a lane are
     // issued before the first is consumed (one memory latency).  Macroblocks whose window (widened to 64 B
     // rows) lies inside the picture use a fixed pattern: lane = (dword column 0..15, row group 0..3), 14 rows
@@ -119,7 +128,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
         const bool inside = wx0 >= 0 && wx0 + 64 <= P.cw && wy0 >= 0 && wy0 + ME_WS <= P.ch;
         if (inside) {
             const int c = lane & 15, rg = lane >> 4;
-            const uint8_t* rp = P.ref[0] + (size_t)(wy0 + rg) * P.cw + wx0 + 4 * c;
+            const uint8_t* rp = RY + (size_t)(wy0 + rg) * P.cw + wx0 + 4 * c;
             const size_t step = (size_t)4 * P.cw;
             uint32_t v[14];
 #pragma unroll
@@ -136,7 +145,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
                 const int row = i / ME_WDW, dw = i - row * ME_WDW;
                 const int gy = clip3(0, P.ch - 1, wy0 + row);
                 const int gx = wx0 + dw * 4;
-                const uint8_t* rp = P.ref[0] + (size_t)gy * P.cw;
+                const uint8_t* rp = RY + (size_t)gy * P.cw;
                 v[t] = 0;
                 if (i < ME_WS * ME_WDW) {
                     if (interior) v[t] = *(const uint32_t*)(rp + gx);
@@ -151,7 +160,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
                 if (lane + 64 * t < ME_WS * ME_WDW) s_win[lane + 64 * t] = v[t];
         }
     }
-    if (lane < 32) {  // co-located chroma
+    if (rf == 0 && lane < 32) {  // co-located chroma (the zero tests)
         const int pl = lane >> 4, row = (lane >> 1) & 7, xs = (lane & 1) * 4;
         *(uint32_t*)(s_refc + pl * 64 + row * 8 + xs) =
             *(const uint32_t*)((pl ? P.ref[2] : P.ref[1]) + (size_t)(8 * my + row) * (P.cw / 2) + 8 * mx + xs);
@@ -164,7 +173,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
     // so one packed forward transform (row pass in the lane, column pass over the DPP quad) serves both.  Tried at
     // the zero vector (static content) and, when that fails, at the macroblock's previous-picture vector rounded to
     // integer samples, if non-zero (scrolling content); a hit fixes the vector and ends the search. ----
-    {
+    if (rf == 0) {
         typedef unsigned short pk16 __attribute__((ext_vector_type(2)));
         const int r = lane & 3, b4 = lane >> 2;
         const int cplz = lane >> 4, cyz = ((lane >> 3) & 1) * 4 + r, cxz = ((lane >> 2) & 1) * 4;   // chroma lane (lanes < 32)
@@ -543,6 +552,29 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
         }
         bestk = best_cost << 4;                          // the next pass starts from "stay" (order 0)
     }
+    {   // this reference picture against the best so far
+        const int rbits = P.nref <= 1 ? 0 : (P.nref == 2 ? 1 : (rf == 0 ? 1 : 3));   // te(v) of ref_idx_l0 (9.1)
+        const unsigned total = best_cost + (unsigned)(P.lambda * rbits);
+        if (total < best_total) {   // wave-uniform
+            best_total = total; bcx = cx; bcy = cy; bref = rf;
+            // the prediction goes to the reconstruction planes (k_tq turns it into the reconstruction in place): luma from the
+            // half-sample planes still in LDS, lane = (row, 4-sample segment); chroma by 8.4.2.2.2
+            const int ox = cx - 4 * ix, oy = cy - 4 * iy;
+            int t0, t1;
+            qpel_taps(ox & 3, oy & 3, t0, t1);
+            const int y = lane >> 2, seg = (lane & 3) * 4;
+            const int gb = (1 + (oy >> 2) + y) * ME_GP + 1 + (ox >> 2) + seg;
+            *(uint32_t*)(P.rec[0] + (size_t)(by + y) * P.cw + bx + seg) = avg4(lds_ld4(s_pl, t0 + gb), lds_ld4(s_pl, t1 + gb));
+            if (lane < 32) {
+                const int pl = lane >> 4, cyy = (lane >> 1) & 7, cxx = (lane & 1) * 4;
+                *(uint32_t*)((pl ? P.rec[2] : P.rec[1]) + (size_t)(8 * my + cyy) * (P.cw / 2) + 8 * mx + cxx) =
+                    chroma_pred4(P.refs[rf][1 + pl], P.cw / 2, P.ch / 2, 8 * mx + cxx + (cx >> 3), 8 * my + cyy + (cy >> 3), cx & 7, cy & 7);
+            }
+        }
+    }
+    __syncthreads();   // the window and the planes are rebuilt for the next reference picture
+    }   // reference pictures
+    const unsigned best_cost = best_total;
     // ---- 5. intra or inter: from the motion cost and the SOURCE picture alone (both final before the launch).  A macroblock
     // whose motion cost is INTRA_TEST_MIN or more is also costed as Intra16x16 with the vertical / horizontal / DC prediction
     // built from the source samples above and to the left (SATD, lane = (mode, 4x4 block)) + 8 lambda; if that is lower it is
@@ -583,24 +615,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
             return;
         }
     }
-    // ---- 6. the winning prediction goes to the reconstruction planes (k_tq turns it into the reconstruction in place):
-    // luma from the half-sample planes still in LDS, lane = (row, 4-sample segment); chroma by 8.4.2.2.2 ----
-    {
-        const int ox = cx - 4 * ix, oy = cy - 4 * iy;
-        int t0, t1;
-        qpel_taps(ox & 3, oy & 3, t0, t1);
-        const int y = lane >> 2, seg = (lane & 3) * 4;
-        const int gb = (1 + (oy >> 2) + y) * ME_GP + 1 + (ox >> 2) + seg;
-        *(uint32_t*)(P.rec[0] + (size_t)(by + y) * P.cw + bx + seg) = avg4(lds_ld4(s_pl, t0 + gb), lds_ld4(s_pl, t1 + gb));
-        if (lane < 32) {
-            const int pl = lane >> 4, cyy = (lane >> 1) & 7, cxx = (lane & 1) * 4;
-            *(uint32_t*)((pl ? P.rec[2] : P.rec[1]) + (size_t)(8 * my + cyy) * (P.cw / 2) + 8 * mx + cxx) =
-                chroma_pred4(pl ? P.ref[2] : P.ref[1], P.cw / 2, P.ch / 2, 8 * mx + cxx + (cx >> 3), 8 * my + cyy + (cy >> 3), cx & 7, cy & 7);
-        }
-    }
     if (lane == 0) {
         uint4* m = (uint4*)(P.mb + mbi);
-        m[0] = make_uint4(((uint32_t)cx & 0xFFFFu) | ((uint32_t)cy << 16), (uint32_t)MB_P16, 0u, 0u);
+        m[0] = make_uint4(((uint32_t)bcx & 0xFFFFu) | ((uint32_t)bcy << 16), (uint32_t)MB_P16 | ((uint32_t)bref << 16), 0u, 0u);   // ref_idx_l0 rides in chroma_mode
         m[1] = make_uint4(0u, 0u, 0u, 0u);
         P.me_cost[mbi] = (uint16_t)(best_cost < 16383u ? best_cost : 16383u);   // scene-change statistic, summed by k_bit_scan
     }

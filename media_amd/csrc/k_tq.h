@@ -438,9 +438,9 @@ __global__ __launch_bounds__(64) void k_mvpred(FrameParams P0)
     const uint2 wB = *(const uint2*)(avB ? base - P.mbw : base);
     const uint2 wC = *(const uint2*)(avC0 ? base - P.mbw + 1 : base);
     const uint2 wD = *(const uint2*)(avD ? base - P.mbw - 1 : base);
-    auto unpack = [](const uint2 w, bool av, int& ref, Mv& mv) {
+    auto unpack = [](const uint2 w, bool av, int& ref, Mv& mv) {   // ref_idx_l0 of an inter macroblock rides in chroma_mode
         ref = -1; mv.x = 0; mv.y = 0;
-        if (av && !mb_is_intra((int)(w.y & 255u))) { ref = 0; mv.x = (int)(int16_t)(w.x & 0xFFFFu); mv.y = (int)(int16_t)(w.x >> 16); }
+        if (av && !mb_is_intra((int)(w.y & 255u))) { ref = (int)((w.y >> 16) & 255u); mv.x = (int)(int16_t)(w.x & 0xFFFFu); mv.y = (int)(int16_t)(w.x >> 16); }
     };
     int rA, rB, rC;
     Mv A, B, C;
@@ -451,13 +451,18 @@ __global__ __launch_bounds__(64) void k_mvpred(FrameParams P0)
     else { unpack(wD, avD, rC, C); aC = avD; }
     const bool zero_skip = !avA || !avB || (rA == 0 && A.x == 0 && A.y == 0) || (rB == 0 && B.x == 0 && B.y == 0);
     if (!avB && !aC && avA) { B = A; C = A; rB = rA; rC = rA; }
-    Mv p;
-    const int n = (rA == 0) + (rB == 0) + (rC == 0);
-    if (n == 1) p = rA == 0 ? A : (rB == 0 ? B : C);
-    else { p.x = med3(A.x, B.x, C.x); p.y = med3(A.y, B.y, C.y); }
-    const Mv skip = zero_skip ? Mv{0, 0} : p;
+    const int cref = (int)((self.y >> 16) & 255u);
+    auto pred_for = [&](int ref) {   // 8.4.1.3.1
+        Mv p;
+        const int n = (rA == ref) + (rB == ref) + (rC == ref);
+        if (n == 1) p = rA == ref ? A : (rB == ref ? B : C);
+        else { p.x = med3(A.x, B.x, C.x); p.y = med3(A.y, B.y, C.y); }
+        return p;
+    };
+    const Mv p = pred_for(cref);
+    const Mv skip = zero_skip ? Mv{0, 0} : (cref == 0 ? p : pred_for(0));   // 8.4.1.1: P_Skip predicts for ref_idx 0
     const int mvx = (int)(int16_t)(self.x & 0xFFFFu), mvy = (int)(int16_t)(self.x >> 16), cbp = (int)(self.y >> 24);
-    const int type = (cbp == 0 && skip.x == mvx && skip.y == mvy) ? MB_PSKIP : MB_P16;
+    const int type = (cbp == 0 && cref == 0 && skip.x == mvx && skip.y == mvy) ? MB_PSKIP : MB_P16;
     // type; i16_mode keeps transform_size_8x8_flag (bit 0, k_tq8), k_me's "nothing to code" mark (0x80) goes
     *(uint16_t*)((uint8_t*)(P.mb + mbi) + 4) = (uint16_t)((unsigned)type | (type == MB_P16 ? ((self.y >> 8) & 1u) << 8 : 0u));
     *(uint32_t*)(P.mvd + 2 * mbi) = (uint32_t)((mvx - p.x) & 0xFFFF) | ((uint32_t)(mvy - p.y) << 16);

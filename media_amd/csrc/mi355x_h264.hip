@@ -160,7 +160,9 @@ struct mi355x_h264_encoder {
     size_t st_y = 0, st_c = 0, st_bitbuf_bytes = 0, st_au = 0, st_handoff = 0;  // per-item strides
     hipStream_t stream = nullptr;
     hipStream_t stream_ec = nullptr;         // entropy coding runs here, beside the deblocking wavefront
-    uint8_t* d_planes[2][3] = {{nullptr}};  // ping-pong: [cur][plane]
+    enum { MAX_REFS = 3 };
+    int nrefs = 1, nbuf = 2;                 // reference frames searched (config.refs) and reconstruction buffers (nrefs + 1)
+    uint8_t* d_planes[MAX_REFS + 1][3] = {{nullptr}};  // ring: [index][plane]; `cur` is written, cur - 1 - r (mod nbuf) is ref_idx_l0 r
     uint8_t* d_pre[3] = {nullptr};           // copy of the reconstruction before the loop filter (debug)
     int cur = 0;                             // index written by the picture being encoded
     MbInfo* d_mb = nullptr;
@@ -226,7 +228,7 @@ void build_parameter_sets(mi355x_h264_encoder* e)
     if (prof == 100) { s.ue(1); s.ue(0); s.ue(0); s.put(1, 0); s.put(1, 0); }
     s.ue(4);      // log2_max_frame_num_minus4
     s.ue(2);      // pic_order_cnt_type
-    s.ue(1);      // max_num_ref_frames (ref :290)
+    s.ue((uint32_t)e->nrefs);   // max_num_ref_frames (ref :290: 1; config.refs)
     s.put(1, 0);  // gaps_in_frame_num_value_allowed_flag
     s.ue((uint32_t)e->mbw - 1);
     s.ue((uint32_t)e->mbh - 1);
@@ -241,7 +243,7 @@ void build_parameter_sets(mi355x_h264_encoder* e)
     p.ue(0); p.ue(0);
     p.put(1, 0);  // CAVLC
     p.put(1, 0);
-    p.ue(0); p.ue(0); p.ue(0);
+    p.ue(0); p.ue((uint32_t)e->nrefs - 1); p.ue(0);   // slice groups, num_ref_idx_l0 / l1_default_active_minus1
     p.put(1, 0); p.put(2, 0);
     p.se(0); p.se(0); p.se(0);
     p.put(1, 1);  // deblocking_filter_control_present_flag
@@ -255,6 +257,8 @@ void build_parameter_sets(mi355x_h264_encoder* e)
 
 // slice_header() of 7.3.3 for this build's fixed choices, from slice_type on (first_mb_in_slice differs per slice and
 // is written by k_bit_scan); returns bit count (< 64)
+int avail_refs(const mi355x_h264_encoder* e, bool idr) { return idr ? 0 : std::min(e->nrefs, e->frame_in_gop); }
+
 int build_slice_header(const mi355x_h264_encoder* e, bool idr, int idr_id, bool no_filter, uint64_t* bits)
 {
     HostBits h;
@@ -262,7 +266,10 @@ int build_slice_header(const mi355x_h264_encoder* e, bool idr, int idr_id, bool 
     h.ue(0);
     h.put(8, (uint32_t)e->frame_num);
     if (idr) h.ue((uint32_t)idr_id);
-    if (!idr) { h.put(1, 0); h.put(1, 0); }
+    if (!idr) {   // num_ref_idx_active_override_flag: the first pictures after an IDR have fewer reference pictures than the PPS announces
+        if (avail_refs(e, false) != e->nrefs) { h.put(1, 1); h.ue((uint32_t)avail_refs(e, false) - 1); } else h.put(1, 0);
+        h.put(1, 0);   // ref_pic_list_modification_flag_l0
+    }
     if (idr) { h.put(1, 0); h.put(1, 0); } else h.put(1, 0);
     h.se(e->qp - 26);
     no_filter = no_filter || e->cfg.disable_deblock;            // (a picture with an I_PCM macroblock is not filtered)
@@ -302,11 +309,16 @@ int submit(mi355x_h264_encoder* e, const uint8_t* d_src, size_t src_item_stride,
     const bool idr = e->force_idr || e->frames == 0 || e->frame_in_gop >= e->cfg.gop;
     if (idr) { e->frame_in_gop = 0; e->frame_num = 0; }
     e->force_idr = 0;
-    const int cur = e->cur, prev = cur ^ 1;
+    const int cur = e->cur;
     FrameParams P{};
     P.src = d_src; P.src_nv12 = nv12 ? 1 : 0; P.w = e->cfg.width; P.h = e->cfg.height;
     P.cw = e->cw; P.ch = e->ch; P.mbw = e->mbw; P.mbh = e->mbh;
-    for (int p = 0; p < 3; p++) { P.rec[p] = e->d_planes[cur][p]; P.ref[p] = e->d_planes[prev][p]; }
+    P.nref = std::max(1, avail_refs(e, idr));
+    for (int p = 0; p < 3; p++) {
+        P.rec[p] = e->d_planes[cur][p];
+        for (int r = 0; r < mi355x_h264_encoder::MAX_REFS; r++) P.refs[r][p] = e->d_planes[(cur + e->nbuf - 1 - std::min(r, e->nrefs - 1)) % e->nbuf][p];
+        P.ref[p] = P.refs[0][p];
+    }
     P.mb = e->d_mb; P.levels = e->d_levels; P.mvd = e->d_mvd; P.me_cost = e->d_me_cost;
     P.st_src = src_item_stride; P.st_y = e->st_y; P.st_c = e->st_c; P.st_mb = e->nmb; P.sl = e->sl;
     P.band.row0 = e->b_row0; P.band.rows = e->b_rows;
@@ -366,7 +378,7 @@ int submit(mi355x_h264_encoder* e, const uint8_t* d_src, size_t src_item_stride,
     // (a small launch of its own on this stream): the two run side by side and the filter never waits for the coder
     hipStream_t ec = e->stream_ec;
     CavlcParams C{};
-    C.mb = e->d_mb; C.levels = e->d_levels; C.mvd = e->d_mvd; C.mbw = e->mbw; C.nmb = e->nmb; C.p_slice = idr ? 0 : 1; C.t8x8 = e->cfg.profile_idc == 100 ? 1 : 0; C.sl = e->sl;
+    C.mb = e->d_mb; C.levels = e->d_levels; C.mvd = e->d_mvd; C.mbw = e->mbw; C.nmb = e->nmb; C.p_slice = idr ? 0 : 1; C.t8x8 = e->cfg.profile_idc == 100 ? 1 : 0; C.nref = avail_refs(e, idr); C.sl = e->sl;
     C.mb_first = e->b_row0 * e->mbw; C.mb_end = C.mb_first + e->b_nmb;
     C.slice_cap = (unsigned)e->slice_cap;
     C.mbdiv = P.mbdiv;
@@ -443,7 +455,7 @@ int submit(mi355x_h264_encoder* e, const uint8_t* d_src, size_t src_item_stride,
     HIPCHK(e, hipGetLastError());
     S.busy = true;
     // bookkeeping for the next picture
-    e->cur ^= 1;
+    e->cur = (e->cur + 1) % e->nbuf;
     if (idr) e->idr_id = (e->idr_id + e->idr_step * e->G) & 0xFF;
     e->frame_num = (e->frame_num + 1) & 255;
     e->frame_in_gop++;
@@ -579,6 +591,7 @@ int mi355x_h264_create(const mi355x_h264_config* cfg, mi355x_h264_encoder** out)
     if (cfg->profile_idc != 66 && cfg->profile_idc != 77 && cfg->profile_idc != 100) return MI355X_H264_E_ARG;
     if (cfg->input_format != MI355X_H264_INPUT_I420 && cfg->input_format != MI355X_H264_INPUT_NV12) return MI355X_H264_E_ARG;
     if (cfg->slices < 0 || cfg->slices > 64) return MI355X_H264_E_ARG;
+    if (cfg->refs < 0 || cfg->refs > mi355x_h264_encoder::MAX_REFS) return MI355X_H264_E_ARG;
     if (cfg->band_count < 0 || cfg->band_index < 0 || (cfg->band_count > 1 && (cfg->band_index >= cfg->band_count || cfg->batch > 1))) return MI355X_H264_E_ARG;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev) return MI355X_H264_E_NODEVICE;
@@ -605,6 +618,8 @@ int mi355x_h264_create(const mi355x_h264_config* cfg, mi355x_h264_encoder** out)
     e->b_row0 = e->b_sl0 * e->sl.rows;
     e->b_rows = std::min(e->mbh, (e->b_sl0 + e->b_nsl) * e->sl.rows) - e->b_row0;
     e->b_nmb = e->b_rows * e->mbw;
+    e->nrefs = cfg->refs > 1 ? cfg->refs : 1;
+    e->nbuf = e->nrefs + 1;
     e->G = cfg->batch > 1 ? cfg->batch : 1;
     if (e->G > MAX_BATCH) { delete e; return MI355X_H264_E_ARG; }
     e->esc_buf.resize((size_t)e->G);
@@ -624,7 +639,7 @@ int mi355x_h264_create(const mi355x_h264_config* cfg, mi355x_h264_encoder** out)
     const size_t ysz = (size_t)e->cw * e->ch;
     const size_t Gn = (size_t)e->G;
     e->st_y = ysz + 256; e->st_c = ysz / 4 + 256;
-    for (int b = 0; b < 2; b++)
+    for (int b = 0; b < e->nbuf; b++)
         for (int p = 0; p < 3; p++) {
             CK(hipMalloc((void**)&e->d_planes[b][p], (p ? e->st_c : e->st_y) * Gn));
             CK(hipMemset(e->d_planes[b][p], 0, (p ? e->st_c : e->st_y) * Gn));
@@ -687,7 +702,7 @@ void mi355x_h264_destroy(mi355x_h264_encoder* e)
     if (!e) return;
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
-    for (int b = 0; b < 2; b++)
+    for (int b = 0; b <= mi355x_h264_encoder::MAX_REFS; b++)
         for (int p = 0; p < 3; p++) (void)hipFree(e->d_planes[b][p]);
     for (int p = 0; p < 3; p++) (void)hipFree(e->d_pre[p]);
     (void)hipFree(e->d_mb); (void)hipFree(e->d_levels); (void)hipFree(e->d_mvd);
@@ -901,7 +916,7 @@ enum { HALO_MB_ROWS = 2 };   // 32 luma rows: the search reaches 16 rows + 0.75 
 // rows [r0, r1) of the newest reconstruction <-> a packed block (Y rows, then U rows, then V rows)
 int halo_copy(mi355x_h264_encoder* e, int r0, int r1, void* d_blk, bool to_block)
 {
-    const int last = e->cur ^ 1;
+    const int last = (e->cur + e->nbuf - 1) % e->nbuf;
     uint8_t* blk = (uint8_t*)d_blk;
     for (int p = 0; p < 3; p++) {
         const size_t pitch = p ? e->cw / 2 : e->cw, rows_per_mb = p ? 8 : 16;
@@ -965,7 +980,7 @@ int64_t mi355x_h264_debug_read(mi355x_h264_encoder* e, int what, void* dst, size
     const void* src = nullptr;
     size_t n = 0;
     const size_t ysz = (size_t)e->cw * e->ch;
-    const int last = e->cur ^ 1;  // picture finished by the last encode
+    const int last = (e->cur + e->nbuf - 1) % e->nbuf;  // picture finished by the last encode
     switch (what) {
         case MI355X_H264_DBG_RECON_Y: case MI355X_H264_DBG_RECON_U: case MI355X_H264_DBG_RECON_V:
             src = e->d_planes[last][what]; n = what ? ysz / 4 : ysz; break;

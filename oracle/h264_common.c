@@ -477,6 +477,7 @@ static int edge_bs(const h264o_mbinfo *p, int bp, const h264o_mbinfo *q, int bq,
     int pi = p->type == H264O_MB_I16 || p->type == H264O_MB_IPCM, qi = q->type == H264O_MB_I16 || q->type == H264O_MB_IPCM;
     if (pi || qi) return mb_edge ? 4 : 3;
     if (blk_nonzero(p, bp) || blk_nonzero(q, bq)) return 2;
+    if (p->chroma_mode != q->chroma_mode) return 1;   /* different reference pictures (ref_idx_l0 rides in chroma_mode; one list, never reordered) */
     if (abs(p->mvx - q->mvx) >= 4 || abs(p->mvy - q->mvy) >= 4) return 1;
     return 0;
 }

@@ -158,7 +158,9 @@ struct h264o_enc {
     int mbw, mbh, cw, ch, level_idc;
     int slice_rows;   /* macroblock rows per slice (mbh for one slice); a slice is a band of whole rows */
     int band_row0, band_row1;   /* rows this instance codes (band_count > 1: its share of the slices), else 0..mbh */
-    uint8_t *src[3], *rec[3], *cur[3], *ref[3]; /* coded size; pitch cw / cw/2 */
+    uint8_t *src[3], *rec[3], *cur[3], *ref[3]; /* coded size; pitch cw / cw/2; ref = the newest reference picture */
+    uint8_t *older[2][3];   /* refs > 1: the reference pictures before it (older[0] = ref_idx 1, older[1] = ref_idx 2) */
+    int nrefs, avail_refs;  /* configured reference frames; those available for the picture being coded */
     h264o_mbinfo *mb;
     int16_t *levels;
     int16_t *slice_of;   /* slice index of every macroblock */
@@ -218,7 +220,9 @@ h264o_enc *h264o_enc_create(const h264o_config *cfg)
         e->rec[p] = (uint8_t *)calloc(sz, 1);
         e->cur[p] = (uint8_t *)calloc(sz, 1);
         e->ref[p] = (uint8_t *)calloc(sz, 1);
+        for (int k = 0; k < 2; k++) e->older[k][p] = (uint8_t *)calloc(sz, 1);
     }
+    e->nrefs = cfg->refs < 1 ? 1 : cfg->refs > 3 ? 3 : cfg->refs;
     e->mb = (h264o_mbinfo *)calloc((size_t)e->mbw * e->mbh, sizeof(h264o_mbinfo));
     e->levels = (int16_t *)calloc((size_t)e->mbw * e->mbh * H264O_LV_STRIDE, sizeof(int16_t));
     e->slice_of = (int16_t *)calloc((size_t)e->mbw * e->mbh, sizeof(int16_t));
@@ -232,7 +236,7 @@ h264o_enc *h264o_enc_create(const h264o_config *cfg)
 void h264o_enc_destroy(h264o_enc *e)
 {
     if (!e) return;
-    for (int p = 0; p < 3; p++) { free(e->src[p]); free(e->rec[p]); free(e->cur[p]); free(e->ref[p]); }
+    for (int p = 0; p < 3; p++) { free(e->src[p]); free(e->rec[p]); free(e->cur[p]); free(e->ref[p]); free(e->older[0][p]); free(e->older[1][p]); }
     free(e->mb);
     free(e->levels);
     free(e->slice_of);
@@ -308,7 +312,7 @@ static void write_sps(h264o_enc *e, bitw *b)
     }
     bw_ue(b, 4);     /* log2_max_frame_num_minus4 -> MaxFrameNum 256 */
     bw_ue(b, 2);     /* pic_order_cnt_type 2: output order == decode order */
-    bw_ue(b, 1);     /* max_num_ref_frames (ref :290 iNumRefFrame = 1) */
+    bw_ue(b, (uint32_t)e->nrefs); /* max_num_ref_frames (ref :290 iNumRefFrame = 1; configs[4]: 3) */
     bw_put(b, 1, 0); /* gaps_in_frame_num_value_allowed_flag */
     bw_ue(b, (uint32_t)e->mbw - 1);
     bw_ue(b, (uint32_t)e->mbh - 1);
@@ -335,7 +339,7 @@ static void write_pps(h264o_enc *e, bitw *b)
     bw_put(b, 1, 0); /* entropy_coding_mode_flag: CAVLC */
     bw_put(b, 1, 0); /* bottom_field_pic_order_in_frame_present_flag */
     bw_ue(b, 0);     /* num_slice_groups_minus1 */
-    bw_ue(b, 0);     /* num_ref_idx_l0_default_active_minus1 */
+    bw_ue(b, (uint32_t)e->nrefs - 1); /* num_ref_idx_l0_default_active_minus1 */
     bw_ue(b, 0);     /* num_ref_idx_l1_default_active_minus1 */
     bw_put(b, 1, 0); /* weighted_pred_flag */
     bw_put(b, 2, 0); /* weighted_bipred_idc */
@@ -361,7 +365,9 @@ static void write_slice_header(h264o_enc *e, bitw *b, int idr, int first_mb)
     bw_put(b, 8, (uint32_t)e->frame_num);
     if (idr) bw_ue(b, (uint32_t)e->idr_id);
     if (!idr) {
-        bw_put(b, 1, 0); /* num_ref_idx_active_override_flag */
+        /* the first pictures after an IDR have fewer reference pictures than the PPS default announces */
+        if (e->avail_refs != e->nrefs) { bw_put(b, 1, 1); bw_ue(b, (uint32_t)e->avail_refs - 1); }
+        else bw_put(b, 1, 0); /* num_ref_idx_active_override_flag */
         bw_put(b, 1, 0); /* ref_pic_list_modification_flag_l0 */
     }
     if (idr) {
@@ -623,6 +629,10 @@ static inline int refpx(const uint8_t *ref, int stride, int w, int h, int x, int
     return ref[clip3(0, h - 1, y) * stride + clip3(0, w - 1, x)];
 }
 
+static uint8_t *const *ref_planes(h264o_enc *e, int ref_idx) { return ref_idx == 0 ? e->ref : e->older[ref_idx - 1]; }
+/* bits of ref_idx_l0, te(v) (9.1): none with one active picture, one bit with two, ue(v) above */
+static int ref_idx_bits(int ref_idx, int active) { return active <= 1 ? 0 : active == 2 ? 1 : (ref_idx == 0 ? 1 : 3); }
+
 /* does the residual of this MB against the prediction at (mvx, mvy) quantise to nothing? */
 static int mv_all_zero(h264o_enc *e, int mx, int my, int mvx, int mvy)
 {
@@ -652,7 +662,7 @@ static int mv_all_zero(h264o_enc *e, int mx, int my, int mvx, int mvy)
 
 /* pmv: the vector this macroblock had in the previous picture (0 after an IDR) - the stand-in for the motion
  * vector predictor in the rate term: it is final before the picture starts, so every macroblock stays independent */
-static mv_t motion_search(h264o_enc *e, int mx, int my, mv_t pmv, int *final_cost)
+static mv_t motion_search(h264o_enc *e, int mx, int my, mv_t pmv, int *final_cost, const uint8_t *refy)
 {
     int cw = e->cw, ch = e->ch, lambda = o_lambda[e->cfg.qp];
     const uint8_t *s = e->src[0] + (16 * my) * cw + 16 * mx;
@@ -661,7 +671,7 @@ static mv_t motion_search(h264o_enc *e, int mx, int my, mv_t pmv, int *final_cos
     enum { R = 16, AP = 4, WS = 16 + 2 * R + 2 * AP };
     static __thread uint8_t win[WS * WS];
     for (int y = 0; y < WS; y++)
-        for (int x = 0; x < WS; x++) win[y * WS + x] = (uint8_t)refpx(e->ref[0], cw, cw, ch, bx - R - AP + x, by - R - AP + y);
+        for (int x = 0; x < WS; x++) win[y * WS + x] = (uint8_t)refpx(refy, cw, cw, ch, bx - R - AP + x, by - R - AP + y);
     uint32_t best_key = 0xFFFFFFFFu;
     for (int dy = -R; dy < R; dy++)
         for (int dx = -R; dx < R; dx++) {
@@ -756,11 +766,12 @@ static void neighbour(const h264o_enc *e, int mx, int my, int cur_my, int *avail
     mv->x = mv->y = 0;
     if (!*avail) return;
     const h264o_mbinfo *m = &e->mb[my * e->mbw + mx];
-    if (m->type != H264O_MB_I16 && m->type != H264O_MB_IPCM) { *ref = 0; mv->x = m->mvx; mv->y = m->mvy; }
+    if (m->type != H264O_MB_I16 && m->type != H264O_MB_IPCM) { *ref = m->chroma_mode; mv->x = m->mvx; mv->y = m->mvy; }   /* (ref_idx_l0 rides in chroma_mode) */
 }
 static int med3(int a, int b, int c) { return a > b ? (b > c ? b : (a > c ? c : a)) : (a > c ? a : (b > c ? c : b)); }
 
-static mv_t predict_mv(const h264o_enc *e, int mx, int my, mv_t *skip_mv)
+/* 8.4.1.3 for a 16x16 partition whose reference index is `ref`; skip_mv (when asked) receives the P_Skip vector (8.4.1.1: prediction for ref 0) */
+static mv_t predict_mv_ref(const h264o_enc *e, int mx, int my, int ref, mv_t *skip_mv)
 {
     int aA, aB, aC, rA, rB, rC;
     mv_t A, B, C;
@@ -768,22 +779,26 @@ static mv_t predict_mv(const h264o_enc *e, int mx, int my, mv_t *skip_mv)
     neighbour(e, mx, my - 1, my, &aB, &rB, &B);
     neighbour(e, mx + 1, my - 1, my, &aC, &rC, &C);
     if (!aC) neighbour(e, mx - 1, my - 1, my, &aC, &rC, &C);
+    int zero_skip = !aA || !aB || (rA == 0 && A.x == 0 && A.y == 0) || (rB == 0 && B.x == 0 && B.y == 0);
     if (!aB && !aC && aA) { B = A; C = A; rB = rA; rC = rA; }
     mv_t p;
-    int n = (rA == 0) + (rB == 0) + (rC == 0);
-    if (n == 1) p = rA == 0 ? A : rB == 0 ? B : C;
+    int n = (rA == ref) + (rB == ref) + (rC == ref);
+    if (n == 1) p = rA == ref ? A : rB == ref ? B : C;
     else { p.x = (int16_t)med3(A.x, B.x, C.x); p.y = (int16_t)med3(A.y, B.y, C.y); }
     if (skip_mv) {
-        int uA, uB, t;
-        mv_t tA, tB;
-        neighbour(e, mx - 1, my, my, &uA, &t, &tA);
-        int refA = t;
-        neighbour(e, mx, my - 1, my, &uB, &t, &tB);
-        int refB = t;
-        if (!uA || !uB || (refA == 0 && tA.x == 0 && tA.y == 0) || (refB == 0 && tB.x == 0 && tB.y == 0)) skip_mv->x = skip_mv->y = 0;
-        else *skip_mv = p;
+        if (zero_skip) skip_mv->x = skip_mv->y = 0;
+        else if (ref == 0) *skip_mv = p;
+        else {
+            int n0 = (rA == 0) + (rB == 0) + (rC == 0);
+            if (n0 == 1) *skip_mv = rA == 0 ? A : rB == 0 ? B : C;
+            else { skip_mv->x = (int16_t)med3(A.x, B.x, C.x); skip_mv->y = (int16_t)med3(A.y, B.y, C.y); }
+        }
     }
     return p;
+}
+static mv_t predict_mv(const h264o_enc *e, int mx, int my, mv_t *skip_mv)
+{
+    return predict_mv_ref(e, mx, my, e->mb[my * e->mbw + mx].chroma_mode, skip_mv);   /* the macroblock's own ref_idx_l0 */
 }
 
 static void encode_inter_mb(h264o_enc *e, int mx, int my)
@@ -793,9 +808,11 @@ static void encode_inter_mb(h264o_enc *e, int mx, int my)
     int16_t *lv = e->levels + (size_t)(my * e->mbw + mx) * H264O_LV_STRIDE;
     memset(lv, 0, H264O_LV_STRIDE * sizeof(int16_t));
     uint8_t pred[256], predc[2][64];
-    h264o_mc_luma(e->ref[0], cw, cw, ch, 16 * mx, 16 * my, mb->mvx, mb->mvy, 16, 16, pred, 16);
+    const int refi = mb->chroma_mode;   /* ref_idx_l0, set by the motion search */
+    uint8_t *const *rp = ref_planes(e, refi);
+    h264o_mc_luma(rp[0], cw, cw, ch, 16 * mx, 16 * my, mb->mvx, mb->mvy, 16, 16, pred, 16);
     for (int pl = 0; pl < 2; pl++)
-        h264o_mc_chroma(e->ref[1 + pl], cs, cs, ch / 2, 8 * mx, 8 * my, mb->mvx, mb->mvy, 8, 8, predc[pl], 8);
+        h264o_mc_chroma(rp[1 + pl], cs, cs, ch / 2, 8 * mx, 8 * my, mb->mvx, mb->mvy, 8, 8, predc[pl], 8);
     const uint8_t *s = e->src[0] + (16 * my) * cw + 16 * mx;
     uint8_t *r = e->rec[0] + (16 * my) * cw + 16 * mx;
     int cbp = 0;
@@ -806,8 +823,8 @@ static void encode_inter_mb(h264o_enc *e, int mx, int my)
         mb->cbp = 0;
         mv_t skip0;
         predict_mv(e, mx, my, &skip0);
-        mb->type = (skip0.x == mb->mvx && skip0.y == mb->mvy) ? H264O_MB_PSKIP : H264O_MB_P16;
-        mb->i16_mode = mb->chroma_mode = 0;
+        mb->type = (refi == 0 && skip0.x == mb->mvx && skip0.y == mb->mvy) ? H264O_MB_PSKIP : H264O_MB_P16;
+        mb->i16_mode = 0;
         return;
     }
     if (e->cfg.profile_idc == 100) {
@@ -855,8 +872,7 @@ static void encode_inter_mb(h264o_enc *e, int mx, int my)
     if (mb_bits_bound(lv, 0) > MB_BITS_LIMIT) { make_pcm(e, mx, my); return; }
     mv_t skip;
     predict_mv(e, mx, my, &skip);
-    mb->type = (mb->cbp == 0 && skip.x == mb->mvx && skip.y == mb->mvy) ? H264O_MB_PSKIP : H264O_MB_P16;
-    mb->chroma_mode = 0;
+    mb->type = (mb->cbp == 0 && refi == 0 && skip.x == mb->mvx && skip.y == mb->mvy) ? H264O_MB_PSKIP : H264O_MB_P16;
     mb->i16_mode = (e->cfg.profile_idc == 100 && (mb->cbp & 15)) ? 1 : 0;   /* transform_size_8x8_flag (sent only with luma coefficients) */
 }
 /* the part of encode_inter_mb that needs every macroblock's FINAL type (an I_PCM / intra neighbour is not a vector): run
@@ -867,7 +883,7 @@ static void finish_inter_mb(h264o_enc *e, int mx, int my)
     if (mb->type != H264O_MB_P16 && mb->type != H264O_MB_PSKIP) return;
     mv_t skip;
     predict_mv(e, mx, my, &skip);
-    mb->type = (mb->cbp == 0 && skip.x == mb->mvx && skip.y == mb->mvy) ? H264O_MB_PSKIP : H264O_MB_P16;
+    mb->type = (mb->cbp == 0 && mb->chroma_mode == 0 && skip.x == mb->mvx && skip.y == mb->mvy) ? H264O_MB_PSKIP : H264O_MB_P16;
 }
 
 /* ------------------------------------------------------------ slice data 7.3.4/7.3.5 */
@@ -918,6 +934,8 @@ static void write_mb(h264o_enc *e, bitw *b, int mx, int my, int p_slice)
         cavlc_block(b, lv + H264O_LV_LUMA_DC, 16, nc_luma(e, mx, my, 0));
     } else {
         bw_ue(b, 0); /* P_L0_16x16 */
+        if (e->avail_refs == 2) bw_put(b, 1, mb->chroma_mode ? 0 : 1);        /* ref_idx_l0, te(v) with cMax 1: the inverted bit */
+        else if (e->avail_refs > 2) bw_ue(b, mb->chroma_mode);
         mv_t p = predict_mv(e, mx, my, NULL);
         bw_se(b, mb->mvx - p.x);
         bw_se(b, mb->mvy - p.y);
@@ -969,6 +987,7 @@ int64_t h264o_enc_encode(h264o_enc *e, const uint8_t *y, int ys, const uint8_t *
     int idr = force_idr || e->frames == 0 || e->frame_in_gop >= e->cfg.gop;
     if (idr) { e->frame_in_gop = 0; e->frame_num = 0; }
     if (is_idr) *is_idr = idr;
+    e->avail_refs = idr ? 0 : (e->frame_in_gop < e->nrefs ? e->frame_in_gop : e->nrefs);
     e->me_cost = 0;
     size_t pos = 0;
     bitw b;
@@ -1007,8 +1026,16 @@ int64_t h264o_enc_encode(h264o_enc *e, const uint8_t *y, int ys, const uint8_t *
                     mb->mvy = rmv.y;
                     e->want_intra[my * e->mbw + mx] = 2;
                 } else {
+                    /* every available reference picture is searched; the cheapest (motion cost + lambda * bits(ref_idx)) wins,
+                     * the lower index on a tie */
                     int cost = 0;
-                    mv_t m = motion_search(e, mx, my, pmv, &cost);
+                    mv_t m = {0, 0};
+                    for (int r = 0; r < e->avail_refs; r++) {
+                        int c = 0;
+                        mv_t mr = motion_search(e, mx, my, pmv, &c, ref_planes(e, r)[0]);
+                        c += o_lambda[e->cfg.qp] * ref_idx_bits(r, e->avail_refs);
+                        if (r == 0 || c < cost) { cost = c; m = mr; mb->chroma_mode = (uint8_t)r; }
+                    }
                     e->me_cost += (uint32_t)(cost < 16383 ? cost : 16383);
                     mb->mvx = m.x;
                     mb->mvy = m.y;
@@ -1016,6 +1043,7 @@ int64_t h264o_enc_encode(h264o_enc *e, const uint8_t *y, int ys, const uint8_t *
                     if (cost >= INTRA_TEST_MIN && intra_estimate(e, mx, my) < cost) {
                         e->want_intra[my * e->mbw + mx] = 1;
                         mb->mvx = mb->mvy = 0;
+                        mb->chroma_mode = 0;
                         mb->type = H264O_MB_I16;
                     }
                 }
@@ -1065,7 +1093,13 @@ int64_t h264o_enc_encode(h264o_enc *e, const uint8_t *y, int ys, const uint8_t *
     if (!e->cfg.disable_deblock && !e->any_pcm)
         h264o_deblock_picture(e->cur[0], e->cur[1], e->cur[2], e->cw, e->ch, e->mb, e->cfg.qp, e->slice_rows < e->mbh ? e->slice_of : NULL,
                               e->band_row0, e->band_row1);
-    for (int p = 0; p < 3; p++) { uint8_t *t = e->ref[p]; e->ref[p] = e->cur[p]; e->cur[p] = t; }
+    for (int p = 0; p < 3; p++) {   /* sliding window (8.2.5.3): the new picture becomes ref_idx 0, the oldest buffer is reused */
+        uint8_t *oldest = e->nrefs >= 3 ? e->older[1][p] : e->nrefs == 2 ? e->older[0][p] : e->ref[p];
+        if (e->nrefs >= 3) e->older[1][p] = e->older[0][p];
+        if (e->nrefs >= 2) e->older[0][p] = e->ref[p];
+        e->ref[p] = e->cur[p];
+        e->cur[p] = oldest;
+    }
     if (idr) e->idr_id = (e->idr_id + e->idr_step) & 0xFF;
     e->frame_num = (e->frame_num + 1) & 255;
     e->frame_in_gop++;

@@ -47,6 +47,8 @@ typedef struct {
                              * ceil(rows / n) macroblock rows, one slice NAL each, no loop filtering across them      */
     int32_t band_index;     /* band_count > 1: this instance codes only its share of the slices (slice bands of one   */
     int32_t band_count;     /* picture on several instances / GPUs, mirrors mi355x_h264_config)                       */
+    int32_t refs;           /* 0/1: one reference frame (the reference preset, iNumRefFrame = 1 :290); 2, 3: the motion
+                             * search runs on the last `refs` pictures (BASELINE.json configs[4]), ref_idx_l0 is coded      */
 } h264o_config;
 
 typedef struct h264o_enc h264o_enc;
@@ -57,7 +59,7 @@ typedef struct {
     int16_t mvx, mvy;      /* quarter-pel motion vector (0 for intra)              */
     uint8_t type;          /* H264O_MB_*                                            */
     uint8_t i16_mode;      /* Intra16x16PredMode 0..3; inter: transform_size_8x8_flag */
-    uint8_t chroma_mode;   /* intra_chroma_pred_mode 0..3                           */
+    uint8_t chroma_mode;   /* intra_chroma_pred_mode 0..3; inter: ref_idx_l0          */
     uint8_t cbp;           /* coded_block_pattern (luma | chroma<<4)                */
     uint8_t tc[24];        /* TotalCoeff per 4x4: 16 luma (blkIdx), 4 Cb, 4 Cr      */
 } h264o_mbinfo;            /* 32 bytes                                              */

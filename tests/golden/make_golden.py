@@ -34,18 +34,20 @@ CASES = [
     ("qcif_cut_qp28", 176, 144, "cut", 28, 30, 5, 66),             # intra macroblocks inside P pictures
     ("qcif_s3_qp10_pcm", 176, 144, "s3", 10, 30, 3, 66),           # I_PCM fallback (IDR and P)
     ("qvga_cut_3slices", 320, 240, "cut", 26, 30, 4, 66, 3),
+    ("qcif_s1_3refs", 176, 144, "s1", 26, 30, 6, 66, 0, 3),          # three reference frames: ref_idx_l0, sliding window
+    ("qvga_cut_2refs_high", 320, 240, "cut", 28, 30, 6, 100, 2, 2),
 ]
 
 
-def run_case(name, w, h, kind, qp, gop, n, prof, slices=0):
-    enc = OracleEncoder(w, h, qp=qp, gop=gop, profile_idc=prof, slices=slices)
+def run_case(name, w, h, kind, qp, gop, n, prof, slices=0, refs=0):
+    enc = OracleEncoder(w, h, qp=qp, gop=gop, profile_idc=prof, slices=slices, refs=refs)
     frames = []
     for f in synth.sequence(kind, w, h, n):
         bs, idr = enc.encode(f)
         rec = hashlib.sha256(b"".join(enc.recon(p).tobytes() for p in range(3))).hexdigest()
         frames.append({"idr": bool(idr), "bytes": len(bs), "sha256": hashlib.sha256(bs).hexdigest(), "recon_sha256": rec})
     enc.close()
-    return {"name": name, "width": w, "height": h, "kind": kind, "qp": qp, "gop": gop, "profile_idc": prof, "slices": slices, "frames": frames}
+    return {"name": name, "width": w, "height": h, "kind": kind, "qp": qp, "gop": gop, "profile_idc": prof, "slices": slices, "refs": refs, "frames": frames}
 
 
 if __name__ == "__main__":

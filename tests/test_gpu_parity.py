@@ -42,9 +42,9 @@ def _compare_all(enc, orc, tag):
 @pytest.mark.parametrize("case", GOLD["cases"], ids=[c["name"] for c in GOLD["cases"]])
 def test_golden_cases_bit_exact(case):
     w, h = case["width"], case["height"]
-    enc = capi.Encoder(w, h, qp=case["qp"], gop=case["gop"], profile_idc=case["profile_idc"], slices=case.get("slices", 0))
+    enc = capi.Encoder(w, h, qp=case["qp"], gop=case["gop"], profile_idc=case["profile_idc"], slices=case.get("slices", 0), refs=case.get("refs", 0))
     enc.keep_pre(True)
-    orc = OracleEncoder(w, h, qp=case["qp"], gop=case["gop"], profile_idc=case["profile_idc"], slices=case.get("slices", 0))
+    orc = OracleEncoder(w, h, qp=case["qp"], gop=case["gop"], profile_idc=case["profile_idc"], slices=case.get("slices", 0), refs=case.get("refs", 0))
     for i, (f, g) in enumerate(zip(synth.sequence(case["kind"], w, h, len(case["frames"])), case["frames"])):
         bs, ft = enc.encode(f)
         obs, idr = orc.encode(f)
@@ -87,6 +87,31 @@ def test_high_profile_8x8_transform(kind, qp, w, h):
         mb = orc.mbinfo()
         n8 += int(((mb["type"] == 1) & (mb["i16_mode"] == 1)).sum())
     assert n8 > 0 or kind == "s3"
+    enc.close()
+
+
+@pytest.mark.parametrize("refs,kind,prof,slices,w,h", [(3, "cut", 66, 0, 352, 288), (2, "s1", 66, 0, 320, 240), (3, "s1", 100, 3, 352, 288), (3, "scroll", 77, 0, 208, 160)])
+def test_multiple_reference_frames(refs, kind, prof, slices, w, h):
+    """config.refs = 2 / 3 (BASELINE.json configs[4]: 3-ref motion search): every available reference picture is searched, the
+    cheapest wins, ref_idx_l0 is coded (te(v)), vector prediction and boundary strengths look at the reference indices, the
+    reconstruction buffers form a ring (sliding window).  Bit-exact against the oracle, decodable by the test decoder."""
+    enc = capi.Encoder(w, h, qp=27, gop=6, profile_idc=prof, slices=slices, refs=refs)
+    enc.keep_pre(True)
+    orc = OracleEncoder(w, h, qp=27, gop=6, profile_idc=prof, slices=slices, refs=refs)
+    dec = OracleDecoder()
+    used = np.zeros(3, int)
+    for i, f in enumerate(synth.sequence(kind, w, h, 9)):      # crosses an IDR: the window restarts
+        bs = enc.encode(f)[0]
+        assert bs == orc.encode(f)[0], "picture %d" % i
+        _compare_all(enc, orc, "%d refs picture %d" % (refs, i))
+        assert dec.decode(bs) == 1
+        for p in range(3):
+            assert np.array_equal(dec.plane(p), enc.debug_read(capi.DBG_RECON_Y + p))
+        mb = orc.mbinfo()
+        inter = (mb["type"] == 1) | (mb["type"] == 2)
+        for r in range(3):
+            used[r] += int((inter & (mb["chroma_mode"] == r)).sum())
+    assert used[0] > 0 and used[refs:].sum() == 0
     enc.close()
 
 

@@ -152,7 +152,7 @@ def _roundtrip_ok(so):
     ok = True
     # two kinds of content and three QPs: the qp 32..38 cases reach the larger table indices, s1 the sub-pel vectors
     for kind, w, h, qp, n in (("s1", 176, 144, 26, 4), ("s1", 176, 144, 33, 4), ("ramp", 128, 96, 38, 3), ("s1", 64, 64, 30, 2)):
-        cfg = ol.Config(w, h, 30, qp, 30, 66, 0, 0, 0, 0)
+        cfg = ol.Config(w, h, 30, qp, 30, 66, 0, 0, 0, 0, 0)
         e = L.h264o_enc_create(C.byref(cfg))
         d = L.h264o_dec_create()
         out = np.zeros(w * h * 8 + 65536, dtype=np.uint8)
