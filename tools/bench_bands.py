@@ -8,8 +8,8 @@
 Every rank holds the pictures of one closed GOP in HBM and an encoder with band_index = rank, band_count = N.  A step
 is the GOP (30 pictures); after every picture the ranks swap two macroblock rows of reconstruction with their
 neighbours (RCCL send/recv, media_amd/shard.py) and the slice NAL units are gathered on rank 0.  Total work is fixed
-as N grows: "scaling": "strong".  The 3-reference search of configs[4] is not built (the reference preset itself uses
-one reference, VideoEncoderOpenH264.cpp:290); the figure is for the one-reference search.  The default bench.py line
+as N grows: "scaling": "strong".  --refs 3 (default) is the 3-reference search configs[4] names (the reference preset
+itself uses one reference, VideoEncoderOpenH264.cpp:290: --refs 1).  The default bench.py line
 (closed-GOP sharding, 1080p) stays the headline; this is the measurement harness of the slice-parallel path."""
 import argparse
 import json
@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--slices", type=int, default=8)
     ap.add_argument("--size", default="4k", choices=["4k", "1080p"])
+    ap.add_argument("--refs", type=int, default=3, help="reference frames searched (configs[4]: 3)")
     args = ap.parse_args()
     if args.gpus > 1 and "RANK" not in os.environ:
         # no launcher: one child per GPU, started before this process touches a GPU; rank 0's line is relayed
@@ -64,7 +65,7 @@ def main():
     gop, qp = 30, 26
     frames = synth.sequence("s1", w, h, gop)
     d_frames = torch.from_numpy(np.stack(frames)).to(dev)
-    enc = capi.Encoder(w, h, qp=qp, gop=gop, device=local_rank, slices=args.slices, band_index=rank if world > 1 else 0,
+    enc = capi.Encoder(w, h, qp=qp, gop=gop, device=local_rank, slices=args.slices, refs=args.refs, band_index=rank if world > 1 else 0,
                        band_count=world if world > 1 else 0)
     halo = shard.BandHalo(enc.band_info()[4], dev) if world > 1 else None
     nbytes = [0]
