@@ -12,11 +12,11 @@
 
 namespace h264 {
 
-enum { MB_I16 = 0, MB_P16 = 1, MB_PSKIP = 2, MB_IPCM = 3 };
-__device__ __forceinline__ bool mb_is_intra(int type) { return type == MB_I16 || type == MB_IPCM; }
+enum { MB_I16 = 0, MB_P16 = 1, MB_PSKIP = 2, MB_IPCM = 3, MB_I4 = 4 };
+__device__ __forceinline__ bool mb_is_intra(int type) { return type == MB_I16 || type == MB_IPCM || type == MB_I4; }
 // A.3.1: macroblock_layer() of a CAVLC macroblock may not exceed 128 + 3072 bits; a macroblock whose BOUND (below) does
 // is coded as I_PCM.  INTRA_TEST_MIN: motion cost from which a P macroblock is also costed as Intra16x16.
-enum { MB_BITS_LIMIT = 3200, MB_HEADER_BOUND = 64, INTRA_TEST_MIN = 2000 };
+enum { MB_BITS_LIMIT = 3200, MB_HEADER_BOUND = 96, INTRA_TEST_MIN = 2000 };
 enum { LV_LUMA_DC = 0, LV_LUMA = 16, LV_CHROMA_DC = 272, LV_CHROMA_AC = 280, LV_STRIDE = 416 };
 
 // 32 bytes; identical to the debug layout documented in include/mi355x_h264.h
@@ -71,9 +71,13 @@ struct FrameParams {
     const uint8_t* ref[3];  // previous deblocked picture (= refs[0])
     const uint8_t* refs[3][3];   // the reference pictures, ref_idx_l0 order (newest first); entries >= nref are not read
     int nref;               // reference pictures available to this picture (1 .. config.refs)
+    int rf, rf_last;        // k_me runs once per reference picture: ref_idx_l0 of this launch (ref = its planes), and of the last launch
+    uint32_t* me_total;     // per macroblock: best motion cost + lambda * bits(ref_idx_l0) so far, 0 = settled without a search
+    int* pmv;               // per macroblock: the previous picture's vector (rate predictor), parked by the first launch
     MbInfo* mb;
     int16_t* levels;     // LV_STRIDE int16 per macroblock
     int16_t* mvd;        // 2 int16 per macroblock (mv - predictor)
+    uint8_t* aux;        // 16 bytes per macroblock: Intra4x4PredMode of the 16 blocks (blkIdx order) of an MB_I4 macroblock
     uint16_t* me_cost;   // per macroblock: min(final motion cost, 16383), 0 where the zero-motion test hit (summed by k_bit_scan)
     Quant qy, qc;        // luma / chroma quantisers
     int lambda;
@@ -103,8 +107,10 @@ __device__ __forceinline__ FrameParams batch_view(FrameParams P, int g)
     P.mb += (size_t)g * P.st_mb;
     P.levels += (size_t)g * P.st_mb * LV_STRIDE;
     P.mvd += (size_t)g * P.st_mb * 2;
+    P.aux += (size_t)g * P.st_mb * 16;
     P.me_cost += (size_t)g * P.st_mb;
     P.anypcm += g; P.anyintra += g;
+    P.me_total += (size_t)g * P.st_mb; P.pmv += (size_t)g * P.st_mb;
     return P;
 }
 

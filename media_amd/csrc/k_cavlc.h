@@ -86,6 +86,9 @@ __constant__ const uint8_t c_cbp2code_inter[48] = {
     0,  2,  3,  7,  4,  8,  17, 13, 5,  18, 9,  14, 10, 15, 16, 11, 1,  32, 33, 36, 34, 37, 44, 40,
     35, 45, 38, 41, 39, 42, 43, 19, 6,  24, 25, 20, 26, 21, 46, 28, 27, 47, 22, 29, 23, 30, 31, 12};
 
+// Table 9-4, inverted: coded_block_pattern -> codeNum (Intra4x4)
+__constant__ const uint8_t c_cbp2code_intra[48] = {3, 29, 30, 17, 31, 18, 37, 8, 32, 38, 19, 9, 20, 10, 11, 2, 16, 33, 34, 21, 35, 22, 39, 4, 36, 40, 23, 5, 24, 6, 7, 1, 41, 42, 43, 25, 44, 26, 46, 12, 45, 47, 27, 13, 28, 14, 15, 0};
+
 // ---- bit sinks ----
 struct BitCount {
     unsigned n;
@@ -285,6 +288,7 @@ struct CavlcParams {
     const uint8_t* src;
     int w, h, src_nv12;
     size_t st_src;
+    const uint8_t* aux;   // 16 bytes per macroblock: Intra4x4PredMode of the blocks of MB_I4 macroblocks (blkIdx order)
 };
 __device__ __forceinline__ CavlcParams batch_view(CavlcParams C, int g)
 {
@@ -293,6 +297,7 @@ __device__ __forceinline__ CavlcParams batch_view(CavlcParams C, int g)
     C.slotbits += (size_t)g * C.st_mb * 32; C.slotcode += (size_t)g * C.st_mb * 32; C.mbbits += (size_t)g * C.st_mb; C.bitbuf += (size_t)g * C.st_bitbuf;
     if (C.bs) C.bs += (size_t)g * C.st_mb * 32;
     C.src += (size_t)g * C.st_src;
+    C.aux += (size_t)g * C.st_mb * 16;
     return C;
 }
 enum { MAX_BATCH = 64 };
@@ -375,7 +380,31 @@ __device__ __forceinline__ void code_slot(S& s, const CavlcParams& C, int mbi, i
             // mb_skip_run: the P_Skip macroblocks right before this one, counted from the slice's first macroblock
             put_ue(s, (unsigned)(mbi - 1 - max(C.prevcoded[mbi], (my - srow) * C.mbw - 1)));
         }
-        if (i16) {
+        if (m->type == MB_I4) {
+            // I_NxN (7.3.5.1): the sixteen Intra4x4 modes against their predictions (8.3.1.1: the smaller of the left and upper
+            // blocks' modes; DC when such a neighbour is not an Intra4x4 macroblock, or missing), then chroma mode and coded_block_pattern
+            const uint8_t* am = C.aux + (size_t)mbi * 16;
+            put_ue(s, C.p_slice ? 5u : 0u);
+            if (C.t8x8) s.put(1, 0u);   // transform_size_8x8_flag: Intra4x4, not Intra8x8
+#pragma unroll 1
+            for (int k = 0; k < 16; k++) {
+                const int x = blk_x(k), y = blk_y(k);
+                int mA, mB;
+                bool dc_only = false;
+                if (x > 0) mA = am[xy2blk(x - 1, y)];
+                else if (mx == 0) { dc_only = true; mA = 2; }
+                else mA = (m - 1)->type == MB_I4 ? (am - 16)[xy2blk(3, y)] : 2;
+                if (y > 0) mB = am[xy2blk(x, y - 1)];
+                else if (!top) { dc_only = true; mB = 2; }
+                else mB = (m - C.mbw)->type == MB_I4 ? (am - 16 * C.mbw)[xy2blk(x, 3)] : 2;
+                const int pm = dc_only ? 2 : min(mA, mB), mode = am[k];
+                if (mode == pm) s.put(1, 1u);
+                else s.put(4, (unsigned)(mode < pm ? mode : mode - 1));   // prev_intra4x4_pred_mode_flag = 0, rem_intra4x4_pred_mode
+            }
+            put_ue(s, m->chroma_mode);
+            put_ue(s, c_cbp2code_intra[m->cbp]);
+            if (m->cbp) put_se(s, 0);
+        } else if (i16) {
             const unsigned t = 1u + m->i16_mode + 4u * (unsigned)cbpc + (cbpl ? 12u : 0u);
             put_ue(s, C.p_slice ? 5u + t : t);
             put_ue(s, m->chroma_mode);

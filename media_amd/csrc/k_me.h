@@ -107,18 +107,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
 
     // the vector this macroblock had in the previous picture (0 after an IDR): stand-in for the motion vector predictor
     // in the rate term of the search; final before the launch, so every macroblock stays independent
-    const int pmw = __builtin_amdgcn_readfirstlane(*(const int*)(P.mb + mbi));
+    // (with several reference pictures the first launch parks it in P.pmv: MbInfo is rewritten by then)
+    const int pmw = __builtin_amdgcn_readfirstlane(P.rf == 0 ? *(const int*)(P.mb + mbi) : P.pmv[mbi]);
+    if (P.rf == 0 && P.rf_last > 0 && lane == 0) P.pmv[mbi] = pmw;
     const int pmx = (int)(int16_t)(pmw & 0xFFFF), pmy = pmw >> 16;
     load_src_mb(P, mx, my, s_src, s_srcc, lane);
-    // One pass per reference picture (config.refs, BASELINE.json configs[4]: 3): window, integer search, half-sample planes,
-    // sub-pel refinement; the cheapest of them (motion cost + lambda * bits(ref_idx_l0), the lower index on a tie) leaves its
-    // prediction in the reconstruction planes.  With one reference picture (the reference preset, iNumRefFrame = 1) this is
-    // one trip through the same code.
-    unsigned best_total = 0xFFFFFFFFu;
-    int bcx = 0, bcy = 0, bref = 0;
-#pragma unroll 1
-    for (int rf = 0; rf < P.nref; rf++) {
-    const uint8_t* const RY = P.refs[rf][0];
+    // Several reference pictures (config.refs, BASELINE.json configs[4]: 3): ONE LAUNCH PER REFERENCE PICTURE, P.ref = the
+    // planes of ref_idx_l0 = P.rf.  A launch after the first leaves a macroblock alone unless its motion cost + lambda *
+    // bits(ref_idx_l0) beats what the earlier launches left in me_total (the lower index keeps a tie); the last launch makes
+    // the intra decision on the overall best.  (A loop over the pictures inside one launch spilled 370 registers.)
+    const int rf = P.rf;
+    unsigned prev_total = 0xFFFFFFFFu;
+    if (rf > 0) {
+        prev_total = (unsigned)__builtin_amdgcn_readfirstlane((int)P.me_total[mbi]);
+        if (prev_total == 0u) return;   // a "nothing left to code" test hit on ref_idx 0: settled
+    }
+    const uint8_t* const RY = P.ref[0];
+    const uint8_t* const RU = P.ref[1];
+    const uint8_t* const RV = P.ref[2];
     // reference window, clamped at the picture edge (unrestricted motion vectors); all requests of a lane are
     // issued before the first is consumed (one memory latency).  Macroblocks whose window (widened to 64 B
     // rows) lies inside the picture use a fixed pattern: lane = (dword column 0..15, row group 0..3), 14 rows
@@ -250,6 +256,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
                 m[0] = make_uint4(((uint32_t)vx & 0xFFFFu) | ((uint32_t)vy << 16), (uint32_t)MB_P16 | (0x80u << 8), 0u, 0u);   // i16_mode = 0x80: mark for k_tq / k_mvpred
                 m[1] = make_uint4(0u, 0u, 0u, 0u);
                 P.me_cost[mbi] = 0;
+                P.me_total[mbi] = 0u;   // settled: later reference pictures are not searched
             }
         };
         {   // the zero vector: co-located samples
@@ -490,7 +497,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
         const int tot = __builtin_amdgcn_readlane(s16, 0) + __builtin_amdgcn_readlane(s16, 16) + __builtin_amdgcn_readlane(s16, 32) + __builtin_amdgcn_readlane(s16, 48);
         centre_key = ((unsigned)(tot >> 1) + (unsigned)(P.lambda * (se_len(cx - pmx) + se_len(cy - pmy)))) << 4;   // order 0
     }
-    unsigned best_cost = 0, bestk = 0xFFFFFFFFu;
+    unsigned best_cost_r = 0, bestk = 0xFFFFFFFFu;
 #pragma unroll 1
     for (int round = 0; round < 2; round++) {
         // round 0: the 8 half-sample neighbours (then the centre joins the comparison); round 1: the 8 quarter-sample neighbours
@@ -544,37 +551,42 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
         if (round == 0) bestk = centre_key < bestk ? centre_key : bestk;
         bestk = wave_min_u32_dpp(bestk);
         const int w = (int)(bestk & 15);
-        best_cost = bestk >> 4;
+        best_cost_r = bestk >> 4;
         if (w) {
             const int n = w - 1, wn = n >= 4 ? n + 1 : n;
             cx += step * ((wn % 3) - 1);
             cy += step * ((wn / 3) - 1);
         }
-        bestk = best_cost << 4;                          // the next pass starts from "stay" (order 0)
+        bestk = best_cost_r << 4;                        // the next pass starts from "stay" (order 0)
     }
-    {   // this reference picture against the best so far
-        const int rbits = P.nref <= 1 ? 0 : (P.nref == 2 ? 1 : (rf == 0 ? 1 : 3));   // te(v) of ref_idx_l0 (9.1)
-        const unsigned total = best_cost + (unsigned)(P.lambda * rbits);
-        if (total < best_total) {   // wave-uniform
-            best_total = total; bcx = cx; bcy = cy; bref = rf;
-            // the prediction goes to the reconstruction planes (k_tq turns it into the reconstruction in place): luma from the
-            // half-sample planes still in LDS, lane = (row, 4-sample segment); chroma by 8.4.2.2.2
-            const int ox = cx - 4 * ix, oy = cy - 4 * iy;
-            int t0, t1;
-            qpel_taps(ox & 3, oy & 3, t0, t1);
-            const int y = lane >> 2, seg = (lane & 3) * 4;
-            const int gb = (1 + (oy >> 2) + y) * ME_GP + 1 + (ox >> 2) + seg;
-            *(uint32_t*)(P.rec[0] + (size_t)(by + y) * P.cw + bx + seg) = avg4(lds_ld4(s_pl, t0 + gb), lds_ld4(s_pl, t1 + gb));
-            if (lane < 32) {
-                const int pl = lane >> 4, cyy = (lane >> 1) & 7, cxx = (lane & 1) * 4;
-                *(uint32_t*)((pl ? P.rec[2] : P.rec[1]) + (size_t)(8 * my + cyy) * (P.cw / 2) + 8 * mx + cxx) =
-                    chroma_pred4(P.refs[rf][1 + pl], P.cw / 2, P.ch / 2, 8 * mx + cxx + (cx >> 3), 8 * my + cyy + (cy >> 3), cx & 7, cy & 7);
-            }
+    // this reference picture against the best so far
+    const int rbits = P.nref <= 1 ? 0 : (P.nref == 2 ? 1 : (rf == 0 ? 1 : 3));   // te(v) of ref_idx_l0 (9.1)
+    const unsigned total = best_cost_r + (unsigned)(P.lambda * rbits);
+    const bool better = total < prev_total;   // wave-uniform; rf == 0: always
+    if (better) {
+        // the prediction goes to the reconstruction planes (k_tq turns it into the reconstruction in place): luma from the
+        // half-sample planes still in LDS, lane = (row, 4-sample segment); chroma by 8.4.2.2.2
+        const int ox = cx - 4 * ix, oy = cy - 4 * iy;
+        int t0, t1;
+        qpel_taps(ox & 3, oy & 3, t0, t1);
+        const int y = lane >> 2, seg = (lane & 3) * 4;
+        const int gb = (1 + (oy >> 2) + y) * ME_GP + 1 + (ox >> 2) + seg;
+        *(uint32_t*)(P.rec[0] + (size_t)(by + y) * P.cw + bx + seg) = avg4(lds_ld4(s_pl, t0 + gb), lds_ld4(s_pl, t1 + gb));
+        if (lane < 32) {
+            const int pl = lane >> 4, cyy = (lane >> 1) & 7, cxx = (lane & 1) * 4;
+            *(uint32_t*)((pl ? P.rec[2] : P.rec[1]) + (size_t)(8 * my + cyy) * (P.cw / 2) + 8 * mx + cxx) =
+                chroma_pred4(pl ? RV : RU, P.cw / 2, P.ch / 2, 8 * mx + cxx + (cx >> 3), 8 * my + cyy + (cy >> 3), cx & 7, cy & 7);
+        }
+        if (lane == 0) {
+            uint4* m = (uint4*)(P.mb + mbi);
+            m[0] = make_uint4(((uint32_t)cx & 0xFFFFu) | ((uint32_t)cy << 16), (uint32_t)MB_P16 | ((uint32_t)rf << 16), 0u, 0u);   // ref_idx_l0 rides in chroma_mode
+            m[1] = make_uint4(0u, 0u, 0u, 0u);
+            P.me_total[mbi] = total;
         }
     }
-    __syncthreads();   // the window and the planes are rebuilt for the next reference picture
-    }   // reference pictures
-    const unsigned best_cost = best_total;
+    const unsigned best_cost = better ? total : prev_total;
+    if (lane == 0) P.me_cost[mbi] = (uint16_t)(best_cost < 16383u ? best_cost : 16383u);   // scene-change statistic, summed by k_bit_scan
+    if (rf != P.rf_last) return;
     // ---- 5. intra or inter: from the motion cost and the SOURCE picture alone (both final before the launch).  A macroblock
     // whose motion cost is INTRA_TEST_MIN or more is also costed as Intra16x16 with the vertical / horizontal / DC prediction
     // built from the source samples above and to the left (SATD, lane = (mode, 4x4 block)) + 8 lambda; if that is lower it is
@@ -614,12 +626,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
             }
             return;
         }
-    }
-    if (lane == 0) {
-        uint4* m = (uint4*)(P.mb + mbi);
-        m[0] = make_uint4(((uint32_t)bcx & 0xFFFFu) | ((uint32_t)bcy << 16), (uint32_t)MB_P16 | ((uint32_t)bref << 16), 0u, 0u);   // ref_idx_l0 rides in chroma_mode
-        m[1] = make_uint4(0u, 0u, 0u, 0u);
-        P.me_cost[mbi] = (uint16_t)(best_cost < 16383u ? best_cost : 16383u);   // scene-change statistic, summed by k_bit_scan
     }
 }
 

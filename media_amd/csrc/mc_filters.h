@@ -148,6 +148,8 @@ __device__ __forceinline__ void idct_quad(int d[4], int r)
     }
 }
 
+__constant__ const uint16_t c_zz_row[4] = {0x6510, 0xC742, 0xDB83, 0xFEA9};  // zig-zag index of raster (r, c), nibble c
+
 // Transform / quantise / reconstruct one 4x4 block held by one lane.
 // d: residual in, reconstructed residual out.  lv: zig-zag levels out.
 // first = 1 skips the DC position (coded separately).  Returns count of non-zero

@@ -168,6 +168,9 @@ struct mi355x_h264_encoder {
     MbInfo* d_mb = nullptr;
     int16_t* d_levels = nullptr;
     int16_t* d_mvd = nullptr;
+    uint8_t* d_aux = nullptr;                // [G][nmb][16] Intra4x4 modes
+    uint32_t* d_me_total = nullptr;          // [G][nmb] best motion cost so far over the reference pictures (k_me, one launch each)
+    int* d_pmv = nullptr;                    // [G][nmb] the previous picture's vectors, parked for the later launches
     uint16_t* d_slotbits = nullptr;
     unsigned long long* d_slotcode = nullptr;
     uint32_t* d_mbbits = nullptr;
@@ -319,7 +322,7 @@ int submit(mi355x_h264_encoder* e, const uint8_t* d_src, size_t src_item_stride,
         for (int r = 0; r < mi355x_h264_encoder::MAX_REFS; r++) P.refs[r][p] = e->d_planes[(cur + e->nbuf - 1 - std::min(r, e->nrefs - 1)) % e->nbuf][p];
         P.ref[p] = P.refs[0][p];
     }
-    P.mb = e->d_mb; P.levels = e->d_levels; P.mvd = e->d_mvd; P.me_cost = e->d_me_cost;
+    P.mb = e->d_mb; P.levels = e->d_levels; P.mvd = e->d_mvd; P.aux = e->d_aux; P.me_cost = e->d_me_cost; P.me_total = e->d_me_total; P.pmv = e->d_pmv;
     P.st_src = src_item_stride; P.st_y = e->st_y; P.st_c = e->st_c; P.st_mb = e->nmb; P.sl = e->sl;
     P.band.row0 = e->b_row0; P.band.rows = e->b_rows;
     P.mbdiv.inv = e->mbw > 1 ? (unsigned)(0x100000000ull / (unsigned)e->mbw) + 1u : 0u;
@@ -352,8 +355,14 @@ int submit(mi355x_h264_encoder* e, const uint8_t* d_src, size_t src_item_stride,
             hipLaunchKernelGGL(k_intra_rows, dim3(e->b_rows, G), dim3(64), 0, st, R);
         }
     } else {
-        { StatScope sc(e, &S, MI355X_H264_K_ME, 1, (uint32_t)(e->b_nmb * e->G));
-          hipLaunchKernelGGL(k_me, dim3(e->b_nmb, G), dim3(64), 0, st, P); }
+        { StatScope sc(e, &S, MI355X_H264_K_ME, (uint32_t)P.nref, (uint32_t)(e->b_nmb * e->G));
+          FrameParams Q = P;   // one launch per reference picture (config.refs): Q.ref = the planes of ref_idx_l0 = Q.rf
+          Q.rf_last = P.nref - 1;
+          for (int r = 0; r < P.nref; r++) {
+              Q.rf = r;
+              for (int p = 0; p < 3; p++) Q.ref[p] = P.refs[r][p];
+              hipLaunchKernelGGL(k_me, dim3(e->b_nmb, G), dim3(64), 0, st, Q);
+          } }
         { StatScope sc(e, &S, MI355X_H264_K_PMB, 1, (uint32_t)(e->b_nmb * e->G));
           if (e->cfg.profile_idc == 100) hipLaunchKernelGGL(k_tq8, dim3((e->b_nmb + 15) / 16, G), dim3(64), 0, st, P);   // High: 8x8 transform, sixteen macroblocks per wave
           else hipLaunchKernelGGL(k_tq, dim3((e->b_nmb + 7) / 8, G), dim3(64), 0, st, P); }   // one wave per eight macroblocks
@@ -385,6 +394,7 @@ int submit(mi355x_h264_encoder* e, const uint8_t* d_src, size_t src_item_stride,
     C.slotbits = e->d_slotbits; C.slotcode = e->d_slotcode; C.mbbits = e->d_mbbits; C.bitbuf = S.d_bitbuf;
     C.bs = (uint8_t*)e->d_bs; C.prevcoded = e->d_prevcoded;
     C.st_mb = e->nmb; C.st_bitbuf = e->st_bitbuf_bytes / 4;
+    C.aux = e->d_aux;
     C.src = d_src; C.w = e->cfg.width; C.h = e->cfg.height; C.src_nv12 = nv12 ? 1 : 0; C.st_src = src_item_stride;
     const int cavlc_grid = (e->b_nmb + 1) / 2;
     unsigned db_serial = 0;
@@ -649,6 +659,10 @@ int mi355x_h264_create(const mi355x_h264_config* cfg, mi355x_h264_encoder** out)
     CK(hipMemset(e->d_mb, 0, Gn * e->nmb * sizeof(MbInfo)));
     CK(hipMalloc((void**)&e->d_levels, Gn * e->nmb * LV_STRIDE * sizeof(int16_t)));
     CK(hipMalloc((void**)&e->d_mvd, Gn * e->nmb * 2 * sizeof(int16_t)));
+    CK(hipMalloc((void**)&e->d_me_total, Gn * e->nmb * sizeof(uint32_t)));
+    CK(hipMalloc((void**)&e->d_pmv, Gn * e->nmb * sizeof(int)));
+    CK(hipMalloc((void**)&e->d_aux, Gn * e->nmb * 16));
+    CK(hipMemset(e->d_aux, 0, Gn * e->nmb * 16));
     CK(hipMalloc((void**)&e->d_slotbits, Gn * e->nmb * 32 * sizeof(uint16_t)));
     CK(hipMalloc((void**)&e->d_slotcode, Gn * e->nmb * 32 * sizeof(unsigned long long)));
     CK(hipMalloc((void**)&e->d_mbbits, Gn * e->nmb * sizeof(uint32_t)));
@@ -705,7 +719,7 @@ void mi355x_h264_destroy(mi355x_h264_encoder* e)
     for (int b = 0; b <= mi355x_h264_encoder::MAX_REFS; b++)
         for (int p = 0; p < 3; p++) (void)hipFree(e->d_planes[b][p]);
     for (int p = 0; p < 3; p++) (void)hipFree(e->d_pre[p]);
-    (void)hipFree(e->d_mb); (void)hipFree(e->d_levels); (void)hipFree(e->d_mvd);
+    (void)hipFree(e->d_mb); (void)hipFree(e->d_levels); (void)hipFree(e->d_mvd); (void)hipFree(e->d_aux); (void)hipFree(e->d_me_total); (void)hipFree(e->d_pmv);
     (void)hipFree(e->d_slotbits); (void)hipFree(e->d_slotcode); (void)hipFree(e->d_mbbits); (void)hipFree(e->d_prevcoded); (void)hipFree(e->d_anybs); (void)hipFree(e->d_anypcm); (void)hipFree(e->d_anyintra); (void)hipFree(e->d_stage);
     (void)hipFree(e->d_handoff); (void)hipFree(e->d_bs); (void)hipFree(e->d_me_cost);
     if (e->h_stage) (void)hipHostFree(e->h_stage);
@@ -988,6 +1002,7 @@ int64_t mi355x_h264_debug_read(mi355x_h264_encoder* e, int what, void* dst, size
             src = e->d_pre[what - MI355X_H264_DBG_PRE_Y]; n = what != MI355X_H264_DBG_PRE_Y ? ysz / 4 : ysz; break;
         case MI355X_H264_DBG_MBINFO: src = e->d_mb; n = (size_t)e->nmb * sizeof(MbInfo); break;
         case MI355X_H264_DBG_LEVELS: src = e->d_levels; n = (size_t)e->nmb * LV_STRIDE * 2; break;
+        case MI355X_H264_DBG_MBAUX: src = e->d_aux; n = (size_t)e->nmb * 16; break;
         default: return MI355X_H264_E_ARG;
     }
     if (cap < n) return MI355X_H264_E_ARG;

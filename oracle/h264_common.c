@@ -370,6 +370,72 @@ void h264o_pred16x16(const uint8_t *rec, int stride, int mode, int avail, uint8_
     }
 }
 
+/* ------------------------------------------------- 8.3.1.2 Intra4x4 pred */
+/* edge samples in one array: E[0..3] = left column bottom to top (p[-1,3] .. p[-1,0]), E[4] = p[-1,-1], E[5..12] = p[0..7,-1] */
+int h264o_pred4x4(const uint8_t *rec, int stride, int mode, int avail, uint8_t pred[16])
+{
+    int left = avail & 1, top = (avail >> 1) & 1, tl = (avail >> 2) & 1, tr = (avail >> 3) & 1;
+    int E[13];
+    for (int y = 0; y < 4; y++) E[3 - y] = left ? rec[y * stride - 1] : 0;
+    E[4] = tl ? rec[-stride - 1] : 0;
+    for (int x = 0; x < 4; x++) E[5 + x] = top ? rec[-stride + x] : 0;
+    for (int x = 4; x < 8; x++) E[5 + x] = top ? (tr ? rec[-stride + x] : rec[-stride + 3]) : 0;
+#define T(x) E[5 + (x)]
+#define L(y) E[3 - (y)]
+    if ((mode == 0 || mode == 3 || mode == 7) && !top) return -1;
+    if ((mode == 1 || mode == 8) && !left) return -1;
+    if ((mode == 4 || mode == 5 || mode == 6) && !(top && left && tl)) return -1;
+    for (int y = 0; y < 4; y++)
+        for (int x = 0; x < 4; x++) {
+            int v;
+            switch (mode) {
+                case 0: v = T(x); break;
+                case 1: v = L(y); break;
+                case 2:
+                    if (top && left) v = (T(0) + T(1) + T(2) + T(3) + L(0) + L(1) + L(2) + L(3) + 4) >> 3;
+                    else if (left) v = (L(0) + L(1) + L(2) + L(3) + 2) >> 2;
+                    else if (top) v = (T(0) + T(1) + T(2) + T(3) + 2) >> 2;
+                    else v = 128;
+                    break;
+                case 3: v = (x == 3 && y == 3) ? (T(6) + 3 * T(7) + 2) >> 2 : (T(x + y) + 2 * T(x + y + 1) + T(x + y + 2) + 2) >> 2; break;
+                case 4: { int i = 4 + x - y; v = (E[i - 1] + 2 * E[i] + E[i + 1] + 2) >> 2; break; }   /* down-right: one filter along the edge array */
+                case 5: {
+                    int z = 2 * x - y, i = 4 + x - (y >> 1);
+                    if (z >= 0 && !(z & 1)) v = (E[i] + E[i + 1] + 1) >> 1;
+                    else if (z >= 0) v = (E[i - 1] + 2 * E[i] + E[i + 1] + 2) >> 2;
+                    else if (z == -1) v = (L(0) + 2 * E[4] + T(0) + 2) >> 2;
+                    else v = (L(y - 1) + 2 * L(y - 2) + L(y - 3) + 2) >> 2;
+                    break;
+                }
+                case 6: {
+                    int z = 2 * y - x, i = 4 - y + (x >> 1);
+                    if (z >= 0 && !(z & 1)) v = (E[i - 1] + E[i] + 1) >> 1;
+                    else if (z >= 0) v = (E[i - 1] + 2 * E[i] + E[i + 1] + 2) >> 2;
+                    else if (z == -1) v = (L(0) + 2 * E[4] + T(0) + 2) >> 2;
+                    else v = (T(x - 1) + 2 * T(x - 2) + T(x - 3) + 2) >> 2;
+                    break;
+                }
+                case 7: {
+                    int i = x + (y >> 1);
+                    v = !(y & 1) ? (T(i) + T(i + 1) + 1) >> 1 : (T(i) + 2 * T(i + 1) + T(i + 2) + 2) >> 2;
+                    break;
+                }
+                default: {
+                    int z = x + 2 * y, i = y + (x >> 1);
+                    if (z > 5) v = L(3);
+                    else if (z == 5) v = (L(2) + 3 * L(3) + 2) >> 2;
+                    else if (!(z & 1)) v = (L(i) + L(i + 1) + 1) >> 1;
+                    else v = (L(i) + 2 * L(i + 1) + L(i + 2) + 2) >> 2;
+                    break;
+                }
+            }
+            pred[4 * y + x] = (uint8_t)v;
+        }
+#undef T
+#undef L
+    return 0;
+}
+
 /* 8.3.4 chroma 8x8 (4:2:0): 0 DC, 1 horizontal, 2 vertical, 3 plane */
 void h264o_pred_chroma8x8(const uint8_t *rec, int stride, int mode, int avail, uint8_t pred[64])
 {
@@ -474,7 +540,8 @@ static int blk_nonzero(const h264o_mbinfo *m, int blk)
 }
 static int edge_bs(const h264o_mbinfo *p, int bp, const h264o_mbinfo *q, int bq, int mb_edge)
 {
-    int pi = p->type == H264O_MB_I16 || p->type == H264O_MB_IPCM, qi = q->type == H264O_MB_I16 || q->type == H264O_MB_IPCM;
+    int pi = p->type == H264O_MB_I16 || p->type == H264O_MB_IPCM || p->type == H264O_MB_I4;
+    int qi = q->type == H264O_MB_I16 || q->type == H264O_MB_IPCM || q->type == H264O_MB_I4;
     if (pi || qi) return mb_edge ? 4 : 3;
     if (blk_nonzero(p, bp) || blk_nonzero(q, bq)) return 2;
     if (p->chroma_mode != q->chroma_mode) return 1;   /* different reference pictures (ref_idx_l0 rides in chroma_mode; one list, never reordered) */

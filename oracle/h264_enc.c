@@ -12,7 +12,11 @@
  * build's own and are written so that every macroblock decision depends only
  * on data that is final before the stage starts (so the GPU can run each stage
  * over all macroblocks at once):
- *   - I pictures: Intra16x16 (4 modes by SATD) + chroma (4 modes by SATD)
+ *   - intra macroblocks: Intra16x16 (4 modes by SATD on the reconstruction) or Intra4x4, + chroma (4 modes by SATD).  Intra4x4
+ *     or 16x16, and the nine-way mode of every 4x4 block, are decided from the SOURCE picture's own samples (every block's
+ *     neighbours are then known up front, so all 16 x 9 candidates are costed side by side); the coding itself predicts
+ *     each block from the true reconstruction, in blkIdx order.  The top-right block of a macroblock never takes the two
+ *     modes that read the macroblock above-right (Diagonal_Down_Left, Vertical_Left): rows stay one macroblock apart
  *   - any macroblock whose CAVLC size could exceed the 3200 bits of A.3.1 is coded as I_PCM.  "Could": decided from an
  *     upper bound on the bits (mb_bits_bound below: sum over the blocks of simple statistics of the levels), not from the
  *     bits themselves, so the decision is made when the macroblock is coded and nothing coded later depends on a later
@@ -171,6 +175,7 @@ struct h264o_enc {
     int64_t last_slice_bits;
     uint32_t me_cost; /* scene-change statistic of the last picture */
     int any_pcm;      /* the picture being coded holds an I_PCM macroblock: it is not loop-filtered */
+    uint8_t *aux;          /* 16 bytes per macroblock: Intra4x4PredMode of the 16 blocks (blkIdx order) */
     uint8_t *want_intra;   /* P pictures: 1 = the motion search handed the macroblock to the intra pass; 2 = one of the "nothing
                             * left to code" tests hit: the prediction is the reconstruction, no transform is run (the tests use
                             * the 4x4 transform whatever transform the profile codes with) */
@@ -227,6 +232,7 @@ h264o_enc *h264o_enc_create(const h264o_config *cfg)
     e->levels = (int16_t *)calloc((size_t)e->mbw * e->mbh * H264O_LV_STRIDE, sizeof(int16_t));
     e->slice_of = (int16_t *)calloc((size_t)e->mbw * e->mbh, sizeof(int16_t));
     e->want_intra = (uint8_t *)calloc((size_t)e->mbw * e->mbh, 1);
+    e->aux = (uint8_t *)calloc((size_t)e->mbw * e->mbh, 16);
     for (int i = 0; i < e->mbw * e->mbh; i++) e->slice_of[i] = (int16_t)(i / e->mbw / e->slice_rows);
     e->rbsp_cap = ysz * 4 + 65536;
     e->rbsp = (uint8_t *)malloc(e->rbsp_cap);
@@ -241,6 +247,7 @@ void h264o_enc_destroy(h264o_enc *e)
     free(e->levels);
     free(e->slice_of);
     free(e->want_intra);
+    free(e->aux);
     free(e->rbsp);
     free(e);
 }
@@ -290,6 +297,7 @@ int h264o_enc_coded_height(const h264o_enc *e) { return e->ch; }
 const uint8_t *h264o_enc_recon(const h264o_enc *e, int p) { return e->ref[p]; }
 const uint8_t *h264o_enc_recon_pre(const h264o_enc *e, int p) { return e->rec[p]; }
 const h264o_mbinfo *h264o_enc_mbinfo(const h264o_enc *e) { return e->mb; }
+const uint8_t *h264o_enc_mbaux(const h264o_enc *e) { return e->aux; }
 const int16_t *h264o_enc_levels(const h264o_enc *e) { return e->levels; }
 int64_t h264o_enc_last_slice_bits(const h264o_enc *e) { return e->last_slice_bits; }
 uint32_t h264o_enc_last_me_cost(const h264o_enc *e) { return e->me_cost; }
@@ -407,7 +415,7 @@ static const uint8_t xy2blk[16] = {0, 1, 4, 5, 2, 3, 6, 7, 8, 9, 12, 13, 10, 11,
  *   from the bitwise OR of the magnitudes (>= m): bits(OR) <= 2 -> 1, else min(bits(OR), 6);
  *   the first level (s = 0: up to 2a, 19 or 28 bits) and an escape at s = 1 (28 bits for 15 <= a <= 26) can exceed that by
  *   at most 12, and only one of the two can happen in a block -> + 12.
- * The macroblock bound adds 64 for mb_type, vectors / prediction modes, coded_block_pattern and mb_qp_delta. */
+ * The macroblock bound adds 96 for mb_type, vectors / prediction modes, coded_block_pattern and mb_qp_delta. */
 static int blk_bits_bound(const int16_t *lv, int n)
 {
     int tc = 0, orv = 0;
@@ -427,7 +435,7 @@ static int blk_bits_bound(const int16_t *lv, int n)
     int z = 2 * tc + 22 < 73 - 4 * tc ? 2 * tc + 22 : 73 - 4 * tc;
     return sum + 12 + 16 + z;
 }
-enum { MB_BITS_LIMIT = 3200, MB_HEADER_BOUND = 64, INTRA_TEST_MIN = 2000 };
+enum { MB_BITS_LIMIT = 3200, MB_HEADER_BOUND = 96, INTRA_TEST_MIN = 2000 };   /* header: I_NxN carries up to 16 x 4 mode bits */
 static int mb_bits_bound(const int16_t *lv, int intra16)
 {
     int b = MB_HEADER_BOUND;
@@ -540,6 +548,87 @@ static void encode_intra_mb(h264o_enc *e, int mx, int my)
     uint8_t *r = e->rec[0] + (16 * my) * cw + 16 * mx;
     uint8_t pred[256], best_pred[256];
     int best = -1, best_cost = 0;
+    /* ---- Intra4x4 or Intra16x16: both costed on the SOURCE picture (its samples stand in for the neighbours'
+     * reconstruction), lambda * 48 / lambda * 8 for the modes' bits ---- */
+    uint8_t i4mode[16];
+    int i4avail[16], use_i4;
+    {
+        int lambda = o_lambda[qp], est16 = -1, sum4 = 0;
+        for (int mode = 0; mode < 4; mode++) {
+            if (mode == 0 && !(avail & 2)) continue;
+            if (mode == 1 && !(avail & 1)) continue;
+            if (mode == 3 && avail != 7) continue;
+            h264o_pred16x16(s, cw, mode, avail, pred);
+            int c = h264o_satd16x16(s, cw, pred, 16);
+            if (est16 < 0 || c < est16) est16 = c;
+        }
+        for (int b = 0; b < 16; b++) {
+            int x = o_blk_x[b], y = o_blk_y[b];
+            int left = x > 0 || mx > 0, tp = y > 0 || top;
+            int tl = (x > 0 && y > 0) ? 1 : x > 0 ? top : y > 0 ? (mx > 0) : (mx > 0 && top);
+            int tr;
+            if (y == 0) tr = x < 3 ? top : (top && mx + 1 < e->mbw);
+            else if (x == 3) tr = 0;
+            else tr = xy2blk[4 * (y - 1) + x + 1] < b;   /* inside the macroblock: available when coded before this block */
+            i4avail[b] = left | (tp << 1) | (tl << 2) | (tr << 3);
+            int bc = -1, bm = 2;
+            for (int m = 0; m < 9; m++) {
+                uint8_t p4[16];
+                if (x == 3 && y == 0 && (m == 3 || m == 7)) continue;   /* would read the macroblock above-right */
+                if (h264o_pred4x4(s + 4 * y * cw + 4 * x, cw, m, i4avail[b], p4)) continue;
+                int16_t d[16];
+                for (int j = 0; j < 4; j++)
+                    for (int i = 0; i < 4; i++) d[4 * j + i] = (int16_t)(s[(4 * y + j) * cw + 4 * x + i] - p4[4 * j + i]);
+                int t[16], c = 0;
+                for (int i = 0; i < 4; i++) {
+                    int s0 = d[4 * i] + d[4 * i + 3], s1 = d[4 * i + 1] + d[4 * i + 2], d0 = d[4 * i] - d[4 * i + 3], d1 = d[4 * i + 1] - d[4 * i + 2];
+                    t[4 * i] = s0 + s1; t[4 * i + 1] = d0 + d1; t[4 * i + 2] = s0 - s1; t[4 * i + 3] = d0 - d1;
+                }
+                for (int j = 0; j < 4; j++) {
+                    int s0 = t[j] + t[12 + j], s1 = t[4 + j] + t[8 + j], d0 = t[j] - t[12 + j], d1 = t[4 + j] - t[8 + j];
+                    c += abs(s0 + s1) + abs(d0 + d1) + abs(s0 - s1) + abs(d0 - d1);
+                }
+                if (bc < 0 || c < bc) { bc = c; bm = m; }
+            }
+            i4mode[b] = (uint8_t)bm;
+            sum4 += bc;
+        }
+        use_i4 = (sum4 >> 1) + 48 * lambda < est16 + 8 * lambda;
+    }
+    if (use_i4) {
+        mb->type = H264O_MB_I4;
+        int cbpl = 0;
+        for (int b = 0; b < 16; b++) {
+            int bx = o_blk_x[b] * 4, by = o_blk_y[b] * 4;
+            uint8_t p4[16];
+            int16_t deq[16];
+            h264o_pred4x4(r + by * cw + bx, cw, i4mode[b], i4avail[b], p4);
+            int nnz = tq_block(s + by * cw + bx, cw, p4, 4, qp, 1, 0, lv + H264O_LV_LUMA + b * 16, deq, NULL);
+            mb->tc[b] = (uint8_t)nnz;
+            for (int j = 0; j < 4; j++) memcpy(r + (by + j) * cw + bx, p4 + 4 * j, 4);
+            if (nnz) { cbpl |= 1 << (b >> 2); h264o_idct4x4_add(deq, r + by * cw + bx, cw); }
+            e->aux[(size_t)(my * e->mbw + mx) * 16 + b] = i4mode[b];
+        }
+        /* chroma exactly as in an Intra16x16 macroblock */
+        uint8_t predc4[2][64], bestc4[2][64];
+        int cb4 = -1, cc4 = 0;
+        for (int mode = 0; mode < 4; mode++) {
+            if (mode == 1 && !(avail & 1)) continue;
+            if (mode == 2 && !(avail & 2)) continue;
+            if (mode == 3 && avail != 7) continue;
+            int cost = 0;
+            for (int pl = 0; pl < 2; pl++) {
+                h264o_pred_chroma8x8(e->rec[1 + pl] + (8 * my) * cs + 8 * mx, cs, mode, avail, predc4[pl]);
+                cost += h264o_satd8x8(e->src[1 + pl] + (8 * my) * cs + 8 * mx, cs, predc4[pl], 8);
+            }
+            if (cb4 < 0 || cost < cc4) { cb4 = mode; cc4 = cost; memcpy(bestc4, predc4, sizeof(predc4)); }
+        }
+        mb->chroma_mode = (uint8_t)cb4;
+        int cbpc4 = code_chroma(e, mx, my, bestc4, 1, lv, mb->tc, 1);
+        mb->cbp = (uint8_t)(cbpl | (cbpc4 << 4));
+        if (mb_bits_bound(lv, 0) > MB_BITS_LIMIT) make_pcm(e, mx, my);
+        return;
+    }
     for (int mode = 0; mode < 4; mode++) {
         if (mode == 0 && !(avail & 2)) continue;
         if (mode == 1 && !(avail & 1)) continue;
@@ -766,7 +855,7 @@ static void neighbour(const h264o_enc *e, int mx, int my, int cur_my, int *avail
     mv->x = mv->y = 0;
     if (!*avail) return;
     const h264o_mbinfo *m = &e->mb[my * e->mbw + mx];
-    if (m->type != H264O_MB_I16 && m->type != H264O_MB_IPCM) { *ref = m->chroma_mode; mv->x = m->mvx; mv->y = m->mvy; }   /* (ref_idx_l0 rides in chroma_mode) */
+    if (m->type != H264O_MB_I16 && m->type != H264O_MB_IPCM && m->type != H264O_MB_I4) { *ref = m->chroma_mode; mv->x = m->mvx; mv->y = m->mvy; }   /* (ref_idx_l0 rides in chroma_mode) */
 }
 static int med3(int a, int b, int c) { return a > b ? (b > c ? b : (a > c ? c : a)) : (a > c ? a : (b > c ? c : b)); }
 
@@ -926,6 +1015,28 @@ static void write_mb(h264o_enc *e, bitw *b, int mx, int my, int p_slice)
                 for (int x = 0; x < 8; x++) bw_put(b, 8, e->src[pl][(8 * my + y) * cs + 8 * mx + x]);
         return;
     }
+    if (mb->type == H264O_MB_I4) {   /* I_NxN: 7.3.5.1 mb_pred with the sixteen Intra4x4 modes, then the residual by coded_block_pattern */
+        const uint8_t *am = e->aux + (size_t)(my * e->mbw + mx) * 16;
+        bw_ue(b, (uint32_t)(p_slice ? 5 : 0));
+        if (e->cfg.profile_idc == 100) bw_put(b, 1, 0);   /* transform_size_8x8_flag: Intra4x4, not Intra8x8 */
+        for (int k = 0; k < 16; k++) {   /* 8.3.1.1: predicted mode = the smaller of the left and upper blocks' modes */
+            int x = o_blk_x[k], y = o_blk_y[k], mA, mB, dc_only = 0;
+            if (x > 0) mA = am[xy2blk[4 * y + x - 1]];
+            else if (mx == 0) { dc_only = 1; mA = 2; }
+            else mA = (mb - 1)->type == H264O_MB_I4 ? (am - 16)[xy2blk[4 * y + 3]] : 2;
+            if (y > 0) mB = am[xy2blk[4 * (y - 1) + x]];
+            else if (!top_in_slice(e, my)) { dc_only = 1; mB = 2; }
+            else mB = (mb - e->mbw)->type == H264O_MB_I4 ? (am - 16 * e->mbw)[xy2blk[12 + x]] : 2;
+            int pm = dc_only ? 2 : (mA < mB ? mA : mB), m = am[k];
+            if (m == pm) bw_put(b, 1, 1);
+            else { bw_put(b, 1, 0); bw_put(b, 3, (uint32_t)(m < pm ? m : m - 1)); }
+        }
+        bw_ue(b, mb->chroma_mode);
+        int code = 0;
+        while (o_cbp_code2intra[code] != mb->cbp) code++;
+        bw_ue(b, (uint32_t)code);
+        if (mb->cbp) bw_se(b, 0); /* mb_qp_delta */
+    } else
     if (mb->type == H264O_MB_I16) {
         int t = 1 + mb->i16_mode + 4 * cbpc + (cbpl ? 12 : 0);
         bw_ue(b, (uint32_t)(p_slice ? 5 + t : t));

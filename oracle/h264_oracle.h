@@ -34,7 +34,7 @@ enum {
     H264O_LV_STRIDE = 416     /* int16 per macroblock (832 B)                       */
 };
 
-enum { H264O_MB_I16 = 0, H264O_MB_P16 = 1, H264O_MB_PSKIP = 2, H264O_MB_IPCM = 3 };
+enum { H264O_MB_I16 = 0, H264O_MB_P16 = 1, H264O_MB_PSKIP = 2, H264O_MB_IPCM = 3, H264O_MB_I4 = 4 };
 
 typedef struct {
     int32_t width, height;  /* display size, even, 16..4096                          */
@@ -87,6 +87,11 @@ int h264o_enc_coded_height(const h264o_enc *e);
 const uint8_t *h264o_enc_recon(const h264o_enc *e, int plane);       /* deblocked */
 const uint8_t *h264o_enc_recon_pre(const h264o_enc *e, int plane);   /* before loop filter */
 const h264o_mbinfo *h264o_enc_mbinfo(const h264o_enc *e);
+/* 16 bytes per macroblock beside mbinfo: Intra4x4PredMode of the 16 blocks (blkIdx order) for H264O_MB_I4 */
+const uint8_t *h264o_enc_mbaux(const h264o_enc *e);
+/* Intra4x4 prediction (8.3.1.2) of one block: rec points at the block inside the picture under reconstruction;
+ * avail bit0 left, bit1 top, bit2 top-left, bit3 top-right.  Returns 0, or -1 when the mode needs unavailable samples */
+int h264o_pred4x4(const uint8_t *rec, int stride, int mode, int avail, uint8_t pred[16]);
 const int16_t *h264o_enc_levels(const h264o_enc *e);
 /* bits of slice_data() of the last slice, before trailing bits (for tests) */
 int64_t h264o_enc_last_slice_bits(const h264o_enc *e);

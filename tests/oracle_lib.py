@@ -50,6 +50,8 @@ def lib():
             getattr(L, n).argtypes = [vp, C.c_int]
         L.h264o_enc_mbinfo.restype = vp
         L.h264o_enc_mbinfo.argtypes = [vp]
+        L.h264o_enc_mbaux.restype = vp
+        L.h264o_enc_mbaux.argtypes = [vp]
         L.h264o_enc_levels.restype = vp
         L.h264o_enc_levels.argtypes = [vp]
         L.h264o_enc_set_qp.argtypes = [vp, C.c_int]
@@ -146,6 +148,12 @@ class OracleEncoder:
         addr = lib().h264o_enc_mbinfo(self.h)
         raw = np.ctypeslib.as_array(C.cast(addr, C.POINTER(C.c_uint8)), shape=(n * 32,)).copy()
         return raw.view(MBINFO_DTYPE)
+
+    def mbaux(self):
+        """16 bytes per macroblock: Intra4x4PredMode of the blocks of an Intra4x4 macroblock (blkIdx order)"""
+        n = (self.cw // 16) * (self.ch // 16)
+        addr = lib().h264o_enc_mbaux(self.h)
+        return np.ctypeslib.as_array(C.cast(addr, C.POINTER(C.c_uint8)), shape=(n, 16)).copy()
 
     def levels(self):
         n = (self.cw // 16) * (self.ch // 16)

@@ -33,6 +33,9 @@ def _compare_all(enc, orc, tag):
     read[(cbp >> 4) >= 1, 272:280] = True
     read[(cbp >> 4) == 2, 280:408] = True
     read[omb["type"] == 3, :] = False            # I_PCM: samples, no levels
+    i4 = omb["type"] == 4                         # Intra4x4: the sixteen modes
+    if i4.any():
+        assert np.array_equal(enc.debug_read(capi.DBG_MBAUX)[i4], orc.mbaux()[i4]), tag + ": Intra4x4 modes"
     assert np.array_equal(np.where(read, glv, 0), np.where(read, olv, 0)), tag + ": levels"
     for p in range(3):
         assert np.array_equal(enc.debug_read(capi.DBG_PRE_Y + p), orc.recon_pre(p)), "%s: pre-filter plane %d" % (tag, p)
@@ -654,7 +657,7 @@ def test_content_that_cannot_be_coded_by_cavlc_goes_i_pcm():
 
 def test_intra_macroblocks_inside_p_pictures():
     """a cut inside a GOP (no scene-change IDR at the C ABI: that is the plugin class's rule): the P picture after it mixes
-    Intra16x16 and inter macroblocks; every stage equals the oracle, with one slice and with slice bands"""
+    intra (16x16 / 4x4) and inter macroblocks; every stage equals the oracle, with one slice and with slice bands"""
     for (w, h, slices) in ((352, 288, 0), (640, 368, 4)):
         enc = capi.Encoder(w, h, qp=28, gop=30, slices=slices)
         enc.keep_pre(True)
@@ -664,6 +667,6 @@ def test_intra_macroblocks_inside_p_pictures():
             assert enc.encode(f)[0] == orc.encode(f)[0], "picture %d" % i
             _compare_all(enc, orc, "cut picture %d" % i)
             if i >= 2:
-                n_intra += int((orc.mbinfo()["type"] == 0).sum())
+                n_intra += int(np.isin(orc.mbinfo()["type"], (0, 3, 4)).sum())   # Intra16x16, I_PCM, Intra4x4
         assert n_intra > 0
         enc.close()

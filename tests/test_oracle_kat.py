@@ -329,3 +329,43 @@ def test_coded_block_pattern_mapping_against_the_standard():
     assert sorted(intra) == sorted(inter) == list(range(48))
     assert _c_table("o_cbp_code2intra") == intra
     assert _c_table("o_cbp_code2inter") == inter
+
+
+def test_intra4x4_prediction_table_against_the_oracle():
+    """media_amd/csrc/k_intra.h predicts Intra4x4 samples through a generated table (tools/gen_i4_table.py: copy / 2-tap /
+    3-tap at a position of the padded edge array).  The table, evaluated on random neighbours, must give what the oracle's
+    h264o_pred4x4 (a direct statement of 8.3.1.2, itself pinned by the independent decoder's round trip) gives."""
+    import importlib.util
+    import os
+    import random
+    spec = importlib.util.spec_from_file_location("gen_i4_table", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "gen_i4_table.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    tab = gen.table()
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "media_amd", "csrc", "k_intra.h")).read()
+    for m in range(9):     # the header holds exactly the generated rows
+        assert "{" + ", ".join("0x%02X" % v for v in tab[m]) + "}" in src, "c_i4tab row %d" % m
+    L = ol.lib()
+    L.h264o_pred4x4.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    rng = random.Random(11)
+    for _ in range(200):
+        pic = np.array([rng.randrange(256) for _ in range(16 * 16)], np.uint8).reshape(16, 16)
+        avail = rng.choice([15, 7, 15, 7, 3, 1, 2, 0, 11])    # bit0 left, bit1 top, bit2 top-left, bit3 top-right
+        left, top, tl, tr = avail & 1, (avail >> 1) & 1, (avail >> 2) & 1, (avail >> 3) & 1
+        blk = pic[5:, 5:]                                     # the block starts at (5, 5): neighbours exist in the array
+        E = [int(pic[5 + 3 - k, 4]) if left else 0 for k in range(4)] + [int(pic[4, 4]) if tl else 0] + \
+            [int(pic[4, 5 + k]) if top else 0 for k in range(4)] + [(int(pic[4, 9 + k]) if tr else int(pic[4, 8])) if top else 0 for k in range(4)]
+        for mode in range(9):
+            out = np.zeros(16, np.uint8)
+            rc = L.h264o_pred4x4(blk.ctypes.data, 16, mode, avail, out.ctypes.data)
+            need = {0: top, 1: left, 2: 1, 3: top, 4: top and left and tl, 5: top and left and tl, 6: top and left and tl, 7: top, 8: left}[mode]
+            assert (rc == 0) == bool(need)
+            if rc:
+                continue
+            for i in range(16):
+                if mode == 2:
+                    st, sl = sum(E[5:9]), sum(E[0:4])
+                    want = (st + sl + 4) >> 3 if (top and left) else (sl + 2) >> 2 if left else (st + 2) >> 2 if top else 128
+                else:
+                    want = gen.table_sample(E, mode, i & 3, i >> 2, tab)
+                assert int(out[i]) == want, (mode, i, avail)

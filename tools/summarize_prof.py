@@ -12,7 +12,7 @@ with open("profiles/%s_kernel_stats.csv" % tag, "w") as f:
     w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
     for r in rows:
         w.writerow([r["Name"], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
-# split k_pmb2 launches by grid size (batched main region vs single-GOP phase) from the trace
+# split the launches by grid size (batched main region vs single-GOP phase) from the trace
 tr = glob.glob(src + "/stats/*/*kernel_trace.csv")[0]
 by = collections.defaultdict(list)
 for r in csv.DictReader(open(tr)):
@@ -42,5 +42,21 @@ if sq:
         d[(r["Kernel_Name"].split("(")[0].replace("void ", "").replace("h264::", ""), int(r["Grid_Size"]))][r["Counter_Name"]].append(float(r["Counter_Value"]))
     out["sq"] = {"%s grid=%d threads" % k: {c: round(sum(v) / len(v)) for c, v in cs.items()} for k, cs in sorted(d.items())}
 json.dump(out, open("profiles/%s_summary.json" % tag, "w"), indent=1)
-print(json.dumps({k: v for k, v in out["pmc"].items() if "pmb2" in k or "k_me" in k}, indent=1))
-print(json.dumps({k: v for k, v in split.items() if "pmb2" in k or "k_me" in k or "deblock" in k}, indent=1))
+print(json.dumps({k: v for k, v in out["pmc"].items() if "k_tq" in k or "k_me" in k}, indent=1))
+print(json.dumps({k: v for k, v in split.items() if "k_tq" in k or "k_me" in k or "deblock" in k}, indent=1))
+# HBM traffic of the roofline kernel (k_tq), corrected as MI355X_MICROARCH.md prescribes: FETCH_SIZE x 2 (gfx950 tallies
+# 128-B requests at 64 B), WRITE_SIZE as is; both counters are in KB -> bytes.  The lockstep launch = the largest grid.
+tq = [(k, v) for k, v in out["pmc"].items() if k.startswith("k_tq ") and v["FETCH_SIZE_KB_raw"] and v["WRITE_SIZE_KB"]]
+if tq:
+    k, v = max(tq, key=lambda kv: int(kv[0].split("grid=")[1].split()[0]))
+    threads = int(k.split("grid=")[1].split()[0])
+    mbs = threads // 64 * 8
+    tr_ = {"kernel": "k_tq", "lockstep_batch": mbs // 8160, "macroblocks_per_launch": mbs,
+           "FETCH_SIZE_bytes_raw": int(v["FETCH_SIZE_KB_raw"] * 1024), "FETCH_SIZE_bytes_corrected_x2": int(v["FETCH_SIZE_KB_raw"] * 2048),
+           "WRITE_SIZE_bytes": int(v["WRITE_SIZE_KB"] * 1024),
+           "traffic_bytes_per_launch": int(v["FETCH_SIZE_KB_raw"] * 2048 + v["WRITE_SIZE_KB"] * 1024),
+           "algorithmic_bytes_per_launch": 1952 * mbs,
+           "note": "separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of `python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-plugin` "
+                   "(profiles/%s_summary.json); FETCH_SIZE doubled per MI355X_MICROARCH.md, WRITE_SIZE taken as is" % tag}
+    json.dump(tr_, open("profiles/%s_traffic.json" % tag, "w"), indent=1)
+    print(json.dumps(tr_, indent=1))
