@@ -227,6 +227,18 @@ __device__ __forceinline__ int quant1(int w, int mf, int f, int qbits)
     const int l = (int)(((unsigned)a * (unsigned)mf + (unsigned)f) >> qbits);
     return w < 0 ? -l : l;
 }
+// keep a wave-uniform value in a VGPR: VOP2 with an SGPR operand issues at half the rate of the all-VGPR form
+__device__ __forceinline__ int vreg(int x)
+{
+    asm volatile("" : "+v"(x));
+    return x;
+}
+// sign(w) * ((|w| * mf + f) >> q) without the absolute value: for w < 0, -floor((|w| mf + f) / 2^q) = floor((w mf + 2^q - 1 - f) / 2^q)
+__device__ __forceinline__ int quant_signed(int w, int mf, int f, int c, int q)
+{
+    const int s = w >> 31;
+    return (__mul24(w, mf) + (f + (s & c))) >> q;
+}
 
 // ---- I_PCM fallback: upper bound on the CAVLC bits of one residual block (oracle/h264_enc.c blk_bits_bound states the
 // derivation): tc levels, `sum16` = sum over all 16 positions of max(min(|level|, 27), h) with h = smax + 1, smax from the
@@ -328,6 +340,16 @@ __device__ __forceinline__ unsigned wave_min_u32_dpp(unsigned v)   // minimum ov
 __device__ __forceinline__ int src_px(const uint8_t* plane, int pw, int ph, int x, int y)
 {
     return plane[(size_t)(y < ph ? y : ph - 1) * pw + (x < pw ? x : pw - 1)];
+}
+
+// The chroma reconstruction plane of component pl (0 Cb, 1 Cr), pl differing between lanes.  Written as a select between
+// P.rec[1] and P.rec[2] it compiles to an indexed load of P.rec[], and that moves the whole parameter block into scratch memory
+// (every later use of P then costs a scratch load); the two pointers therefore pass through an opaque no-op first.
+__device__ __forceinline__ uint8_t* rec_chroma(const FrameParams& P, int pl)
+{
+    uint8_t *a = P.rec[1], *b = P.rec[2];
+    asm volatile("" : "+s"(a), "+s"(b));
+    return pl ? b : a;
 }
 
 // four source chroma samples (plane pl, columns gx..gx+3 of row gy) packed into one word, clamped like src_px.

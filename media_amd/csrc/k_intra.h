@@ -11,6 +11,7 @@
 #pragma once
 #include "dev_common.h"
 #include "mc_filters.h"
+#include "k_intra4.h"
 
 namespace h264 {
 
@@ -106,6 +107,8 @@ __device__ __forceinline__ C8Params c8_params(const uint8_t* top_, const uint8_t
     q.c = (34 * V + 32) >> 6;
     return q;
 }
+// element k of four values held in registers (an index into the array would move it to scratch memory)
+__device__ __forceinline__ int pick4(const int v[4], int k) { return k == 0 ? v[0] : (k == 1 ? v[1] : (k == 2 ? v[2] : v[3])); }
 __device__ __forceinline__ int c8_px(int mode, int x, int y, const uint8_t* top, const uint8_t* left, const C8Params& q)
 {
     return mode == 0 ? q.dc[(y >> 2) * 2 + (x >> 2)] : mode == 1 ? left[y] : mode == 2 ? top[1 + x]
@@ -124,210 +127,29 @@ struct IntraLds {
     int dc[16];
     uint8_t top[20], left[16];        // luma neighbours; top[0] = top-left
     uint8_t ctop[2][12], cleft[2][8];
-    // Intra4x4: neighbours of the macroblock in the SOURCE picture (stop[0] = corner, stop[1..20] = row above incl. 4 samples to
-    // the right), 13 edge samples per block (E[0..3] left column bottom to top, E[4] corner, E[5..12] row above), chosen modes
-    __attribute__((aligned(4))) uint8_t stop[24];
-    __attribute__((aligned(4))) uint8_t sleft[16];
-    __attribute__((aligned(4))) uint8_t e4[16][16];
-    __attribute__((aligned(4))) uint8_t i4m[16];
+    I4Lds i4;                         // Intra4x4 macroblocks (k_intra4.h)
 };
 
-// ---- Intra4x4 (8.3.1.2).  Every predicted sample is a copy, a 2-tap or a 3-tap filter at one position of the block's 13
-// edge samples E = [L3 L2 L1 L0 TL T0..T7] (top-right already folded in: repeated when unavailable), padded by one repeated
-// sample at both ends: Ep[0] = E[0], Ep[1 + k] = E[k], Ep[14] = E[12].  Table entry = kind << 4 | p: 0 copy Ep[p], 1 two-tap
-// Ep[p], Ep[p + 1], 2 three-tap Ep[p - 1], Ep[p], Ep[p + 1], 3 DC.  Branch-free: a mode is data, not control flow (the first
-// form, a switch per sample, compiled to ~250 basic blocks inside the sequential 16-block loop and ran 6x slower). ----
-// generated by tools/gen_i4_table.py (checked there against 8.3.1.2's formulas)
-__constant__ const uint8_t c_i4tab[9][16] = {
-    {0x06, 0x07, 0x08, 0x09, 0x06, 0x07, 0x08, 0x09, 0x06, 0x07, 0x08, 0x09, 0x06, 0x07, 0x08, 0x09},
-    {0x04, 0x04, 0x04, 0x04, 0x03, 0x03, 0x03, 0x03, 0x02, 0x02, 0x02, 0x02, 0x01, 0x01, 0x01, 0x01},
-    {0x31, 0x31, 0x31, 0x31, 0x31, 0x31, 0x31, 0x31, 0x31, 0x31, 0x31, 0x31, 0x31, 0x31, 0x31, 0x31},
-    {0x27, 0x28, 0x29, 0x2A, 0x28, 0x29, 0x2A, 0x2B, 0x29, 0x2A, 0x2B, 0x2C, 0x2A, 0x2B, 0x2C, 0x2D},
-    {0x25, 0x26, 0x27, 0x28, 0x24, 0x25, 0x26, 0x27, 0x23, 0x24, 0x25, 0x26, 0x22, 0x23, 0x24, 0x25},
-    {0x15, 0x16, 0x17, 0x18, 0x25, 0x26, 0x27, 0x28, 0x24, 0x15, 0x16, 0x17, 0x23, 0x25, 0x26, 0x27},
-    {0x14, 0x25, 0x26, 0x27, 0x13, 0x24, 0x14, 0x25, 0x12, 0x23, 0x13, 0x24, 0x11, 0x22, 0x12, 0x23},
-    {0x16, 0x17, 0x18, 0x19, 0x27, 0x28, 0x29, 0x2A, 0x17, 0x18, 0x19, 0x1A, 0x28, 0x29, 0x2A, 0x2B},
-    {0x13, 0x23, 0x12, 0x22, 0x12, 0x22, 0x11, 0x21, 0x11, 0x21, 0x01, 0x01, 0x01, 0x01, 0x01, 0x01},
-};
-__device__ __forceinline__ int pred4_tab(const uint8_t* Ep, int e, int dc)
-{
-    const int p = e & 15, k = e >> 4;
-    const int A = Ep[p - 1], B = Ep[p], C = Ep[p + 1];
-    const int t2 = (B + C + 1) >> 1, t3 = (A + 2 * B + C + 2) >> 2;
-    return k == 0 ? B : k == 1 ? t2 : k == 2 ? t3 : dc;
-}
-// DC prediction (8.3.1.2.3) from the padded edge array; avail bit0 left, bit1 top
-__device__ __forceinline__ int pred4_dc(const uint8_t* Ep, int avail)
-{
-    const bool l = avail & 1, t = avail & 2;
-    const int st = Ep[6] + Ep[7] + Ep[8] + Ep[9], sl = Ep[1] + Ep[2] + Ep[3] + Ep[4];
-    return (t && l) ? (st + sl + 4) >> 3 : l ? (sl + 2) >> 2 : t ? (st + 2) >> 2 : 128;
-}
-// availability of the neighbours of block (x, y) of macroblock mx (6.4.11.4): bit0 left, bit1 top, bit2 top-left, bit3 top-right
-__device__ __forceinline__ int i4_avail(int b, int x, int y, int mx, bool top, int mbw)
-{
-    const int left = (x > 0 || mx > 0) ? 1 : 0, tp = (y > 0 || top) ? 1 : 0;
-    const int tl = (x > 0 && y > 0) ? 1 : (x > 0 ? (top ? 1 : 0) : (y > 0 ? (mx > 0 ? 1 : 0) : ((mx > 0 && top) ? 1 : 0)));
-    int tr;
-    if (y == 0) tr = x < 3 ? (top ? 1 : 0) : ((top && mx + 1 < mbw) ? 1 : 0);
-    else if (x == 3) tr = 0;
-    else tr = xy2blk(x + 1, y - 1) < b ? 1 : 0;
-    return left | (tp << 1) | (tl << 2) | (tr << 3);
-}
-// padded edge sample kp (0..14) of block (x, y): mb = the macroblock's 16x16 samples (pitch 16), top[0] = corner, top[1..] = row
-// above, left[0..15] = column to the left.  Unavailable samples read as 0; an unavailable top-right repeats the last sample above.
-__device__ __forceinline__ int i4_edge(const uint8_t* mb, const uint8_t* top, const uint8_t* left, int x, int y, int av, int kp)
-{
-    const int k = kp == 0 ? 0 : (kp == 14 ? 12 : kp - 1);
-    if (k < 4) {   // left column, bottom to top: row 4y + 3 - k
-        if (!(av & 1)) return 0;
-        const int r = 4 * y + 3 - k;
-        return x > 0 ? mb[r * 16 + 4 * x - 1] : left[r];
-    }
-    if (k == 4) {
-        if (!(av & 4)) return 0;
-        if (y > 0) return x > 0 ? mb[(4 * y - 1) * 16 + 4 * x - 1] : left[4 * y - 1];
-        return top[4 * x];        // (x = 0: the corner top[0])
-    }
-    if (!(av & 2)) return 0;
-    int c = k - 5;               // 0..7 along the row above
-    if (c > 3 && !(av & 8)) c = 3;
-    return y > 0 ? mb[(4 * y - 1) * 16 + 4 * x + c] : top[1 + 4 * x + c];
-}
-
-
-// Mode decision, transform, quantisation and reconstruction of one Intra16x16 macroblock whose source and
+// Mode decision, transform, quantisation and reconstruction of one intra macroblock (Intra16x16, or Intra4x4 with the
+// modes k_i4_decide chose) whose source and
 // neighbour samples are already in S (and visible to the whole wave).  Writes recon (global + S.rec_*),
 // levels, MbInfo, mvd.
-__device__ __forceinline__ void intra_mb_core(const FrameParams& P, int mx, int my, IntraLds& S, int lane)
+__device__ __forceinline__ void intra_mb_core(const FrameParams& P, int mx, int my, IntraLds& S, int lane, bool use_i4, uint32_t auxw)
 {
     const int mbi = my * P.mbw + mx, bx = 16 * mx, by = 16 * my, cs = P.cw / 2;
     const bool top = P.sl.has_top(my);   // the row above belongs to this slice
     const int avail = (mx > 0 ? 1 : 0) | (top ? 2 : 0) | ((mx > 0 && top) ? 4 : 0);
     for (int i = lane; i < LV_STRIDE / 2; i += 64) ((uint32_t*)S.lv)[i] = 0;
 
-    // ---- Intra4x4 or Intra16x16, and the mode of every 4x4 block: decided on the SOURCE picture (its samples stand in for
-    // the neighbours' reconstruction, so all blocks' neighbours are known at once), oracle/h264_enc.c encode_intra_mb ----
-    bool use_i4;
+    // ---- Intra4x4 (type and modes chosen by k_i4_decide; use_i4 is wave-uniform, auxw = lanes 0..3: the sixteen modes) ----
     int cbp_luma_i4 = 0;
-    {
-        // neighbours of the macroblock in the source picture
-        if (lane < 17) S.stop[lane] = (top && (lane > 0 || mx > 0)) ? (uint8_t)src_px(P.src, P.w, P.h, bx - 1 + lane, by - 1) : 0;
-        else if (lane < 33) S.sleft[lane - 17] = mx > 0 ? (uint8_t)src_px(P.src, P.w, P.h, bx - 1, by + lane - 17) : 0;
-        wave_sync();
-        // Intra16x16 estimate: lane = (mode, block), as the real decision below but on source neighbours
-        int est16;
-        {
-            const I16Params sp = i16_params(S.stop, S.sleft, avail);
-            const int mode = lane >> 4, blk = lane & 15, x0 = (blk & 3) * 4, y0 = (blk >> 2) * 4;
-            const int pl0 = sp.a + sp.b * (x0 - 7) + sp.c * (y0 - 7) + 16;
-            int d[16];
-#pragma unroll
-            for (int y = 0; y < 4; y++) {
-                const uint32_t sw = *(const uint32_t*)(S.src + (y0 + y) * 16 + x0);
-#pragma unroll
-                for (int x = 0; x < 4; x++) {
-                    const int pr = mode == 0 ? S.stop[1 + x0 + x] : mode == 1 ? S.sleft[y0 + y] : mode == 2 ? sp.dc : clip255((pl0 + sp.b * x + sp.c * y) >> 5);
-                    d[4 * y + x] = (int)((sw >> (8 * x)) & 255) - pr;
-                }
-            }
-            const int sum = row_sum16_dpp(hadamard_abs(d)) >> 1;
-            const bool ok = mode == 0 ? (avail & 2) : mode == 1 ? (avail & 1) : mode == 2 ? true : avail == 7;
-            est16 = (int)wave_min_u32_dpp(ok ? (unsigned)sum : 0xFFFFFFFFu);
-        }
-        // edge samples of the 16 blocks from the source (block (3, 0) without its top-right: it never takes the two modes that read it)
-        for (int i = lane; i < 16 * 16; i += 64) {
-            const int b = i >> 4, k = i & 15, x = blk_x(b), y = blk_y(b);
-            if (k == 15) continue;
-            int av = i4_avail(b, x, y, mx, top, P.mbw);
-            if (x == 3 && y == 0) av &= ~8;
-            S.e4[b][k] = (uint8_t)i4_edge(S.src, S.stop, S.sleft, x, y, av, k);
-        }
-        wave_sync();
-        // nine modes x sixteen blocks: three passes of (three modes, sixteen blocks); key = cost << 4 | mode
-        unsigned bestk = 0xFFFFFFFFu;
-        {
-            const int b = lane & 15, x = blk_x(b), y = blk_y(b), grp = lane >> 4;
-            const int av = i4_avail(b, x, y, mx, top, P.mbw);
-            uint32_t sw[4];
-#pragma unroll
-            for (int r = 0; r < 4; r++) sw[r] = *(const uint32_t*)(S.src + (4 * y + r) * 16 + 4 * x);
-#pragma unroll 1
-            for (int pass = 0; pass < 3; pass++) {
-                const int m = 3 * pass + grp;
-                bool ok = grp < 3;
-                if ((m == 0 || m == 3 || m == 7) && !(av & 2)) ok = false;
-                if ((m == 1 || m == 8) && !(av & 1)) ok = false;
-                if ((m == 4 || m == 5 || m == 6) && (av & 7) != 7) ok = false;
-                if (x == 3 && y == 0 && (m == 3 || m == 7)) ok = false;
-                if (ok) {
-                    const uint4 row = *(const uint4*)c_i4tab[m];
-                    const uint32_t rw[4] = {row.x, row.y, row.z, row.w};
-                    const int dc = pred4_dc(S.e4[b], av);
-                    int d[16];
-#pragma unroll
-                    for (int r = 0; r < 4; r++)
-#pragma unroll
-                        for (int c = 0; c < 4; c++) d[4 * r + c] = (int)((sw[r] >> (8 * c)) & 255) - pred4_tab(S.e4[b], (int)((rw[r] >> (8 * c)) & 255u), dc);
-                    const unsigned key = ((unsigned)hadamard_abs(d) << 4) | (unsigned)m;
-                    bestk = key < bestk ? key : bestk;
-                }
-            }
-            // the three groups of a block sit 16 lanes apart
-            const unsigned k1 = (unsigned)__shfl((int)bestk, b + 16), k2 = (unsigned)__shfl((int)bestk, b + 32);
-            bestk = min(bestk, min(k1, k2));
-        }
-        const int s16 = row_sum16_dpp(lane < 16 ? (int)(bestk >> 4) : 0);
-        const int sum4 = __builtin_amdgcn_readlane(s16, 0);
-        use_i4 = (sum4 >> 1) + 48 * P.lambda < est16 + 8 * P.lambda;   // wave-uniform
-        if (lane < 16) S.i4m[lane] = (uint8_t)(bestk & 15u);
-        wave_sync();
-    }
     if (use_i4) {
-        // ---- Intra4x4 coding: the 16 blocks in blkIdx order, each predicted from the TRUE reconstruction (this macroblock's
-        // earlier blocks in S.rec_y, the neighbours in S.top / S.left); lanes 0..3 = the block's rows, transforms over the DPP quad ----
-#pragma unroll 1
-        for (int b = 0; b < 16; b++) {
-            const int x = blk_x(b), y = blk_y(b), mode = S.i4m[b];
-            int av = i4_avail(b, x, y, mx, top, P.mbw);
-            if (x == 3 && y == 0) av &= ~8;
-            if (lane < 15) S.e4[0][lane] = (uint8_t)i4_edge(S.rec_y, S.top, S.left, x, y, av, lane);
-            wave_sync();
-            int nz = 0;
-            if (lane < 4) {
-                const int r = lane;
-                const uint32_t sw = *(const uint32_t*)(S.src + (4 * y + r) * 16 + 4 * x);
-                const uint32_t tw = ((const uint32_t*)c_i4tab[mode])[r];   // this row's four table entries
-                const int dc = pred4_dc(S.e4[0], av);
-                int pv[4], d[4];
-#pragma unroll
-                for (int c = 0; c < 4; c++) { pv[c] = pred4_tab(S.e4[0], (int)((tw >> (8 * c)) & 255u), dc); d[c] = (int)((sw >> (8 * c)) & 255) - pv[c]; }
-                fdct_quad(d, r);
-                const Quant& qn = P.qy;
-                const int mf0 = (r & 1) ? qn.mf[2] : qn.mf[0], mf1 = (r & 1) ? qn.mf[1] : qn.mf[2];
-                const int dq0 = (r & 1) ? qn.dq[2] : qn.dq[0], dq1 = (r & 1) ? qn.dq[1] : qn.dq[2];
-                const int zz = c_zz_row[r];
-#pragma unroll
-                for (int c = 0; c < 4; c++) {
-                    const int l = quant1(d[c], (c & 1) ? mf1 : mf0, qn.f_intra, qn.qbits);
-                    S.lv[LV_LUMA + b * 16 + ((zz >> (4 * c)) & 15)] = (int16_t)l;
-                    nz += l != 0;
-                    d[c] = l * ((c & 1) ? dq1 : dq0);
-                }
-                nz += __builtin_amdgcn_mov_dpp(nz, 0xB1, 0xf, 0xf, false);
-                nz += __builtin_amdgcn_mov_dpp(nz, 0x4E, 0xf, 0xf, false);
-                idct_quad(d, r);
-                const uint32_t o = pack4(clip255(pv[0] + d[0]), clip255(pv[1] + d[1]), clip255(pv[2] + d[2]), clip255(pv[3] + d[3]));
-                *(uint32_t*)(S.rec_y + (4 * y + r) * 16 + 4 * x) = o;
-            }
-            nz = __builtin_amdgcn_readlane(nz, 0);
-            if (nz) cbp_luma_i4 |= 1 << (b >> 2);
-            if (lane == 0) S.dc[b] = nz;   // (S.dc doubles as the TotalCoeff store of the 16 blocks)
-            wave_sync();
-        }
-        // the macroblock's luma reconstruction and its modes leave in one go (nothing inside the loop waits for global memory)
-        *(uint32_t*)(P.rec[0] + (size_t)(by + (lane >> 2)) * P.cw + bx + (lane & 3) * 4) = *(const uint32_t*)(S.rec_y + (lane >> 2) * 16 + (lane & 3) * 4);
-        if (lane < 4) *(uint32_t*)(P.aux + (size_t)mbi * 16 + 4 * lane) = *(const uint32_t*)(S.i4m + 4 * lane);
+        const uint32_t m0 = (uint32_t)__builtin_amdgcn_readlane((int)auxw, 0), m1 = (uint32_t)__builtin_amdgcn_readlane((int)auxw, 1);
+        const uint32_t m2 = (uint32_t)__builtin_amdgcn_readlane((int)auxw, 2), m3 = (uint32_t)__builtin_amdgcn_readlane((int)auxw, 3);
+        cbp_luma_i4 = i4_code_luma(P.qy, S.i4, S.top, S.left, S.src, m0, m1, m2, m3, S.lv, S.dc, mx, top, lane);   // (S.dc: TotalCoeff of the 16 blocks)
+        const uint32_t o = *(const uint32_t*)(S.i4.rb + (1 + (lane >> 2)) * 32 + 4 + (lane & 3) * 4);
+        *(uint32_t*)(S.rec_y + (lane >> 2) * 16 + (lane & 3) * 4) = o;
+        *(uint32_t*)(P.rec[0] + (size_t)(by + (lane >> 2)) * P.cw + bx + (lane & 3) * 4) = o;
     }
 
     // ---- luma mode decision: lane = (mode, 4x4 block), SATD per mode ----
@@ -380,7 +202,7 @@ __device__ __forceinline__ void intra_mb_core(const FrameParams& P, int mx, int 
 #pragma unroll
         for (int k = 0; k < 4; k++) { tp[k] = S.ctop[pl][1 + x0 + k]; lf[k] = S.cleft[pl][y0 + k]; }
         const int ca = pl ? cp[1].a : cp[0].a, cbb = pl ? cp[1].b : cp[0].b, cc = pl ? cp[1].c : cp[0].c;
-        const int cdc = pl ? cp[1].dc[blk] : cp[0].dc[blk];       // blk = (y0 >> 2) * 2 + (x0 >> 2)
+        const int cdc = pl ? pick4(cp[1].dc, blk) : pick4(cp[0].dc, blk);       // blk = (y0 >> 2) * 2 + (x0 >> 2)
         const int pl0 = ca + cbb * (x0 - 3) + cc * (y0 - 3) + 16;
         int d[16];
 #pragma unroll
@@ -405,7 +227,7 @@ __device__ __forceinline__ void intra_mb_core(const FrameParams& P, int mx, int 
     if (lane < 32) {
         const int pl = lane >> 4, y = (lane >> 1) & 7, xs = (lane & 1) * 4;
         uint32_t o = 0;
-        if (best_cmode == 0) o = 0x01010101u * (uint32_t)(pl ? cp[1].dc[(y >> 2) * 2 + (xs >> 2)] : cp[0].dc[(y >> 2) * 2 + (xs >> 2)]);
+        if (best_cmode == 0) o = 0x01010101u * (uint32_t)(pl ? pick4(cp[1].dc, (y >> 2) * 2 + (xs >> 2)) : pick4(cp[0].dc, (y >> 2) * 2 + (xs >> 2)));
         else if (best_cmode == 1) o = 0x01010101u * (uint32_t)S.cleft[pl][y];
         else if (best_cmode == 2) {
 #pragma unroll
@@ -446,24 +268,37 @@ __device__ __forceinline__ void intra_mb_core(const FrameParams& P, int mx, int 
         nnz = tq4x4(d, P.qc, P.qc.f_intra, 1, S.lv + LV_CHROMA_AC + (cpl * 4 + cb) * 16, &dcw, 0, false);
     }
     wave_sync();
-    if (!use_i4) {   // luma DC: forward Hadamard, quantise at qbits+2, inverse Hadamard, 8.5.10 scaling
-        int h[16];
-#pragma unroll
-        for (int i = 0; i < 16; i++) h[i] = S.dc[i];
-        hadamard4x4(h);
+    if (!use_i4) {
+        // luma DC (8.5.10): 4x4 Hadamard of the sixteen transformed DCs, quantised at qbits + 2, inverse Hadamard, scaling.
+        // Lane = raster position of the block; each transform is four exchange stages (lane ^ 1, ^ 2: DPP quad permutes,
+        // ^ 4, ^ 8: DPP row moves).  After the forward pass lane (i, j) holds coefficient (sg(i), sg(j)), sg = [0 3 1 2] (the
+        // exchange network yields natural Hadamard order, the standard's matrix is that with its rows permuted); fed back in that
+        // arrangement the same network returns the inverse in raster order, the matrix being symmetric.
+        const int i = lane & 3, j = (lane >> 2) & 3;
+        const int s1 = (i & 1) ? -1 : 1, s2 = (i & 2) ? -1 : 1, s4 = (j & 1) ? -1 : 1, s8 = (j & 2) ? -1 : 1;
+        auto wht = [&](int v) {
+            v = __builtin_amdgcn_mov_dpp(v, 0xB1, 0xf, 0xf, false) + s1 * v;
+            v = __builtin_amdgcn_mov_dpp(v, 0x4E, 0xf, 0xf, false) + s2 * v;
+            int q = __builtin_amdgcn_update_dpp(0, v, 0x104, 0xf, 0x5, false);   // row_shl:4 into quads 0, 2: from lane + 4
+            q = __builtin_amdgcn_update_dpp(q, v, 0x114, 0xf, 0xa, false);       // row_shr:4 into quads 1, 3: from lane - 4
+            v = q + s4 * v;
+            return __builtin_amdgcn_mov_dpp(v, 0x128, 0xf, 0xf, false) + s8 * v; // row_ror:8 = lane ^ 8
+        };
+        const int hw = wht(lane < 16 ? S.dc[lane] : 0);
         const int qb = P.qy.qbits;
-#pragma unroll
-        for (int i = 0; i < 16; i++) {
-            const unsigned a = (unsigned)iabs(h[i]);
-            const int l = (int)((a * (unsigned)P.qy.mf[0] + 4u * (unsigned)P.qy.f_intra) >> (qb + 2));
-            h[i] = h[i] < 0 ? -l : l;
+        const unsigned a = (unsigned)iabs(hw);
+        const int lq = (int)((a * (unsigned)P.qy.mf[0] + 4u * (unsigned)P.qy.f_intra) >> (qb + 2));
+        const int ldc = hw < 0 ? -lq : lq;
+        if (lane < 16) {
+            const int cu = (0x2130 >> (4 * i)) & 3, cv = (0x2130 >> (4 * j)) & 3;   // sg: 0 3 1 2
+            S.lv[LV_LUMA_DC + ((c_zz_row[cv] >> (4 * cu)) & 15)] = (int16_t)ldc;
         }
-        if (lane == 0)
-#pragma unroll
-            for (int i = 0; i < 16; i++) S.lv[LV_LUMA_DC + c_zigzag_inv[i]] = (int16_t)h[i];
-        hadamard4x4(h);
+        const int fi_r = wht(ldc);
+        wave_sync();   // every lane has taken its S.dc value
+        if (lane < 16) S.dc[lane] = fi_r;
+        wave_sync();
         if (is_luma) {
-            const int fi = h[blk_y(lane) * 4 + blk_x(lane)];
+            const int fi = S.dc[blk_y(lane) * 4 + blk_x(lane)];
             const int qp = P.qy.qp, ls = 16 * (P.qy.dq[0] >> (qp / 6));
             d[0] = qp >= 36 ? (fi * ls) << (qp / 6 - 6) : (fi * ls + (1 << (5 - qp / 6))) >> (6 - qp / 6);
         }
@@ -496,7 +331,7 @@ __device__ __forceinline__ void intra_mb_core(const FrameParams& P, int mx, int 
             pp = S.py + y * 16 + x; ppitch = 16; ldst = S.rec_y + y * 16 + x;
         } else {
             const int x = (cb & 1) * 4, y = (cb >> 1) * 4;
-            dst = (cpl ? P.rec[2] : P.rec[1]) + (size_t)(8 * my + y) * cs + 8 * mx + x; dp = cs;
+            dst = rec_chroma(P, cpl) + (size_t)(8 * my + y) * cs + 8 * mx + x; dp = cs;
             pp = S.pc + cpl * 64 + y * 8 + x; ppitch = 8; ldst = S.rec_c + cpl * 64 + y * 8 + x;
         }
 #pragma unroll
@@ -531,7 +366,7 @@ __device__ __forceinline__ void intra_mb_core(const FrameParams& P, int mx, int 
             if (lane < 32) {
                 const int pl = lane >> 4, row = (lane >> 1) & 7, xs = (lane & 1) * 4;
                 const uint32_t v = *(const uint32_t*)(S.srcc + pl * 64 + row * 8 + xs);
-                *(uint32_t*)((pl ? P.rec[2] : P.rec[1]) + (size_t)(8 * my + row) * cs + 8 * mx + xs) = v;
+                *(uint32_t*)(rec_chroma(P, pl) + (size_t)(8 * my + row) * cs + 8 * mx + xs) = v;
                 *(uint32_t*)(S.rec_c + pl * 64 + row * 8 + xs) = v;
             }
             if (lane < 6) ((uint32_t*)m)[2 + lane] = 0x10101010u;
@@ -577,15 +412,19 @@ __global__ __launch_bounds__(64) void k_intra_diag(FrameParams P0, int s)
         else if (lane < 33) S.left[lane - 17] = mx > 0 ? R[(size_t)(by + lane - 17) * P.cw + bx - 1] : 0;
         else if (lane < 33 + 18) {
             const int k = lane - 33, pl = k / 9, i = k % 9;
-            S.ctop[pl][i] = (P.sl.has_top(my) && (i > 0 || mx > 0)) ? (pl ? P.rec[2] : P.rec[1])[(size_t)(8 * my - 1) * cs + 8 * mx - 1 + i] : 0;
+            S.ctop[pl][i] = (P.sl.has_top(my) && (i > 0 || mx > 0)) ? rec_chroma(P, pl)[(size_t)(8 * my - 1) * cs + 8 * mx - 1 + i] : 0;
         }
         if (lane < 16) {
             const int pl = lane >> 3, i = lane & 7;
-            S.cleft[pl][i] = mx > 0 ? (pl ? P.rec[2] : P.rec[1])[(size_t)(8 * my + i) * cs + 8 * mx - 1] : 0;
+            S.cleft[pl][i] = mx > 0 ? rec_chroma(P, pl)[(size_t)(8 * my + i) * cs + 8 * mx - 1] : 0;
         }
     }
+    i4_lds_init(S.i4, lane);
     wave_sync();
-    intra_mb_core(P, mx, my, S, lane);
+    const int mbi = my * P.mbw + mx;
+    const bool use_i4 = ((const uint8_t*)(P.mb + mbi))[4] == MB_I4;
+    const uint32_t auxw = lane < 4 ? *(const uint32_t*)(P.aux + (size_t)mbi * 16 + 4 * lane) : 0u;
+    intra_mb_core(P, mx, my, S, lane, __builtin_amdgcn_readfirstlane((int)use_i4) != 0, auxw);
 }
 
 // ===========================================================================
@@ -616,9 +455,16 @@ __global__ __launch_bounds__(64) void k_intra_rows(IntraRowParams R)
     bool timed_out = false;
     const uint8_t* Y = P.src;
     // source fetch of one macroblock into registers (same clamping as load_src_mb)
-    uint32_t pf_y = 0, pf_c = 0;
+    uint32_t pf_y = 0, pf_c = 0, pf_aux = 0;
+    int pf_type = 0;
     unsigned long long pf_g = 0;
+    i4_lds_init(S.i4, lane);
     auto prefetch = [&](int mx) {
+        {   // k_i4_decide's verdict for the macroblock: type and, lanes 0..3, the sixteen Intra4x4 modes
+            const int mbi = my * P.mbw + mx;
+            pf_type = ((const uint8_t*)(P.mb + mbi))[4];
+            if (lane < 4) pf_aux = *(const uint32_t*)(P.aux + (size_t)mbi * 16 + 4 * lane);
+        }
         {
             const int row = lane >> 2, xs = (lane & 3) * 4;
             const int gy = 16 * my + row, gx = 16 * mx + xs;
@@ -638,7 +484,8 @@ __global__ __launch_bounds__(64) void k_intra_rows(IntraRowParams R)
     };
     prefetch(0);
     for (int mx = 0; mx < P.mbw; mx++) {
-        const uint32_t cur_y = pf_y, cur_c = pf_c;
+        const uint32_t cur_y = pf_y, cur_c = pf_c, cur_aux = pf_aux;
+        const bool cur_i4 = __builtin_amdgcn_readfirstlane(pf_type) == MB_I4;
         unsigned long long g = pf_g;
         if (mx + 1 < P.mbw) prefetch(mx + 1);
         // left neighbours = last column of the previous reconstruction; corner = last sample of the previous top row
@@ -670,7 +517,7 @@ __global__ __launch_bounds__(64) void k_intra_rows(IntraRowParams R)
             }
         }
         wave_sync();
-        intra_mb_core(P, mx, my, S, lane);
+        intra_mb_core(P, mx, my, S, lane, cur_i4, cur_aux);
         // publish this macroblock's bottom sample row for the row below
         if (my + 1 < P.mbh && lane < 8) {
             uint32_t v;
@@ -702,6 +549,7 @@ __global__ __launch_bounds__(64) void k_pintra_rows(IntraRowParams R)
     const int lane = threadIdx.x, my = P.band.row0 + blockIdx.x, cs = P.cw / 2;
     const bool top = P.sl.has_top(my);
     __shared__ IntraLds S;
+    i4_lds_init(S.i4, lane);
     bool timed_out = false;
     int last_done = -2;   // the macroblock whose reconstruction S.rec_* holds
     // bit 15 of me_cost = "handed to this pass by k_me": unlike MbInfo.type (an I_PCM conversion changes it, here or in k_tq)
@@ -733,7 +581,7 @@ __global__ __launch_bounds__(64) void k_pintra_rows(IntraRowParams R)
                     else if (lane < 32) S.cleft[(lane >> 3) & 1][lane & 7] = S.rec_c[((lane >> 3) & 1) * 64 + (lane & 7) * 8 + 7];
                 } else {
                     if (lane < 16) S.left[lane] = P.rec[0][(size_t)(16 * my + lane) * P.cw + 16 * mx - 1];
-                    else if (lane < 32) S.cleft[(lane >> 3) & 1][lane & 7] = ((lane & 8) ? P.rec[2] : P.rec[1])[(size_t)(8 * my + (lane & 7)) * cs + 8 * mx - 1];
+                    else if (lane < 32) S.cleft[(lane >> 3) & 1][lane & 7] = rec_chroma(P, lane & 8)[(size_t)(8 * my + (lane & 7)) * cs + 8 * mx - 1];
                 }
             }
             wave_sync();
@@ -750,7 +598,7 @@ __global__ __launch_bounds__(64) void k_pintra_rows(IntraRowParams R)
                     }
                 } else {
                     if (lane < 16) S.top[1 + lane] = P.rec[0][(size_t)(16 * my - 1) * P.cw + 16 * mx + lane];
-                    else if (lane < 32) S.ctop[(lane >> 3) & 1][1 + (lane & 7)] = ((lane & 8) ? P.rec[2] : P.rec[1])[(size_t)(8 * my - 1) * cs + 8 * mx + (lane & 7)];
+                    else if (lane < 32) S.ctop[(lane >> 3) & 1][1 + (lane & 7)] = rec_chroma(P, lane & 8)[(size_t)(8 * my - 1) * cs + 8 * mx + (lane & 7)];
                 }
                 if (mx > 0) {
                     if (dI) {   // last samples of the bottom rows of the macroblock above-left: granules 3 (luma), 5 (Cb), 7 (Cr)
@@ -767,7 +615,12 @@ __global__ __launch_bounds__(64) void k_pintra_rows(IntraRowParams R)
                 }
             }
             wave_sync();
-            intra_mb_core(P, mx, my, S, lane);
+            {
+                const int mbi = my * P.mbw + mx;
+                const bool use_i4 = ((const uint8_t*)(P.mb + mbi))[4] == MB_I4;
+                const uint32_t auxw = lane < 4 ? *(const uint32_t*)(P.aux + (size_t)mbi * 16 + 4 * lane) : 0u;
+                intra_mb_core(P, mx, my, S, lane, __builtin_amdgcn_readfirstlane((int)use_i4) != 0, auxw);
+            }
             last_done = mx;
             // publish the bottom sample row for the row below (it asks only where this macroblock is its neighbour)
             if (my + 1 < P.mbh && lane < 8) {

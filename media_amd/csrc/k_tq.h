@@ -29,13 +29,6 @@
 
 namespace h264 {
 
-// keep a wave-uniform value in a VGPR: VOP2 with an SGPR operand issues at half the rate of the all-VGPR form
-__device__ __forceinline__ int vreg(int x)
-{
-    asm volatile("" : "+v"(x));
-    return x;
-}
-
 struct TqConst { int mf[3], dq[3], f, c, q; };   // c = 2^q - 1 - 2 f (bias of negative values minus f)
 __device__ __forceinline__ TqConst tq_consts(const Quant& qn)
 {
@@ -47,13 +40,6 @@ __device__ __forceinline__ TqConst tq_consts(const Quant& qn)
     k.q = vreg(qn.qbits);
     return k;
 }
-// sign(w) * ((|w| * mf + f) >> q) without the absolute value: for w < 0, -floor((|w| mf + f) / 2^q) = floor((w mf + 2^q - 1 - f) / 2^q)
-__device__ __forceinline__ int quant_signed(int w, int mf, int f, int c, int q)
-{
-    const int s = w >> 31;
-    return (__mul24(w, mf) + (f + (s & c))) >> q;
-}
-
 // forward transform, quantisation, scaling and inverse transform of the 4x4 block in d[] (raster; residual in, decoded
 // residual out).  CHROMA: position 0 is left out of the levels (it goes through the 2x2 Hadamard), *dcw receives the
 // transformed DC and dc_deq() supplies the scaled DC before the inverse transform.

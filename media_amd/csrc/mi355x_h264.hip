@@ -342,6 +342,7 @@ int submit(mi355x_h264_encoder* e, const uint8_t* d_src, size_t src_item_stride,
 
     if (idr) {
         StatScope sc(e, &S, MI355X_H264_K_INTRA, (uint32_t)(e->diag_mode ? e->mbw + e->mbh - 1 : 1), (uint32_t)(e->b_nmb * e->G));
+        hipLaunchKernelGGL(k_i4_decide, dim3((e->b_nmb + 3) / 4, G), dim3(64), 0, st, P, 0);   // Intra4x4 or Intra16x16, and the block modes: from the source alone
         if (e->diag_mode) {
             for (int s = 0; s < e->mbw + e->mbh - 1; s++) {
                 const int ymin = std::max(0, s - e->mbw + 1), ymax = std::min(e->mbh - 1, s);
@@ -371,6 +372,7 @@ int submit(mi355x_h264_encoder* e, const uint8_t* d_src, size_t src_item_stride,
             R.p = P; R.handoff = e->d_handoff; R.st_handoff = e->st_handoff; R.err = S.h_err;
             e->serial = e->serial == 0xFFFFFFFFu ? 1 : e->serial + 1;
             R.serial = e->serial;
+            hipLaunchKernelGGL(k_i4_decide, dim3((e->b_nmb + 3) / 4, G), dim3(64), 0, st, P, 1);
             hipLaunchKernelGGL(k_pintra_rows, dim3(e->b_rows, G), dim3(64), 0, st, R);
         }
     }

@@ -332,7 +332,7 @@ def test_coded_block_pattern_mapping_against_the_standard():
 
 
 def test_intra4x4_prediction_table_against_the_oracle():
-    """media_amd/csrc/k_intra.h predicts Intra4x4 samples through a generated table (tools/gen_i4_table.py: copy / 2-tap /
+    """media_amd/csrc/k_intra4.h predicts Intra4x4 samples through a generated table (tools/gen_i4_table.py: copy / 2-tap /
     3-tap at a position of the padded edge array).  The table, evaluated on random neighbours, must give what the oracle's
     h264o_pred4x4 (a direct statement of 8.3.1.2, itself pinned by the independent decoder's round trip) gives."""
     import importlib.util
@@ -342,7 +342,7 @@ def test_intra4x4_prediction_table_against_the_oracle():
     gen = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(gen)
     tab = gen.table()
-    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "media_amd", "csrc", "k_intra.h")).read()
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "media_amd", "csrc", "k_intra4.h")).read()
     for m in range(9):     # the header holds exactly the generated rows
         assert "{" + ", ".join("0x%02X" % v for v in tab[m]) + "}" in src, "c_i4tab row %d" % m
     L = ol.lib()
