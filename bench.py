@@ -168,31 +168,41 @@ def openh264_differential(frames, count):
         return {"oracle": "absent", "reason": "differential tool failed: %s" % exc}
 
 
+def latest_profile(suffix):
+    """the newest committed profiles/rNN?_<suffix> (tools/prof.sh + tools/summarize_prof.py), or None"""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]?_" + suffix)))
+    return files[-1] if files else None
+
+
 def valu_issue_bound(nmb):
     """What actually bounds the pipeline: VALU instruction issue.  From the committed PMC pass
-    (profiles/r01?_summary.json, SQ_INSTS_VALU of the lockstep launches of this same default workload): instructions per
-    macroblock over all kernels of a P picture -> pictures per second 1 024 SIMDs can issue (one VALU instruction per
-    wave per 4 cycles at 2.4 GHz).  Informational; None when no summary is committed."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r01?_summary.json")))
-    if not files:
+    (profiles/rNN?_summary.json, SQ_INSTS_VALU of the lockstep launches of this same default workload): instructions per
+    macroblock over all kernels, averaged over a GOP of 1 IDR + 29 P pictures -> pictures per second 1 024 SIMDs can
+    issue (one VALU instruction per wave per 4 cycles at 2.4 GHz).  Informational; None when no summary is committed."""
+    f = latest_profile("summary.json")
+    if f is None:
         return None
     try:
-        sq = json.load(open(files[-1])).get("sq", {})
+        sq = json.load(open(f)).get("sq", {})
         per = {}
         for name, v in sq.items():
             k = name.split(" grid=")[0]
-            if not k.startswith(("k_me", "k_pmb2", "k_bs", "k_cavlc", "k_deblock_rows<false>")) or not v.get("SQ_WAVES"):
+            if not k.startswith("k_") or not v.get("SQ_WAVES"):
                 continue
-            if k not in per or v["SQ_INSTS_VALU"] > per[k][0]:          # the lockstep (largest) launch of each kernel
-                per[k] = (v["SQ_INSTS_VALU"], name)
-        if len(per) < 5:
+            if k not in per or v["SQ_INSTS_VALU"] > per[k]:              # the lockstep (largest) launch of each kernel
+                per[k] = v["SQ_INSTS_VALU"]
+        entropy = sum(per.get(k, 0) for k in ("k_bs", "k_cavlc<false>", "k_cavlc<true>", "k_bit_scan", "k_pack"))
+        p_pic = entropy + sum(per.get(k, 0) for k in ("k_me", "k_tq", "k_mvpred", "k_skip_scan", "k_pintra_rows", "k_deblock_rows<false>"))
+        idr = entropy + sum(per.get(k, 0) for k in ("k_i4_decide", "k_intra_rows", "k_deblock_rows<true>"))
+        if not per.get("k_me") or not per.get("k_tq"):
             return None
         mbs = 32 * nmb                                                   # the profiled launches cover 32 pictures
-        total = sum(v[0] for v in per.values()) / mbs
-        return {"valu_per_macroblock": round(total, 1), "source": os.path.basename(files[-1]),
+        total = ((GOP - 1) * p_pic + idr) / GOP / mbs
+        return {"valu_per_macroblock": round(total, 1), "p_picture": round(p_pic / mbs, 1), "idr_picture": round(idr / mbs, 1),
+                "source": os.path.basename(f),
                 "bound_fps": round(1024 * 2.4e9 / 4 / (total * nmb), 1),
-                "note": "P-picture kernels (k_me, k_pmb2, k_bs, k_cavlc count + write, k_deblock_rows); 256 CUs x 4 SIMDs, one VALU instruction per wave per 4 cycles at 2.4 GHz"}
+                "note": "all kernels, GOP average (1 IDR + %d P); 256 CUs x 4 SIMDs, one VALU instruction per wave per 4 cycles at 2.4 GHz" % (GOP - 1)}
     except Exception:
         return None
 
@@ -422,10 +432,13 @@ def main():
                                     "ms_per_launch": round(v["ms"] / v["launches"], 4),
                                     "pictures_per_launch": round(v["mbs"] / nmb / v["launches"], 2)}
         traffic = None
-        try:  # HBM bytes per k_pmb2 launch from the committed PMC passes (profiles/), valid for the same batch size
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-            if tj.get("lockstep_batch") == B:
+        traffic_src = None
+        try:  # HBM bytes per k_tq launch from the newest committed PMC passes (profiles/), valid for the same batch size
+            tf = latest_profile("traffic.json")
+            tj = json.load(open(tf))
+            if tj.get("lockstep_batch") == B and "k_tq" in tj.get("kernel", "k_tq"):
                 traffic = tj["traffic_bytes_per_launch"]
+                traffic_src = "profiles/" + os.path.basename(tf)
         except Exception:
             traffic = None
         res = {
@@ -442,7 +455,7 @@ def main():
                        "(oracle unpinned vs OpenH264: no libopenh264 available)"},
             "roofline": {"kernel": "k_tq (residual + fDCT + quant + dequant + iDCT + recon, 8 macroblocks per wave)", "bound": "hbm",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "bytes_per_launch": PMB_BYTES_PER_MB * nmb * B, "macroblocks_per_launch": nmb * B,
                          "avg_launch_ms": round(pmb_ms, 5)},
             "kernels": per_kernel,
