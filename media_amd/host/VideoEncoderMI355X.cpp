@@ -22,6 +22,10 @@ bool VideoEncoderMI355X::EngineOpen(const Settings &s)
 {
     // the preset of InitParams / InitParamExt (ref :228-296) in the C ABI's terms: one layer, one slice per
     // picture, one reference frame, loop filter on, CAVLC, IDR every gop pictures
+    if (((s.width | s.height) & 1u) != 0) {   // 4:2:0: the chroma planes are (width / 2) x (height / 2)
+        ERR("picture size %ux%u: width and height must be even", s.width, s.height);
+        return false;
+    }
     mi355x_h264_config cfg;
     mi355x_h264_default_config(&cfg);
     cfg.width = static_cast<int32_t>(s.width);
@@ -30,6 +34,10 @@ bool VideoEncoderMI355X::EngineOpen(const Settings &s)
     cfg.bitrate = static_cast<int32_t>(s.bitrate);
     cfg.gop = static_cast<int32_t>(s.gop);
     cfg.profile_idc = ProfileIdc(s.profile);
+    if (cfg.profile_idc != 66) {
+        // the reference preset asks for CABAC (iEntropyCodingModeFlag = 1, ref :291); this engine codes CAVLC in every profile
+        INFO("profile_idc %d is coded with CAVLC (entropy_coding_mode_flag = 0): CABAC is not built", cfg.profile_idc);
+    }
     cfg.disable_deblock = 0;
     cfg.batch = 1;
     cfg.device = std::max(0, GetIntEncParam("persist.vmi.video.encode.device"));
