@@ -179,7 +179,8 @@ enum {
     MI355X_H264_DBG_PRE_Y = 5,     /* reconstruction before the loop filter (needs          */
     MI355X_H264_DBG_PRE_U = 6,     /*  mi355x_h264_debug_keep_pre(enc, 1))                  */
     MI355X_H264_DBG_PRE_V = 7,
-    MI355X_H264_DBG_MBAUX = 8      /* 16 B per macroblock: Intra4x4PredMode of the blocks of type-4 macroblocks   */
+    MI355X_H264_DBG_MBAUX = 8,     /* 16 B per macroblock: Intra4x4PredMode of the blocks of type-4 macroblocks   */
+    MI355X_H264_DBG_MVQ = 9        /* 8 int16 per macroblock: (x, y) vectors of the four 8x8 quadrants of an inter macroblock */
 };
 int mi355x_h264_debug_keep_pre(mi355x_h264_encoder *enc, int on);
 /* copies the named device buffer of the last encoded picture (batch item 0) to dst; returns bytes or <0 */

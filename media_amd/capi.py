@@ -15,7 +15,7 @@ LV_STRIDE = 416
 MBINFO_DTYPE = np.dtype([("mvx", "<i2"), ("mvy", "<i2"), ("type", "u1"), ("i16_mode", "u1"),
                          ("chroma_mode", "u1"), ("cbp", "u1"), ("tc", "u1", (24,))])
 FRAME_IDR, FRAME_P = 1, 3
-DBG_RECON_Y, DBG_RECON_U, DBG_RECON_V, DBG_MBINFO, DBG_LEVELS, DBG_PRE_Y, DBG_PRE_U, DBG_PRE_V, DBG_MBAUX = range(9)
+DBG_RECON_Y, DBG_RECON_U, DBG_RECON_V, DBG_MBINFO, DBG_LEVELS, DBG_PRE_Y, DBG_PRE_U, DBG_PRE_V, DBG_MBAUX, DBG_MVQ = range(10)
 K_NAMES = ["me", "pmb", "intra", "cavlc", "deblock"]
 
 EXPORTS = [
@@ -196,6 +196,8 @@ class Encoder:
             a = np.empty(self.nmb, MBINFO_DTYPE)
         elif what == DBG_MBAUX:
             a = np.empty((self.nmb, 16), np.uint8)
+        elif what == DBG_MVQ:
+            a = np.empty((self.nmb, 8), np.int16)
         else:
             a = np.empty((self.nmb, LV_STRIDE), np.int16)
         n = lib().mi355x_h264_debug_read(self.h, what, a.ctypes.data, a.nbytes)

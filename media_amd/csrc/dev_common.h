@@ -12,11 +12,11 @@
 
 namespace h264 {
 
-enum { MB_I16 = 0, MB_P16 = 1, MB_PSKIP = 2, MB_IPCM = 3, MB_I4 = 4 };
+enum { MB_I16 = 0, MB_P16 = 1, MB_PSKIP = 2, MB_IPCM = 3, MB_I4 = 4, MB_P16X8 = 5, MB_P8X16 = 6, MB_P8X8 = 7 };   // 5..7: two 16x8, two 8x16, four 8x8 partitions
 __device__ __forceinline__ bool mb_is_intra(int type) { return type == MB_I16 || type == MB_IPCM || type == MB_I4; }
 // A.3.1: macroblock_layer() of a CAVLC macroblock may not exceed 128 + 3072 bits; a macroblock whose BOUND (below) does
 // is coded as I_PCM.  INTRA_TEST_MIN: motion cost from which a P macroblock is also costed as Intra16x16.
-enum { MB_BITS_LIMIT = 3200, MB_HEADER_BOUND = 96, INTRA_TEST_MIN = 2000 };
+enum { MB_BITS_LIMIT = 3200, MB_HEADER_BOUND = 96, INTRA_TEST_MIN = 2000, PART_TEST_MIN = 2000 };   // PART_TEST_MIN: 16x16 motion cost from which the partitions are tried
 enum { LV_LUMA_DC = 0, LV_LUMA = 16, LV_CHROMA_DC = 272, LV_CHROMA_AC = 280, LV_STRIDE = 416 };
 
 // 32 bytes; identical to the debug layout documented in include/mi355x_h264.h
@@ -76,7 +76,8 @@ struct FrameParams {
     int* pmv;               // per macroblock: the previous picture's vector (rate predictor), parked by the first launch
     MbInfo* mb;
     int16_t* levels;     // LV_STRIDE int16 per macroblock
-    int16_t* mvd;        // 2 int16 per macroblock (mv - predictor)
+    int16_t* mvd;        // 8 int16 per macroblock: (mv - predictor) of its partitions, in coding order
+    int16_t* mvq;        // 8 int16 per macroblock: the vectors (x, y) of its four 8x8 quadrants (a 16x16 macroblock carries its vector four times)
     uint8_t* aux;        // 16 bytes per macroblock: Intra4x4PredMode of the 16 blocks (blkIdx order) of an MB_I4 macroblock
     uint16_t* me_cost;   // per macroblock: min(final motion cost, 16383), 0 where the zero-motion test hit (summed by k_bit_scan)
     Quant qy, qc;        // luma / chroma quantisers
@@ -106,7 +107,8 @@ __device__ __forceinline__ FrameParams batch_view(FrameParams P, int g)
     for (int r = 0; r < 3; r++) { P.refs[r][0] += (size_t)g * P.st_y; P.refs[r][1] += (size_t)g * P.st_c; P.refs[r][2] += (size_t)g * P.st_c; }
     P.mb += (size_t)g * P.st_mb;
     P.levels += (size_t)g * P.st_mb * LV_STRIDE;
-    P.mvd += (size_t)g * P.st_mb * 2;
+    P.mvd += (size_t)g * P.st_mb * 8;
+    P.mvq += (size_t)g * P.st_mb * 8;
     P.aux += (size_t)g * P.st_mb * 16;
     P.me_cost += (size_t)g * P.st_mb;
     P.anypcm += g; P.anyintra += g;

@@ -268,7 +268,8 @@ __device__ __forceinline__ int nc_chroma(const MbInfo* m, int mx, bool top, int 
 struct CavlcParams {
     const MbInfo* mb;
     const int16_t* levels;
-    const int16_t* mvd;
+    const int16_t* mvd;   // 8 per macroblock: mvd_l0 of its partitions, coding order
+    const int16_t* mvq;   // 8 per macroblock: vectors of its four 8x8 quadrants
     int mbw, nmb, p_slice;
     int t8x8;             // PPS transform_8x8_mode_flag (High profile)
     int nref;             // num_ref_idx_l0_active of the slice (ref_idx_l0 is coded when > 1)
@@ -292,7 +293,7 @@ struct CavlcParams {
 };
 __device__ __forceinline__ CavlcParams batch_view(CavlcParams C, int g)
 {
-    C.mb += (size_t)g * C.st_mb; C.levels += (size_t)g * C.st_mb * LV_STRIDE; C.mvd += (size_t)g * C.st_mb * 2;
+    C.mb += (size_t)g * C.st_mb; C.levels += (size_t)g * C.st_mb * LV_STRIDE; C.mvd += (size_t)g * C.st_mb * 8; C.mvq += (size_t)g * C.st_mb * 8;
     C.prevcoded += (size_t)g * (C.st_mb + 1);
     C.slotbits += (size_t)g * C.st_mb * 32; C.slotcode += (size_t)g * C.st_mb * 32; C.mbbits += (size_t)g * C.st_mb; C.bitbuf += (size_t)g * C.st_bitbuf;
     if (C.bs) C.bs += (size_t)g * C.st_mb * 32;
@@ -310,23 +311,27 @@ struct HdrBatch { unsigned long long bits[MAX_BATCH]; unsigned char len[MAX_BATC
 // 8.7.2.1 boundary strength of one 4-sample edge segment; l = (dir, edge, segment) within the macroblock.
 // top: the macroblock above is in this slice; with several slices the stream says disable_deblocking_filter_idc 2
 // and the edge between two slices is not filtered.
-__device__ __forceinline__ int mb_edge_strength(const MbInfo* q, int mx, bool top, int mbw, int l)
+// qv: the quadrant vectors of q's macroblock (8 int16; the neighbours' lie 8 * (macroblock distance) before it)
+__device__ __forceinline__ int mb_edge_strength(const MbInfo* q, const int16_t* qv, int mx, bool top, int mbw, int l)
 {
     const int dir = l >> 4, e = (l >> 2) & 3, k = l & 3;
     if (e == 0 && (dir == 0 ? mx == 0 : !top)) return 0;
     const MbInfo* p = e == 0 ? (dir == 0 ? q - 1 : q - mbw) : q;
+    const int16_t* pv = e == 0 ? (dir == 0 ? qv - 8 : qv - 8 * mbw) : qv;
     const int bq = dir == 0 ? xy2blk(e, k) : xy2blk(k, e);
     const int bp = dir == 0 ? (e == 0 ? xy2blk(3, k) : xy2blk(e - 1, k)) : (e == 0 ? xy2blk(k, 3) : xy2blk(k, e - 1));
     if (mb_is_intra(p->type) || mb_is_intra(q->type)) return e == 0 ? 4 : 3;
     // transform_size_8x8_flag (i16_mode of an inter macroblock): no 4x4-internal edges, and "contains non-zero coefficients"
     // (8.7.2.1) refers to the 8x8 block = the four interleaved lists of the quadrant
-    const bool q8 = q->type == MB_P16 && q->i16_mode == 1, p8 = p->type == MB_P16 && p->i16_mode == 1;
+    const bool q8 = (q->type == MB_P16 || q->type >= MB_P16X8) && q->i16_mode == 1, p8 = (p->type == MB_P16 || p->type >= MB_P16X8) && p->i16_mode == 1;
     if (q8 && (e & 1)) return 0;
     const bool nzq = q8 ? (*(const uint32_t*)(q->tc + (bq & ~3)) != 0) : q->tc[bq] != 0;
     const bool nzp = p8 ? (*(const uint32_t*)(p->tc + (bp & ~3)) != 0) : p->tc[bp] != 0;
     if (nzp || nzq) return 2;
     if (p->chroma_mode != q->chroma_mode) return 1;   // different reference pictures (ref_idx_l0 rides in chroma_mode; one list, never reordered)
-    if (iabs(p->mvx - q->mvx) >= 4 || iabs(p->mvy - q->mvy) >= 4) return 1;
+    // the vectors of the two blocks' partitions (block b lies in quadrant b >> 2)
+    const uint32_t vp = *(const uint32_t*)(pv + 2 * (bp >> 2)), vq = *(const uint32_t*)(qv + 2 * (bq >> 2));
+    if (iabs((int)(int16_t)(vp & 0xFFFFu) - (int)(int16_t)(vq & 0xFFFFu)) >= 4 || iabs((int)(int16_t)(vp >> 16) - (int)(int16_t)(vq >> 16)) >= 4) return 1;
     return 0;
 }
 
@@ -410,11 +415,19 @@ __device__ __forceinline__ void code_slot(S& s, const CavlcParams& C, int mbi, i
             put_ue(s, m->chroma_mode);
             put_se(s, 0);
         } else {
-            put_ue(s, 0);
-            if (C.nref == 2) s.put(1, m->chroma_mode ? 0u : 1u);   // ref_idx_l0, te(v): with two pictures the inverted bit (9.1)
-            else if (C.nref > 2) put_ue(s, m->chroma_mode);
-            put_se(s, C.mvd[2 * mbi]);
-            put_se(s, C.mvd[2 * mbi + 1]);
+            // 7.3.5.1 / 7.3.5.2: mb_type (0 P_L0_16x16, 1 P_L0_L0_16x8, 2 P_L0_L0_8x16, 3 P_8x8 with four sub_mb_type P_L0_8x8),
+            // every partition's ref_idx_l0, then every partition's mvd_l0 (k_mvpred left them in coding order)
+            const int shape = m->type >= MB_P16X8 ? m->type - MB_P16X8 + 1 : 0, nparts = shape == 0 ? 1 : (shape == 3 ? 4 : 2);
+            put_ue(s, (unsigned)shape);
+            if (shape == 3) s.put(4, 15u);   // four times ue(0)
+            for (int k = 0; k < nparts; k++) {
+                if (C.nref == 2) s.put(1, m->chroma_mode ? 0u : 1u);   // ref_idx_l0, te(v): with two pictures the inverted bit (9.1)
+                else if (C.nref > 2) put_ue(s, m->chroma_mode);
+            }
+            for (int k = 0; k < nparts; k++) {
+                put_se(s, C.mvd[8 * mbi + 2 * k]);
+                put_se(s, C.mvd[8 * mbi + 2 * k + 1]);
+            }
             put_ue(s, c_cbp2code_inter[m->cbp]);
             if (C.t8x8 && cbpl) s.put(1, m->i16_mode & 1u);   // transform_size_8x8_flag (High profile, luma coefficients present)
             if (m->cbp) put_se(s, 0);
@@ -449,7 +462,7 @@ __global__ __launch_bounds__(64) void k_bs(CavlcParams C0, unsigned* anybs, unsi
     int bs = 0;
     if (mbi < C.mb_end) {
         const int my = C.mbdiv.row(mbi);
-        bs = mb_edge_strength(C.mb + mbi, mbi - my * C.mbw, C.sl.has_top(my), C.mbw, slot);
+        bs = mb_edge_strength(C.mb + mbi, C.mvq + (size_t)mbi * 8, mbi - my * C.mbw, C.sl.has_top(my), C.mbw, slot);
         C.bs[(size_t)mbi * 32 + slot] = (uint8_t)bs;
     }
     if (__ballot(bs != 0) != 0ull && lane == 0) anybs[blockIdx.y] = serial;   // same value from every writer: a plain store

@@ -38,6 +38,7 @@ struct DbParams {
     int alpha_y, beta_y, alpha_c, beta_c;
     int tc0_y[3], tc0_c[3];  // by bS-1
     SliceRows sl;        // several slices: disable_deblocking_filter_idc 2, the edge between two slices is left alone
+    const uint8_t* bs;   // k_bs's boundary strengths, 32 per macroblock: [dir][edge][segment] (the diagonal form reads them here)
 };
 
 // filter one line across an edge; p points at q0 inside LDS, xs = distance between samples across the edge
@@ -82,16 +83,6 @@ __device__ __forceinline__ void filter_line(uint8_t* pix, int xs, int bS, int al
     }
 }
 
-// 8.7.2.1 boundary strength (frame macroblocks, one reference, one vector per MB)
-__device__ __forceinline__ int edge_bs(const MbInfo* p, int bp, const MbInfo* q, int bq, bool mb_edge)
-{
-    if (mb_is_intra(p->type) || mb_is_intra(q->type)) return mb_edge ? 4 : 3;
-    if (p->tc[bp] || q->tc[bq]) return 2;
-    if (p->chroma_mode != q->chroma_mode) return 1;
-    if (iabs(p->mvx - q->mvx) >= 4 || iabs(p->mvy - q->mvy) >= 4) return 1;
-    return 0;
-}
-
 enum { DB_LP = 24, DB_CP = 12 };  // LDS pitches: luma 20 wide, chroma 10 wide (4 / 2 apron)
 
 __global__ __launch_bounds__(64) void k_deblock_diag(DbParams D, int s)
@@ -102,8 +93,6 @@ __global__ __launch_bounds__(64) void k_deblock_diag(DbParams D, int s)
     const int my = ymin + blockIdx.x, mx = s - 2 * my;
     if (my >= D.mbh || mx < 0 || mx >= D.mbw) return;
     const int cs = D.cw / 2;
-    const MbInfo* q = D.mb + (size_t)my * D.mbw + mx;
-
     __shared__ __attribute__((aligned(16))) uint8_t s_y[20 * DB_LP];      // rows/cols -4..15
     __shared__ __attribute__((aligned(16))) uint8_t s_c[2][10 * DB_CP];   // rows/cols -2..7
     __shared__ uint8_t s_bs[2][16];  // [dir][edge*4 + segment]
@@ -125,18 +114,7 @@ __global__ __launch_bounds__(64) void k_deblock_diag(DbParams D, int s)
     }
     if (lane < 32) {
         const int dir = lane >> 4, e = (lane >> 2) & 3, k = lane & 3;  // k: segment along the edge
-        int bS = 0;
-        if (dir == 0) {
-            if (!(e == 0 && mx == 0)) {
-                const MbInfo* p = e == 0 ? q - 1 : q;
-                bS = edge_bs(p, e == 0 ? xy2blk(3, k) : xy2blk(e - 1, k), q, xy2blk(e, k), e == 0);
-            }
-        } else {
-            if (!(e == 0 && !D.sl.has_top(my))) {
-                const MbInfo* p = e == 0 ? q - D.mbw : q;
-                bS = edge_bs(p, e == 0 ? xy2blk(k, 3) : xy2blk(k, e - 1), q, xy2blk(k, e), e == 0);
-            }
-        }
+        const int bS = D.bs[((size_t)my * D.mbw + mx) * 32 + lane];   // k_bs (k_cavlc.h mb_edge_strength), same (dir, edge, segment) order
         s_bs[dir][e * 4 + k] = (uint8_t)bS;
     }
     __syncthreads();

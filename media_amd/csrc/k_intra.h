@@ -372,7 +372,7 @@ __device__ __forceinline__ void intra_mb_core(const FrameParams& P, int mx, int 
             if (lane < 6) ((uint32_t*)m)[2 + lane] = 0x10101010u;
             if (lane == 6) {
                 *(uint2*)m = make_uint2(0u, (uint32_t)MB_IPCM | (0x2Fu << 24));
-                P.mvd[2 * mbi] = 0; P.mvd[2 * mbi + 1] = 0;
+                *(uint32_t*)(P.mvd + 8 * (size_t)mbi) = 0u;
                 *P.anypcm = P.pic_serial;
             }
             wave_sync();
@@ -385,7 +385,7 @@ __device__ __forceinline__ void intra_mb_core(const FrameParams& P, int mx, int 
         m->mvx = 0; m->mvy = 0; m->type = use_i4 ? MB_I4 : MB_I16;
         m->i16_mode = (uint8_t)best_mode; m->chroma_mode = (uint8_t)best_cmode;
         m->cbp = (uint8_t)(cbp_luma | (cbp_chroma << 4));
-        P.mvd[2 * mbi] = 0; P.mvd[2 * mbi + 1] = 0;
+        *(uint32_t*)(P.mvd + 8 * (size_t)mbi) = 0u;
     }
     {
         uint4* g = (uint4*)(P.levels + (size_t)mbi * LV_STRIDE);

@@ -255,6 +255,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
                 uint4* m = (uint4*)(P.mb + mbi);
                 m[0] = make_uint4(((uint32_t)vx & 0xFFFFu) | ((uint32_t)vy << 16), (uint32_t)MB_P16 | (0x80u << 8), 0u, 0u);   // i16_mode = 0x80: mark for k_tq / k_mvpred
                 m[1] = make_uint4(0u, 0u, 0u, 0u);
+                const uint32_t v = ((uint32_t)vx & 0xFFFFu) | ((uint32_t)vy << 16);
+                *(uint4*)(P.mvq + (size_t)mbi * 8) = make_uint4(v, v, v, v);
                 P.me_cost[mbi] = 0;
                 P.me_total[mbi] = 0u;   // settled: later reference pictures are not searched
             }
@@ -559,28 +561,166 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
         }
         bestk = best_cost_r << 4;                        // the next pass starts from "stay" (order 0)
     }
-    // this reference picture against the best so far
     const int rbits = P.nref <= 1 ? 0 : (P.nref == 2 ? 1 : (rf == 0 ? 1 : 3));   // te(v) of ref_idx_l0 (9.1)
+    // ---- 4b. partitions (oracle/h264_enc.c motion_search): a macroblock whose 16x16 cost reaches PART_TEST_MIN is also costed
+    // as two 16x8, two 8x16 and four 8x8 partitions, each refined on its own (half-, then quarter-sample neighbours, SATD +
+    // lambda * bits(mv - pmv)) from the integer winner - all within the half-sample planes already in LDS.  Same lane layout
+    // as above (candidate, pair of 4x4 blocks); the low half of every register belongs to a block of the upper two
+    // quadrants, the high half to one of the lower two, and each half follows its own partition's centre.
+    int shape = 0;
+    int qvx0 = cx, qvy0 = cy, qvx1 = cx, qvy1 = cy, qvx2 = cx, qvy2 = cy, qvx3 = cx, qvy3 = cy;   // vectors of the four quadrants
+    if (best_cost_r >= (unsigned)PART_TEST_MIN) {   // wave-uniform
+        // sums of |Hadamard| of the lane's two blocks (low | high << 16) with the low block predicted at (qlx, qly), the high at (qhx, qhy)
+        auto eval = [&](int qlx, int qly, int qhx, int qhy) -> uint32_t {
+            const int oxl = qlx - 4 * ix, oyl = qly - 4 * iy, oxh = qhx - 4 * ix, oyh = qhy - 4 * iy;
+            int t0, t1, u0, u1;
+            qpel_taps(oxl & 3, oyl & 3, t0, t1);
+            qpel_taps(oxh & 3, oyh & 3, u0, u1);
+            const int gbl = (1 + (oyl >> 2) + b4y) * ME_GP + 1 + (oxl >> 2) + b4x;
+            const int gbh = (1 + (oyh >> 2) + b4y + 8) * ME_GP + 1 + (oxh >> 2) + b4x;
+            lds_u32p pal = (lds_u32p)(s_pl + ((t0 + gbl) & ~3)), pbl = (lds_u32p)(s_pl + ((t1 + gbl) & ~3));
+            lds_u32p pah = (lds_u32p)(s_pl + ((u0 + gbh) & ~3)), pbh = (lds_u32p)(s_pl + ((u1 + gbh) & ~3));
+            const int sal = (t0 + gbl) & 3, sbl = (t1 + gbl) & 3, sah = (u0 + gbh) & 3, sbh = (u1 + gbh) & 3;
+            pk16 d[16];
+#pragma unroll
+            for (int y = 0; y < 4; y++) {
+                const int r = (ME_GP / 4) * y;
+                const uint32_t pl = avg4(__builtin_amdgcn_alignbyte(pal[r + 1], pal[r], sal), __builtin_amdgcn_alignbyte(pbl[r + 1], pbl[r], sbl));
+                const uint32_t ph = avg4(__builtin_amdgcn_alignbyte(pah[r + 1], pah[r], sah), __builtin_amdgcn_alignbyte(pbh[r + 1], pbh[r], sbh));
+#pragma unroll
+                for (int x = 0; x < 4; x++)
+                    d[4 * y + x] = S[4 * y + x] - __builtin_bit_cast(pk16, __builtin_amdgcn_perm(ph, pl, sel0 + 0x00010001u * x));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const pk16 s0 = d[4 * i] + d[4 * i + 3], s1 = d[4 * i + 1] + d[4 * i + 2];
+                const pk16 d0 = d[4 * i] - d[4 * i + 3], d1 = d[4 * i + 1] - d[4 * i + 2];
+                d[4 * i] = s0 + s1; d[4 * i + 1] = d0 + d1; d[4 * i + 2] = s0 - s1; d[4 * i + 3] = d0 - d1;
+            }
+            // every output carries the bias 0x8000 of source sample 0 (above); |x - bias| per half, summed per half (<= 16 320)
+            typedef short spk16 __attribute__((ext_vector_type(2)));
+            pk16 acc = {0, 0};
+            auto add_abs = [&](pk16 v) {
+                const spk16 t = __builtin_bit_cast(spk16, __builtin_bit_cast(uint32_t, v) ^ 0x80008000u);
+                acc += __builtin_bit_cast(pk16, __builtin_elementwise_max(t, -t));
+            };
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const pk16 s0 = d[j] + d[12 + j], s1 = d[4 + j] + d[8 + j];
+                const pk16 d0 = d[j] - d[12 + j], d1 = d[4 + j] - d[8 + j];
+                add_abs(s0 + s1); add_abs(d0 + d1); add_abs(s0 - s1); add_abs(d0 - d1);
+            }
+            return __builtin_bit_cast(uint32_t, acc);
+        };
+        auto xor4 = [](int v) {   // the value of lane ^ 4
+            int q = __builtin_amdgcn_update_dpp(0, v, 0x104, 0xf, 0x5, false);   // row_shl:4 into quads 0, 2: from lane + 4
+            return __builtin_amdgcn_update_dpp(q, v, 0x114, 0xf, 0xa, false);    // row_shr:4 into quads 1, 3: from lane - 4
+        };
+        // a partition's sum from the blocks' sums, for the partition of the lane's low block (slo) and of its high block (shi)
+        auto part_sums = [&](int sh, uint32_t acc, int& slo, int& shi) {
+            const int alo = (int)(acc & 0xFFFFu), ahi = (int)(acc >> 16);
+            if (sh == 1) { slo = group_sum8_dpp(alo); shi = group_sum8_dpp(ahi); }   // 16x8: all upper / all lower blocks
+            else if (sh == 2) {   // 8x16: the blocks of the left (b4x < 8) or right half, both register halves
+                int v = alo + ahi;
+                v += __builtin_amdgcn_mov_dpp(v, 0xB1, 0xf, 0xf, false);
+                v += xor4(v);
+                slo = v; shi = v;
+            } else {              // 8x8: left / right half, register halves apart
+                int v = alo, u = ahi;
+                v += __builtin_amdgcn_mov_dpp(v, 0xB1, 0xf, 0xf, false);
+                u += __builtin_amdgcn_mov_dpp(u, 0xB1, 0xf, 0xf, false);
+                slo = v + xor4(v); shi = u + xor4(u);
+            }
+        };
+        auto min_over_candidates = [](unsigned k) {   // lanes 8 apart hold the same blocks for the eight candidates
+            k = min(k, (unsigned)__shfl_xor((int)k, 8));
+            k = min(k, (unsigned)__shfl_xor((int)k, 16));
+            return min(k, (unsigned)__shfl_xor((int)k, 32));
+        };
+        const uint32_t acc0 = eval(4 * ix, 4 * iy, 4 * ix, 4 * iy);   // the common starting point of every partition
+        const int nn = cand >= 4 ? cand + 1 : cand, ddx = (nn % 3) - 1, ddy = (nn / 3) - 1;
+        unsigned best_all = best_cost_r;
+#pragma unroll 1
+        for (int sh = 1; sh <= 3; sh++) {
+            int clx = 4 * ix, cly = 4 * iy, chx = 4 * ix, chy = 4 * iy;   // centre of the low / high block's partition
+            unsigned klo, khi;
+            {
+                int slo, shi;
+                part_sums(sh, acc0, slo, shi);
+                const unsigned mvb = (unsigned)(P.lambda * (se_len(4 * ix - pmx) + se_len(4 * iy - pmy)));
+                klo = ((unsigned)(slo >> 1) + mvb) << 4; khi = ((unsigned)(shi >> 1) + mvb) << 4;   // order 0: stay
+            }
+#pragma unroll 1
+            for (int round = 0; round < 2; round++) {
+                const int step = round == 1 ? 1 : 2;
+                const int qlx = clx + step * ddx, qly = cly + step * ddy, qhx = chx + step * ddx, qhy = chy + step * ddy;
+                int slo, shi;
+                part_sums(sh, eval(qlx, qly, qhx, qhy), slo, shi);
+                const unsigned cl = (unsigned)(slo >> 1) + (unsigned)(P.lambda * (se_len(qlx - pmx) + se_len(qly - pmy)));
+                const unsigned chh = (unsigned)(shi >> 1) + (unsigned)(P.lambda * (se_len(qhx - pmx) + se_len(qhy - pmy)));
+                klo = min_over_candidates(min(klo, (cl << 4) | (unsigned)(cand + 1)));
+                khi = min_over_candidates(min(khi, (chh << 4) | (unsigned)(cand + 1)));
+                const int wl = (int)(klo & 15u), wh = (int)(khi & 15u);
+                if (wl) { const int n = wl - 1, wn = n >= 4 ? n + 1 : n; clx += step * ((wn % 3) - 1); cly += step * ((wn / 3) - 1); }
+                if (wh) { const int n = wh - 1, wn = n >= 4 ? n + 1 : n; chx += step * ((wn % 3) - 1); chy += step * ((wn / 3) - 1); }
+                klo &= ~15u; khi &= ~15u;   // the next round starts from "stay"
+            }
+            // lane 0 holds quadrants 0 (low) and 2 (high), lane 2 quadrants 1 and 3
+            const unsigned l0 = (unsigned)__builtin_amdgcn_readlane((int)klo, 0) >> 4, l2 = (unsigned)__builtin_amdgcn_readlane((int)klo, 2) >> 4;
+            const unsigned h0 = (unsigned)__builtin_amdgcn_readlane((int)khi, 0) >> 4, h2 = (unsigned)__builtin_amdgcn_readlane((int)khi, 2) >> 4;
+            const unsigned tot = (sh == 1 ? l0 + h0 : (sh == 2 ? l0 + l2 : l0 + l2 + h0 + h2)) + (unsigned)(P.lambda * (sh == 3 ? 8 + 3 * rbits : 2 + rbits));
+            if (tot < best_all) {
+                best_all = tot; shape = sh;
+                qvx0 = __builtin_amdgcn_readlane(clx, 0); qvy0 = __builtin_amdgcn_readlane(cly, 0);
+                qvx1 = __builtin_amdgcn_readlane(clx, 2); qvy1 = __builtin_amdgcn_readlane(cly, 2);
+                qvx2 = __builtin_amdgcn_readlane(chx, 0); qvy2 = __builtin_amdgcn_readlane(chy, 0);
+                qvx3 = __builtin_amdgcn_readlane(chx, 2); qvy3 = __builtin_amdgcn_readlane(chy, 2);
+            }
+        }
+        best_cost_r = best_all;
+    }
+    // this reference picture against the best so far
     const unsigned total = best_cost_r + (unsigned)(P.lambda * rbits);
     const bool better = total < prev_total;   // wave-uniform; rf == 0: always
     if (better) {
         // the prediction goes to the reconstruction planes (k_tq turns it into the reconstruction in place): luma from the
-        // half-sample planes still in LDS, lane = (row, 4-sample segment); chroma by 8.4.2.2.2
-        const int ox = cx - 4 * ix, oy = cy - 4 * iy;
-        int t0, t1;
-        qpel_taps(ox & 3, oy & 3, t0, t1);
+        // half-sample planes still in LDS, lane = (row, 4-sample segment); chroma by 8.4.2.2.2; every sample by the vector of
+        // its quadrant
         const int y = lane >> 2, seg = (lane & 3) * 4;
-        const int gb = (1 + (oy >> 2) + y) * ME_GP + 1 + (ox >> 2) + seg;
-        *(uint32_t*)(P.rec[0] + (size_t)(by + y) * P.cw + bx + seg) = avg4(lds_ld4(s_pl, t0 + gb), lds_ld4(s_pl, t1 + gb));
-        if (lane < 32) {
-            const int pl = lane >> 4, cyy = (lane >> 1) & 7, cxx = (lane & 1) * 4;
-            *(uint32_t*)((pl ? P.rec[2] : P.rec[1]) + (size_t)(8 * my + cyy) * (P.cw / 2) + 8 * mx + cxx) =
-                chroma_pred4(pl ? RV : RU, P.cw / 2, P.ch / 2, 8 * mx + cxx + (cx >> 3), 8 * my + cyy + (cy >> 3), cx & 7, cy & 7);
+        const int pl = lane >> 4, cyy = (lane >> 1) & 7, cxx = (lane & 1) * 4;   // chroma: lanes < 32
+        if (shape == 0) {   // one vector: the tap selection stays on the scalar unit
+            const int ox = cx - 4 * ix, oy = cy - 4 * iy;
+            int t0, t1;
+            qpel_taps(ox & 3, oy & 3, t0, t1);
+            const int gb = (1 + (oy >> 2) + y) * ME_GP + 1 + (ox >> 2) + seg;
+            *(uint32_t*)(P.rec[0] + (size_t)(by + y) * P.cw + bx + seg) = avg4(lds_ld4(s_pl, t0 + gb), lds_ld4(s_pl, t1 + gb));
+            if (lane < 32)
+                *(uint32_t*)((pl ? P.rec[2] : P.rec[1]) + (size_t)(8 * my + cyy) * (P.cw / 2) + 8 * mx + cxx) =
+                    chroma_pred4(pl ? RV : RU, P.cw / 2, P.ch / 2, 8 * mx + cxx + (cx >> 3), 8 * my + cyy + (cy >> 3), cx & 7, cy & 7);
+        } else {
+            {
+                const bool lowq = y < 8, leftq = seg < 8;
+                const int vx = lowq ? (leftq ? qvx0 : qvx1) : (leftq ? qvx2 : qvx3), vy = lowq ? (leftq ? qvy0 : qvy1) : (leftq ? qvy2 : qvy3);
+                const int ox = vx - 4 * ix, oy = vy - 4 * iy;
+                int t0, t1;
+                qpel_taps(ox & 3, oy & 3, t0, t1);
+                const int gb = (1 + (oy >> 2) + y) * ME_GP + 1 + (ox >> 2) + seg;
+                *(uint32_t*)(P.rec[0] + (size_t)(by + y) * P.cw + bx + seg) = avg4(lds_ld4(s_pl, t0 + gb), lds_ld4(s_pl, t1 + gb));
+            }
+            if (lane < 32) {
+                const bool lowq = cyy < 4, leftq = cxx < 4;
+                const int vx = lowq ? (leftq ? qvx0 : qvx1) : (leftq ? qvx2 : qvx3), vy = lowq ? (leftq ? qvy0 : qvy1) : (leftq ? qvy2 : qvy3);
+                *(uint32_t*)((pl ? P.rec[2] : P.rec[1]) + (size_t)(8 * my + cyy) * (P.cw / 2) + 8 * mx + cxx) =
+                    chroma_pred4(pl ? RV : RU, P.cw / 2, P.ch / 2, 8 * mx + cxx + (vx >> 3), 8 * my + cyy + (vy >> 3), vx & 7, vy & 7);
+            }
         }
         if (lane == 0) {
             uint4* m = (uint4*)(P.mb + mbi);
-            m[0] = make_uint4(((uint32_t)cx & 0xFFFFu) | ((uint32_t)cy << 16), (uint32_t)MB_P16 | ((uint32_t)rf << 16), 0u, 0u);   // ref_idx_l0 rides in chroma_mode
+            const uint32_t type = shape ? (uint32_t)(MB_P16X8 + shape - 1) : (uint32_t)MB_P16;
+            auto pk = [](int x, int yv) { return ((uint32_t)x & 0xFFFFu) | ((uint32_t)yv << 16); };
+            m[0] = make_uint4(pk(qvx0, qvy0), type | ((uint32_t)rf << 16), 0u, 0u);   // ref_idx_l0 rides in chroma_mode
             m[1] = make_uint4(0u, 0u, 0u, 0u);
+            *(uint4*)(P.mvq + (size_t)mbi * 8) = make_uint4(pk(qvx0, qvy0), pk(qvx1, qvy1), pk(qvx2, qvy2), pk(qvx3, qvy3));
             P.me_total[mbi] = total;
         }
     }

@@ -29,6 +29,10 @@
 
 namespace h264 {
 
+// {type, i16_mode} of a macroblock k_tq / k_tq8 must code: an inter macroblock (16x16 or partitioned) whose i16_mode byte is
+// still 0 (k_me sets 0x80 there when nothing is left to code, and type MB_I16 for the intra pass)
+__device__ __forceinline__ bool mb_to_code(unsigned type_mode) { return type_mode == (unsigned)MB_P16 || (type_mode >= (unsigned)MB_P16X8 && type_mode <= (unsigned)MB_P8X8); }
+
 struct TqConst { int mf[3], dq[3], f, c, q; };   // c = 2^q - 1 - 2 f (bias of negative values minus f)
 __device__ __forceinline__ TqConst tq_consts(const Quant& qn)
 {
@@ -93,7 +97,7 @@ __device__ __forceinline__ void tq_chroma8(const FrameParams& P, const int first
         const TqConst K = tq_consts(P.qc);
         const int m8 = lane >> 3, pl = (lane >> 2) & 1, cb = lane & 3, mbi = first + m8;
         bool act = mbi < end;
-        if (act) act = *(const uint16_t*)((const uint8_t*)P.mb + (uint32_t)(mbi * 32 + 4)) == (uint16_t)MB_P16;
+        if (act) act = mb_to_code(*(const uint16_t*)((const uint8_t*)P.mb + (uint32_t)(mbi * 32 + 4)));
         int cnz = 0, ldc = 0, bb = 0;
         if (act) {
             const int my = P.mbdiv.row(mbi), mx = mbi - my * P.mbw;
@@ -196,7 +200,7 @@ __global__ __launch_bounds__(64) void k_tq(FrameParams P0)
             const int blk = lane & 15, mbi = first + 4 * p + (lane >> 4);
             bool act = mbi < end;
             // MbInfo.type == MB_P16 and i16_mode == 0 (k_me sets i16_mode when nothing is left to code, type MB_I16 for the intra pass)
-            if (act) act = *(const uint16_t*)((const uint8_t*)P.mb + (uint32_t)(mbi * 32 + 4)) == (uint16_t)MB_P16;
+            if (act) act = mb_to_code(*(const uint16_t*)((const uint8_t*)P.mb + (uint32_t)(mbi * 32 + 4)));
             int nz = 0, bb = 0;
             if (act) {
                 const int my = P.mbdiv.row(mbi), mx = mbi - my * P.mbw;
@@ -311,7 +315,7 @@ __global__ __launch_bounds__(64) void k_tq8(FrameParams P0)
         const int qp6 = P.qy.qp / 6;
         const int b8 = lane & 3, mbi = first + (lane >> 2);
         bool act = mbi < end;
-        if (act) act = *(const uint16_t*)((const uint8_t*)P.mb + (uint32_t)(mbi * 32 + 4)) == (uint16_t)MB_P16;
+        if (act) act = mb_to_code(*(const uint16_t*)((const uint8_t*)P.mb + (uint32_t)(mbi * 32 + 4)));
         int nzany = 0, bb = 0;
         if (act) {
             const int my = P.mbdiv.row(mbi), mx = mbi - my * P.mbw;
@@ -405,8 +409,11 @@ __global__ __launch_bounds__(64) void k_tq8(FrameParams P0)
     }
 }
 
-// Motion vector differences and P_Skip: lane = macroblock.  Needs every macroblock's final vector (k_me) and
+// Motion vector differences and P_Skip: lane = macroblock.  Needs every macroblock's final vectors (k_me) and
 // coded_block_pattern (k_tq); writes mvd and MbInfo.type / i16_mode (k_me's "nothing to code" mark is cleared).
+// 8.4.1.3 with vectors kept per 8x8 quadrant (mvq), the granularity of the smallest partition: a neighbouring partition
+// is the quadrant (qx, qy) of its macroblock; A left of the partition's top-left sample, B above it, C above-right of its
+// top-right sample or, when that is outside or later in decoding order, D above-left (6.4.11.7).
 __global__ __launch_bounds__(64) void k_mvpred(FrameParams P0)
 {
     __builtin_amdgcn_s_setprio(1);
@@ -416,42 +423,92 @@ __global__ __launch_bounds__(64) void k_mvpred(FrameParams P0)
     if (i >= nmb) return;
     const int mbi = mb0 + i, my = P.mbdiv.row(mbi), mx = mbi - my * P.mbw;
     const bool top = P.sl.has_top(my);
-    const bool avA = mx > 0, avB = top, avC0 = top && mx + 1 < P.mbw, avD = mx > 0 && top;
+    const bool avL = mx > 0, avT = top, avTR = top && mx + 1 < P.mbw, avTL = mx > 0 && top;
     const MbInfo* base = P.mb + mbi;
     const uint2 self = *(const uint2*)base;
-    if (mb_is_intra((int)(self.y & 255u))) return;   // (intra macroblocks carry no vector)
-    const uint2 wA = *(const uint2*)(avA ? base - 1 : base);
-    const uint2 wB = *(const uint2*)(avB ? base - P.mbw : base);
-    const uint2 wC = *(const uint2*)(avC0 ? base - P.mbw + 1 : base);
-    const uint2 wD = *(const uint2*)(avD ? base - P.mbw - 1 : base);
-    auto unpack = [](const uint2 w, bool av, int& ref, Mv& mv) {   // ref_idx_l0 of an inter macroblock rides in chroma_mode
-        ref = -1; mv.x = 0; mv.y = 0;
-        if (av && !mb_is_intra((int)(w.y & 255u))) { ref = (int)((w.y >> 16) & 255u); mv.x = (int)(int16_t)(w.x & 0xFFFFu); mv.y = (int)(int16_t)(w.x >> 16); }
-    };
-    int rA, rB, rC;
-    Mv A, B, C;
-    unpack(wA, avA, rA, A);
-    unpack(wB, avB, rB, B);
-    bool aC = avC0;
-    if (avC0) unpack(wC, true, rC, C);
-    else { unpack(wD, avD, rC, C); aC = avD; }
-    const bool zero_skip = !avA || !avB || (rA == 0 && A.x == 0 && A.y == 0) || (rB == 0 && B.x == 0 && B.y == 0);
-    if (!avB && !aC && avA) { B = A; C = A; rB = rA; rC = rA; }
+    const int stype = (int)(self.y & 255u);
+    if (mb_is_intra(stype)) return;   // (intra macroblocks carry no vector)
     const int cref = (int)((self.y >> 16) & 255u);
-    auto pred_for = [&](int ref) {   // 8.4.1.3.1
-        Mv p;
-        const int n = (rA == ref) + (rB == ref) + (rC == ref);
-        if (n == 1) p = rA == ref ? A : (rB == ref ? B : C);
-        else { p.x = med3(A.x, B.x, C.x); p.y = med3(A.y, B.y, C.y); }
+    // {type, ref} of the four neighbouring macroblocks and the quadrant vectors that can be asked for
+    struct Nb { int ref; uint32_t v[4]; };   // ref -1: not available or intra; v[q] = vector of quadrant q (x | y << 16)
+    auto load = [&](bool av, int d, Nb& n) {
+        n.ref = -1; n.v[0] = n.v[1] = n.v[2] = n.v[3] = 0u;
+        if (av) {
+            const uint32_t w = *(const uint32_t*)((const uint8_t*)(base + d) + 4);
+            if (!mb_is_intra((int)(w & 255u))) {
+                n.ref = (int)((w >> 16) & 255u);
+                const uint4 q = *(const uint4*)(P.mvq + (size_t)(mbi + d) * 8);
+                n.v[0] = q.x; n.v[1] = q.y; n.v[2] = q.z; n.v[3] = q.w;
+            }
+        }
+    };
+    Nb L, T, TR, TL, S;
+    load(avL, -1, L);
+    load(avT, -P.mbw, T);
+    load(avTR, -P.mbw + 1, TR);
+    load(avTL, -P.mbw - 1, TL);
+    load(true, 0, S);
+    struct Cand { bool av; int ref; Mv mv; };
+    auto from = [](const Nb& n, bool av, int q) {
+        Cand c;
+        c.av = av; c.ref = av ? n.ref : -1;
+        const uint32_t v = q == 0 ? n.v[0] : (q == 1 ? n.v[1] : (q == 2 ? n.v[2] : n.v[3]));
+        c.mv.x = c.ref >= 0 ? (int)(int16_t)(v & 0xFFFFu) : 0; c.mv.y = c.ref >= 0 ? (int)(int16_t)(v >> 16) : 0;
+        return c;
+    };
+    // predictor of the partition covering quadrants x0 .. x0 + w - 1, y0 .. y0 + h - 1; skip (16x16 geometry) = the P_Skip vector
+    auto predict = [&](int x0, int y0, int w, int h, Mv* skip) {
+        const Cand A = x0 == 0 ? from(L, avL, 2 * y0 + 1) : from(S, true, 2 * y0);
+        const Cand B = y0 == 0 ? from(T, avT, 2 + x0) : from(S, true, x0);
+        Cand C;
+        if (y0 == 0) C = x0 + w <= 1 ? from(T, avT, 2 + x0 + w) : from(TR, avTR, 2);
+        else if (x0 + w <= 1) C = from(S, true, x0 + w);        // the quadrant above-right, coded before this one
+        else { C.av = false; C.ref = -1; C.mv = Mv{0, 0}; }    // in the macroblock to the right: not yet coded
+        if (!C.av) {
+            if (x0 == 0 && y0 == 0) C = from(TL, avTL, 3);
+            else if (y0 == 0) C = from(T, avT, 2);
+            else if (x0 == 0) C = from(L, avL, 1);
+            else C = from(S, true, 0);
+        }
+        Cand a = A, b = B, c = C;
+        const bool zero_skip = !a.av || !b.av || (a.ref == 0 && a.mv.x == 0 && a.mv.y == 0) || (b.ref == 0 && b.mv.x == 0 && b.mv.y == 0);
+        if (w == 2 && h == 1) {          // 16x8: upper partition B, lower partition A, when that neighbour uses the same picture
+            if (y0 == 0 && b.ref == cref) return b.mv;
+            if (y0 == 1 && a.ref == cref) return a.mv;
+        } else if (w == 1 && h == 2) {   // 8x16: left A, right C
+            if (x0 == 0 && a.ref == cref) return a.mv;
+            if (x0 == 1 && c.ref == cref) return c.mv;
+        }
+        if (!b.av && !c.av && a.av) { b = a; c = a; }
+        auto pred_for = [&](int ref) {   // 8.4.1.3.1
+            Mv p;
+            const int n = (a.ref == ref) + (b.ref == ref) + (c.ref == ref);
+            if (n == 1) p = a.ref == ref ? a.mv : (b.ref == ref ? b.mv : c.mv);
+            else { p.x = med3(a.mv.x, b.mv.x, c.mv.x); p.y = med3(a.mv.y, b.mv.y, c.mv.y); }
+            return p;
+        };
+        const Mv p = pred_for(cref);
+        if (skip) *skip = zero_skip ? Mv{0, 0} : (cref == 0 ? p : pred_for(0));   // 8.4.1.1: P_Skip predicts for ref_idx 0
         return p;
     };
-    const Mv p = pred_for(cref);
-    const Mv skip = zero_skip ? Mv{0, 0} : (cref == 0 ? p : pred_for(0));   // 8.4.1.1: P_Skip predicts for ref_idx 0
-    const int mvx = (int)(int16_t)(self.x & 0xFFFFu), mvy = (int)(int16_t)(self.x >> 16), cbp = (int)(self.y >> 24);
-    const int type = (cbp == 0 && cref == 0 && skip.x == mvx && skip.y == mvy) ? MB_PSKIP : MB_P16;
+    uint32_t d[4] = {0u, 0u, 0u, 0u};
+    auto diff = [](uint32_t v, Mv p) { return (uint32_t)(((int)(int16_t)(v & 0xFFFFu) - p.x) & 0xFFFF) | ((uint32_t)((int)(int16_t)(v >> 16) - p.y) << 16); };
+    int type = stype;
+    if (stype == MB_P16X8) { d[0] = diff(S.v[0], predict(0, 0, 2, 1, nullptr)); d[1] = diff(S.v[2], predict(0, 1, 2, 1, nullptr)); }
+    else if (stype == MB_P8X16) { d[0] = diff(S.v[0], predict(0, 0, 1, 2, nullptr)); d[1] = diff(S.v[1], predict(1, 0, 1, 2, nullptr)); }
+    else if (stype == MB_P8X8) {
+        d[0] = diff(S.v[0], predict(0, 0, 1, 1, nullptr)); d[1] = diff(S.v[1], predict(1, 0, 1, 1, nullptr));
+        d[2] = diff(S.v[2], predict(0, 1, 1, 1, nullptr)); d[3] = diff(S.v[3], predict(1, 1, 1, 1, nullptr));
+    } else {
+        Mv skip;
+        const Mv p = predict(0, 0, 2, 2, &skip);
+        const int mvx = (int)(int16_t)(self.x & 0xFFFFu), mvy = (int)(int16_t)(self.x >> 16), cbp = (int)(self.y >> 24);
+        type = (cbp == 0 && cref == 0 && skip.x == mvx && skip.y == mvy) ? MB_PSKIP : MB_P16;
+        d[0] = diff(self.x, p);
+    }
     // type; i16_mode keeps transform_size_8x8_flag (bit 0, k_tq8), k_me's "nothing to code" mark (0x80) goes
-    *(uint16_t*)((uint8_t*)(P.mb + mbi) + 4) = (uint16_t)((unsigned)type | (type == MB_P16 ? ((self.y >> 8) & 1u) << 8 : 0u));
-    *(uint32_t*)(P.mvd + 2 * mbi) = (uint32_t)((mvx - p.x) & 0xFFFF) | ((uint32_t)(mvy - p.y) << 16);
+    *(uint16_t*)((uint8_t*)(P.mb + mbi) + 4) = (uint16_t)((unsigned)type | (type != MB_PSKIP ? ((self.y >> 8) & 1u) << 8 : 0u));
+    *(uint4*)(P.mvd + 8 * (size_t)mbi) = make_uint4(d[0], d[1], d[2], d[3]);
 }
 
 }  // namespace h264

@@ -169,6 +169,7 @@ struct mi355x_h264_encoder {
     int16_t* d_levels = nullptr;
     int16_t* d_mvd = nullptr;
     uint8_t* d_aux = nullptr;                // [G][nmb][16] Intra4x4 modes
+    int16_t* d_mvq = nullptr;                // [G][nmb][8] vectors of the four 8x8 quadrants of inter macroblocks
     uint32_t* d_me_total = nullptr;          // [G][nmb] best motion cost so far over the reference pictures (k_me, one launch each)
     int* d_pmv = nullptr;                    // [G][nmb] the previous picture's vectors, parked for the later launches
     uint16_t* d_slotbits = nullptr;
@@ -322,7 +323,7 @@ int submit(mi355x_h264_encoder* e, const uint8_t* d_src, size_t src_item_stride,
         for (int r = 0; r < mi355x_h264_encoder::MAX_REFS; r++) P.refs[r][p] = e->d_planes[(cur + e->nbuf - 1 - std::min(r, e->nrefs - 1)) % e->nbuf][p];
         P.ref[p] = P.refs[0][p];
     }
-    P.mb = e->d_mb; P.levels = e->d_levels; P.mvd = e->d_mvd; P.aux = e->d_aux; P.me_cost = e->d_me_cost; P.me_total = e->d_me_total; P.pmv = e->d_pmv;
+    P.mb = e->d_mb; P.levels = e->d_levels; P.mvd = e->d_mvd; P.mvq = e->d_mvq; P.aux = e->d_aux; P.me_cost = e->d_me_cost; P.me_total = e->d_me_total; P.pmv = e->d_pmv;
     P.st_src = src_item_stride; P.st_y = e->st_y; P.st_c = e->st_c; P.st_mb = e->nmb; P.sl = e->sl;
     P.band.row0 = e->b_row0; P.band.rows = e->b_rows;
     P.mbdiv.inv = e->mbw > 1 ? (unsigned)(0x100000000ull / (unsigned)e->mbw) + 1u : 0u;
@@ -396,11 +397,11 @@ int submit(mi355x_h264_encoder* e, const uint8_t* d_src, size_t src_item_stride,
     C.slotbits = e->d_slotbits; C.slotcode = e->d_slotcode; C.mbbits = e->d_mbbits; C.bitbuf = S.d_bitbuf;
     C.bs = (uint8_t*)e->d_bs; C.prevcoded = e->d_prevcoded;
     C.st_mb = e->nmb; C.st_bitbuf = e->st_bitbuf_bytes / 4;
-    C.aux = e->d_aux;
+    C.aux = e->d_aux; C.mvq = e->d_mvq;
     C.src = d_src; C.w = e->cfg.width; C.h = e->cfg.height; C.src_nv12 = nv12 ? 1 : 0; C.st_src = src_item_stride;
     const int cavlc_grid = (e->b_nmb + 1) / 2;
     unsigned db_serial = 0;
-    if (!e->cfg.disable_deblock && !e->diag_mode) {
+    if (!e->cfg.disable_deblock) {   // (the diagonal debug form of the filter reads the strengths too)
         e->serial = e->serial == 0xFFFFFFFFu ? 1 : e->serial + 1;   // the serial the loop filter of this picture will run under
         db_serial = e->serial;
         hipLaunchKernelGGL(k_bs, dim3(cavlc_grid, G), dim3(64), 0, st, C, e->d_anybs, db_serial);
@@ -438,7 +439,7 @@ int submit(mi355x_h264_encoder* e, const uint8_t* d_src, size_t src_item_stride,
         StatScope sc(e, &S, MI355X_H264_K_DEBLOCK, (uint32_t)(e->diag_mode ? steps : 1), (uint32_t)(e->b_nmb * e->G));
         DbParams D{};
         for (int p = 0; p < 3; p++) D.pl[p] = e->d_planes[cur][p];
-        D.mb = e->d_mb; D.cw = e->cw; D.ch = e->ch; D.mbw = e->mbw; D.mbh = e->mbh; D.sl = e->sl;
+        D.mb = e->d_mb; D.cw = e->cw; D.ch = e->ch; D.mbw = e->mbw; D.mbh = e->mbh; D.sl = e->sl; D.bs = (const uint8_t*)e->d_bs;
         const int qp = e->qp, qpc = h_chroma_qp[qp];
         D.alpha_y = h_alpha[qp]; D.beta_y = h_beta[qp]; D.alpha_c = h_alpha[qpc]; D.beta_c = h_beta[qpc];
         for (int i = 0; i < 3; i++) { D.tc0_y[i] = h_tc0[qp][i]; D.tc0_c[i] = h_tc0[qpc][i]; }
@@ -660,7 +661,9 @@ int mi355x_h264_create(const mi355x_h264_config* cfg, mi355x_h264_encoder** out)
     CK(hipMalloc((void**)&e->d_mb, Gn * e->nmb * sizeof(MbInfo)));
     CK(hipMemset(e->d_mb, 0, Gn * e->nmb * sizeof(MbInfo)));
     CK(hipMalloc((void**)&e->d_levels, Gn * e->nmb * LV_STRIDE * sizeof(int16_t)));
-    CK(hipMalloc((void**)&e->d_mvd, Gn * e->nmb * 2 * sizeof(int16_t)));
+    CK(hipMalloc((void**)&e->d_mvd, Gn * e->nmb * 8 * sizeof(int16_t)));
+    CK(hipMalloc((void**)&e->d_mvq, Gn * e->nmb * 8 * sizeof(int16_t)));
+    CK(hipMemset(e->d_mvq, 0, Gn * e->nmb * 8 * sizeof(int16_t)));
     CK(hipMalloc((void**)&e->d_me_total, Gn * e->nmb * sizeof(uint32_t)));
     CK(hipMalloc((void**)&e->d_pmv, Gn * e->nmb * sizeof(int)));
     CK(hipMalloc((void**)&e->d_aux, Gn * e->nmb * 16));
@@ -721,7 +724,7 @@ void mi355x_h264_destroy(mi355x_h264_encoder* e)
     for (int b = 0; b <= mi355x_h264_encoder::MAX_REFS; b++)
         for (int p = 0; p < 3; p++) (void)hipFree(e->d_planes[b][p]);
     for (int p = 0; p < 3; p++) (void)hipFree(e->d_pre[p]);
-    (void)hipFree(e->d_mb); (void)hipFree(e->d_levels); (void)hipFree(e->d_mvd); (void)hipFree(e->d_aux); (void)hipFree(e->d_me_total); (void)hipFree(e->d_pmv);
+    (void)hipFree(e->d_mb); (void)hipFree(e->d_levels); (void)hipFree(e->d_mvd); (void)hipFree(e->d_mvq); (void)hipFree(e->d_aux); (void)hipFree(e->d_me_total); (void)hipFree(e->d_pmv);
     (void)hipFree(e->d_slotbits); (void)hipFree(e->d_slotcode); (void)hipFree(e->d_mbbits); (void)hipFree(e->d_prevcoded); (void)hipFree(e->d_anybs); (void)hipFree(e->d_anypcm); (void)hipFree(e->d_anyintra); (void)hipFree(e->d_stage);
     (void)hipFree(e->d_handoff); (void)hipFree(e->d_bs); (void)hipFree(e->d_me_cost);
     if (e->h_stage) (void)hipHostFree(e->h_stage);
@@ -1005,6 +1008,7 @@ int64_t mi355x_h264_debug_read(mi355x_h264_encoder* e, int what, void* dst, size
         case MI355X_H264_DBG_MBINFO: src = e->d_mb; n = (size_t)e->nmb * sizeof(MbInfo); break;
         case MI355X_H264_DBG_LEVELS: src = e->d_levels; n = (size_t)e->nmb * LV_STRIDE * 2; break;
         case MI355X_H264_DBG_MBAUX: src = e->d_aux; n = (size_t)e->nmb * 16; break;
+        case MI355X_H264_DBG_MVQ: src = e->d_mvq; n = (size_t)e->nmb * 16; break;
         default: return MI355X_H264_E_ARG;
     }
     if (cap < n) return MI355X_H264_E_ARG;

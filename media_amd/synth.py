@@ -93,8 +93,33 @@ def frame_cut(width, height, index):
     return np.concatenate([np.ascontiguousarray(y).ravel(), np.ascontiguousarray(u).ravel(), np.ascontiguousarray(v).ravel()])
 
 
+def frame_split(width, height, index):
+    """two layers of a texture that drift apart by a fraction of a sample per picture - (+3, +1) and (-3, -1) QUARTER samples -
+    interleaved in 8-sample stripes: rows of 8 in the upper third of the picture (a macroblock's halves move apart: 16x8
+    partitions), columns of 8 in the middle third (8x16), an 8x8 checkerboard in the lower third (8x8).  The texture is
+    evaluated on a 4x finer grid, so the motion is a true sub-sample shift.  Light noise.  Not one of the SURVEY inputs: it
+    exists for the sub-16x16 partitions (test-size pictures only: the fine grid is 16x the picture)."""
+    out = []
+    base = 0
+    for pi, (w, h, cell, div) in enumerate(((width, height, 8, 1), (width // 2, height // 2, 4, 2), (width // 2, height // 2, 4, 2))):
+        la = _texture(4 * w, 4 * h, (-3 * index) // div + 11 * pi, (-1 * index) // div, 1)[::4, ::4]
+        lb = _texture(4 * w, 4 * h, (3 * index) // div + 170 + 11 * pi, (1 * index) // div + 90, 1)[::4, ::4]
+        yy, xx = np.arange(h)[:, None] // cell, np.arange(w)[None, :] // cell
+        third = (np.arange(h)[:, None] * 3) // h
+        mask = np.where(third == 0, yy & 1, np.where(third == 1, xx & 1, (xx + yy) & 1)).astype(bool)
+        p = np.where(mask, lb, la)
+        if pi:
+            p = p // 2 + 64
+        n = w * h
+        r = _hash_u32(SEED_S1 + 7919 + index, base + n)[base:]
+        p = p + (r % np.uint32(3)).astype(np.int32).reshape(p.shape) - 1
+        base += n
+        out.append(np.clip(p, 0, 255).astype(np.uint8).ravel())
+    return np.concatenate(out)
+
+
 def sequence(kind, width, height, count, start=0):
-    fn = {"s1": frame_s1, "s2": frame_s2, "s3": frame_s3, "ramp": frame_ramp, "scroll": frame_scroll, "cut": frame_cut}[kind]
+    fn = {"s1": frame_s1, "s2": frame_s2, "s3": frame_s3, "ramp": frame_ramp, "scroll": frame_scroll, "cut": frame_cut, "split": frame_split}[kind]
     return [fn(width, height, start + i) for i in range(count)]
 
 

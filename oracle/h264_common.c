@@ -215,6 +215,13 @@ int h264o_satd16x16(const uint8_t *a, int as, const uint8_t *b, int bs)
     return s >> 1;
 }
 
+int h264o_satd_rect(const uint8_t *a, int as, const uint8_t *b, int bs, int w, int h)
+{
+    int s = 0;
+    for (int y = 0; y < h; y += 4)
+        for (int x = 0; x < w; x += 4) s += hadamard4x4_abs(a + y * as + x, as, b + y * bs + x, bs);
+    return s >> 1;
+}
 int h264o_satd8x8(const uint8_t *a, int as, const uint8_t *b, int bs)
 {
     int s = 0;
@@ -531,21 +538,20 @@ static void filter_line(uint8_t *pix, int xs, int bS, int alpha, int beta, int t
  * (8.7.2.1, frame pictures, single reference, one motion vector per MB) */
 /* transform_size_8x8_flag of an inter macroblock rides in i16_mode (unused there); its residual blocks are 8x8: "contains
  * non-zero coefficients" (8.7.2.1) then refers to the 8x8 block, i.e. to the four interleaved 4x4 lists of the quadrant */
-static int mb_t8x8(const h264o_mbinfo *m) { return m->type == H264O_MB_P16 && m->i16_mode == 1; }
+static int mb_t8x8(const h264o_mbinfo *m) { return (m->type == H264O_MB_P16 || m->type >= H264O_MB_P16X8) && m->i16_mode == 1; }
 static int blk_nonzero(const h264o_mbinfo *m, int blk)
 {
     if (!mb_t8x8(m)) return m->tc[blk] != 0;
     int q = blk & ~3;
     return (m->tc[q] | m->tc[q + 1] | m->tc[q + 2] | m->tc[q + 3]) != 0;
 }
-static int edge_bs(const h264o_mbinfo *p, int bp, const h264o_mbinfo *q, int bq, int mb_edge)
+/* pv / qv: the four quadrant vectors of the two macroblocks (8 int16 each); block b lies in quadrant b >> 2 */
+static int edge_bs(const h264o_mbinfo *p, const int16_t *pv, int bp, const h264o_mbinfo *q, const int16_t *qv, int bq, int mb_edge)
 {
-    int pi = p->type == H264O_MB_I16 || p->type == H264O_MB_IPCM || p->type == H264O_MB_I4;
-    int qi = q->type == H264O_MB_I16 || q->type == H264O_MB_IPCM || q->type == H264O_MB_I4;
-    if (pi || qi) return mb_edge ? 4 : 3;
+    if (H264O_MB_IS_INTRA(p->type) || H264O_MB_IS_INTRA(q->type)) return mb_edge ? 4 : 3;
     if (blk_nonzero(p, bp) || blk_nonzero(q, bq)) return 2;
     if (p->chroma_mode != q->chroma_mode) return 1;   /* different reference pictures (ref_idx_l0 rides in chroma_mode; one list, never reordered) */
-    if (abs(p->mvx - q->mvx) >= 4 || abs(p->mvy - q->mvy) >= 4) return 1;
+    if (abs(pv[2 * (bp >> 2)] - qv[2 * (bq >> 2)]) >= 4 || abs(pv[2 * (bp >> 2) + 1] - qv[2 * (bq >> 2) + 1]) >= 4) return 1;
     return 0;
 }
 
@@ -553,7 +559,7 @@ static int edge_bs(const h264o_mbinfo *p, int bp, const h264o_mbinfo *q, int bq,
 static const uint8_t xy2blk[16] = {0, 1, 4, 5, 2, 3, 6, 7, 8, 9, 12, 13, 10, 11, 14, 15};
 
 void h264o_deblock_picture(uint8_t *Y, uint8_t *U, uint8_t *V, int cw, int ch,
-                           const h264o_mbinfo *mbs, int qp, const int16_t *slice_of, int row0, int row1)
+                           const h264o_mbinfo *mbs, const int16_t *mvq, int qp, const int16_t *slice_of, int row0, int row1)
 {
     int mbw = cw / 16, mbh = ch / 16;
     int qpc = o_chroma_qp[clip3(0, 51, qp)];
@@ -570,9 +576,10 @@ void h264o_deblock_picture(uint8_t *Y, uint8_t *U, uint8_t *V, int cw, int ch,
                 /* disable_deblocking_filter_idc 2: edges between slices stay unfiltered (slice_of given) */
                 if (e == 0 && slice_of && slice_of[my * mbw + mx] != slice_of[my * mbw + mx - 1]) continue;
                 const h264o_mbinfo *p = e == 0 ? q - 1 : q;
+                const int16_t *qv = mvq + (size_t)(my * mbw + mx) * 8, *pv = e == 0 ? qv - 8 : qv;
                 for (int r = 0; r < 4; r++) { /* four rows of 4x4 blocks */
                     int bq = xy2blk[4 * r + e], bp = e == 0 ? xy2blk[4 * r + 3] : xy2blk[4 * r + e - 1];
-                    int bS = edge_bs(p, bp, q, bq, e == 0);
+                    int bS = edge_bs(p, pv, bp, q, qv, bq, e == 0);
                     if (!bS) continue;
                     for (int k = 0; k < 4; k++)
                         filter_line(Y + (16 * my + 4 * r + k) * cw + 16 * mx + 4 * e, 1, bS, aY, bY,
@@ -591,9 +598,10 @@ void h264o_deblock_picture(uint8_t *Y, uint8_t *U, uint8_t *V, int cw, int ch,
                 if ((e & 1) && mb_t8x8(q)) continue;
                 if (e == 0 && slice_of && slice_of[my * mbw + mx] != slice_of[(my - 1) * mbw + mx]) continue;
                 const h264o_mbinfo *p = e == 0 ? q - mbw : q;
+                const int16_t *qv = mvq + (size_t)(my * mbw + mx) * 8, *pv = e == 0 ? qv - 8 * mbw : qv;
                 for (int c = 0; c < 4; c++) {
                     int bq = xy2blk[4 * e + c], bp = e == 0 ? xy2blk[12 + c] : xy2blk[4 * (e - 1) + c];
-                    int bS = edge_bs(p, bp, q, bq, e == 0);
+                    int bS = edge_bs(p, pv, bp, q, qv, bq, e == 0);
                     if (!bS) continue;
                     for (int k = 0; k < 4; k++)
                         filter_line(Y + (16 * my + 4 * e) * cw + 16 * mx + 4 * c + k, cw, bS, aY, bY,

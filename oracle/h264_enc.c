@@ -176,6 +176,8 @@ struct h264o_enc {
     uint32_t me_cost; /* scene-change statistic of the last picture */
     int any_pcm;      /* the picture being coded holds an I_PCM macroblock: it is not loop-filtered */
     uint8_t *aux;          /* 16 bytes per macroblock: Intra4x4PredMode of the 16 blocks (blkIdx order) */
+    int16_t *mvq;          /* 8 int16 per macroblock: vectors of the four 8x8 quadrants of an inter macroblock */
+    uint8_t *pshape;       /* P pictures: partition shape the motion search chose (0 16x16, 1 16x8, 2 8x16, 3 8x8) */
     uint8_t *want_intra;   /* P pictures: 1 = the motion search handed the macroblock to the intra pass; 2 = one of the "nothing
                             * left to code" tests hit: the prediction is the reconstruction, no transform is run (the tests use
                             * the 4x4 transform whatever transform the profile codes with) */
@@ -233,6 +235,8 @@ h264o_enc *h264o_enc_create(const h264o_config *cfg)
     e->slice_of = (int16_t *)calloc((size_t)e->mbw * e->mbh, sizeof(int16_t));
     e->want_intra = (uint8_t *)calloc((size_t)e->mbw * e->mbh, 1);
     e->aux = (uint8_t *)calloc((size_t)e->mbw * e->mbh, 16);
+    e->mvq = (int16_t *)calloc((size_t)e->mbw * e->mbh, 8 * sizeof(int16_t));
+    e->pshape = (uint8_t *)calloc((size_t)e->mbw * e->mbh, 1);
     for (int i = 0; i < e->mbw * e->mbh; i++) e->slice_of[i] = (int16_t)(i / e->mbw / e->slice_rows);
     e->rbsp_cap = ysz * 4 + 65536;
     e->rbsp = (uint8_t *)malloc(e->rbsp_cap);
@@ -248,6 +252,8 @@ void h264o_enc_destroy(h264o_enc *e)
     free(e->slice_of);
     free(e->want_intra);
     free(e->aux);
+    free(e->mvq);
+    free(e->pshape);
     free(e->rbsp);
     free(e);
 }
@@ -298,6 +304,7 @@ const uint8_t *h264o_enc_recon(const h264o_enc *e, int p) { return e->ref[p]; }
 const uint8_t *h264o_enc_recon_pre(const h264o_enc *e, int p) { return e->rec[p]; }
 const h264o_mbinfo *h264o_enc_mbinfo(const h264o_enc *e) { return e->mb; }
 const uint8_t *h264o_enc_mbaux(const h264o_enc *e) { return e->aux; }
+const int16_t *h264o_enc_mvq(const h264o_enc *e) { return e->mvq; }
 const int16_t *h264o_enc_levels(const h264o_enc *e) { return e->levels; }
 int64_t h264o_enc_last_slice_bits(const h264o_enc *e) { return e->last_slice_bits; }
 uint32_t h264o_enc_last_me_cost(const h264o_enc *e) { return e->me_cost; }
@@ -749,15 +756,66 @@ static int mv_all_zero(h264o_enc *e, int mx, int my, int mvx, int mvy)
     return 1;
 }
 
+/* half-sample planes (8.4.2.2.1: G integer, b, h, j) on an 18x18 grid whose origin is one sample up-left of the integer
+ * search's winner (ix, iy): every quarter-sample position within +-3 quarter samples of it is two taps away */
+enum { ME_GS = 18 };
+typedef struct { uint8_t G[ME_GS][ME_GS], B[ME_GS][ME_GS], H[ME_GS][ME_GS], J[ME_GS][ME_GS]; int ix, iy; } hp_planes;
+
+/* prediction of the w x h rectangle at (x0, y0) of the macroblock for the vector (qx, qy) (quarter samples), into pred (pitch 16) */
+static void hp_pred(const hp_planes *P, int qx, int qy, int x0, int y0, int w, int h, uint8_t *pred)
+{
+    int ox = qx - 4 * P->ix, oy = qy - 4 * P->iy; /* -3..3 relative to the integer winner */
+    int gx = 1 + (ox >> 2), gy = 1 + (oy >> 2), fx = ox & 3, fy = oy & 3;
+    for (int y = y0; y < y0 + h; y++)
+        for (int x = x0; x < x0 + w; x++) {
+            int X = gx + x, Y = gy + y, v;
+            if (fy == 0) v = fx == 0 ? P->G[Y][X] : fx == 2 ? P->B[Y][X] : fx == 1 ? (P->G[Y][X] + P->B[Y][X] + 1) >> 1 : (P->G[Y][X + 1] + P->B[Y][X] + 1) >> 1;
+            else if (fx == 0) v = fy == 2 ? P->H[Y][X] : fy == 1 ? (P->G[Y][X] + P->H[Y][X] + 1) >> 1 : (P->G[Y + 1][X] + P->H[Y][X] + 1) >> 1;
+            else if (fx == 2 && fy == 2) v = P->J[Y][X];
+            else if (fx == 2) v = ((fy == 1 ? P->B[Y][X] : P->B[Y + 1][X]) + P->J[Y][X] + 1) >> 1;
+            else if (fy == 2) v = ((fx == 1 ? P->H[Y][X] : P->H[Y][X + 1]) + P->J[Y][X] + 1) >> 1;
+            else v = ((fy == 1 ? P->B[Y][X] : P->B[Y + 1][X]) + (fx == 1 ? P->H[Y][X] : P->H[Y][X + 1]) + 1) >> 1;
+            pred[16 * y + x] = (uint8_t)v;
+        }
+}
+
+/* half- then quarter-sample refinement of one partition (rectangle x0, y0, w, h of the macroblock) starting at the integer
+ * winner: SATD + lambda * bits(mv - pmv); the centre wins a tie, then the neighbours in the order below */
+static int refine_part(const hp_planes *P, const uint8_t *s, int cw, int x0, int y0, int w, int h, mv_t pmv, int lambda, mv_t *out)
+{
+    static const int8_t nb[8][2] = {{-1, -1}, {0, -1}, {1, -1}, {-1, 0}, {1, 0}, {-1, 1}, {0, 1}, {1, 1}};
+    int cx = 4 * P->ix, cy = 4 * P->iy, best_cost = 0;
+    uint8_t pred[256];
+    for (int pass = 0; pass < 2; pass++) {
+        int step = pass == 0 ? 2 : 1, bcx = cx, bcy = cy;
+        for (int k = (pass == 0 ? -1 : 0); k < 8; k++) {
+            int qx = k < 0 ? cx : cx + step * nb[k][0], qy = k < 0 ? cy : cy + step * nb[k][1];
+            hp_pred(P, qx, qy, x0, y0, w, h, pred);
+            int cost = h264o_satd_rect(s + y0 * cw + x0, cw, pred + 16 * y0 + x0, 16, w, h) + lambda * (se_len(qx - pmv.x) + se_len(qy - pmv.y));
+            if (k < 0 || cost < best_cost) { best_cost = cost; bcx = qx; bcy = qy; }
+        }
+        cx = bcx;
+        cy = bcy;
+    }
+    out->x = (int16_t)cx;
+    out->y = (int16_t)cy;
+    return best_cost;
+}
+
 /* pmv: the vector this macroblock had in the previous picture (0 after an IDR) - the stand-in for the motion
- * vector predictor in the rate term: it is final before the picture starts, so every macroblock stays independent */
-static mv_t motion_search(h264o_enc *e, int mx, int my, mv_t pmv, int *final_cost, const uint8_t *refy)
+ * vector predictor in the rate term: it is final before the picture starts, so every macroblock stays independent.
+ * Returns the motion cost; qmv[4] receives the vectors of the four 8x8 quadrants, *shape the partitioning (0 16x16, 1 16x8,
+ * 2 8x16, 3 8x8).  A macroblock whose 16x16 cost reaches PART_TEST_MIN is also costed as two 16x8, two 8x16 and four 8x8
+ * partitions, each refined on its own from the same integer winner; a split pays lambda * (its extra mb_type / sub_mb_type
+ * bits + one more ref_idx_l0 per further partition) and must be strictly cheaper than the larger partitions before it. */
+enum { PART_TEST_MIN = 2000 };
+static int motion_search(h264o_enc *e, int mx, int my, mv_t pmv, const uint8_t *refy, int refbits, mv_t qmv[4], int *shape)
 {
     int cw = e->cw, ch = e->ch, lambda = o_lambda[e->cfg.qp];
     const uint8_t *s = e->src[0] + (16 * my) * cw + 16 * mx;
     int bx = 16 * mx, by = 16 * my;
     /* clamped 54x54 window: integer range [-16,15] + 16 + 3-tap apron each side */
-    enum { R = 16, AP = 4, WS = 16 + 2 * R + 2 * AP };
+    enum { R = 16, AP = 4, WS = 16 + 2 * R + 2 * AP, GS = ME_GS };
     static __thread uint8_t win[WS * WS];
     for (int y = 0; y < WS; y++)
         for (int x = 0; x < WS; x++) win[y * WS + x] = (uint8_t)refpx(refy, cw, cw, ch, bx - R - AP + x, by - R - AP + y);
@@ -770,53 +828,38 @@ static mv_t motion_search(h264o_enc *e, int mx, int my, mv_t pmv, int *final_cos
             if (key < best_key) best_key = key;
         }
     int idx = best_key & 1023, ix = (idx & 31) - R, iy = (idx >> 5) - R;
-    /* half-sample planes on an 18x18 grid with origin (ix-1, iy-1) */
-    enum { GS = 18 };
-    uint8_t G[GS][GS], B[GS][GS], H[GS][GS], J[GS][GS];
+    static __thread hp_planes P;
     int b1[GS + 5][GS];
     const uint8_t *o = win + (iy + R + AP - 1) * WS + ix + R + AP - 1; /* grid (0,0) */
+    P.ix = ix;
+    P.iy = iy;
 #define WP(x, y) o[(y) * WS + (x)]
     for (int y = -2; y < GS + 3; y++)
         for (int x = 0; x < GS; x++)
             b1[y + 2][x] = WP(x - 2, y) - 5 * WP(x - 1, y) + 20 * WP(x, y) + 20 * WP(x + 1, y) - 5 * WP(x + 2, y) + WP(x + 3, y);
     for (int y = 0; y < GS; y++)
         for (int x = 0; x < GS; x++) {
-            G[y][x] = WP(x, y);
-            B[y][x] = clip1((b1[y + 2][x] + 16) >> 5);
-            H[y][x] = clip1((WP(x, y - 2) - 5 * WP(x, y - 1) + 20 * WP(x, y) + 20 * WP(x, y + 1) - 5 * WP(x, y + 2) + WP(x, y + 3) + 16) >> 5);
-            J[y][x] = clip1((b1[y][x] - 5 * b1[y + 1][x] + 20 * b1[y + 2][x] + 20 * b1[y + 3][x] - 5 * b1[y + 4][x] + b1[y + 5][x] + 512) >> 10);
+            P.G[y][x] = WP(x, y);
+            P.B[y][x] = clip1((b1[y + 2][x] + 16) >> 5);
+            P.H[y][x] = clip1((WP(x, y - 2) - 5 * WP(x, y - 1) + 20 * WP(x, y) + 20 * WP(x, y + 1) - 5 * WP(x, y + 2) + WP(x, y + 3) + 16) >> 5);
+            P.J[y][x] = clip1((b1[y][x] - 5 * b1[y + 1][x] + 20 * b1[y + 2][x] + 20 * b1[y + 3][x] - 5 * b1[y + 4][x] + b1[y + 5][x] + 512) >> 10);
         }
 #undef WP
-    int cx = 4 * ix, cy = 4 * iy; /* best so far, quarter units */
-    int best_cost = 0;
-    uint8_t pred[256];
-    static const int8_t nb[8][2] = {{-1, -1}, {0, -1}, {1, -1}, {-1, 0}, {1, 0}, {-1, 1}, {0, 1}, {1, 1}};
-    for (int pass = 0; pass < 2; pass++) {
-        int step = pass == 0 ? 2 : 1, bcx = cx, bcy = cy;
-        for (int k = (pass == 0 ? -1 : 0); k < 8; k++) {
-            int qx = k < 0 ? cx : cx + step * nb[k][0], qy = k < 0 ? cy : cy + step * nb[k][1];
-            int ox = qx - 4 * ix, oy = qy - 4 * iy; /* -3..3 relative to integer best */
-            int gx = 1 + (ox >> 2), gy = 1 + (oy >> 2), fx = ox & 3, fy = oy & 3;
-            for (int y = 0; y < 16; y++)
-                for (int x = 0; x < 16; x++) {
-                    int X = gx + x, Y = gy + y, v;
-                    if (fy == 0) v = fx == 0 ? G[Y][X] : fx == 2 ? B[Y][X] : fx == 1 ? (G[Y][X] + B[Y][X] + 1) >> 1 : (G[Y][X + 1] + B[Y][X] + 1) >> 1;
-                    else if (fx == 0) v = fy == 2 ? H[Y][X] : fy == 1 ? (G[Y][X] + H[Y][X] + 1) >> 1 : (G[Y + 1][X] + H[Y][X] + 1) >> 1;
-                    else if (fx == 2 && fy == 2) v = J[Y][X];
-                    else if (fx == 2) v = ((fy == 1 ? B[Y][X] : B[Y + 1][X]) + J[Y][X] + 1) >> 1;
-                    else if (fy == 2) v = ((fx == 1 ? H[Y][X] : H[Y][X + 1]) + J[Y][X] + 1) >> 1;
-                    else v = ((fy == 1 ? B[Y][X] : B[Y + 1][X]) + (fx == 1 ? H[Y][X] : H[Y][X + 1]) + 1) >> 1;
-                    pred[16 * y + x] = (uint8_t)v;
-                }
-            int cost = h264o_satd16x16(s, cw, pred, 16) + lambda * (se_len(qx - pmv.x) + se_len(qy - pmv.y));
-            if (k < 0 || cost < best_cost) { best_cost = cost; bcx = qx; bcy = qy; }
-        }
-        cx = bcx;
-        cy = bcy;
+    mv_t m16;
+    int best = refine_part(&P, s, cw, 0, 0, 16, 16, pmv, lambda, &m16);
+    *shape = 0;
+    for (int q = 0; q < 4; q++) qmv[q] = m16;
+    if (best >= PART_TEST_MIN) {
+        mv_t t[4];
+        int c = refine_part(&P, s, cw, 0, 0, 16, 8, pmv, lambda, &t[0]) + refine_part(&P, s, cw, 0, 8, 16, 8, pmv, lambda, &t[2]) + lambda * (2 + refbits);
+        if (c < best) { best = c; *shape = 1; qmv[0] = qmv[1] = t[0]; qmv[2] = qmv[3] = t[2]; }
+        c = refine_part(&P, s, cw, 0, 0, 8, 16, pmv, lambda, &t[0]) + refine_part(&P, s, cw, 8, 0, 8, 16, pmv, lambda, &t[1]) + lambda * (2 + refbits);
+        if (c < best) { best = c; *shape = 2; qmv[0] = qmv[2] = t[0]; qmv[1] = qmv[3] = t[1]; }
+        c = lambda * (8 + 3 * refbits);
+        for (int q = 0; q < 4; q++) c += refine_part(&P, s, cw, (q & 1) * 8, (q >> 1) * 8, 8, 8, pmv, lambda, &t[q]);
+        if (c < best) { best = c; *shape = 3; for (int q = 0; q < 4; q++) qmv[q] = t[q]; }
     }
-    *final_cost = best_cost;
-    mv_t r = {(int16_t)cx, (int16_t)cy};
-    return r;
+    return best;
 }
 
 /* Intra16x16 cost estimate of a P macroblock from the SOURCE picture's own neighbouring samples (final before the picture
@@ -847,28 +890,55 @@ static int intra_estimate(const h264o_enc *e, int mx, int my)
     return best + 8 * lambda;
 }
 
-/* 8.4.1.3 median prediction for a 16x16 partition, single reference */
-static void neighbour(const h264o_enc *e, int mx, int my, int cur_my, int *avail, int *ref, mv_t *mv)
+/* 8.4.1.3 motion vector prediction.  Vectors are kept per 8x8 quadrant (mvq), which is the granularity of the smallest
+ * partition this encoder produces: a neighbouring partition is looked up as the quadrant (qx, qy) of its macroblock. */
+static void neighbour_q(const h264o_enc *e, int mx, int my, int qx, int qy, int cur_my, int *avail, int *ref, mv_t *mv)
 {
     *avail = mx >= 0 && mx < e->mbw && my >= cur_my - cur_my % e->slice_rows;   /* inside the picture and the current slice */
     *ref = -1;
     mv->x = mv->y = 0;
     if (!*avail) return;
     const h264o_mbinfo *m = &e->mb[my * e->mbw + mx];
-    if (m->type != H264O_MB_I16 && m->type != H264O_MB_IPCM && m->type != H264O_MB_I4) { *ref = m->chroma_mode; mv->x = m->mvx; mv->y = m->mvy; }   /* (ref_idx_l0 rides in chroma_mode) */
+    if (!H264O_MB_IS_INTRA(m->type)) {   /* (ref_idx_l0 rides in chroma_mode: one reference per macroblock) */
+        const int16_t *v = e->mvq + (size_t)(my * e->mbw + mx) * 8 + 2 * (2 * qy + qx);
+        *ref = m->chroma_mode;
+        mv->x = v[0];
+        mv->y = v[1];
+    }
 }
 static int med3(int a, int b, int c) { return a > b ? (b > c ? b : (a > c ? c : a)) : (a > c ? a : (b > c ? c : b)); }
 
-/* 8.4.1.3 for a 16x16 partition whose reference index is `ref`; skip_mv (when asked) receives the P_Skip vector (8.4.1.1: prediction for ref 0) */
-static mv_t predict_mv_ref(const h264o_enc *e, int mx, int my, int ref, mv_t *skip_mv)
+/* predictor of the partition that covers quadrants x0 .. x0 + w - 1, y0 .. y0 + h - 1 (w, h in 1, 2) of macroblock (mx, my)
+ * with reference index `ref`: neighbours A (left of its top-left sample), B (above it), C (above-right of its top-right
+ * sample, or D above-left when C is not available: outside, or later in decoding order) - 6.4.11.7; directional rules of
+ * 8.4.1.3 for 16x8 and 8x16; skip_mv (16x16 geometry only) receives the P_Skip vector (8.4.1.1) */
+static mv_t predict_mv_part(const h264o_enc *e, int mx, int my, int x0, int y0, int w, int h, int ref, mv_t *skip_mv)
 {
     int aA, aB, aC, rA, rB, rC;
     mv_t A, B, C;
-    neighbour(e, mx - 1, my, my, &aA, &rA, &A);
-    neighbour(e, mx, my - 1, my, &aB, &rB, &B);
-    neighbour(e, mx + 1, my - 1, my, &aC, &rC, &C);
-    if (!aC) neighbour(e, mx - 1, my - 1, my, &aC, &rC, &C);
+    if (x0 == 0) neighbour_q(e, mx - 1, my, 1, y0, my, &aA, &rA, &A);
+    else neighbour_q(e, mx, my, 0, y0, my, &aA, &rA, &A);
+    if (y0 == 0) neighbour_q(e, mx, my - 1, x0, 1, my, &aB, &rB, &B);
+    else neighbour_q(e, mx, my, x0, 0, my, &aB, &rB, &B);
+    if (y0 == 0) {
+        if (x0 + w <= 1) neighbour_q(e, mx, my - 1, x0 + w, 1, my, &aC, &rC, &C);
+        else neighbour_q(e, mx + 1, my - 1, 0, 1, my, &aC, &rC, &C);
+    } else if (x0 + w <= 1) neighbour_q(e, mx, my, x0 + w, 0, my, &aC, &rC, &C);   /* the quadrant above-right, coded before this one */
+    else { aC = 0; rC = -1; C.x = C.y = 0; }                                        /* in the macroblock to the right: not yet coded */
+    if (!aC) {
+        if (x0 == 0 && y0 == 0) neighbour_q(e, mx - 1, my - 1, 1, 1, my, &aC, &rC, &C);
+        else if (y0 == 0) neighbour_q(e, mx, my - 1, 0, 1, my, &aC, &rC, &C);
+        else if (x0 == 0) neighbour_q(e, mx - 1, my, 1, 0, my, &aC, &rC, &C);
+        else neighbour_q(e, mx, my, 0, 0, my, &aC, &rC, &C);
+    }
     int zero_skip = !aA || !aB || (rA == 0 && A.x == 0 && A.y == 0) || (rB == 0 && B.x == 0 && B.y == 0);
+    if (w == 2 && h == 1) {   /* 16x8: the upper partition takes B, the lower one A, when that neighbour uses the same picture */
+        if (y0 == 0 && rB == ref) return B;
+        if (y0 == 1 && rA == ref) return A;
+    } else if (w == 1 && h == 2) {   /* 8x16: left A, right C */
+        if (x0 == 0 && rA == ref) return A;
+        if (x0 == 1 && rC == ref) return C;
+    }
     if (!aB && !aC && aA) { B = A; C = A; rB = rA; rC = rA; }
     mv_t p;
     int n = (rA == ref) + (rB == ref) + (rC == ref);
@@ -887,7 +957,14 @@ static mv_t predict_mv_ref(const h264o_enc *e, int mx, int my, int ref, mv_t *sk
 }
 static mv_t predict_mv(const h264o_enc *e, int mx, int my, mv_t *skip_mv)
 {
-    return predict_mv_ref(e, mx, my, e->mb[my * e->mbw + mx].chroma_mode, skip_mv);   /* the macroblock's own ref_idx_l0 */
+    return predict_mv_part(e, mx, my, 0, 0, 2, 2, e->mb[my * e->mbw + mx].chroma_mode, skip_mv);   /* 16x16, the macroblock's own ref_idx_l0 */
+}
+/* partition k of a macroblock of shape 1 (16x8), 2 (8x16), 3 (8x8): its rectangle in quadrant units */
+static void part_rect(int shape, int k, int *x0, int *y0, int *w, int *h)
+{
+    if (shape == 1) { *x0 = 0; *y0 = k; *w = 2; *h = 1; }
+    else if (shape == 2) { *x0 = k; *y0 = 0; *w = 1; *h = 2; }
+    else { *x0 = k & 1; *y0 = k >> 1; *w = 1; *h = 1; }
 }
 
 static void encode_inter_mb(h264o_enc *e, int mx, int my)
@@ -899,9 +976,16 @@ static void encode_inter_mb(h264o_enc *e, int mx, int my)
     uint8_t pred[256], predc[2][64];
     const int refi = mb->chroma_mode;   /* ref_idx_l0, set by the motion search */
     uint8_t *const *rp = ref_planes(e, refi);
-    h264o_mc_luma(rp[0], cw, cw, ch, 16 * mx, 16 * my, mb->mvx, mb->mvy, 16, 16, pred, 16);
-    for (int pl = 0; pl < 2; pl++)
-        h264o_mc_chroma(rp[1 + pl], cs, cs, ch / 2, 8 * mx, 8 * my, mb->mvx, mb->mvy, 8, 8, predc[pl], 8);
+    /* motion compensation quadrant by quadrant (a partition larger than 8x8 carries its vector in each of its quadrants:
+     * prediction is a per-sample function of the vector, so this equals predicting the partition in one piece) */
+    const int16_t *qv = e->mvq + (size_t)(my * e->mbw + mx) * 8;
+    const int shape = e->pshape[my * e->mbw + mx];
+    for (int q = 0; q < 4; q++) {
+        int qx = (q & 1) * 8, qy = (q >> 1) * 8;
+        h264o_mc_luma(rp[0], cw, cw, ch, 16 * mx + qx, 16 * my + qy, qv[2 * q], qv[2 * q + 1], 8, 8, pred + 16 * qy + qx, 16);
+        for (int pl = 0; pl < 2; pl++)
+            h264o_mc_chroma(rp[1 + pl], cs, cs, ch / 2, 8 * mx + qx / 2, 8 * my + qy / 2, qv[2 * q], qv[2 * q + 1], 4, 4, predc[pl] + 8 * (qy / 2) + qx / 2, 8);
+    }
     const uint8_t *s = e->src[0] + (16 * my) * cw + 16 * mx;
     uint8_t *r = e->rec[0] + (16 * my) * cw + 16 * mx;
     int cbp = 0;
@@ -959,9 +1043,12 @@ static void encode_inter_mb(h264o_enc *e, int mx, int my)
     int cbpc = code_chroma(e, mx, my, predc, 0, lv, mb->tc, 1);
     mb->cbp = (uint8_t)(cbp | (cbpc << 4));
     if (mb_bits_bound(lv, 0) > MB_BITS_LIMIT) { make_pcm(e, mx, my); return; }
-    mv_t skip;
-    predict_mv(e, mx, my, &skip);
-    mb->type = (mb->cbp == 0 && refi == 0 && skip.x == mb->mvx && skip.y == mb->mvy) ? H264O_MB_PSKIP : H264O_MB_P16;
+    if (shape) mb->type = (uint8_t)(H264O_MB_P16X8 + shape - 1);
+    else {
+        mv_t skip;
+        predict_mv(e, mx, my, &skip);
+        mb->type = (mb->cbp == 0 && refi == 0 && skip.x == mb->mvx && skip.y == mb->mvy) ? H264O_MB_PSKIP : H264O_MB_P16;
+    }
     mb->i16_mode = (e->cfg.profile_idc == 100 && (mb->cbp & 15)) ? 1 : 0;   /* transform_size_8x8_flag (sent only with luma coefficients) */
 }
 /* the part of encode_inter_mb that needs every macroblock's FINAL type (an I_PCM / intra neighbour is not a vector): run
@@ -1044,12 +1131,23 @@ static void write_mb(h264o_enc *e, bitw *b, int mx, int my, int p_slice)
         bw_se(b, 0); /* mb_qp_delta */
         cavlc_block(b, lv + H264O_LV_LUMA_DC, 16, nc_luma(e, mx, my, 0));
     } else {
-        bw_ue(b, 0); /* P_L0_16x16 */
-        if (e->avail_refs == 2) bw_put(b, 1, mb->chroma_mode ? 0 : 1);        /* ref_idx_l0, te(v) with cMax 1: the inverted bit */
-        else if (e->avail_refs > 2) bw_ue(b, mb->chroma_mode);
-        mv_t p = predict_mv(e, mx, my, NULL);
-        bw_se(b, mb->mvx - p.x);
-        bw_se(b, mb->mvy - p.y);
+        /* 7.3.5.1 / 7.3.5.2: mb_type (P_L0_16x16, P_L0_L0_16x8, P_L0_L0_8x16, P_8x8 with four sub_mb_type P_L0_8x8), then
+         * every partition's ref_idx_l0, then every partition's mvd_l0 */
+        const int shape = mb->type >= H264O_MB_P16X8 ? mb->type - H264O_MB_P16X8 + 1 : 0, nparts = shape == 0 ? 1 : shape == 3 ? 4 : 2;
+        const int16_t *qv = e->mvq + (size_t)(my * e->mbw + mx) * 8;
+        bw_ue(b, (uint32_t)shape);
+        if (shape == 3) for (int k = 0; k < 4; k++) bw_ue(b, 0);
+        for (int k = 0; k < nparts; k++) {
+            if (e->avail_refs == 2) bw_put(b, 1, mb->chroma_mode ? 0 : 1);        /* ref_idx_l0, te(v) with cMax 1: the inverted bit */
+            else if (e->avail_refs > 2) bw_ue(b, mb->chroma_mode);
+        }
+        for (int k = 0; k < nparts; k++) {
+            int x0 = 0, y0 = 0, w = 2, h = 2;
+            if (shape) part_rect(shape, k, &x0, &y0, &w, &h);
+            mv_t p = predict_mv_part(e, mx, my, x0, y0, w, h, mb->chroma_mode, NULL);
+            bw_se(b, qv[2 * (2 * y0 + x0)] - p.x);
+            bw_se(b, qv[2 * (2 * y0 + x0) + 1] - p.y);
+        }
         int code = 0;
         while (o_cbp_code2inter[code] != mb->cbp) code++;
         bw_ue(b, (uint32_t)code);
@@ -1125,9 +1223,12 @@ int64_t h264o_enc_encode(h264o_enc *e, const uint8_t *y, int ys, const uint8_t *
                 h264o_mbinfo *mb = &e->mb[my * e->mbw + mx];
                 const mv_t pmv = {mb->mvx, mb->mvy};   /* previous picture's vector here (intra macroblocks carry 0) */
                 const mv_t rmv = {(int16_t)(((pmv.x + 2) >> 2) * 4), (int16_t)(((pmv.y + 2) >> 2) * 4)};   /* nearest integer-sample vector */
+                int16_t *qv = e->mvq + (size_t)(my * e->mbw + mx) * 8;
                 memset(mb, 0, sizeof(*mb));
+                memset(qv, 0, 8 * sizeof(int16_t));
                 mb->type = H264O_MB_P16;
                 e->want_intra[my * e->mbw + mx] = 0;
+                e->pshape[my * e->mbw + mx] = 0;
                 if (mv_all_zero(e, mx, my, 0, 0)) {
                     /* static: vector 0, no search */
                     e->want_intra[my * e->mbw + mx] = 2;
@@ -1135,24 +1236,31 @@ int64_t h264o_enc_encode(h264o_enc *e, const uint8_t *y, int ys, const uint8_t *
                     /* scrolling: the previous vector, rounded to integer samples, predicts the macroblock completely */
                     mb->mvx = rmv.x;
                     mb->mvy = rmv.y;
+                    for (int q = 0; q < 4; q++) { qv[2 * q] = rmv.x; qv[2 * q + 1] = rmv.y; }
                     e->want_intra[my * e->mbw + mx] = 2;
                 } else {
                     /* every available reference picture is searched; the cheapest (motion cost + lambda * bits(ref_idx)) wins,
                      * the lower index on a tie */
                     int cost = 0;
-                    mv_t m = {0, 0};
                     for (int r = 0; r < e->avail_refs; r++) {
-                        int c = 0;
-                        mv_t mr = motion_search(e, mx, my, pmv, &c, ref_planes(e, r)[0]);
-                        c += o_lambda[e->cfg.qp] * ref_idx_bits(r, e->avail_refs);
-                        if (r == 0 || c < cost) { cost = c; m = mr; mb->chroma_mode = (uint8_t)r; }
+                        mv_t qm[4];
+                        int shape = 0, rb = ref_idx_bits(r, e->avail_refs);
+                        int c = motion_search(e, mx, my, pmv, ref_planes(e, r)[0], rb, qm, &shape) + o_lambda[e->cfg.qp] * rb;
+                        if (r == 0 || c < cost) {
+                            cost = c;
+                            mb->chroma_mode = (uint8_t)r;
+                            e->pshape[my * e->mbw + mx] = (uint8_t)shape;
+                            for (int q = 0; q < 4; q++) { qv[2 * q] = qm[q].x; qv[2 * q + 1] = qm[q].y; }
+                        }
                     }
                     e->me_cost += (uint32_t)(cost < 16383 ? cost : 16383);
-                    mb->mvx = m.x;
-                    mb->mvy = m.y;
+                    mb->mvx = qv[0];
+                    mb->mvy = qv[1];
                     /* intra or inter: decided from the source picture and the motion cost alone */
                     if (cost >= INTRA_TEST_MIN && intra_estimate(e, mx, my) < cost) {
                         e->want_intra[my * e->mbw + mx] = 1;
+                        e->pshape[my * e->mbw + mx] = 0;
+                        memset(qv, 0, 8 * sizeof(int16_t));
                         mb->mvx = mb->mvy = 0;
                         mb->chroma_mode = 0;
                         mb->type = H264O_MB_I16;
@@ -1202,7 +1310,7 @@ int64_t h264o_enc_encode(h264o_enc *e, const uint8_t *y, int ys, const uint8_t *
     memcpy(e->cur[1], e->rec[1], ysz / 4);
     memcpy(e->cur[2], e->rec[2], ysz / 4);
     if (!e->cfg.disable_deblock && !e->any_pcm)
-        h264o_deblock_picture(e->cur[0], e->cur[1], e->cur[2], e->cw, e->ch, e->mb, e->cfg.qp, e->slice_rows < e->mbh ? e->slice_of : NULL,
+        h264o_deblock_picture(e->cur[0], e->cur[1], e->cur[2], e->cw, e->ch, e->mb, e->mvq, e->cfg.qp, e->slice_rows < e->mbh ? e->slice_of : NULL,
                               e->band_row0, e->band_row1);
     for (int p = 0; p < 3; p++) {   /* sliding window (8.2.5.3): the new picture becomes ref_idx 0, the oldest buffer is reused */
         uint8_t *oldest = e->nrefs >= 3 ? e->older[1][p] : e->nrefs == 2 ? e->older[0][p] : e->ref[p];

@@ -34,7 +34,9 @@ enum {
     H264O_LV_STRIDE = 416     /* int16 per macroblock (832 B)                       */
 };
 
-enum { H264O_MB_I16 = 0, H264O_MB_P16 = 1, H264O_MB_PSKIP = 2, H264O_MB_IPCM = 3, H264O_MB_I4 = 4 };
+enum { H264O_MB_I16 = 0, H264O_MB_P16 = 1, H264O_MB_PSKIP = 2, H264O_MB_IPCM = 3, H264O_MB_I4 = 4,
+       H264O_MB_P16X8 = 5, H264O_MB_P8X16 = 6, H264O_MB_P8X8 = 7 };   /* 5..7: two 16x8, two 8x16, four 8x8 partitions (one reference) */
+#define H264O_MB_IS_INTRA(t) ((t) == H264O_MB_I16 || (t) == H264O_MB_IPCM || (t) == H264O_MB_I4)
 
 typedef struct {
     int32_t width, height;  /* display size, even, 16..4096                          */
@@ -56,7 +58,7 @@ typedef struct h264o_dec h264o_dec;
 
 /* per-macroblock side information exposed for stage-by-stage parity checks */
 typedef struct {
-    int16_t mvx, mvy;      /* quarter-pel motion vector (0 for intra)              */
+    int16_t mvx, mvy;      /* quarter-pel motion vector (0 for intra); with partitions: that of the first one */
     uint8_t type;          /* H264O_MB_*                                            */
     uint8_t i16_mode;      /* Intra16x16PredMode 0..3; inter: transform_size_8x8_flag */
     uint8_t chroma_mode;   /* intra_chroma_pred_mode 0..3; inter: ref_idx_l0          */
@@ -87,6 +89,9 @@ int h264o_enc_coded_height(const h264o_enc *e);
 const uint8_t *h264o_enc_recon(const h264o_enc *e, int plane);       /* deblocked */
 const uint8_t *h264o_enc_recon_pre(const h264o_enc *e, int plane);   /* before loop filter */
 const h264o_mbinfo *h264o_enc_mbinfo(const h264o_enc *e);
+/* 8 int16 per macroblock beside mbinfo: the vectors (x, y) of the four 8x8 quadrants of an inter macroblock (a 16x16
+ * macroblock carries its vector four times, a 16x8 one twice twice ...) */
+const int16_t *h264o_enc_mvq(const h264o_enc *e);
 /* 16 bytes per macroblock beside mbinfo: Intra4x4PredMode of the 16 blocks (blkIdx order) for H264O_MB_I4 */
 const uint8_t *h264o_enc_mbaux(const h264o_enc *e);
 /* Intra4x4 prediction (8.3.1.2) of one block: rec points at the block inside the picture under reconstruction;
@@ -121,13 +126,15 @@ void h264o_mc_chroma(const uint8_t *ref, int stride, int w, int h, int x, int y,
 int h264o_sad16x16(const uint8_t *a, int as, const uint8_t *b, int bs);
 int h264o_satd16x16(const uint8_t *a, int as, const uint8_t *b, int bs);
 int h264o_satd8x8(const uint8_t *a, int as, const uint8_t *b, int bs);
+/* (sum over the 4x4 blocks of a w x h rectangle of |Hadamard|) >> 1; w, h multiples of 4 */
+int h264o_satd_rect(const uint8_t *a, int as, const uint8_t *b, int bs, int w, int h);
 /* intra predictors; avail bit0 = left, bit1 = top, bit2 = top-left */
 void h264o_pred16x16(const uint8_t *rec, int stride, int mode, int avail, uint8_t pred[256]);
 void h264o_pred_chroma8x8(const uint8_t *rec, int stride, int mode, int avail, uint8_t pred[64]);
 /* deblock a whole picture in place given per-MB info (8.7); slice_of (slice index per macroblock) non-NULL =
  * disable_deblocking_filter_idc 2, edges between different slices are left alone; macroblock rows row0..row1-1 */
 void h264o_deblock_picture(uint8_t *y, uint8_t *u, uint8_t *v, int cw, int ch,
-                           const h264o_mbinfo *mbs, int qp, const int16_t *slice_of, int row0, int row1);
+                           const h264o_mbinfo *mbs, const int16_t *mvq, int qp, const int16_t *slice_of, int row0, int row1);
 /* Exp-Golomb / CAVLC helpers for known-answer tests */
 int h264o_ue_bits(uint32_t v, uint32_t *code); /* returns length, *code = bit pattern */
 int h264o_se_bits(int32_t v, uint32_t *code);

@@ -36,6 +36,8 @@ CASES = [
     ("qvga_cut_3slices", 320, 240, "cut", 26, 30, 4, 66, 3),
     ("qcif_s1_3refs", 176, 144, "s1", 26, 30, 6, 66, 0, 3),          # three reference frames: ref_idx_l0, sliding window
     ("qvga_cut_2refs_high", 320, 240, "cut", 28, 30, 6, 100, 2, 2),
+    ("qcif_split_partitions", 176, 144, "split", 26, 30, 4, 66),      # 16x8 / 8x16 / 8x8 partitions
+    ("cif_split_3refs_high_2slices", 352, 288, "split", 30, 30, 4, 100, 2, 3),
 ]
 
 

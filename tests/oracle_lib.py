@@ -51,6 +51,8 @@ def lib():
         L.h264o_enc_mbinfo.restype = vp
         L.h264o_enc_mbinfo.argtypes = [vp]
         L.h264o_enc_mbaux.restype = vp
+        L.h264o_enc_mvq.restype = vp
+        L.h264o_enc_mvq.argtypes = [vp]
         L.h264o_enc_mbaux.argtypes = [vp]
         L.h264o_enc_levels.restype = vp
         L.h264o_enc_levels.argtypes = [vp]
@@ -96,7 +98,7 @@ def lib():
             getattr(L, n).argtypes = [vp, C.c_int, vp, C.c_int]
         L.h264o_pred16x16.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp]
         L.h264o_pred_chroma8x8.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp]
-        L.h264o_deblock_picture.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int]
+        L.h264o_deblock_picture.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp, C.c_int, vp, C.c_int, C.c_int]
         L.h264o_ue_bits.argtypes = [C.c_uint32, C.POINTER(C.c_uint32)]
         L.h264o_se_bits.argtypes = [C.c_int32, C.POINTER(C.c_uint32)]
         L.h264o_cavlc_block.argtypes = [vp, C.c_int, C.c_int, vp]
@@ -154,6 +156,12 @@ class OracleEncoder:
         n = (self.cw // 16) * (self.ch // 16)
         addr = lib().h264o_enc_mbaux(self.h)
         return np.ctypeslib.as_array(C.cast(addr, C.POINTER(C.c_uint8)), shape=(n, 16)).copy()
+
+    def mvq(self):
+        """(x, y) vectors of the four 8x8 quadrants of every macroblock (meaningful for inter macroblocks)"""
+        n = (self.cw // 16) * (self.ch // 16)
+        addr = lib().h264o_enc_mvq(self.h)
+        return np.ctypeslib.as_array(C.cast(addr, C.POINTER(C.c_int16)), shape=(n, 8)).copy()
 
     def levels(self):
         n = (self.cw // 16) * (self.ch // 16)

@@ -33,6 +33,9 @@ def _compare_all(enc, orc, tag):
     read[(cbp >> 4) >= 1, 272:280] = True
     read[(cbp >> 4) == 2, 280:408] = True
     read[omb["type"] == 3, :] = False            # I_PCM: samples, no levels
+    inter = np.isin(omb["type"], (1, 2, 5, 6, 7))  # the vectors of the four 8x8 quadrants (16x8 / 8x16 / 8x8 partitions)
+    if inter.any():
+        assert np.array_equal(enc.debug_read(capi.DBG_MVQ)[inter], orc.mvq()[inter]), tag + ": quadrant vectors"
     i4 = omb["type"] == 4                         # Intra4x4: the sixteen modes
     if i4.any():
         assert np.array_equal(enc.debug_read(capi.DBG_MBAUX)[i4], orc.mbaux()[i4]), tag + ": Intra4x4 modes"
@@ -388,7 +391,7 @@ def test_randomized_configurations():
         nodb = rng.random() < 0.25
         nv12 = rng.random() < 0.5
         G = rng.choice([1, 1, 2, 3])
-        kind = rng.choice(["s1", "s1", "s2", "s3", "ramp", "scroll", "scroll"])
+        kind = rng.choice(["s1", "s1", "s2", "s3", "ramp", "scroll", "scroll"]) if case % 6 != 5 else "split"
         frames = synth.sequence(kind, w, h, gop * G if G > 1 else 5)
         tag = "case %d: %dx%d qp %d gop %d profile %d nodeblock %d nv12 %d batch %d %s" % (case, w, h, qp, gop, prof, nodb, nv12, G, kind)
         orc = OracleEncoder(w, h, qp=qp, gop=gop, profile_idc=prof, disable_deblock=int(nodb))
@@ -407,6 +410,38 @@ def test_randomized_configurations():
             for g in range(G):
                 assert out[g * cap: g * cap + int(gb[g])].tobytes() == b"".join(want[g * gop:(g + 1) * gop]), tag + " GOP %d" % g
         enc.close()
+
+
+@pytest.mark.parametrize("w,h,qp,prof,refs,slices", [(352, 288, 26, 66, 0, 0), (320, 240, 30, 100, 2, 0), (208, 160, 22, 77, 3, 3), (130, 98, 34, 100, 3, 2)])
+def test_partitions_16x8_8x16_8x8(w, h, qp, prof, refs, slices):
+    """two layers drifting apart by a fraction of a sample in 8-sample stripes ("split" content): the macroblocks split into
+    16x8 (upper third), 8x16 (middle) and 8x8 (lower third) partitions.  Quadrant vectors, types, levels, reconstruction and
+    bitstream equal the oracle's, whose streams the independent decoder reconstructs (tests/test_oracle_roundtrip.py);
+    also through the lockstep batch."""
+    enc = capi.Encoder(w, h, qp=qp, gop=30, profile_idc=prof, refs=refs, slices=slices)
+    enc.keep_pre(True)
+    orc = OracleEncoder(w, h, qp=qp, gop=30, profile_idc=prof, refs=refs, slices=slices)
+    seen = np.zeros(8, np.int64)
+    frames = synth.sequence("split", w, h, 5)
+    for i, f in enumerate(frames):
+        assert enc.encode(f)[0] == orc.encode(f)[0], "picture %d" % i
+        _compare_all(enc, orc, "split picture %d" % i)
+        if i:
+            seen += np.bincount(orc.mbinfo()["type"], minlength=8)
+    enc.close()
+    assert seen[5] > 0 and seen[6] > 0 and seen[7] > 0, seen
+    import torch
+    G, gop, fbytes = 2, 3, w * h * 3 // 2
+    dev = torch.from_numpy(np.stack(frames + frames[:1])).cuda()
+    enc = capi.Encoder(w, h, qp=qp, gop=gop, profile_idc=prof, refs=refs, slices=slices, batch=G)
+    cap = 2 * gop * fbytes
+    out, szs, gb = np.zeros(G * cap, np.uint8), np.zeros(G * gop, np.uint32), np.zeros(G, np.uint64)
+    enc.encode_gops_device(dev.data_ptr(), fbytes, gop * fbytes, gop, out, cap, szs, gb)
+    orc = OracleEncoder(w, h, qp=qp, gop=gop, profile_idc=prof, refs=refs, slices=slices)
+    want = [orc.encode(f)[0] for f in frames + frames[:1]]
+    for g in range(G):
+        assert out[g * cap: g * cap + int(gb[g])].tobytes() == b"".join(want[g * gop:(g + 1) * gop]), "GOP %d" % g
+    enc.close()
 
 
 def test_scrolling_content_takes_the_previous_vector():

@@ -106,7 +106,7 @@ MUTANTS = [
     ("dequant_table_entry", "h264_tables.h", "{13, 20, 16}, {14, 23, 18}", "{13, 20, 16}, {14, 23, 19}"),
     ("tc0_table_entry", "h264_tables.h", "{1, 1, 2},   {1, 1, 2},   {1, 1, 2},\n    {1, 1, 2},   {1, 2, 3}", "{1, 1, 2},   {1, 1, 2},   {1, 1, 2},\n    {1, 1, 1},   {1, 2, 3}"),
     ("alpha_table_entry", "h264_tables.h", "15, 17, 20, 22, 25, 28, 32, 36, 40", "15, 17, 20, 22, 25, 28, 32, 30, 40"),
-    ("deblock_bs_mv_threshold", "h264_common.c", "if (abs(p->mvx - q->mvx) >= 4 || abs(p->mvy - q->mvy) >= 4) return 1;", "if (abs(p->mvx - q->mvx) >= 5 || abs(p->mvy - q->mvy) >= 4) return 1;"),
+    ("deblock_bs_mv_threshold", "h264_common.c", "if (abs(pv[2 * (bp >> 2)] - qv[2 * (bq >> 2)]) >= 4 ||", "if (abs(pv[2 * (bp >> 2)] - qv[2 * (bq >> 2)]) >= 5 ||"),
     ("deblock_strong_filter_tap", "h264_common.c", "pix[-2 * xs] = (uint8_t)((p2 + p1 + p0 + q0 + 2) >> 2);", "pix[-2 * xs] = (uint8_t)((p2 + p1 + p0 + q0 + 1) >> 2);"),
     ("deblock_normal_delta", "h264_common.c", "int d = clip3(-tc, tc, (((q0 - p0) << 2) + (p1 - q1) + 4) >> 3);\n        pix[-xs] = clip1(p0 + d);\n        pix[0] = clip1(q0 - d);\n        if (ap < beta)",
      "int d = clip3(-tc, tc, (((q0 - p0) << 2) + (p1 - q1) + 3) >> 3);\n        pix[-xs] = clip1(p0 + d);\n        pix[0] = clip1(q0 - d);\n        if (ap < beta)"),

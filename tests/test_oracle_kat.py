@@ -208,29 +208,31 @@ def test_intra_prediction_known_answers():
 def test_deblock_known_answers():
     L = lib()
     mb = np.zeros(2, ol.MBINFO_DTYPE)  # two intra macroblocks side by side -> bS 4 on the shared edge
+    mvq = np.zeros((2, 8), np.int16)   # the vectors of the macroblocks' 8x8 quadrants
     y = np.zeros((16, 32), np.uint8)
     y[:, :16], y[:, 16:] = 60, 70
     u = np.full((8, 16), 128, np.uint8)
     v = u.copy()
     y0 = y.copy()
-    L.h264o_deblock_picture(_ptr(y), _ptr(u), _ptr(v), 32, 16, _ptr(mb), 40, None, 0, 1)
+    L.h264o_deblock_picture(_ptr(y), _ptr(u), _ptr(v), 32, 16, _ptr(mb), _ptr(mvq), 40, None, 0, 1)
     # alpha(40)=80, beta(40)=13: |p0-q0|=10 < (alpha>>2)+2 -> strong filter on both sides
     # p0' = (p2+2p1+2p0+2q0+q1+4)>>3 = (60+120+120+140+70+4)>>3 = 64 ; p1' = (60+60+60+70+2)>>2 = 63 ; p2' = (120+180+60+60+70+4)>>3 = 61
     assert list(y[5, 13:19]) == [61, 63, 64, 66, 68, 69]
     assert (y[:, :12] == 60).all() and (y[:, 20:] == 70).all()
     # below QP 16 alpha is 0: nothing is filtered
     y = y0.copy()
-    L.h264o_deblock_picture(_ptr(y), _ptr(u), _ptr(v), 32, 16, _ptr(mb), 15, None, 0, 1)
+    L.h264o_deblock_picture(_ptr(y), _ptr(u), _ptr(v), 32, 16, _ptr(mb), _ptr(mvq), 15, None, 0, 1)
     assert np.array_equal(y, y0)
     # two inter macroblocks, no coefficients, equal vectors: bS 0 everywhere
     mb["type"] = 1
     y = y0.copy()
-    L.h264o_deblock_picture(_ptr(y), _ptr(u), _ptr(v), 32, 16, _ptr(mb), 40, None, 0, 1)
+    L.h264o_deblock_picture(_ptr(y), _ptr(u), _ptr(v), 32, 16, _ptr(mb), _ptr(mvq), 40, None, 0, 1)
     assert np.array_equal(y, y0)
     # vectors differing by a full sample: bS 1, normal filter with tC0(40, bS=1) = 4
     mb["mvx"] = [0, 4]
+    mvq[1, 0::2] = 4
     y = y0.copy()
-    L.h264o_deblock_picture(_ptr(y), _ptr(u), _ptr(v), 32, 16, _ptr(mb), 40, None, 0, 1)
+    L.h264o_deblock_picture(_ptr(y), _ptr(u), _ptr(v), 32, 16, _ptr(mb), _ptr(mvq), 40, None, 0, 1)
     # ap = aq = 0 < beta -> tc = 6; delta = clip(((10<<2)+(60-70)+4)>>3 = 4) -> p0 64, q0 66; p1' = 60 + clip3(-4,4,(60+65-120)>>1 = 2) = 62; q1' = 70 + clip3(-4,4,(70+65-140)>>1 = -3) = 67
     assert list(y[3, 13:19]) == [60, 62, 64, 66, 67, 70]
 

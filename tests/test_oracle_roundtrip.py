@@ -68,6 +68,29 @@ def test_mode_set_intra_in_p_and_pcm_are_legal_streams():
         assert dec.max_mb_bits <= 3200 and dec.max_level_prefix <= 15
 
 
+@pytest.mark.parametrize("w,h,qp,prof,refs,slices", [(176, 144, 26, 66, 0, 0), (208, 160, 30, 100, 2, 0), (176, 144, 22, 77, 3, 3)])
+def test_partitions_16x8_8x16_8x8_roundtrip(w, h, qp, prof, refs, slices):
+    """two layers drifting apart by a fraction of a sample in 8-sample stripes: the macroblocks of the upper third split into
+    two 16x8 partitions, the middle third into 8x16, the lower third into four 8x8.  The independent decoder - which derives
+    every vector from mvd_l0 and ITS OWN statement of 8.4.1.3 (neighbour partitions, directional rules) - must arrive at the
+    encoder's vectors and reconstruction; with several reference pictures, the 8x8 transform and slices."""
+    enc, dec = OracleEncoder(w, h, qp=qp, gop=30, profile_idc=prof, refs=refs, slices=slices), OracleDecoder()
+    seen = np.zeros(8, np.int64)
+    for i, f in enumerate(synth.sequence("split", w, h, 4)):
+        assert dec.decode(enc.encode(f)[0]) == 1
+        for p in range(3):
+            assert np.array_equal(dec.plane(p), enc.recon(p)), "picture %d plane %d" % (i, p)
+        assert dec.max_mb_bits <= 3200 and dec.max_level_prefix <= 15
+        mb, mvq = enc.mbinfo(), enc.mvq()
+        if i:
+            seen += np.bincount(mb["type"], minlength=8)
+            for a in np.where(mb["type"] >= 5)[0][::7]:   # a sample of the partitioned macroblocks, every quadrant
+                for q in range(4):
+                    x, y, r = dec.mb_mv(int(a), (q >> 1) * 8 + (q & 1) * 2)
+                    assert (x, y, r) == (mvq[a, 2 * q], mvq[a, 2 * q + 1], mb["chroma_mode"][a]), (i, a, q)
+    assert seen[5] > 0 and seen[6] > 0 and seen[7] > 0, seen
+
+
 def test_quality_and_skip_behaviour():
     w, h = 320, 240
     enc = OracleEncoder(w, h, qp=26)
