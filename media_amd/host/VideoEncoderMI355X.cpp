@@ -64,18 +64,23 @@ bool VideoEncoderMI355X::EngineOpen(const Settings &s)
 }
 
 // Frame-level rate control for the bitrate mode.  Integer arithmetic only, so a test can replay the QP
-// sequence on the oracle.  Target per picture = bitrate / fps; an IDR picture is budgeted four pictures' worth.
+// sequence on the oracle.  The picture budgets of a GOP add up to the GOP's share of the rate: an IDR picture is budgeted
+// kIdrWeight P pictures' worth, a P picture rate / fps * gop / (gop - 1 + kIdrWeight).  A picture that misses its budget moves
+// the QP by one or two steps; a quarter / half second of debt (credit) in the virtual buffer pushes one / two steps further.
 // PARITY UNPINNED: OpenH264's own rate-control model is not available.
 void VideoEncoderMI355X::RateControlUpdate(uint32_t frameBytes, bool isIdr)
 {
     if (m_fixedQp >= 0) {
         return;
     }
+    constexpr int64_t kIdrWeight = 4;
     const int64_t rate = static_cast<int64_t>(Active().bitrate);
     const int64_t target = rate / std::max<uint32_t>(1, Active().fps);
+    const int64_t gop = std::max<int64_t>(1, static_cast<int64_t>(Active().gop));
+    const int64_t pBudget = gop > 1 ? target * gop / (gop - 1 + kIdrWeight) : target;
     const int64_t bits = static_cast<int64_t>(frameBytes) * 8;
     m_bufferBits = std::max<int64_t>(m_bufferBits + bits - target, -rate);
-    const int64_t budget = isIdr ? 4 * target : target;
+    const int64_t budget = (isIdr && gop > 1) ? kIdrWeight * pBudget : pBudget;
     int32_t step = 0;
     if (bits * 2 > budget * 3) {
         step = 2;   // more than 1.5x the budget
@@ -86,9 +91,14 @@ void VideoEncoderMI355X::RateControlUpdate(uint32_t frameBytes, bool isIdr)
     } else if (bits * 10 < budget * 9) {
         step = -1;  // less than 0.9x
     }
-    // half a second of debt (credit) in the virtual buffer pushes one step further
+    if (m_bufferBits * 4 > rate) {
+        step += 1;
+    }
     if (m_bufferBits * 2 > rate) {
         step += 1;
+    }
+    if (m_bufferBits * 4 < -rate) {
+        step -= 1;
     }
     if (m_bufferBits * 2 < -rate) {
         step -= 1;

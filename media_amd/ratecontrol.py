@@ -9,12 +9,14 @@ all that ever crosses xGMI when one stream's closed GOPs are sharded in bitrate 
 """
 
 QP_MIN, QP_MAX, QP_START = 12, 48, 30
+IDR_WEIGHT = 4   # an IDR picture is budgeted this many P pictures' worth; the budgets of a GOP add up to its share of the rate
 
 
 class RateControl:
-    def __init__(self, bitrate, fps, qp=QP_START):
+    def __init__(self, bitrate, fps, qp=QP_START, gop=30):
         self.bitrate = int(bitrate)
         self.fps = max(1, int(fps))
+        self.gop = max(1, int(gop))
         self.qp = int(qp)
         self.buffer_bits = 0
 
@@ -31,7 +33,8 @@ class RateControl:
         target = rate // self.fps
         bits = int(frame_bytes) * 8
         self.buffer_bits = max(self.buffer_bits + bits - target, -rate)
-        budget = 4 * target if is_idr else target
+        p_budget = target * self.gop // (self.gop - 1 + IDR_WEIGHT) if self.gop > 1 else target
+        budget = IDR_WEIGHT * p_budget if (is_idr and self.gop > 1) else p_budget
         step = 0
         if bits * 2 > budget * 3:
             step = 2
@@ -41,8 +44,12 @@ class RateControl:
             step = -2
         elif bits * 10 < budget * 9:
             step = -1
+        if self.buffer_bits * 4 > rate:     # a quarter second of debt, then half a second
+            step += 1
         if self.buffer_bits * 2 > rate:
             step += 1
+        if self.buffer_bits * 4 < -rate:
+            step -= 1
         if self.buffer_bits * 2 < -rate:
             step -= 1
         self.qp = min(QP_MAX, max(QP_MIN, self.qp + step))

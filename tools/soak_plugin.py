@@ -19,7 +19,7 @@ for case in range(ncase):
     assert e.rc_create == vc.SUCCESS and e.init() == vc.SUCCESS and e.start() == vc.SUCCESS
     orc = OracleEncoder(w, h, qp=30, gop=gop, fps=fps, profile_idc={"baseline": 66, "main": 77, "high": 100}[prof])
     dec = OracleDecoder()
-    mirror = RateControl(bitrate, fps)
+    mirror = RateControl(bitrate, fps, gop=gop)
     nmb = (w // 16) * (h // 16)
     n = rng.randint(20, 50)
     start = 0
