@@ -1,0 +1,652 @@
+// media_amd/csrc/h264_parse.h -- host side of the decoder peer (row f4 of SURVEY.md 8: a VideoDecoder next to
+// /root/reference/video_decoder/VideoDecoderNetint.cpp, interface video_decoder/include/VideoDecoder.h:83).
+//
+// CAVLC slice data is a serial code: bit i cannot be placed before bit i - 1 has been understood.  The decoder therefore
+// splits like every software-assisted GPU decoder does: THIS file walks the NAL units of an access unit, parses parameter
+// sets, slice headers and slice data on the host and fills, per macroblock, exactly the side arrays the encoder's kernels
+// exchange (MbInfo, quadrant vectors, Intra4x4 modes, level lists); the reconstruction - motion compensation, inverse
+// transforms, intra prediction in row-wavefront order, the loop filter - then runs on the GPU (k_dec.h and the encoder's own
+// k_bs / k_deblock_rows).  Nothing here touches samples except I_PCM's raw bytes.
+//
+// Supported streams = what this repository's encoder can produce, which is also what the reference preset asks of OpenH264
+// minus CABAC: baseline / main / high with CAVLC, frame macroblocks, I and P slices; Intra16x16, Intra4x4, I_PCM;
+// P_L0_16x16, 16x8, 8x16, P_8x8 / P_8x8ref0 with 8x8 sub-macroblocks, P_Skip; up to 3 reference pictures by sliding window,
+// no reordering, one reference per macroblock; 4x4 transform, 8x8 transform on inter macroblocks; one QP per picture;
+// slices = bands of whole macroblock rows of equal height; loop filter idc 0 / 1 (one slice) or 1 / 2 (several).
+// Anything else is refused with a message naming the syntax element (never decoded wrongly).
+#pragma once
+#include <stdint.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include "h264_vlc_tables.h"
+
+namespace h264dec {
+
+enum { T_I16 = 0, T_P16 = 1, T_PSKIP = 2, T_IPCM = 3, T_I4 = 4, T_P16X8 = 5, T_P8X16 = 6, T_P8X8 = 7 };   // = dev_common.h MB_*
+enum { L_LUMA_DC = 0, L_LUMA = 16, L_CHROMA_DC = 272, L_CHROMA_AC = 280, L_STRIDE = 416 };                // = dev_common.h LV_*
+
+struct MbRec {   // = dev_common.h MbInfo (32 bytes)
+    int16_t mvx, mvy;
+    uint8_t type, i16_mode, chroma_mode, cbp;
+    uint8_t tc[24];
+};
+static_assert(sizeof(MbRec) == 32, "MbRec layout");
+
+struct Sps {
+    bool valid = false;
+    int profile_idc = 0, level_idc = 0, log2_max_frame_num = 4, poc_type = 0, log2_max_poc_lsb = 4, max_refs = 1;
+    int mbw = 0, mbh = 0, crop_l = 0, crop_r = 0, crop_t = 0, crop_b = 0;
+    bool delta_pic_order_always_zero = false;
+};
+struct Pps {
+    bool valid = false;
+    int sps_id = 0, num_ref_default = 1, pic_init_qp = 26;
+    bool deblock_control = false, t8x8 = false, bottom_field_pic_order = false, redundant_pic_cnt = false;
+};
+
+class BitReader {
+public:
+    BitReader(const uint8_t* p, size_t n) : p_(p), n_(n)
+    {
+        // rbsp_trailing_bits: the last 1 bit of the payload is the stop bit; more_rbsp_data() = something before it
+        size_t k = n;
+        while (k > 0 && p[k - 1] == 0) k--;
+        stop_ = 0;
+        if (k > 0) {
+            int b = 0;
+            while (!((p[k - 1] >> b) & 1)) b++;
+            stop_ = (k - 1) * 8 + (size_t)(7 - b);
+        }
+    }
+    bool bad() const { return bad_; }
+    size_t pos() const { return pos_; }
+    bool more_data() const { return pos_ < stop_; }
+    bool aligned() const { return (pos_ & 7) == 0; }
+    uint32_t peek(int k)   // k <= 25; bits past the end read as 0
+    {
+        uint64_t v = 0;
+        const size_t byte = pos_ >> 3;
+        for (int i = 0; i < 5; i++) v = (v << 8) | (byte + (size_t)i < n_ ? p_[byte + (size_t)i] : 0);
+        return (uint32_t)((v >> (40 - (int)(pos_ & 7) - k)) & ((1ull << k) - 1));
+    }
+    void skip(int k) { pos_ += (size_t)k; if (pos_ > n_ * 8) bad_ = true; }
+    uint32_t u(int k)
+    {
+        uint32_t v = 0;
+        while (k > 24) { v = (v << 24) | peek(24); skip(24); k -= 24; }
+        if (k > 0) { v = (v << k) | peek(k); skip(k); }
+        return v;
+    }
+    uint32_t ue()
+    {
+        int z = 0;
+        while (z < 32 && peek(1) == 0 && !bad_) { skip(1); z++; }
+        if (z >= 32) { bad_ = true; return 0; }
+        skip(1);
+        return z ? ((1u << z) - 1u + u(z)) : 0u;
+    }
+    int32_t se() { const uint32_t k = ue(); return (k & 1) ? (int32_t)((k + 1) >> 1) : -(int32_t)(k >> 1); }
+    const uint8_t* byte_ptr() const { return p_ + (pos_ >> 3); }
+private:
+    const uint8_t* p_;
+    size_t n_, pos_ = 0, stop_ = 0;
+    bool bad_ = false;
+};
+
+// ---- VLC look-ups built once from the (length, bits) tables ----
+struct VlcLut {
+    // entry: len << 8 | symbol; 0 = no code
+    std::vector<uint16_t> ct[4], cdc, tz[15], ctz[3], run[7];
+    uint8_t code2cbp_inter[48], code2cbp_intra[48];
+    VlcLut()
+    {
+        static const uint8_t ct_len[4][68] = H264_TAB_CT_LEN, ct_bits[4][68] = H264_TAB_CT_BITS;
+        static const uint8_t cdc_len[20] = H264_TAB_CDC_LEN, cdc_bits[20] = H264_TAB_CDC_BITS;
+        static const uint8_t tz_len[15][16] = H264_TAB_TZ_LEN, tz_bits[15][16] = H264_TAB_TZ_BITS;
+        static const uint8_t ctz_len[3][4] = H264_TAB_CTZ_LEN, ctz_bits[3][4] = H264_TAB_CTZ_BITS;
+        static const uint8_t run_len[7][16] = H264_TAB_RUN_LEN, run_bits[7][16] = H264_TAB_RUN_BITS;
+        static const uint8_t c2i[48] = H264_TAB_CBP2CODE_INTER, c2a[48] = H264_TAB_CBP2CODE_INTRA;
+        for (int c = 0; c < 4; c++) {
+            ct[c].assign(1u << 16, 0);
+            for (int s = 0; s < 68; s++) fill(ct[c], 16, ct_len[c][s], ct_bits[c][s], s, (s & 3) <= (s >> 2));
+        }
+        cdc.assign(1u << 8, 0);
+        for (int s = 0; s < 20; s++) fill(cdc, 8, cdc_len[s], cdc_bits[s], s, (s & 3) <= (s >> 2));
+        for (int t = 0; t < 15; t++) {
+            tz[t].assign(1u << 9, 0);
+            for (int s = 0; s < 16 - t; s++) fill(tz[t], 9, tz_len[t][s], tz_bits[t][s], s, true);
+        }
+        for (int t = 0; t < 3; t++) {
+            ctz[t].assign(1u << 3, 0);
+            for (int s = 0; s < 4 - t; s++) fill(ctz[t], 3, ctz_len[t][s], ctz_bits[t][s], s, true);
+        }
+        for (int t = 0; t < 7; t++) {
+            run[t].assign(1u << 11, 0);
+            for (int s = 0; s < (t < 6 ? t + 2 : 15); s++) fill(run[t], 11, run_len[t][s], run_bits[t][s], s, true);
+        }
+        for (int v = 0; v < 48; v++) { code2cbp_inter[c2i[v]] = (uint8_t)v; code2cbp_intra[c2a[v]] = (uint8_t)v; }
+    }
+private:
+    static void fill(std::vector<uint16_t>& lut, int width, int len, unsigned bits, int sym, bool legal)
+    {
+        if (!len || !legal) return;
+        const unsigned base = bits << (width - len);
+        for (unsigned i = 0; i < (1u << (width - len)); i++) lut[base + i] = (uint16_t)((len << 8) | sym);
+    }
+};
+inline const VlcLut& vlc() { static const VlcLut L; return L; }
+
+struct Picture {
+    int mbw = 0, mbh = 0, width = 0, height = 0;   // macroblocks; cropped size
+    bool idr = false, is_ref = true;
+    int qp = 26, slice_rows = 0, deblock_idc = 0, num_ref_active = 0, t8x8_mode = 0, profile_idc = 66;
+    bool has_pcm = false, has_intra = false, has_inter = false;
+    std::vector<MbRec> mb;
+    std::vector<int16_t> mvq;      // 8 per macroblock
+    std::vector<uint8_t> aux;      // 16 per macroblock
+    std::vector<int16_t> levels;   // L_STRIDE per macroblock (I_PCM: its 384 samples as bytes at the start)
+};
+
+class Parser {
+public:
+    const std::string& error() const { return err_; }
+    const Picture& picture() const { return pic_; }
+    const Sps& sps() const { return sps_[active_sps_]; }
+
+    // one access unit (Annex B).  Returns 1: a picture is ready in picture(); 0: no slice in it (parameter sets only); -1: error()
+    int parse_access_unit(const uint8_t* au, size_t len)
+    {
+        err_.clear();
+        bool have_pic = false;
+        int next_mb = 0;
+        size_t i = 0;
+        while (i + 3 < len) {
+            // next start code
+            if (!(au[i] == 0 && au[i + 1] == 0 && (au[i + 2] == 1 || (au[i + 2] == 0 && i + 3 < len && au[i + 3] == 1)))) { i++; continue; }
+            const size_t s = i + (au[i + 2] == 1 ? 3 : 4);
+            size_t e = s;
+            while (e + 2 < len && !(au[e] == 0 && au[e + 1] == 0 && (au[e + 2] == 1 || (au[e + 2] == 0 && e + 3 < len && au[e + 3] == 1)))) e++;
+            if (e + 2 >= len) e = len;
+            if (s < e && !nal(au + s, e - s, have_pic, next_mb)) return -1;
+            i = e;
+        }
+        if (!have_pic) return 0;
+        if (next_mb != pic_.mbw * pic_.mbh) return fail("picture incomplete: slices cover %d of %d macroblocks", next_mb, pic_.mbw * pic_.mbh);
+        return 1;
+    }
+
+private:
+    Sps sps_[32];
+    Pps pps_[256];
+    int active_sps_ = 0;
+    Picture pic_;
+    std::string err_;
+    std::vector<uint8_t> rbsp_;
+    // state of the slice being parsed
+    int slice_first_ = 0, slice_type_ = 0, slice_qp_ = 26, num_ref_ = 1;
+
+    int fail(const char* fmt, int a = 0, int b = 0)
+    {
+        char buf[256];
+        snprintf(buf, sizeof(buf), fmt, a, b);
+        err_ = buf;
+        return -1;
+    }
+    bool nal(const uint8_t* p, size_t n, bool& have_pic, int& next_mb)
+    {
+        const int hdr = p[0], ref_idc = (hdr >> 5) & 3, type = hdr & 31;
+        if (hdr & 0x80) { fail("forbidden_zero_bit set"); return false; }
+        // emulation prevention (7.4.1.1): 00 00 03 -> 00 00
+        rbsp_.clear();
+        rbsp_.reserve(n);
+        int zeros = 0;
+        for (size_t i = 1; i < n; i++) {
+            if (zeros >= 2 && p[i] == 3) { zeros = 0; continue; }
+            rbsp_.push_back(p[i]);
+            zeros = p[i] == 0 ? zeros + 1 : 0;
+        }
+        BitReader br(rbsp_.data(), rbsp_.size());
+        if (type == 7) return parse_sps(br);
+        if (type == 8) return parse_pps(br);
+        if (type == 1 || type == 5) return parse_slice(br, type == 5, ref_idc, have_pic, next_mb);
+        if (type == 2 || type == 3 || type == 4) { fail("data partitioning (nal_unit_type %d) is not supported", type); return false; }
+        return true;   // SEI, AUD, end of sequence, filler ...: nothing to decode
+    }
+
+    bool parse_sps(BitReader& br)
+    {
+        Sps s;
+        s.profile_idc = (int)br.u(8);
+        br.u(8);   // constraint flags + reserved
+        s.level_idc = (int)br.u(8);
+        const unsigned id = br.ue();
+        if (id > 31) { fail("seq_parameter_set_id %d", (int)id); return false; }
+        if (s.profile_idc == 100 || s.profile_idc == 110 || s.profile_idc == 122 || s.profile_idc == 244 || s.profile_idc == 44 ||
+            s.profile_idc == 83 || s.profile_idc == 86 || s.profile_idc == 118 || s.profile_idc == 128) {
+            const unsigned cf = br.ue();
+            if (cf != 1) { fail("chroma_format_idc %d (only 4:2:0)", (int)cf); return false; }
+            if (br.ue() != 0 || br.ue() != 0) { fail("bit depth above 8"); return false; }
+            br.u(1);   // qpprime_y_zero_transform_bypass_flag
+            if (br.u(1)) { fail("seq_scaling_matrix_present_flag"); return false; }
+        } else if (s.profile_idc != 66 && s.profile_idc != 77 && s.profile_idc != 88) { fail("profile_idc %d", s.profile_idc); return false; }
+        s.log2_max_frame_num = (int)br.ue() + 4;
+        s.poc_type = (int)br.ue();
+        if (s.poc_type == 0) s.log2_max_poc_lsb = (int)br.ue() + 4;
+        else if (s.poc_type == 1) {
+            s.delta_pic_order_always_zero = br.u(1) != 0;
+            br.se(); br.se();
+            const unsigned n = br.ue();
+            for (unsigned k = 0; k < n && !br.bad(); k++) br.se();
+        } else if (s.poc_type != 2) { fail("pic_order_cnt_type %d", s.poc_type); return false; }
+        s.max_refs = (int)br.ue();
+        br.u(1);   // gaps_in_frame_num_value_allowed_flag
+        s.mbw = (int)br.ue() + 1;
+        s.mbh = (int)br.ue() + 1;
+        if (!br.u(1)) { fail("frame_mbs_only_flag = 0 (interlaced coding)"); return false; }
+        br.u(1);   // direct_8x8_inference_flag
+        if (br.u(1)) { s.crop_l = (int)br.ue(); s.crop_r = (int)br.ue(); s.crop_t = (int)br.ue(); s.crop_b = (int)br.ue(); }
+        // (vui_parameters are not needed to decode samples)
+        if (br.bad() || s.mbw > 256 || s.mbh > 256) { fail("sequence parameter set damaged"); return false; }
+        if (s.max_refs > 3) { fail("max_num_ref_frames %d (up to 3)", s.max_refs); return false; }
+        s.valid = true;
+        sps_[id] = s;
+        return true;
+    }
+    bool parse_pps(BitReader& br)
+    {
+        Pps p;
+        const unsigned id = br.ue();
+        p.sps_id = (int)br.ue();
+        if (id > 255 || p.sps_id > 31) { fail("pic_parameter_set_id %d", (int)id); return false; }
+        if (br.u(1)) { fail("entropy_coding_mode_flag = 1 (CABAC)"); return false; }
+        p.bottom_field_pic_order = br.u(1) != 0;
+        if (br.ue() != 0) { fail("num_slice_groups_minus1 > 0 (FMO)"); return false; }
+        p.num_ref_default = (int)br.ue() + 1;
+        br.ue();   // num_ref_idx_l1_default_active_minus1
+        if (br.u(1) || br.u(2)) { fail("weighted prediction"); return false; }
+        p.pic_init_qp = 26 + br.se();
+        br.se();   // pic_init_qs_minus26
+        if (br.se() != 0) { fail("chroma_qp_index_offset != 0"); return false; }
+        p.deblock_control = br.u(1) != 0;
+        if (br.u(1)) { fail("constrained_intra_pred_flag = 1"); return false; }
+        p.redundant_pic_cnt = br.u(1) != 0;
+        if (br.more_data()) {
+            p.t8x8 = br.u(1) != 0;
+            if (br.u(1)) { fail("pic_scaling_matrix_present_flag"); return false; }
+            if (br.se() != 0) { fail("second_chroma_qp_index_offset != 0"); return false; }
+        }
+        if (br.bad()) { fail("picture parameter set damaged"); return false; }
+        p.valid = true;
+        pps_[id] = p;
+        return true;
+    }
+
+    // ---- neighbourhood helpers (6.4.9 .. 6.4.11): an address is available inside the picture and not before the slice's start
+    bool avail(int mx, int my) const { return mx >= 0 && mx < pic_.mbw && my >= 0 && my * pic_.mbw + mx >= slice_first_; }
+    MbRec& M(int mx, int my) { return pic_.mb[(size_t)my * pic_.mbw + mx]; }
+    static bool intra(int t) { return t == T_I16 || t == T_IPCM || t == T_I4; }
+    static int blk_idx(int x, int y) { return (x & 1) | ((y & 1) << 1) | ((x & 2) << 1) | ((y & 2) << 2); }   // 4x4 raster -> blkIdx
+
+    int nc_luma(int mx, int my, int bx, int by)   // 9.2.1: nC of the 4x4 luma block at raster (bx, by)
+    {
+        int nA = -1, nB = -1;
+        if (bx > 0) nA = M(mx, my).tc[blk_idx(bx - 1, by)];
+        else if (avail(mx - 1, my)) nA = M(mx - 1, my).tc[blk_idx(3, by)];
+        if (by > 0) nB = M(mx, my).tc[blk_idx(bx, by - 1)];
+        else if (avail(mx, my - 1)) nB = M(mx, my - 1).tc[blk_idx(bx, 3)];
+        if (nA >= 0 && nB >= 0) return (nA + nB + 1) >> 1;
+        return nA >= 0 ? nA : (nB >= 0 ? nB : 0);
+    }
+    int nc_chroma(int mx, int my, int pl, int bx, int by)
+    {
+        const int base = 16 + 4 * pl;
+        int nA = -1, nB = -1;
+        if (bx > 0) nA = M(mx, my).tc[base + 2 * by];
+        else if (avail(mx - 1, my)) nA = M(mx - 1, my).tc[base + 2 * by + 1];
+        if (by > 0) nB = M(mx, my).tc[base + bx];
+        else if (avail(mx, my - 1)) nB = M(mx, my - 1).tc[base + 2 + bx];
+        if (nA >= 0 && nB >= 0) return (nA + nB + 1) >> 1;
+        return nA >= 0 ? nA : (nB >= 0 ? nB : 0);
+    }
+
+    // 9.2: one residual block; out[0 .. maxc - 1] in scan order (out is zeroed by the caller); returns TotalCoeff or -1
+    int residual_block(BitReader& br, int16_t* out, int maxc, int nC)
+    {
+        const VlcLut& L = vlc();
+        int tc, t1;
+        if (nC < 0) {
+            const uint16_t e = L.cdc[br.peek(8)];
+            if (!e) return -1;
+            br.skip(e >> 8); tc = (e & 255) >> 2; t1 = e & 3;
+        } else {
+            const int cls = nC < 2 ? 0 : (nC < 4 ? 1 : (nC < 8 ? 2 : 3));
+            const uint16_t e = L.ct[cls][br.peek(16)];
+            if (!e) return -1;
+            br.skip(e >> 8); tc = (e & 255) >> 2; t1 = e & 3;
+        }
+        if (tc == 0) return 0;
+        if (tc > maxc) return -1;
+        int level[16];
+        int suffix_len = (tc > 10 && t1 < 3) ? 1 : 0;
+        for (int i = 0; i < tc; i++) {
+            if (i < t1) { level[i] = br.u(1) ? -1 : 1; continue; }
+            int prefix = 0;
+            while (prefix < 32 && br.peek(1) == 0 && !br.bad()) { br.skip(1); prefix++; }
+            if (prefix >= 32) return -1;
+            br.skip(1);
+            int code = (prefix < 15 ? prefix : 15) << suffix_len;
+            if (suffix_len > 0 || prefix >= 14) {
+                const int size = (prefix == 14 && suffix_len == 0) ? 4 : (prefix >= 15 ? prefix - 3 : suffix_len);
+                if (size > 0) code += (int)br.u(size);
+            }
+            if (prefix >= 15 && suffix_len == 0) code += 15;
+            if (prefix >= 16) code += (1 << (prefix - 3)) - 4096;
+            if (i == t1 && t1 < 3) code += 2;
+            level[i] = (code & 1) ? (-code - 1) >> 1 : (code + 2) >> 1;
+            if (suffix_len == 0) suffix_len = 1;
+            const int a = level[i] < 0 ? -level[i] : level[i];
+            if (a > (3 << (suffix_len - 1)) && suffix_len < 6) suffix_len++;
+        }
+        int zeros_left = 0;
+        if (tc < maxc) {
+            if (maxc == 4) {
+                const uint16_t e = L.ctz[tc - 1][br.peek(3)];
+                if (!e) return -1;
+                br.skip(e >> 8); zeros_left = e & 255;
+            } else {
+                const uint16_t e = L.tz[tc - 1][br.peek(9)];
+                if (!e) return -1;
+                br.skip(e >> 8); zeros_left = e & 255;
+                if (zeros_left + tc > maxc) return -1;   // (a 15-coefficient block shares the 16-coefficient tables)
+            }
+        }
+        int pos = tc + zeros_left - 1;   // scan position of the first (highest-frequency) coefficient
+        for (int i = 0; i < tc; i++) {
+            if (pos < 0) return -1;
+            out[pos] = (int16_t)level[i];
+            int run = 0;
+            if (i < tc - 1 && zeros_left > 0) {
+                const uint16_t e = L.run[(zeros_left < 7 ? zeros_left : 7) - 1][br.peek(11)];
+                if (!e) return -1;
+                br.skip(e >> 8); run = e & 255;
+                if (run > zeros_left) return -1;
+                zeros_left -= run;
+            }
+            pos -= 1 + run;
+        }
+        return br.bad() ? -1 : tc;
+    }
+
+    // ---- 8.4.1.3 with vectors per 8x8 quadrant (all partitions here are 8x8 or larger) ----
+    struct Cand { bool av; int ref, x, y; };
+    Cand quadrant(int mx, int my, int q, bool self = false)
+    {
+        Cand c{false, -1, 0, 0};
+        if (!self && !avail(mx, my)) return c;
+        c.av = true;
+        const MbRec& m = M(mx, my);
+        if (!intra(m.type)) {
+            c.ref = m.chroma_mode;
+            c.x = pic_.mvq[((size_t)my * pic_.mbw + mx) * 8 + 2 * q];
+            c.y = pic_.mvq[((size_t)my * pic_.mbw + mx) * 8 + 2 * q + 1];
+        }
+        return c;
+    }
+    static int med3(int a, int b, int c) { return a > b ? (b > c ? b : (a > c ? c : a)) : (a > c ? a : (b > c ? c : b)); }
+    void predict(int mx, int my, int x0, int y0, int w, int h, int ref, int& px, int& py, bool skip_rule = false)
+    {
+        const Cand A = x0 == 0 ? quadrant(mx - 1, my, 2 * y0 + 1) : quadrant(mx, my, 2 * y0, true);
+        const Cand B = y0 == 0 ? quadrant(mx, my - 1, 2 + x0) : quadrant(mx, my, x0, true);
+        Cand C{false, -1, 0, 0};
+        if (y0 == 0) C = x0 + w <= 1 ? quadrant(mx, my - 1, 2 + x0 + w) : quadrant(mx + 1, my - 1, 2);
+        else if (x0 + w <= 1) C = quadrant(mx, my, x0 + w, true);
+        if (!C.av) {
+            if (x0 == 0 && y0 == 0) C = quadrant(mx - 1, my - 1, 3);
+            else if (y0 == 0) C = quadrant(mx, my - 1, 2);
+            else if (x0 == 0) C = quadrant(mx - 1, my, 1);
+            else C = quadrant(mx, my, 0, true);
+        }
+        if (skip_rule && (!A.av || !B.av || (A.ref == 0 && A.x == 0 && A.y == 0) || (B.ref == 0 && B.x == 0 && B.y == 0))) { px = py = 0; return; }
+        if (w == 2 && h == 1) {
+            if (y0 == 0 && B.ref == ref) { px = B.x; py = B.y; return; }
+            if (y0 == 1 && A.ref == ref) { px = A.x; py = A.y; return; }
+        } else if (w == 1 && h == 2) {
+            if (x0 == 0 && A.ref == ref) { px = A.x; py = A.y; return; }
+            if (x0 == 1 && C.ref == ref) { px = C.x; py = C.y; return; }
+        }
+        Cand a = A, b = B, c = C;
+        if (!b.av && !c.av && a.av) { b = a; c = a; }
+        const int n = (a.ref == ref) + (b.ref == ref) + (c.ref == ref);
+        if (n == 1) { const Cand& o = a.ref == ref ? a : (b.ref == ref ? b : c); px = o.x; py = o.y; }
+        else { px = med3(a.x, b.x, c.x); py = med3(a.y, b.y, c.y); }
+    }
+
+    bool parse_slice(BitReader& br, bool idr, int ref_idc, bool& have_pic, int& next_mb)
+    {
+        const int first_mb = (int)br.ue();
+        int st = (int)br.ue();
+        if (st > 4) st -= 5;
+        if (st != 0 && st != 2) { fail("slice_type %d (only I and P)", st); return false; }
+        const unsigned pps_id = br.ue();
+        if (pps_id > 255 || !pps_[pps_id].valid || !sps_[pps_[pps_id].sps_id].valid) { fail("slice refers to a missing parameter set"); return false; }
+        const Pps& pps = pps_[pps_id];
+        active_sps_ = pps.sps_id;
+        const Sps& sps = sps_[active_sps_];
+        br.u(sps.log2_max_frame_num);   // frame_num (sliding window only: not needed)
+        if (idr) br.ue();               // idr_pic_id
+        if (sps.poc_type == 0) {
+            br.u(sps.log2_max_poc_lsb);
+            if (pps.bottom_field_pic_order) br.se();
+        } else if (sps.poc_type == 1 && !sps.delta_pic_order_always_zero) {
+            br.se();
+            if (pps.bottom_field_pic_order) br.se();
+        }
+        if (pps.redundant_pic_cnt) br.ue();
+        int num_ref = pps.num_ref_default;
+        if (st == 0) {
+            if (br.u(1)) num_ref = (int)br.ue() + 1;
+            if (br.u(1)) { fail("ref_pic_list_modification"); return false; }
+        }
+        if (ref_idc != 0) {
+            if (idr) { br.u(1); if (br.u(1)) { fail("long_term_reference_flag"); return false; } }
+            else if (br.u(1)) { fail("adaptive_ref_pic_marking_mode_flag"); return false; }
+        }
+        const int qp = pps.pic_init_qp + br.se();
+        int idc = 0;
+        if (pps.deblock_control) {
+            idc = (int)br.ue();
+            if (idc != 1 && (br.se() != 0 || br.se() != 0)) { fail("slice_alpha_c0 / beta offset != 0"); return false; }
+        }
+        if (br.bad() || qp < 0 || qp > 51 || idc > 2 || num_ref < 1 || num_ref > 3) { fail("slice header damaged"); return false; }
+
+        if (!have_pic) {   // first slice of the picture
+            if (first_mb != 0) { fail("first slice of the access unit starts at macroblock %d", first_mb); return false; }
+            pic_.mbw = sps.mbw; pic_.mbh = sps.mbh;
+            pic_.width = 16 * sps.mbw - 2 * (sps.crop_l + sps.crop_r); pic_.height = 16 * sps.mbh - 2 * (sps.crop_t + sps.crop_b);
+            pic_.idr = idr; pic_.is_ref = ref_idc != 0; pic_.qp = qp; pic_.deblock_idc = idc; pic_.slice_rows = 0;
+            pic_.num_ref_active = st == 0 ? num_ref : 0; pic_.t8x8_mode = pps.t8x8 ? 1 : 0; pic_.profile_idc = sps.profile_idc;
+            pic_.has_pcm = pic_.has_intra = pic_.has_inter = false;
+            const size_t n = (size_t)sps.mbw * sps.mbh;
+            pic_.mb.assign(n, MbRec{});
+            pic_.mvq.assign(n * 8, 0);
+            pic_.aux.assign(n * 16, 0);
+            pic_.levels.assign(n * L_STRIDE, 0);
+            have_pic = true;
+        } else {
+            if (first_mb != next_mb) { fail("slices out of order (first_mb_in_slice %d, expected %d)", first_mb, next_mb); return false; }
+            if (first_mb % pic_.mbw) { fail("slice starts inside a macroblock row (first_mb_in_slice %d)", first_mb); return false; }
+            if (pic_.slice_rows == 0) pic_.slice_rows = first_mb / pic_.mbw;
+            else if ((first_mb / pic_.mbw) % pic_.slice_rows) { fail("slices are not bands of equal height"); return false; }
+            if (qp != pic_.qp) { fail("slice QP %d differs from the picture's %d", qp, pic_.qp); return false; }
+            if (idc != pic_.deblock_idc) { fail("disable_deblocking_filter_idc differs between slices"); return false; }
+            if (st == 0 && pic_.num_ref_active && num_ref != pic_.num_ref_active) { fail("num_ref_idx_active differs between slices"); return false; }
+            if (st == 0 && !pic_.num_ref_active) pic_.num_ref_active = num_ref;
+            if (idc == 0) { fail("several slices with disable_deblocking_filter_idc 0 (filtering across slice edges)"); return false; }
+        }
+        slice_first_ = first_mb; slice_type_ = st; slice_qp_ = qp; num_ref_ = num_ref;
+
+        // ---- slice_data (7.3.4) ----
+        int addr = first_mb;
+        const int nmb = pic_.mbw * pic_.mbh;
+        bool more = true;
+        while (more) {
+            if (st == 0) {
+                unsigned run = br.ue();
+                if (br.bad() || (int)run > nmb - addr) { fail("mb_skip_run past the picture"); return false; }
+                while (run--) { skip_mb(addr % pic_.mbw, addr / pic_.mbw); addr++; }
+                more = br.more_data();
+                if (!more) break;
+            }
+            if (addr >= nmb) { fail("slice data past the picture"); return false; }
+            if (!macroblock(br, addr % pic_.mbw, addr / pic_.mbw, pps)) return false;
+            addr++;
+            more = br.more_data();
+        }
+        if (pic_.slice_rows && (addr % pic_.mbw)) { fail("slice ends inside a macroblock row"); return false; }
+        next_mb = addr;
+        return true;
+    }
+
+    void set_vectors(int mx, int my, int q, int x, int y)
+    {
+        int16_t* v = &pic_.mvq[((size_t)my * pic_.mbw + mx) * 8 + 2 * q];
+        v[0] = (int16_t)x; v[1] = (int16_t)y;
+    }
+    void skip_mb(int mx, int my)
+    {
+        MbRec& m = M(mx, my);
+        m = MbRec{};
+        m.type = T_PSKIP;
+        m.chroma_mode = 0;   // ref_idx_l0 = 0
+        int px, py;
+        predict(mx, my, 0, 0, 2, 2, 0, px, py, true);
+        m.mvx = (int16_t)px; m.mvy = (int16_t)py;
+        for (int q = 0; q < 4; q++) set_vectors(mx, my, q, px, py);
+        pic_.has_inter = true;
+    }
+
+    bool macroblock(BitReader& br, int mx, int my, const Pps& pps)
+    {
+        MbRec& m = M(mx, my);
+        m = MbRec{};
+        int16_t* lv = &pic_.levels[((size_t)my * pic_.mbw + mx) * L_STRIDE];
+        uint8_t* am = &pic_.aux[((size_t)my * pic_.mbw + mx) * 16];
+        unsigned t = br.ue();
+        bool is_intra = slice_type_ == 2;
+        if (slice_type_ == 0 && t >= 5) { is_intra = true; t -= 5; }
+        if (br.bad() || (is_intra && t > 25) || (!is_intra && t > 4)) { fail("mb_type %d", (int)t); return false; }
+        int cbp = 0;
+        bool i16 = false, t8flag = false;
+        if (is_intra && t == 25) {   // I_PCM
+            while (!br.aligned()) br.u(1);
+            uint8_t* raw = (uint8_t*)lv;
+            for (int i = 0; i < 384; i++) raw[i] = (uint8_t)br.u(8);
+            if (br.bad()) { fail("I_PCM samples past the slice"); return false; }
+            m.type = T_IPCM; m.cbp = 0x2F;
+            memset(m.tc, 16, 24);
+            pic_.has_pcm = pic_.has_intra = true;
+            return true;
+        }
+        if (is_intra) {
+            pic_.has_intra = true;
+            if (t == 0) {   // I_NxN
+                m.type = T_I4;
+                if (pps.t8x8 && br.u(1)) { fail("Intra8x8 (transform_size_8x8_flag in an I_NxN macroblock)"); return false; }
+                for (int k = 0; k < 16; k++) {   // 8.3.1.1
+                    const int x = (k & 1) | ((k >> 1) & 2), y = ((k >> 1) & 1) | ((k >> 2) & 2);
+                    int mA, mB;
+                    bool dc = false;
+                    if (x > 0) mA = am[blk_idx(x - 1, y)];
+                    else if (!avail(mx - 1, my)) { dc = true; mA = 2; }
+                    else mA = M(mx - 1, my).type == T_I4 ? (am - 16)[blk_idx(3, y)] : 2;
+                    if (y > 0) mB = am[blk_idx(x, y - 1)];
+                    else if (!avail(mx, my - 1)) { dc = true; mB = 2; }
+                    else mB = M(mx, my - 1).type == T_I4 ? (am - 16 * pic_.mbw)[blk_idx(x, 3)] : 2;
+                    const int pm = dc ? 2 : (mA < mB ? mA : mB);
+                    int mode = pm;
+                    if (!br.u(1)) { const int rem = (int)br.u(3); mode = rem < pm ? rem : rem + 1; }
+                    am[k] = (uint8_t)mode;
+                }
+            } else {
+                i16 = true;
+                m.type = T_I16;
+                m.i16_mode = (uint8_t)((t - 1) & 3);
+                cbp = (int)(((t - 1) >> 2) % 3) << 4 | ((t - 1) >= 12 ? 15 : 0);
+            }
+            const unsigned cm = br.ue();
+            if (cm > 3) { fail("intra_chroma_pred_mode %d", (int)cm); return false; }
+            m.chroma_mode = (uint8_t)cm;
+        } else {
+            pic_.has_inter = true;
+            const int shape = t == 4 ? 3 : (int)t;
+            m.type = (uint8_t)(shape == 0 ? T_P16 : T_P16X8 + shape - 1);
+            const int nparts = shape == 0 ? 1 : (shape == 3 ? 4 : 2);
+            if (shape == 3)
+                for (int k = 0; k < 4; k++)
+                    if (br.ue() != 0) { fail("sub_mb_type other than P_L0_8x8"); return false; }
+            int ref = 0;
+            if (num_ref_ > 1 && t != 4) {
+                for (int k = 0; k < nparts; k++) {
+                    const int r = num_ref_ == 2 ? (int)(1 - br.u(1)) : (int)br.ue();
+                    if (r >= num_ref_) { fail("ref_idx_l0 %d", r); return false; }
+                    if (k && r != ref) { fail("partitions of one macroblock with different reference pictures"); return false; }
+                    ref = r;
+                }
+            }
+            m.chroma_mode = (uint8_t)ref;
+            for (int k = 0; k < nparts; k++) {
+                int x0 = 0, y0 = 0, w = 2, h = 2;
+                if (shape == 1) { y0 = k; h = 1; }
+                else if (shape == 2) { x0 = k; w = 1; }
+                else if (shape == 3) { x0 = k & 1; y0 = k >> 1; w = h = 1; }
+                int px, py;
+                predict(mx, my, x0, y0, w, h, ref, px, py);
+                const int vx = px + br.se(), vy = py + br.se();
+                for (int qy = y0; qy < y0 + h; qy++)
+                    for (int qx = x0; qx < x0 + w; qx++) set_vectors(mx, my, 2 * qy + qx, vx, vy);
+                if (k == 0) { m.mvx = (int16_t)vx; m.mvy = (int16_t)vy; }
+            }
+        }
+        if (!i16) {
+            const unsigned code = br.ue();
+            if (code > 47) { fail("coded_block_pattern code %d", (int)code); return false; }
+            cbp = is_intra ? vlc().code2cbp_intra[code] : vlc().code2cbp_inter[code];
+            if ((cbp & 15) && pps.t8x8 && !is_intra) t8flag = br.u(1) != 0;
+        }
+        m.cbp = (uint8_t)cbp;
+        if (!is_intra) m.i16_mode = t8flag ? 1 : 0;
+        if (cbp > 0 || i16) {
+            if (br.se() != 0) { fail("mb_qp_delta != 0 (one QP per picture)"); return false; }
+            // residual (7.3.5.3)
+            if (i16) {
+                int16_t dc[16] = {0};
+                if (residual_block(br, dc, 16, nc_luma(mx, my, 0, 0)) < 0) { fail("Intra16x16 DC levels"); return false; }
+                memcpy(lv + L_LUMA_DC, dc, sizeof(dc));
+            }
+            for (int b8 = 0; b8 < 4; b8++)
+                for (int k = 0; k < 4; k++) {
+                    const int b = 4 * b8 + k, bx = (b & 1) | ((b >> 1) & 2), by = ((b >> 1) & 1) | ((b >> 2) & 2);
+                    if (!(cbp & (1 << b8))) continue;
+                    const int n = residual_block(br, lv + L_LUMA + b * 16 + (i16 ? 1 : 0), i16 ? 15 : 16, nc_luma(mx, my, bx, by));
+                    if (n < 0) { fail("luma levels of macroblock %d", my * pic_.mbw + mx); return false; }
+                    m.tc[b] = (uint8_t)n;
+                }
+            if (cbp >> 4) {
+                for (int pl = 0; pl < 2; pl++)
+                    if (residual_block(br, lv + L_CHROMA_DC + 4 * pl, 4, -1) < 0) { fail("chroma DC levels"); return false; }
+                if ((cbp >> 4) == 2)
+                    for (int pl = 0; pl < 2; pl++)
+                        for (int k = 0; k < 4; k++) {
+                            const int n = residual_block(br, lv + L_CHROMA_AC + (4 * pl + k) * 16 + 1, 15, nc_chroma(mx, my, pl, k & 1, k >> 1));
+                            if (n < 0) { fail("chroma AC levels"); return false; }
+                            m.tc[16 + 4 * pl + k] = (uint8_t)n;
+                        }
+            }
+        }
+        if (br.bad()) { fail("macroblock %d runs past the slice", my * pic_.mbw + mx); return false; }
+        return true;
+    }
+};
+
+}  // namespace h264dec

@@ -16,78 +16,26 @@
 //                   byte patterns that need emulation prevention (7.4.1)
 #pragma once
 #include "dev_common.h"
+#include "h264_vlc_tables.h"
 
 namespace h264 {
 
-// ---- Table 9-5 .. 9-10 (ITU-T H.264) ----
-__constant__ const uint8_t c_ct_len[4][68] = {
-    {1,  0,  0,  0,  6,  2,  0,  0,  8,  6,  3,  0,  9,  8,  7,  5,  10, 9,  8,  6,  11, 10, 9,
-     7,  13, 11, 10, 8,  13, 13, 11, 9,  13, 13, 13, 10, 14, 14, 13, 11, 14, 14, 14, 13, 15, 15,
-     14, 14, 15, 15, 15, 14, 16, 15, 15, 15, 16, 16, 16, 15, 16, 16, 16, 16, 16, 16, 16, 16},
-    {2,  0,  0,  0,  6,  2,  0,  0,  6,  5,  3,  0,  7,  6,  6,  4,  8,  6,  6,  4,  8,  7,  7,
-     5,  9,  8,  8,  6,  11, 9,  9,  6,  11, 11, 11, 7,  12, 11, 11, 9,  12, 12, 12, 11, 12, 12,
-     12, 11, 13, 13, 13, 12, 13, 13, 13, 13, 13, 14, 13, 13, 14, 14, 14, 13, 14, 14, 14, 14},
-    {4,  0,  0,  0,  6,  4,  0,  0,  6,  5,  4,  0,  6,  5,  5,  4,  7,  5,  5,  4,  7,  5,  5,
-     4,  7,  6,  6,  4,  7,  6,  6,  4,  8,  7,  7,  5,  8,  8,  7,  6,  9,  8,  8,  7,  9,  9,
-     8,  8,  9,  9,  9,  8,  10, 9,  9,  9,  10, 10, 10, 10, 10, 10, 10, 10, 10, 10, 10, 10},
-    {6, 0, 0, 0, 6, 6, 0, 0, 6, 6, 6, 0, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6,
-     6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6}};
-__constant__ const uint8_t c_ct_bits[4][68] = {
-    {1,  0,  0,  0,  5,  1,  0,  0,  7,  4,  1,  0,  7,  6,  5,  3,  7,  6,  5,  3,  7,  6,  5,
-     4,  15, 6,  5,  4,  11, 14, 5,  4,  8,  10, 13, 4,  15, 14, 9,  4,  11, 10, 13, 12, 15, 14,
-     9,  12, 11, 10, 13, 8,  15, 1,  9,  12, 11, 14, 13, 8,  7,  10, 9,  12, 4,  6,  5,  8},
-    {3,  0,  0,  0,  11, 2,  0,  0,  7,  7,  3,  0,  7,  10, 9,  5,  7,  6,  5,  4,  4,  6,  5,
-     6,  7,  6,  5,  8,  15, 6,  5,  4,  11, 14, 13, 4,  15, 10, 9,  4,  11, 14, 13, 12, 8,  10,
-     9,  8,  15, 14, 13, 12, 11, 10, 9,  12, 7,  11, 6,  8,  9,  8,  10, 1,  7,  6,  5,  4},
-    {15, 0,  0,  0,  15, 14, 0,  0,  11, 15, 13, 0,  8,  12, 14, 12, 15, 10, 11, 11, 11, 8,  9,
-     10, 9,  14, 13, 9,  8,  10, 9,  8,  15, 14, 13, 13, 11, 14, 10, 12, 15, 10, 13, 12, 11, 14,
-     9,  12, 8,  10, 13, 8,  13, 7,  9,  12, 9,  12, 11, 10, 5,  8,  7,  6,  1,  4,  3,  2},
-    {3,  0,  0,  0,  0,  1,  0,  0,  4,  5,  6,  0,  8,  9,  10, 11, 12, 13, 14, 15, 16, 17, 18,
-     19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35, 36, 37, 38, 39, 40, 41,
-     42, 43, 44, 45, 46, 47, 48, 49, 50, 51, 52, 53, 54, 55, 56, 57, 58, 59, 60, 61, 62, 63}};
-__constant__ const uint8_t c_cdc_len[20] = {2, 0, 0, 0, 6, 1, 0, 0, 6, 6, 3, 0, 6, 7, 7, 6, 6, 8, 8, 7};
-__constant__ const uint8_t c_cdc_bits[20] = {1, 0, 0, 0, 7, 1, 0, 0, 4, 6, 1, 0, 3, 3, 2, 5, 2, 3, 2, 0};
-__constant__ const uint8_t c_tz_len[15][16] = {
-    {1, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 9}, {3, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 6, 6, 6, 6},
-    {4, 3, 3, 3, 4, 4, 3, 3, 4, 5, 5, 6, 5, 6},       {5, 3, 4, 4, 3, 3, 3, 4, 3, 4, 5, 5, 5},
-    {4, 4, 4, 3, 3, 3, 3, 3, 4, 5, 4, 5},             {6, 5, 3, 3, 3, 3, 3, 3, 4, 3, 6},
-    {6, 5, 3, 3, 3, 2, 3, 4, 3, 6},                   {6, 4, 5, 3, 2, 2, 3, 3, 6},
-    {6, 6, 4, 2, 2, 3, 2, 5},                         {5, 5, 3, 2, 2, 2, 4},
-    {4, 4, 3, 3, 1, 3},                               {4, 4, 2, 1, 3},
-    {3, 3, 1, 2},                                     {2, 2, 1},
-    {1, 1}};
-__constant__ const uint8_t c_tz_bits[15][16] = {
-    {1, 3, 2, 3, 2, 3, 2, 3, 2, 3, 2, 3, 2, 3, 2, 1}, {7, 6, 5, 4, 3, 5, 4, 3, 2, 3, 2, 3, 2, 1, 0},
-    {5, 7, 6, 5, 4, 3, 4, 3, 2, 3, 2, 1, 1, 0},       {3, 7, 5, 4, 6, 5, 4, 3, 3, 2, 2, 1, 0},
-    {5, 4, 3, 7, 6, 5, 4, 3, 2, 1, 1, 0},             {1, 1, 7, 6, 5, 4, 3, 2, 1, 1, 0},
-    {1, 1, 5, 4, 3, 3, 2, 1, 1, 0},                   {1, 1, 1, 3, 3, 2, 2, 1, 0},
-    {1, 0, 1, 3, 2, 1, 1, 1},                         {1, 0, 1, 3, 2, 1, 1},
-    {0, 1, 1, 2, 1, 3},                               {0, 1, 1, 1, 1},
-    {0, 1, 1, 1},                                     {0, 1, 1},
-    {0, 1}};
-__constant__ const uint8_t c_ctz_len[3][4] = {{1, 2, 3, 3}, {1, 2, 2, 0}, {1, 1, 0, 0}};
-__constant__ const uint8_t c_ctz_bits[3][4] = {{1, 1, 1, 0}, {1, 1, 0, 0}, {1, 0, 0, 0}};
-__constant__ const uint8_t c_run_len[7][16] = {{1, 1},
-                                               {1, 2, 2},
-                                               {2, 2, 2, 2},
-                                               {2, 2, 2, 3, 3},
-                                               {2, 2, 3, 3, 3, 3},
-                                               {2, 3, 3, 3, 3, 3, 3},
-                                               {3, 3, 3, 3, 3, 3, 3, 4, 5, 6, 7, 8, 9, 10, 11}};
-__constant__ const uint8_t c_run_bits[7][16] = {{1, 0},
-                                                {1, 1, 0},
-                                                {3, 2, 1, 0},
-                                                {3, 2, 1, 1, 0},
-                                                {3, 2, 3, 2, 1, 0},
-                                                {3, 0, 1, 3, 2, 5, 4},
-                                                {7, 6, 5, 4, 3, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1}};
+// ---- Table 9-5 .. 9-10 (ITU-T H.264): initialisers in h264_vlc_tables.h ----
+__constant__ const uint8_t c_ct_len[4][68] = H264_TAB_CT_LEN;
+__constant__ const uint8_t c_ct_bits[4][68] = H264_TAB_CT_BITS;
+__constant__ const uint8_t c_cdc_len[20] = H264_TAB_CDC_LEN;
+__constant__ const uint8_t c_cdc_bits[20] = H264_TAB_CDC_BITS;
+__constant__ const uint8_t c_tz_len[15][16] = H264_TAB_TZ_LEN;
+__constant__ const uint8_t c_tz_bits[15][16] = H264_TAB_TZ_BITS;
+__constant__ const uint8_t c_ctz_len[3][4] = H264_TAB_CTZ_LEN;
+__constant__ const uint8_t c_ctz_bits[3][4] = H264_TAB_CTZ_BITS;
+__constant__ const uint8_t c_run_len[7][16] = H264_TAB_RUN_LEN;
+__constant__ const uint8_t c_run_bits[7][16] = H264_TAB_RUN_BITS;
 // Table 9-4, inverted for the encoder: coded_block_pattern -> codeNum (inter)
-__constant__ const uint8_t c_cbp2code_inter[48] = {
-    0,  2,  3,  7,  4,  8,  17, 13, 5,  18, 9,  14, 10, 15, 16, 11, 1,  32, 33, 36, 34, 37, 44, 40,
-    35, 45, 38, 41, 39, 42, 43, 19, 6,  24, 25, 20, 26, 21, 46, 28, 27, 47, 22, 29, 23, 30, 31, 12};
+__constant__ const uint8_t c_cbp2code_inter[48] = H264_TAB_CBP2CODE_INTER;
 
 // Table 9-4, inverted: coded_block_pattern -> codeNum (Intra4x4)
-__constant__ const uint8_t c_cbp2code_intra[48] = {3, 29, 30, 17, 31, 18, 37, 8, 32, 38, 19, 9, 20, 10, 11, 2, 16, 33, 34, 21, 35, 22, 39, 4, 36, 40, 23, 5, 24, 6, 7, 1, 41, 42, 43, 25, 44, 26, 46, 12, 45, 47, 27, 13, 28, 14, 15, 0};
+__constant__ const uint8_t c_cbp2code_intra[48] = H264_TAB_CBP2CODE_INTRA;
 
 // ---- bit sinks ----
 struct BitCount {

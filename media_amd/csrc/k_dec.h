@@ -1,0 +1,186 @@
+// media_amd/csrc/k_dec.h -- reconstruction kernels of the decoder peer (row f4 of SURVEY.md 8; the interface it serves is
+// /root/reference/video_decoder/include/VideoDecoder.h:83).  The host parser (h264_parse.h) has filled MbInfo, the quadrant
+// vectors, the Intra4x4 modes and the level lists - the very arrays the encoder's kernels exchange - so that decoding is the
+// encoder's own reconstruction path run from given decisions:
+//   k_dec_inter   motion-compensated prediction of every inter macroblock (8.4.2.2: luma by the 6-tap / bilinear quarter-
+//                 sample rules straight from the reference plane, chroma by the 1/8-sample bilinear rule), written into the
+//                 picture; lane = (row, four samples), one wave per macroblock
+//   k_dec_resid   scaling + inverse transform (4x4: 8.5.12, 8x8: 8.5.13, chroma DC: 8.5.11) of the inter macroblocks' levels,
+//                 added to the prediction in place; lane = one 4x4 block, four macroblocks per wave
+//   k_pintra_rows<true> (k_intra.h)  the intra macroblocks in row-wavefront order, intra_mb_core<true>
+//   k_bs / k_deblock_rows (encoder)  boundary strengths and the loop filter, unchanged
+#pragma once
+#include "dev_common.h"
+#include "mc_filters.h"
+#include "k_me.h"   // chroma_pred4
+#include "k_tq.h"   // idct8_line, pos_class8, recon4
+
+namespace h264 {
+
+// four luma samples (x .. x + 3, y) of the prediction with quarter-sample vector (vx, vy) from plane R (pitch cw, ch rows);
+// samples outside the picture repeat the edge (8.4.2.2.1, Table 8-12 spelled out)
+__device__ __forceinline__ uint32_t mc_luma4(const uint8_t* R, int cw, int ch, int x, int y, int vx, int vy)
+{
+    const int ix = x + (vx >> 2), iy = y + (vy >> 2), fx = vx & 3, fy = vy & 3;
+    int G[6][9];   // rows iy - 2 .. iy + 3, columns ix - 2 .. ix + 6
+    const bool inside = ix - 2 >= 0 && ((ix - 2) & ~3) + 12 <= cw;
+#pragma unroll
+    for (int r = 0; r < 6; r++) {
+        const uint8_t* row = R + (size_t)clip3(0, ch - 1, iy - 2 + r) * cw;
+        if (inside) {
+            const int xa = (ix - 2) & ~3, sh = (ix - 2) & 3;
+            const uint32_t a = *(const uint32_t*)(row + xa), b = *(const uint32_t*)(row + xa + 4), c = *(const uint32_t*)(row + xa + 8);
+            const uint32_t w0 = __builtin_amdgcn_alignbyte(b, a, sh), w1 = __builtin_amdgcn_alignbyte(c, b, sh), w2 = c >> (8 * sh);
+#pragma unroll
+            for (int k = 0; k < 4; k++) { G[r][k] = (int)byte_of(w0, k); G[r][4 + k] = (int)byte_of(w1, k); }
+            G[r][8] = (int)(w2 & 255u);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 9; k++) G[r][k] = row[clip3(0, cw - 1, ix - 2 + k)];
+        }
+    }
+    uint32_t out = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        auto b1 = [&](int r) { return G[r][i] - 5 * G[r][i + 1] + 20 * G[r][i + 2] + 20 * G[r][i + 3] - 5 * G[r][i + 4] + G[r][i + 5]; };
+        auto h1 = [&](int c) { return G[0][c] - 5 * G[1][c] + 20 * G[2][c] + 20 * G[3][c] - 5 * G[4][c] + G[5][c]; };
+        const int g0 = G[2][i + 2];
+        int v;
+        if ((fx | fy) == 0) v = g0;
+        else if (fy == 0) {
+            const int b = clip255((b1(2) + 16) >> 5);
+            v = fx == 2 ? b : ((fx == 1 ? g0 : G[2][i + 3]) + b + 1) >> 1;
+        } else if (fx == 0) {
+            const int h = clip255((h1(i + 2) + 16) >> 5);
+            v = fy == 2 ? h : ((fy == 1 ? g0 : G[3][i + 2]) + h + 1) >> 1;
+        } else if (fx != 2 && fy != 2) {   // e, g, p, r: a horizontal and a vertical half sample
+            const int b = clip255((b1(fy == 1 ? 2 : 3) + 16) >> 5), h = clip255((h1(fx == 1 ? i + 2 : i + 3) + 16) >> 5);
+            v = (b + h + 1) >> 1;
+        } else {
+            const int j = clip255((b1(0) - 5 * b1(1) + 20 * b1(2) + 20 * b1(3) - 5 * b1(4) + b1(5) + 512) >> 10);
+            if (fx == 2 && fy == 2) v = j;
+            else if (fx == 2) v = (clip255((b1(fy == 1 ? 2 : 3) + 16) >> 5) + j + 1) >> 1;     // f, q
+            else v = (clip255((h1(fx == 1 ? i + 2 : i + 3) + 16) >> 5) + j + 1) >> 1;           // i, k
+        }
+        out |= (uint32_t)v << (8 * i);
+    }
+    return out;
+}
+
+// the plane of reference picture ref_idx (0 .. 2) and component pl; the pointers pass through an opaque no-op so that the
+// selection is a select between registers, not an indexed load of the parameter block (dev_common.h rec_chroma)
+__device__ __forceinline__ const uint8_t* ref_plane(const FrameParams& P, int ref, int pl)
+{
+    const uint8_t *a = P.refs[0][0], *b = P.refs[1][0], *c = P.refs[2][0];
+    const uint8_t *au = P.refs[0][1], *bu = P.refs[1][1], *cu = P.refs[2][1];
+    const uint8_t *av = P.refs[0][2], *bv = P.refs[1][2], *cv = P.refs[2][2];
+    asm volatile("" : "+s"(a), "+s"(b), "+s"(c), "+s"(au), "+s"(bu), "+s"(cu), "+s"(av), "+s"(bv), "+s"(cv));
+    const uint8_t* y = ref == 0 ? a : (ref == 1 ? b : c);
+    const uint8_t* u = ref == 0 ? au : (ref == 1 ? bu : cu);
+    const uint8_t* v = ref == 0 ? av : (ref == 1 ? bv : cv);
+    return pl == 0 ? y : (pl == 1 ? u : v);
+}
+
+__global__ __launch_bounds__(64) void k_dec_inter(FrameParams P0)
+{
+    const FrameParams P = batch_view(P0, blockIdx.y);
+    const int lane = threadIdx.x;
+    const int mbi = P.band.row0 * P.mbw + (int)blockIdx.x, my = P.mbdiv.row(mbi), mx = mbi - my * P.mbw;
+    const uint32_t w1 = *(const uint32_t*)((const uint8_t*)(P.mb + mbi) + 4);
+    if (mb_is_intra((int)(w1 & 255u))) return;
+    const int ref = (int)((w1 >> 16) & 255u);
+    const uint4 qv = *(const uint4*)(P.mvq + (size_t)mbi * 8);
+    auto vec = [&](bool low, bool left, int& vx, int& vy) {
+        const uint32_t v = low ? (left ? qv.x : qv.y) : (left ? qv.z : qv.w);
+        vx = (int)(int16_t)(v & 0xFFFFu); vy = (int)(int16_t)(v >> 16);
+    };
+    {
+        const int y = lane >> 2, seg = (lane & 3) * 4;
+        int vx, vy;
+        vec(y < 8, seg < 8, vx, vy);
+        *(uint32_t*)(P.rec[0] + (size_t)(16 * my + y) * P.cw + 16 * mx + seg) = mc_luma4(ref_plane(P, ref, 0), P.cw, P.ch, 16 * mx + seg, 16 * my + y, vx, vy);
+    }
+    if (lane < 32) {
+        const int pl = lane >> 4, cyy = (lane >> 1) & 7, cxx = (lane & 1) * 4;
+        int vx, vy;
+        vec(cyy < 4, cxx < 4, vx, vy);
+        *(uint32_t*)(rec_chroma(P, pl) + (size_t)(8 * my + cyy) * (P.cw / 2) + 8 * mx + cxx) =
+            chroma_pred4(ref_plane(P, ref, 1 + pl), P.cw / 2, P.ch / 2, 8 * mx + cxx + (vx >> 3), 8 * my + cyy + (vy >> 3), vx & 7, vy & 7);
+    }
+}
+
+__global__ __launch_bounds__(64) void k_dec_resid(FrameParams P0)
+{
+    const FrameParams P = batch_view(P0, blockIdx.y);
+    const int lane = threadIdx.x, blk = lane & 15;
+    const int first = P.band.row0 * P.mbw, end = first + P.band.rows * P.mbw;
+    const int mbi = first + 4 * (int)blockIdx.x + (lane >> 4);
+    if (mbi >= end) return;
+    const uint32_t w1 = *(const uint32_t*)((const uint8_t*)(P.mb + mbi) + 4);
+    const int type = (int)(w1 & 255u), cbp = (int)(w1 >> 24);
+    if (mb_is_intra(type) || type == MB_PSKIP || cbp == 0) return;
+    const bool t8 = ((w1 >> 8) & 1u) != 0;
+    const int my = P.mbdiv.row(mbi), mx = mbi - my * P.mbw, cs = P.cw / 2;
+    const int16_t* lv = P.levels + (size_t)mbi * LV_STRIDE;
+    if (cbp & (1 << (blk >> 2))) {
+        if (!t8) {
+            int d[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) d[i] = (int)lv[LV_LUMA + blk * 16 + c_zigzag_inv[i]] * P.qy.dq[pos_class(i)];
+            idct4x4(d);
+            uint8_t* dst = P.rec[0] + (size_t)(16 * my + 4 * blk_y(blk)) * P.cw + 16 * mx + 4 * blk_x(blk);
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                uint32_t* q = (uint32_t*)(dst + (size_t)r * P.cw);
+                *q = recon4(*q, d[4 * r], d[4 * r + 1], d[4 * r + 2], d[4 * r + 3]);
+            }
+        } else if ((blk & 3) == 0) {
+            // 8x8 block blk >> 2: coefficient k of the 8x8 zig-zag scan is element k >> 2 of the quadrant's list k & 3 (7.3.5.3.2)
+            constexpr int ZZ8[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6,  7,  14, 21, 28,
+                                     35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+            const int b8 = blk >> 2, qp6 = P.qy.qp / 6;
+            int ls[6];
+#pragma unroll
+            for (int c = 0; c < 6; c++) ls[c] = vreg(P.qy.ls8[c]);
+            int d[64];
+#pragma unroll
+            for (int k = 0; k < 64; k++) {
+                const int pos = ZZ8[k];
+                const int t = (int)lv[LV_LUMA + (4 * b8 + (k & 3)) * 16 + (k >> 2)] * ls[pos_class8(pos)];
+                d[pos] = qp6 >= 6 ? t << (qp6 - 6) : (t + (1 << (5 - qp6))) >> (6 - qp6);
+            }
+#pragma unroll
+            for (int r = 0; r < 8; r++) idct8_line<1>(d + 8 * r);
+#pragma unroll
+            for (int c = 0; c < 8; c++) idct8_line<8>(d + c);
+            uint8_t* dst = P.rec[0] + (size_t)(16 * my + 8 * (b8 >> 1)) * P.cw + 16 * mx + 8 * (b8 & 1);
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                uint32_t* q = (uint32_t*)(dst + (size_t)r * P.cw);
+                int* e = d + 8 * r;
+                q[0] = recon4(q[0], (e[0] + 32) >> 6, (e[1] + 32) >> 6, (e[2] + 32) >> 6, (e[3] + 32) >> 6);
+                q[1] = recon4(q[1], (e[4] + 32) >> 6, (e[5] + 32) >> 6, (e[6] + 32) >> 6, (e[7] + 32) >> 6);
+            }
+        }
+    }
+    if ((cbp >> 4) && blk < 8) {   // chroma: lane = (plane, block)
+        const int pl = blk >> 2, cb = blk & 3;
+        int dc[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) dc[i] = (int)lv[LV_CHROMA_DC + 4 * pl + i];
+        const int fi[4] = {dc[0] + dc[1] + dc[2] + dc[3], dc[0] - dc[1] + dc[2] - dc[3], dc[0] + dc[1] - dc[2] - dc[3], dc[0] - dc[1] - dc[2] + dc[3]};
+        int d[16];
+#pragma unroll
+        for (int i = 1; i < 16; i++) d[i] = (int)lv[LV_CHROMA_AC + (4 * pl + cb) * 16 + c_zigzag_inv[i]] * P.qc.dq[pos_class(i)];
+        d[0] = ((cb == 0 ? fi[0] : (cb == 1 ? fi[1] : (cb == 2 ? fi[2] : fi[3]))) * 16 * P.qc.dq[0]) >> 5;
+        idct4x4(d);
+        uint8_t* dst = rec_chroma(P, pl) + (size_t)(8 * my + 4 * (cb >> 1)) * cs + 8 * mx + 4 * (cb & 1);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            uint32_t* q = (uint32_t*)(dst + (size_t)r * cs);
+            *q = recon4(*q, d[4 * r], d[4 * r + 1], d[4 * r + 2], d[4 * r + 3]);
+        }
+    }
+}
+
+}  // namespace h264

@@ -134,19 +134,44 @@ struct IntraLds {
 // modes k_i4_decide chose) whose source and
 // neighbour samples are already in S (and visible to the whole wave).  Writes recon (global + S.rec_*),
 // levels, MbInfo, mvd.
+// DEC (the decoder peer, k_dec.h): types, modes and levels are given (MbInfo, aux, levels); prediction, scaling, inverse
+// transforms and reconstruction are the code the encoder runs, nothing is decided, transformed forward or written back.
+template <bool DEC = false>
 __device__ __forceinline__ void intra_mb_core(const FrameParams& P, int mx, int my, IntraLds& S, int lane, bool use_i4, uint32_t auxw)
 {
     const int mbi = my * P.mbw + mx, bx = 16 * mx, by = 16 * my, cs = P.cw / 2;
     const bool top = P.sl.has_top(my);   // the row above belongs to this slice
     const int avail = (mx > 0 ? 1 : 0) | (top ? 2 : 0) | ((mx > 0 && top) ? 4 : 0);
-    for (int i = lane; i < LV_STRIDE / 2; i += 64) ((uint32_t*)S.lv)[i] = 0;
+    MbInfo* const mbp = P.mb + mbi;
+    if (DEC) {
+        if (lane < LV_STRIDE * 2 / 16) ((uint4*)S.lv)[lane] = ((const uint4*)(P.levels + (size_t)mbi * LV_STRIDE))[lane];
+        wave_sync();
+        if (mbp->type == MB_IPCM) {   // the 384 samples travel as bytes at the start of the macroblock's level area
+            const uint8_t* raw = (const uint8_t*)S.lv;
+            {
+                const int row = lane >> 2, xs = (lane & 3) * 4;
+                const uint32_t v = *(const uint32_t*)(raw + row * 16 + xs);
+                *(uint32_t*)(P.rec[0] + (size_t)(by + row) * P.cw + bx + xs) = v;
+                *(uint32_t*)(S.rec_y + row * 16 + xs) = v;
+            }
+            if (lane < 32) {
+                const int pl = lane >> 4, row = (lane >> 1) & 7, xs = (lane & 1) * 4;
+                const uint32_t v = *(const uint32_t*)(raw + 256 + pl * 64 + row * 8 + xs);
+                *(uint32_t*)(rec_chroma(P, pl) + (size_t)(8 * my + row) * cs + 8 * mx + xs) = v;
+                *(uint32_t*)(S.rec_c + pl * 64 + row * 8 + xs) = v;
+            }
+            wave_sync();
+            return;
+        }
+    } else
+        for (int i = lane; i < LV_STRIDE / 2; i += 64) ((uint32_t*)S.lv)[i] = 0;
 
     // ---- Intra4x4 (type and modes chosen by k_i4_decide; use_i4 is wave-uniform, auxw = lanes 0..3: the sixteen modes) ----
     int cbp_luma_i4 = 0;
     if (use_i4) {
         const uint32_t m0 = (uint32_t)__builtin_amdgcn_readlane((int)auxw, 0), m1 = (uint32_t)__builtin_amdgcn_readlane((int)auxw, 1);
         const uint32_t m2 = (uint32_t)__builtin_amdgcn_readlane((int)auxw, 2), m3 = (uint32_t)__builtin_amdgcn_readlane((int)auxw, 3);
-        cbp_luma_i4 = i4_code_luma(P.qy, S.i4, S.top, S.left, S.src, m0, m1, m2, m3, S.lv, S.dc, mx, top, lane);   // (S.dc: TotalCoeff of the 16 blocks)
+        cbp_luma_i4 = i4_code_luma<DEC>(P.qy, S.i4, S.top, S.left, S.src, m0, m1, m2, m3, S.lv, S.dc, mx, top, lane);   // (S.dc: TotalCoeff of the 16 blocks)
         const uint32_t o = *(const uint32_t*)(S.i4.rb + (1 + (lane >> 2)) * 32 + 4 + (lane & 3) * 4);
         *(uint32_t*)(S.rec_y + (lane >> 2) * 16 + (lane & 3) * 4) = o;
         *(uint32_t*)(P.rec[0] + (size_t)(by + (lane >> 2)) * P.cw + bx + (lane & 3) * 4) = o;
@@ -154,8 +179,8 @@ __device__ __forceinline__ void intra_mb_core(const FrameParams& P, int mx, int 
 
     // ---- luma mode decision: lane = (mode, 4x4 block), SATD per mode ----
     const I16Params ip = i16_params(S.top, S.left, avail);
-    int best_mode = 0;
-    if (!use_i4) {
+    int best_mode = DEC ? (int)mbp->i16_mode : 0;
+    if (!DEC && !use_i4) {
         const int mode = lane >> 4, blk = lane & 15, x0 = (blk & 3) * 4, y0 = (blk >> 2) * 4;
         // this lane's block: four source dwords, the four top and left neighbours, the plane value of its corner -
         // fetched once instead of per sample
@@ -194,9 +219,9 @@ __device__ __forceinline__ void intra_mb_core(const FrameParams& P, int mx, int 
         *(uint32_t*)(S.py + y * 16 + xs) = o;
     }
     // ---- chroma mode decision: lane<32 = (mode, plane, block) ----
-    int best_cmode;
+    int best_cmode = DEC ? (int)mbp->chroma_mode : 0;
     C8Params cp[2] = {c8_params(S.ctop[0], S.cleft[0], avail), c8_params(S.ctop[1], S.cleft[1], avail)};
-    {
+    if (!DEC) {
         const int mode = (lane >> 3) & 3, pl = (lane >> 2) & 1, blk = lane & 3, x0 = (blk & 1) * 4, y0 = (blk >> 1) * 4;
         int tp[4], lf[4];
 #pragma unroll
@@ -255,8 +280,14 @@ __device__ __forceinline__ void intra_mb_core(const FrameParams& P, int mx, int 
 #pragma unroll
             for (int c = 0; c < 4; c++) d[4 * r + c] = (int)((sw >> (8 * c)) & 255) - (int)((pw >> (8 * c)) & 255);
         }
-        nnz = tq4x4(d, P.qy, P.qy.f_intra, 1, S.lv + LV_LUMA + lane * 16, &dcw, 0, false);
-        S.dc[blk_y(lane) * 4 + blk_x(lane)] = dcw;
+        if (DEC) {   // scaled coefficients from the given levels (the DC position comes through the Hadamard path below)
+#pragma unroll
+            for (int i = 1; i < 16; i++) d[i] = (int)S.lv[LV_LUMA + lane * 16 + c_zigzag_inv[i]] * P.qy.dq[pos_class(i)];
+            d[0] = 0;
+        } else {
+            nnz = tq4x4(d, P.qy, P.qy.f_intra, 1, S.lv + LV_LUMA + lane * 16, &dcw, 0, false);
+            S.dc[blk_y(lane) * 4 + blk_x(lane)] = dcw;
+        }
     } else if (is_chroma) {
         const int x = (cb & 1) * 4, y = (cb >> 1) * 4;
 #pragma unroll
@@ -265,7 +296,12 @@ __device__ __forceinline__ void intra_mb_core(const FrameParams& P, int mx, int 
 #pragma unroll
             for (int c = 0; c < 4; c++) d[4 * r + c] = (int)((sw >> (8 * c)) & 255) - (int)((pw >> (8 * c)) & 255);
         }
-        nnz = tq4x4(d, P.qc, P.qc.f_intra, 1, S.lv + LV_CHROMA_AC + (cpl * 4 + cb) * 16, &dcw, 0, false);
+        if (DEC) {
+#pragma unroll
+            for (int i = 1; i < 16; i++) d[i] = (int)S.lv[LV_CHROMA_AC + (cpl * 4 + cb) * 16 + c_zigzag_inv[i]] * P.qc.dq[pos_class(i)];
+            d[0] = 0;
+        } else
+            nnz = tq4x4(d, P.qc, P.qc.f_intra, 1, S.lv + LV_CHROMA_AC + (cpl * 4 + cb) * 16, &dcw, 0, false);
     }
     wave_sync();
     if (!use_i4) {
@@ -284,14 +320,16 @@ __device__ __forceinline__ void intra_mb_core(const FrameParams& P, int mx, int 
             v = q + s4 * v;
             return __builtin_amdgcn_mov_dpp(v, 0x128, 0xf, 0xf, false) + s8 * v; // row_ror:8 = lane ^ 8
         };
-        const int hw = wht(lane < 16 ? S.dc[lane] : 0);
-        const int qb = P.qy.qbits;
-        const unsigned a = (unsigned)iabs(hw);
-        const int lq = (int)((a * (unsigned)P.qy.mf[0] + 4u * (unsigned)P.qy.f_intra) >> (qb + 2));
-        const int ldc = hw < 0 ? -lq : lq;
-        if (lane < 16) {
-            const int cu = (0x2130 >> (4 * i)) & 3, cv = (0x2130 >> (4 * j)) & 3;   // sg: 0 3 1 2
-            S.lv[LV_LUMA_DC + ((c_zz_row[cv] >> (4 * cu)) & 15)] = (int16_t)ldc;
+        const int cu = (0x2130 >> (4 * i)) & 3, cv = (0x2130 >> (4 * j)) & 3;   // sg: 0 3 1 2
+        int ldc;
+        if (DEC) ldc = lane < 16 ? (int)S.lv[LV_LUMA_DC + ((c_zz_row[cv] >> (4 * cu)) & 15)] : 0;
+        else {
+            const int hw = wht(lane < 16 ? S.dc[lane] : 0);
+            const int qb = P.qy.qbits;
+            const unsigned a = (unsigned)iabs(hw);
+            const int lq = (int)((a * (unsigned)P.qy.mf[0] + 4u * (unsigned)P.qy.f_intra) >> (qb + 2));
+            ldc = hw < 0 ? -lq : lq;
+            if (lane < 16) S.lv[LV_LUMA_DC + ((c_zz_row[cv] >> (4 * cu)) & 15)] = (int16_t)ldc;
         }
         const int fi_r = wht(ldc);
         wave_sync();   // every lane has taken its S.dc value
@@ -307,13 +345,23 @@ __device__ __forceinline__ void intra_mb_core(const FrameParams& P, int mx, int 
         const int base = 16 + ((lane - 16) & 4);
         const int w4[4] = {__shfl(dcw, base), __shfl(dcw, base + 1), __shfl(dcw, base + 2), __shfl(dcw, base + 3)};
         int lv[4], deq[4];
-        chroma_dc(w4, P.qc, P.qc.f_intra, lv, deq);
-        if (is_chroma) {
-            d[0] = deq[cb];
-            if (cb == 0)
+        if (DEC) {   // inverse 2x2 Hadamard + scaling (8.5.11) of the given chroma DC levels
+            const int pl = is_chroma ? cpl : 0;
 #pragma unroll
-                for (int i = 0; i < 4; i++) S.lv[LV_CHROMA_DC + cpl * 4 + i] = (int16_t)lv[i];
-            dcw = (lv[0] | lv[1] | lv[2] | lv[3]) != 0;
+            for (int i = 0; i < 4; i++) lv[i] = (int)S.lv[LV_CHROMA_DC + pl * 4 + i];
+            const int fi[4] = {lv[0] + lv[1] + lv[2] + lv[3], lv[0] - lv[1] + lv[2] - lv[3], lv[0] + lv[1] - lv[2] - lv[3], lv[0] - lv[1] - lv[2] + lv[3]};
+#pragma unroll
+            for (int i = 0; i < 4; i++) deq[i] = (fi[i] * 16 * P.qc.dq[0]) >> 5;
+            if (is_chroma) d[0] = pick4(deq, cb);
+        } else {
+            chroma_dc(w4, P.qc, P.qc.f_intra, lv, deq);
+            if (is_chroma) {
+                d[0] = deq[cb];
+                if (cb == 0)
+#pragma unroll
+                    for (int i = 0; i < 4; i++) S.lv[LV_CHROMA_DC + cpl * 4 + i] = (int16_t)lv[i];
+                dcw = (lv[0] | lv[1] | lv[2] | lv[3]) != 0;
+            }
         }
     }
     const unsigned long long nzmask = __ballot(nnz != 0);
@@ -345,6 +393,7 @@ __device__ __forceinline__ void intra_mb_core(const FrameParams& P, int mx, int 
         }
     }
     wave_sync();
+    if (DEC) return;
     MbInfo* m = P.mb + mbi;
     {   // I_PCM fallback (dev_common.h): bit bound of the 27 blocks, one per lane; above the limit of A.3.1 the macroblock is
         // re-written as I_PCM: reconstruction = source, for the picture and for this row's next prediction alike
@@ -540,11 +589,14 @@ __global__ __launch_bounds__(64) void k_intra_rows(IntraRowParams R)
 // publishes (above, above-left) - the same {tag, 4 samples} hand-off as k_intra_rows.  A row waits only for intra
 // macroblocks of the row above, which are coded left to right: no cycle.  Pictures without marked macroblocks return at once.
 // ===========================================================================
+// DEC (the decoder peer): the intra macroblocks are those of intra type in the MbInfo the host parser filled (every macroblock
+// of an I picture); they are reconstructed from the given modes and levels.
+template <bool DEC>
 __global__ __launch_bounds__(64) void k_pintra_rows(IntraRowParams R)
 {
     __builtin_amdgcn_s_setprio(3);
     const FrameParams P = batch_view(R.p, blockIdx.y);
-    if (*P.anyintra != P.pic_serial) return;
+    if (!DEC && *P.anyintra != P.pic_serial) return;
     unsigned long long* const handoff = R.handoff + (size_t)blockIdx.y * R.st_handoff;
     const int lane = threadIdx.x, my = P.band.row0 + blockIdx.x, cs = P.cw / 2;
     const bool top = P.sl.has_top(my);
@@ -554,7 +606,10 @@ __global__ __launch_bounds__(64) void k_pintra_rows(IntraRowParams R)
     int last_done = -2;   // the macroblock whose reconstruction S.rec_* holds
     // bit 15 of me_cost = "handed to this pass by k_me": unlike MbInfo.type (an I_PCM conversion changes it, here or in k_tq)
     // it does not change during the launch, so every row sees the same set of macroblocks to wait for
-    auto marked = [&](int x, int y) { return (P.me_cost[(size_t)y * P.mbw + x] & 0x8000u) != 0; };
+    auto marked = [&](int x, int y) {
+        if (DEC) return mb_is_intra(P.mb[(size_t)y * P.mbw + x].type);
+        return (P.me_cost[(size_t)y * P.mbw + x] & 0x8000u) != 0;
+    };
     auto wait_granules = [&](int gx, int nlanes, unsigned long long& g) {   // lanes < nlanes: granule `lane` of macroblock (gx, my - 1)
         const unsigned long long* src = handoff + ((size_t)(my - 1) * P.mbw + gx) * 8;
         unsigned spins = 0;
@@ -573,7 +628,7 @@ __global__ __launch_bounds__(64) void k_pintra_rows(IntraRowParams R)
         while (todo) {
             const int mx = base + __ffsll((long long)todo) - 1;
             todo &= todo - 1;
-            load_src_mb(P, mx, my, S.src, S.srcc, lane);
+            if (!DEC) load_src_mb(P, mx, my, S.src, S.srcc, lane);
             // left column + corner sources
             if (mx > 0) {
                 if (last_done == mx - 1) {
@@ -619,7 +674,7 @@ __global__ __launch_bounds__(64) void k_pintra_rows(IntraRowParams R)
                 const int mbi = my * P.mbw + mx;
                 const bool use_i4 = ((const uint8_t*)(P.mb + mbi))[4] == MB_I4;
                 const uint32_t auxw = lane < 4 ? *(const uint32_t*)(P.aux + (size_t)mbi * 16 + 4 * lane) : 0u;
-                intra_mb_core(P, mx, my, S, lane, __builtin_amdgcn_readfirstlane((int)use_i4) != 0, auxw);
+                intra_mb_core<DEC>(P, mx, my, S, lane, __builtin_amdgcn_readfirstlane((int)use_i4) != 0, auxw);
             }
             last_done = mx;
             // publish the bottom sample row for the row below (it asks only where this macroblock is its neighbour)

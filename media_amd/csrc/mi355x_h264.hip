@@ -23,6 +23,9 @@
 #include "k_intra.h"
 #include "k_me.h"
 #include "k_tq.h"
+#include "k_dec.h"
+#include "h264_parse.h"
+#include "../../include/mi355x_h264_dec.h"
 
 using namespace h264;
 
@@ -374,7 +377,7 @@ int submit(mi355x_h264_encoder* e, const uint8_t* d_src, size_t src_item_stride,
             e->serial = e->serial == 0xFFFFFFFFu ? 1 : e->serial + 1;
             R.serial = e->serial;
             hipLaunchKernelGGL(k_i4_decide, dim3((e->b_nmb + 3) / 4, G), dim3(64), 0, st, P, 1);
-            hipLaunchKernelGGL(k_pintra_rows, dim3(e->b_rows, G), dim3(64), 0, st, R);
+            hipLaunchKernelGGL(k_pintra_rows<false>, dim3(e->b_rows, G), dim3(64), 0, st, R);
         }
     }
     // entropy coding
@@ -1030,6 +1033,288 @@ int mi355x_h264_stats_read(mi355x_h264_encoder* e, mi355x_h264_stats* out, int r
     *out = e->stats;
     if (reset) memset(&e->stats, 0, sizeof(e->stats));
     return MI355X_H264_OK;
+}
+
+}  // extern "C"
+
+// ===========================================================================
+// Decoder peer (include/mi355x_h264_dec.h): host parser (h264_parse.h) + the reconstruction kernels (k_dec.h, k_intra.h,
+// k_cavlc.h k_bs, k_deblock.h).  The decoder owns an engine instance for its device buffers (reconstruction ring, per-macroblock
+// arrays, hand-off granules, streams): decoding is the encoder's reconstruction path run from parsed decisions.
+// ===========================================================================
+struct mi355x_h264_decoder {
+    h264dec::Parser parser;
+    mi355x_h264_encoder* eng = nullptr;
+    int device = 0;
+    int mbw = 0, mbh = 0;
+    int have_refs = 0;   // reference pictures in the ring (sliding window)
+    int max_refs = 1;
+    int last = -1;       // ring index of the last decoded picture
+    int width = 0, height = 0, crop_x = 0, crop_y = 0;
+    uint64_t pictures = 0;
+    double parse_ms = 0, gpu_ms = 0;
+    char err[256] = {0};
+};
+
+namespace {
+
+int dfail(mi355x_h264_decoder* d, int code, const char* fmt, ...)
+{
+    if (d) {
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(d->err, sizeof(d->err), fmt, ap);
+        va_end(ap);
+    }
+    return code;
+}
+#define DHIP(d, call)                                                                                \
+    do {                                                                                             \
+        hipError_t _r = (call);                                                                      \
+        if (_r != hipSuccess) return dfail((d), MI355X_H264_E_HIP, "%s: %s", #call, hipGetErrorString(_r)); \
+    } while (0)
+
+double now_ms()
+{
+    timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    return t.tv_sec * 1e3 + t.tv_nsec * 1e-6;
+}
+
+// launch the reconstruction of the parsed picture into ring slot e->cur
+int dec_submit(mi355x_h264_decoder* d, const h264dec::Picture& pic)
+{
+    mi355x_h264_encoder* e = d->eng;
+    const size_t nmb = (size_t)e->nmb;
+    hipStream_t st = e->stream;
+    DHIP(d, hipMemcpyAsync(e->d_mb, pic.mb.data(), nmb * sizeof(MbInfo), hipMemcpyHostToDevice, st));
+    DHIP(d, hipMemcpyAsync(e->d_mvq, pic.mvq.data(), nmb * 16, hipMemcpyHostToDevice, st));
+    DHIP(d, hipMemcpyAsync(e->d_aux, pic.aux.data(), nmb * 16, hipMemcpyHostToDevice, st));
+    DHIP(d, hipMemcpyAsync(e->d_levels, pic.levels.data(), nmb * LV_STRIDE * sizeof(int16_t), hipMemcpyHostToDevice, st));
+    const int cur = e->cur;
+    FrameParams P{};
+    P.w = e->cw; P.h = e->ch; P.cw = e->cw; P.ch = e->ch; P.mbw = e->mbw; P.mbh = e->mbh;
+    P.nref = std::max(1, d->have_refs);
+    for (int p = 0; p < 3; p++) {
+        P.rec[p] = e->d_planes[cur][p];
+        for (int r = 0; r < mi355x_h264_encoder::MAX_REFS; r++)
+            P.refs[r][p] = e->d_planes[(cur + e->nbuf - 1 - std::min(r, std::max(0, d->have_refs - 1))) % e->nbuf][p];
+        P.ref[p] = P.refs[0][p];
+    }
+    P.mb = e->d_mb; P.levels = e->d_levels; P.mvd = e->d_mvd; P.mvq = e->d_mvq; P.aux = e->d_aux; P.me_cost = e->d_me_cost; P.me_total = e->d_me_total; P.pmv = e->d_pmv;
+    P.st_y = e->st_y; P.st_c = e->st_c; P.st_mb = e->nmb;
+    P.sl.rows = pic.slice_rows ? pic.slice_rows : e->mbh;
+    P.sl.inv = P.sl.rows > 1 ? (unsigned)(0x100000000ull / (unsigned)P.sl.rows) + 1u : 0u;
+    P.band.row0 = 0; P.band.rows = e->mbh;
+    P.mbdiv.inv = e->mbw > 1 ? (unsigned)(0x100000000ull / (unsigned)e->mbw) + 1u : 0u;
+    e->pic_serial = e->pic_serial == 0xFFFFFFFFu ? 1u : e->pic_serial + 1u;
+    P.anypcm = e->d_anypcm; P.anyintra = e->d_anyintra; P.pic_serial = e->pic_serial;
+    fill_quant(P.qy, pic.qp);
+    fill_quant(P.qc, h_chroma_qp[pic.qp]);
+    {   // the flags the loop filter launches look at: intra macroblocks present (bS 3 / 4 form); I_PCM never switches the filter off here
+        const unsigned flags[2] = {0u, pic.has_intra ? e->pic_serial : 0u};
+        DHIP(d, hipMemcpyAsync(e->d_anypcm, &flags[0], sizeof(unsigned), hipMemcpyHostToDevice, st));
+        DHIP(d, hipMemcpyAsync(e->d_anyintra, &flags[1], sizeof(unsigned), hipMemcpyHostToDevice, st));
+    }
+    Slot& S = e->slots[0];
+    if (pic.has_inter) {
+        hipLaunchKernelGGL(k_dec_inter, dim3(e->nmb, 1), dim3(64), 0, st, P);
+        hipLaunchKernelGGL(k_dec_resid, dim3((e->nmb + 3) / 4, 1), dim3(64), 0, st, P);
+    }
+    if (pic.has_intra) {
+        IntraRowParams R{};
+        R.p = P; R.handoff = e->d_handoff; R.st_handoff = e->st_handoff; R.err = S.h_err;
+        e->serial = e->serial == 0xFFFFFFFFu ? 1 : e->serial + 1;
+        R.serial = e->serial;
+        hipLaunchKernelGGL(k_pintra_rows<true>, dim3(e->mbh, 1), dim3(64), 0, st, R);
+    }
+    if (pic.deblock_idc != 1) {
+        CavlcParams C{};
+        C.mb = e->d_mb; C.levels = e->d_levels; C.mvd = e->d_mvd; C.mvq = e->d_mvq; C.mbw = e->mbw; C.nmb = e->nmb; C.sl = P.sl;
+        C.mb_first = 0; C.mb_end = e->nmb; C.mbdiv = P.mbdiv; C.bs = (uint8_t*)e->d_bs; C.st_mb = e->nmb; C.aux = e->d_aux;
+        C.slotbits = e->d_slotbits; C.slotcode = e->d_slotcode; C.mbbits = e->d_mbbits; C.prevcoded = e->d_prevcoded;
+        e->serial = e->serial == 0xFFFFFFFFu ? 1 : e->serial + 1;
+        const unsigned db_serial = e->serial;
+        hipLaunchKernelGGL(k_bs, dim3((e->nmb + 1) / 2, 1), dim3(64), 0, st, C, e->d_anybs, db_serial);
+        DbParams D{};
+        for (int p = 0; p < 3; p++) D.pl[p] = e->d_planes[cur][p];
+        D.mb = e->d_mb; D.cw = e->cw; D.ch = e->ch; D.mbw = e->mbw; D.mbh = e->mbh; D.sl = P.sl; D.bs = (const uint8_t*)e->d_bs;
+        const int qp = pic.qp, qpc = h_chroma_qp[qp];
+        D.alpha_y = h_alpha[qp]; D.beta_y = h_beta[qp]; D.alpha_c = h_alpha[qpc]; D.beta_c = h_beta[qpc];
+        for (int i = 0; i < 3; i++) { D.tc0_y[i] = h_tc0[qp][i]; D.tc0_c[i] = h_tc0[qpc][i]; }
+        DbRowParams R{};
+        R.d = D; R.handoff = e->d_handoff; R.err = S.h_err;
+        R.st_y = e->st_y; R.st_c = e->st_c; R.st_handoff = e->st_handoff; R.st_mb = e->nmb;
+        R.serial = db_serial; R.row0 = 0;
+        R.bs = e->d_bs; R.anybs = e->d_anybs;
+        R.anypcm = e->d_anypcm; R.anyintra = e->d_anyintra; R.pic_serial = e->pic_serial;
+        if (!pic.has_inter) { R.need_intra = 0; hipLaunchKernelGGL(k_deblock_rows<true>, dim3(e->mbh, 1), dim3(64), 0, st, R); }
+        else {
+            R.need_intra = -1; hipLaunchKernelGGL(k_deblock_rows<false>, dim3(e->mbh, 1), dim3(64), 0, st, R);
+            R.need_intra = 1; hipLaunchKernelGGL(k_deblock_rows<true>, dim3(e->mbh, 1), dim3(64), 0, st, R);
+        }
+    }
+    DHIP(d, hipGetLastError());
+    DHIP(d, hipStreamSynchronize(st));
+    if (*S.h_err) {
+        const unsigned flag = *S.h_err;
+        *S.h_err = 0;
+        return dfail(d, MI355X_H264_E_INTERNAL, "wavefront kernel hand-off timed out (flag %u)", flag);
+    }
+    return MI355X_H264_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mi355x_h264_dec_create(int device, mi355x_h264_decoder** out)
+{
+    if (!out) return MI355X_H264_E_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return MI355X_H264_E_NODEVICE;
+    mi355x_h264_decoder* d = new (std::nothrow) mi355x_h264_decoder();
+    if (!d) return MI355X_H264_E_NOMEM;
+    d->device = device;
+    *out = d;
+    return MI355X_H264_OK;
+}
+
+void mi355x_h264_dec_destroy(mi355x_h264_decoder* d)
+{
+    if (!d) return;
+    if (d->eng) mi355x_h264_destroy(d->eng);
+    delete d;
+}
+
+const char* mi355x_h264_dec_last_error(const mi355x_h264_decoder* d) { return d ? d->err : "no decoder"; }
+
+int mi355x_h264_dec_decode(mi355x_h264_decoder* d, const uint8_t* au, size_t len, int* got_picture)
+{
+    if (!d || !au) return MI355X_H264_E_ARG;
+    if (got_picture) *got_picture = 0;
+    d->err[0] = 0;
+    const double t0 = now_ms();
+    const int rc = d->parser.parse_access_unit(au, len);
+    const double t1 = now_ms();
+    d->parse_ms += t1 - t0;
+    if (rc < 0) return dfail(d, MI355X_H264_E_STREAM, "%s", d->parser.error().c_str());
+    if (rc == 0) return MI355X_H264_OK;
+    const h264dec::Picture& pic = d->parser.picture();
+    const h264dec::Sps& sps = d->parser.sps();
+    if (pic.has_pcm && pic.deblock_idc != 1)
+        return dfail(d, MI355X_H264_E_STREAM, "I_PCM macroblock in a loop-filtered picture (qP 0 edges are not supported)");
+    if (!d->eng || d->mbw != pic.mbw || d->mbh != pic.mbh) {
+        if (!pic.idr) return dfail(d, MI355X_H264_E_STREAM, "the stream must start with an IDR picture");
+        if (d->eng) { mi355x_h264_destroy(d->eng); d->eng = nullptr; }
+        mi355x_h264_config cfg;
+        mi355x_h264_default_config(&cfg);
+        cfg.width = 16 * pic.mbw; cfg.height = 16 * pic.mbh; cfg.refs = 3; cfg.device = d->device; cfg.batch = 1;
+        const int crc = mi355x_h264_create(&cfg, &d->eng);
+        if (crc != MI355X_H264_OK) return dfail(d, crc, "engine for %dx%d macroblocks could not be created", pic.mbw, pic.mbh);
+        d->mbw = pic.mbw; d->mbh = pic.mbh; d->have_refs = 0; d->last = -1;
+    }
+    if (hipSetDevice(d->device) != hipSuccess) return dfail(d, MI355X_H264_E_HIP, "hipSetDevice");
+    d->width = pic.width; d->height = pic.height; d->crop_x = 2 * sps.crop_l; d->crop_y = 2 * sps.crop_t;
+    d->max_refs = std::max(1, sps.max_refs);
+    if (pic.idr) d->have_refs = 0;
+    if (pic.has_inter && (d->have_refs < 1 || pic.num_ref_active > d->have_refs))
+        return dfail(d, MI355X_H264_E_STREAM, "a P picture refers to %d reference pictures, %d are held", pic.num_ref_active, d->have_refs);
+    const int src = dec_submit(d, pic);
+    d->gpu_ms += now_ms() - t1;
+    if (src != MI355X_H264_OK) return src;
+    d->last = d->eng->cur;
+    if (pic.is_ref) {   // sliding window (8.2.5.3)
+        d->eng->cur = (d->eng->cur + 1) % d->eng->nbuf;
+        d->have_refs = std::min(d->have_refs + 1, std::min(d->max_refs, d->eng->nrefs));
+    }
+    d->pictures++;
+    if (got_picture) *got_picture = 1;
+    return MI355X_H264_OK;
+}
+
+int mi355x_h264_dec_picture_info(const mi355x_h264_decoder* d, int* width, int* height, int* coded_width, int* coded_height)
+{
+    if (!d || d->last < 0) return MI355X_H264_E_ARG;
+    if (width) *width = d->width;
+    if (height) *height = d->height;
+    if (coded_width) *coded_width = 16 * d->mbw;
+    if (coded_height) *coded_height = 16 * d->mbh;
+    return MI355X_H264_OK;
+}
+
+// the last decoded picture, cropped, as tight I420 (Y, U, V); to_device: dst is device memory
+static int64_t dec_read(mi355x_h264_decoder* d, void* dst, size_t cap, bool to_device)
+{
+    if (!d || !dst || d->last < 0) return MI355X_H264_E_ARG;
+    const size_t w = (size_t)d->width, h = (size_t)d->height, need = w * h * 3 / 2;
+    if (cap < need) return MI355X_H264_E_ARG;
+    const mi355x_h264_encoder* e = d->eng;
+    uint8_t* o = (uint8_t*)dst;
+    const hipMemcpyKind kind = to_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    for (int p = 0; p < 3; p++) {
+        const size_t pw = p ? w / 2 : w, ph = p ? h / 2 : h, pitch = p ? (size_t)e->cw / 2 : (size_t)e->cw;
+        const uint8_t* s = e->d_planes[d->last][p] + (size_t)(p ? d->crop_y / 2 : d->crop_y) * pitch + (size_t)(p ? d->crop_x / 2 : d->crop_x);
+        if (hipMemcpy2D(o, pw, s, pitch, pw, ph, kind) != hipSuccess) return dfail(d, MI355X_H264_E_HIP, "hipMemcpy2D");
+        o += pw * ph;
+    }
+    return (int64_t)need;
+}
+int64_t mi355x_h264_dec_read_i420(mi355x_h264_decoder* d, uint8_t* dst, size_t cap) { return dec_read(d, dst, cap, false); }
+int64_t mi355x_h264_dec_read_i420_device(mi355x_h264_decoder* d, void* d_dst, size_t cap) { return dec_read(d, d_dst, cap, true); }
+
+// coded-size planes of the last picture (test hook: compared with the oracle decoder's planes)
+int64_t mi355x_h264_dec_debug_plane(mi355x_h264_decoder* d, int plane, void* dst, size_t cap)
+{
+    if (!d || !dst || d->last < 0 || plane < 0 || plane > 2) return MI355X_H264_E_ARG;
+    const mi355x_h264_encoder* e = d->eng;
+    const size_t n = (size_t)e->cw * e->ch / (plane ? 4 : 1);
+    if (cap < n) return MI355X_H264_E_ARG;
+    if (hipMemcpy(dst, e->d_planes[d->last][plane], n, hipMemcpyDeviceToHost) != hipSuccess) return MI355X_H264_E_HIP;
+    return (int64_t)n;
+}
+
+int mi355x_h264_dec_timing(const mi355x_h264_decoder* d, uint64_t* pictures, double* parse_ms, double* gpu_ms)
+{
+    if (!d) return MI355X_H264_E_ARG;
+    if (pictures) *pictures = d->pictures;
+    if (parse_ms) *parse_ms = d->parse_ms;
+    if (gpu_ms) *gpu_ms = d->gpu_ms;
+    return MI355X_H264_OK;
+}
+
+// ---- the host parser alone (no GPU): what it recovered from the last access unit, for the CPU tests ----
+struct mi355x_h264_parser { h264dec::Parser p; };
+mi355x_h264_parser* mi355x_h264_parser_create(void) { return new (std::nothrow) mi355x_h264_parser(); }
+void mi355x_h264_parser_destroy(mi355x_h264_parser* p) { delete p; }
+int mi355x_h264_parser_parse(mi355x_h264_parser* p, const uint8_t* au, size_t len) { return p && au ? p->p.parse_access_unit(au, len) : -1; }
+const char* mi355x_h264_parser_error(const mi355x_h264_parser* p) { return p ? p->p.error().c_str() : "no parser"; }
+int mi355x_h264_parser_info(const mi355x_h264_parser* p, int32_t* out, int n)
+{
+    if (!p || !out || n < 12) return -1;
+    const h264dec::Picture& c = p->p.picture();
+    const int32_t v[12] = {c.mbw, c.mbh, c.width, c.height, c.idr, c.qp, c.slice_rows, c.deblock_idc, c.num_ref_active, c.t8x8_mode, c.has_pcm, c.has_intra | (c.has_inter << 1)};
+    memcpy(out, v, sizeof(v));
+    return 12;
+}
+// what: 0 MbInfo (32 B / macroblock), 1 quadrant vectors (16 B), 2 Intra4x4 modes (16 B), 3 levels (832 B)
+int64_t mi355x_h264_parser_read(const mi355x_h264_parser* p, int what, void* dst, size_t cap)
+{
+    if (!p || !dst) return -1;
+    const h264dec::Picture& c = p->p.picture();
+    const void* src = nullptr;
+    size_t n = 0;
+    switch (what) {
+        case 0: src = c.mb.data(); n = c.mb.size() * sizeof(h264dec::MbRec); break;
+        case 1: src = c.mvq.data(); n = c.mvq.size() * sizeof(int16_t); break;
+        case 2: src = c.aux.data(); n = c.aux.size(); break;
+        case 3: src = c.levels.data(); n = c.levels.size() * sizeof(int16_t); break;
+        default: return -1;
+    }
+    if (cap < n) return -1;
+    memcpy(dst, src, n);
+    return (int64_t)n;
 }
 
 }  // extern "C"

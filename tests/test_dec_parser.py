@@ -1,0 +1,64 @@
+"""Decoder peer, host side (media_amd/csrc/h264_parse.h through the C ABI of include/mi355x_h264_dec.h): the parser must
+recover from a stream exactly the side information of the encoder that wrote it - macroblock types, modes, reference
+indices, coded_block_pattern, TotalCoeff, the quadrant vectors (mvd + its own statement of 8.4.1.3), the Intra4x4 modes
+(8.3.1.1) and every level the stream carries.  CPU only: the oracle encoder writes the streams."""
+import numpy as np
+import pytest
+from media_amd import synth, h264dec
+from oracle_lib import OracleEncoder
+
+CASES = [("s1", 176, 144, 26, 66, 0, 0), ("cut", 208, 160, 28, 66, 0, 0), ("split", 176, 144, 26, 66, 0, 0), ("s3", 96, 80, 30, 66, 0, 0),
+         ("s3", 64, 48, 10, 66, 0, 0), ("split", 208, 160, 30, 100, 2, 0), ("cut", 176, 144, 22, 77, 3, 3), ("scroll", 130, 98, 30, 100, 0, 2),
+         ("s1", 16, 16, 26, 66, 0, 0)]
+
+
+@pytest.mark.parametrize("kind,w,h,qp,prof,refs,slices", CASES)
+def test_parser_recovers_the_encoders_side_information(kind, w, h, qp, prof, refs, slices):
+    enc = OracleEncoder(w, h, qp=qp, gop=30, profile_idc=prof, refs=refs, slices=slices)
+    par = h264dec.Parser()
+    for i, f in enumerate(synth.sequence(kind, w, h, 5)):
+        au, idr = enc.encode(f)
+        assert par.parse(au), "picture %d" % i
+        info = par.info()
+        assert (info["width"], info["height"], info["qp"], bool(info["idr"])) == (w, h, qp, bool(idr))
+        mb, mvq, aux, lv = par.arrays()
+        omb, omvq, oaux, olv = enc.mbinfo(), enc.mvq(), enc.mbaux(), enc.levels()
+        for fld in ("type", "cbp", "chroma_mode", "tc", "mvx", "mvy"):
+            assert np.array_equal(mb[fld], omb[fld]), "picture %d: %s" % (i, fld)
+        i16 = omb["type"] == 0
+        inter = np.isin(omb["type"], (1, 2, 5, 6, 7))
+        assert np.array_equal(mb["i16_mode"][i16 | inter], omb["i16_mode"][i16 | inter])
+        assert np.array_equal(mvq[inter], omvq[inter]), "picture %d: quadrant vectors" % i
+        i4 = omb["type"] == 4
+        assert np.array_equal(aux[i4], oaux[i4]), "picture %d: Intra4x4 modes" % i
+        # every level list the stream carries (by type and coded_block_pattern)
+        read = np.zeros(olv.shape, bool)
+        cbp = omb["cbp"].astype(np.int32)
+        read[i16, 0:16] = True
+        for q in range(4):
+            read[(cbp >> q) & 1 == 1, 16 + 64 * q: 16 + 64 * (q + 1)] = True
+        read[(cbp >> 4) >= 1, 272:280] = True
+        read[(cbp >> 4) == 2, 280:408] = True
+        read[np.isin(omb["type"], (2, 3)), :] = False
+        assert np.array_equal(np.where(read, lv, 0), np.where(read, olv, 0)), "picture %d: levels" % i
+        assert not np.where(~read & (omb["type"] != 3)[:, None], lv, 0).any(), "levels outside what the stream carries must stay 0"
+        pcm = omb["type"] == 3
+        if pcm.any():   # the 384 samples of an I_PCM macroblock travel as bytes at the start of its level area
+            raw = lv[pcm].view(np.uint8)[:, :384]
+            k = int(np.where(pcm)[0][0])
+            mx, my = k % ((w + 15) // 16), k // ((w + 15) // 16)
+            src = enc.recon_pre(0)[16 * my:16 * my + 16, 16 * mx:16 * mx + 16]
+            assert np.array_equal(raw[0, :256].reshape(16, 16), src)
+    par.close()
+
+
+def test_parser_refuses_what_it_does_not_support():
+    par = h264dec.Parser()
+    with pytest.raises(h264dec.StreamError):
+        par.parse(b"\x00\x00\x00\x01\x65\x88\x84\x00")          # a slice without parameter sets
+    enc = OracleEncoder(64, 48, qp=26, gop=30)
+    au = enc.encode(synth.sequence("s1", 64, 48, 1)[0])[0]
+    assert par.parse(au)
+    with pytest.raises(h264dec.StreamError):
+        par.parse(au[: len(au) * 2 // 3])                      # truncated slice data
+    par.close()

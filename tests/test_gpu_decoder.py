@@ -1,0 +1,58 @@
+"""Decoder peer on the GPU (include/mi355x_h264_dec.h: host parser + the encoder's reconstruction kernels run from parsed
+decisions): every picture it decodes must equal, sample for sample, the reconstruction of the encoder that wrote the stream -
+which tests/test_oracle_roundtrip.py ties to the independent spec-literal decoder of oracle/h264_dec.c."""
+import numpy as np
+import pytest
+from media_amd import capi, synth, h264dec
+from oracle_lib import OracleEncoder, OracleDecoder
+
+pytestmark = pytest.mark.gpu
+
+CASES = [("s1", 176, 144, 26, 66, 0, 0, 0), ("cut", 208, 160, 28, 66, 0, 0, 0), ("split", 176, 144, 26, 66, 0, 0, 0), ("s3", 96, 80, 30, 66, 0, 0, 0),
+         ("s3", 64, 48, 10, 66, 0, 0, 0), ("split", 208, 160, 30, 100, 2, 0, 0), ("cut", 176, 144, 22, 77, 3, 3, 0), ("scroll", 130, 98, 30, 100, 0, 2, 0),
+         ("s1", 16, 16, 26, 66, 0, 0, 0), ("s1", 320, 240, 34, 66, 0, 0, 1), ("cut", 352, 288, 40, 100, 3, 4, 0), ("ramp", 128, 96, 38, 66, 0, 0, 0)]
+
+
+@pytest.mark.parametrize("kind,w,h,qp,prof,refs,slices,nodb", CASES)
+def test_decoder_equals_the_encoders_reconstruction(kind, w, h, qp, prof, refs, slices, nodb):
+    enc = OracleEncoder(w, h, qp=qp, gop=4, profile_idc=prof, refs=refs, slices=slices, disable_deblock=nodb)
+    ref_dec = OracleDecoder()
+    dec = h264dec.Decoder()
+    for i, f in enumerate(synth.sequence(kind, w, h, 7)):
+        au, _ = enc.encode(f)
+        assert dec.decode(au), "picture %d" % i
+        assert ref_dec.decode(au) == 1
+        assert dec.info()[:2] == (w, h)
+        for p in range(3):
+            got = dec.plane(p)
+            assert np.array_equal(got, enc.recon(p)), "picture %d plane %d" % (i, p)
+            assert np.array_equal(got, ref_dec.plane(p))
+        out = dec.i420()
+        assert np.array_equal(out[: w * h].reshape(h, w), enc.recon(0)[:h, :w])
+        assert np.array_equal(out[w * h: w * h * 5 // 4].reshape(h // 2, w // 2), enc.recon(1)[: h // 2, : w // 2])
+    dec.close()
+
+
+def test_decoder_on_the_hip_encoders_streams_and_size_change():
+    """streams written by the HIP encoder (1080p, then a smaller size: the decoder re-creates its engine at the new IDR);
+    a P picture without its reference is refused, as is an access unit with a feature outside the supported set"""
+    dec = h264dec.Decoder()
+    for (w, h, qp) in ((1920, 1080, 26), (640, 368, 30)):
+        enc = capi.Encoder(w, h, qp=qp, gop=30)
+        for i, f in enumerate(synth.sequence("s1", w, h, 4)):
+            au = enc.encode(f)[0]
+            assert dec.decode(au)
+            cw, ch = dec.info()[2:]
+            for p in range(3):
+                assert np.array_equal(dec.plane(p), enc.debug_read(capi.DBG_RECON_Y + p)), "%dx%d picture %d plane %d" % (w, h, i, p)
+            y = f[: w * h].reshape(h, w)
+            assert synth.psnr(y, dec.i420()[: w * h].reshape(h, w)) > 34.0
+        enc.close()
+    fresh = h264dec.Decoder()
+    enc = OracleEncoder(64, 48, qp=26, gop=30)
+    aus = [enc.encode(f)[0] for f in synth.sequence("s1", 64, 48, 2)]
+    with pytest.raises(h264dec.StreamError):
+        fresh.decode(aus[1])          # a P picture first
+    assert fresh.decode(aus[0]) and fresh.decode(aus[1])
+    fresh.close()
+    dec.close()
