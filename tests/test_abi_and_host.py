@@ -20,9 +20,9 @@ def built():
 
 def test_every_declared_symbol_is_exported():
     from media_amd import capi
-    hdr = open(os.path.join(ROOT, "include", "mi355x_h264.h")).read()
+    hdr = open(os.path.join(ROOT, "include", "mi355x_h264.h")).read() + open(os.path.join(ROOT, "include", "mi355x_h264_dec.h")).read()
     declared = set(re.findall(r"\b(mi355x_h264_[a-z_0-9]+)\s*\(", hdr))
-    assert len(declared) >= 15
+    assert len(declared) >= 30 and "mi355x_h264_dec_decode" in declared and "mi355x_h264_parser_parse" in declared
     out = subprocess.check_output(["nm", "-D", "--defined-only", capi.LIB_PATH]).decode()
     exported = set(re.findall(r" T (mi355x_h264_[a-z_0-9]+)", out))
     assert declared <= exported, "missing: %s" % sorted(declared - exported)
@@ -43,6 +43,14 @@ def test_plugin_library_exports_factory():
     assert "VideoEncoderMI355X" in subprocess.check_output(["nm", "-DC", videocodec.LIB_PATH]).decode()
 
 
+def test_decoder_plugin_library_exports_factory():
+    from media_amd import videodecoder
+    out = subprocess.check_output(["nm", "-D", "--defined-only", videodecoder.LIB_PATH]).decode()
+    for sym in ("CreateVideoDecoder", "DestroyVideoDecoder"):
+        assert re.search(r" T %s\b" % sym, out), sym
+    assert "VideoDecoderMI355X" in subprocess.check_output(["nm", "-DC", videodecoder.LIB_PATH]).decode()
+
+
 def _no_gpu():
     import torch
     return not torch.cuda.is_available()
@@ -58,6 +66,13 @@ def test_no_cpu_fallback_without_device():
     assert not h.value
     with pytest.raises(capi.EncoderError):
         capi.Encoder(320, 240)
+    # the decoder peer likewise: no device, no decoder (the host parser alone is not a decoder)
+    from media_amd import h264dec, videodecoder as vd
+    with pytest.raises(capi.EncoderError):
+        h264dec.Decoder()
+    d = vd.PluginDecoder()
+    assert d.rc_create == vd.SUCCESS and d.create_decoder() == vd.SUCCESS and d.start() == vd.START_FAIL
+    assert d.delete() == vd.SUCCESS
 
 
 def test_create_rejects_bad_config():
