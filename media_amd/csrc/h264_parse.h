@@ -16,6 +16,7 @@
 // Anything else is refused with a message naming the syntax element (never decoded wrongly).
 #pragma once
 #include <stdint.h>
+#include <stdio.h>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -230,25 +231,41 @@ private:
             br.u(1);   // qpprime_y_zero_transform_bypass_flag
             if (br.u(1)) { fail("seq_scaling_matrix_present_flag"); return false; }
         } else if (s.profile_idc != 66 && s.profile_idc != 77 && s.profile_idc != 88) { fail("profile_idc %d", s.profile_idc); return false; }
-        s.log2_max_frame_num = (int)br.ue() + 4;
-        s.poc_type = (int)br.ue();
-        if (s.poc_type == 0) s.log2_max_poc_lsb = (int)br.ue() + 4;
+        const unsigned l2f = br.ue();
+        if (l2f > 12) { fail("log2_max_frame_num_minus4 %d", (int)l2f); return false; }
+        s.log2_max_frame_num = (int)l2f + 4;
+        const unsigned pt = br.ue();
+        if (pt > 2) { fail("pic_order_cnt_type %d", (int)pt); return false; }
+        s.poc_type = (int)pt;
+        if (s.poc_type == 0) {
+            const unsigned l2p = br.ue();
+            if (l2p > 12) { fail("log2_max_pic_order_cnt_lsb_minus4 %d", (int)l2p); return false; }
+            s.log2_max_poc_lsb = (int)l2p + 4;
+        }
         else if (s.poc_type == 1) {
             s.delta_pic_order_always_zero = br.u(1) != 0;
             br.se(); br.se();
             const unsigned n = br.ue();
+            if (n > 255) { fail("num_ref_frames_in_pic_order_cnt_cycle %d", (int)n); return false; }
             for (unsigned k = 0; k < n && !br.bad(); k++) br.se();
-        } else if (s.poc_type != 2) { fail("pic_order_cnt_type %d", s.poc_type); return false; }
-        s.max_refs = (int)br.ue();
+        }
+        const unsigned mr = br.ue();
+        if (mr > 3) { fail("max_num_ref_frames %d (up to 3)", (int)mr); return false; }
+        s.max_refs = (int)mr;
         br.u(1);   // gaps_in_frame_num_value_allowed_flag
-        s.mbw = (int)br.ue() + 1;
-        s.mbh = (int)br.ue() + 1;
+        const unsigned wmb = br.ue(), hmb = br.ue();
+        if (wmb > 255 || hmb > 255) { fail("picture of %d x %d macroblocks (up to 256 x 256)", (int)wmb + 1, (int)hmb + 1); return false; }
+        s.mbw = (int)wmb + 1;
+        s.mbh = (int)hmb + 1;
         if (!br.u(1)) { fail("frame_mbs_only_flag = 0 (interlaced coding)"); return false; }
         br.u(1);   // direct_8x8_inference_flag
-        if (br.u(1)) { s.crop_l = (int)br.ue(); s.crop_r = (int)br.ue(); s.crop_t = (int)br.ue(); s.crop_b = (int)br.ue(); }
+        if (br.u(1)) {
+            const unsigned cl = br.ue(), cr = br.ue(), ct = br.ue(), cb = br.ue();
+            if (cl + cr >= 8u * (unsigned)s.mbw || ct + cb >= 8u * (unsigned)s.mbh || cl > 4096 || cr > 4096 || ct > 4096 || cb > 4096) { fail("frame cropping larger than the picture"); return false; }
+            s.crop_l = (int)cl; s.crop_r = (int)cr; s.crop_t = (int)ct; s.crop_b = (int)cb;
+        }
         // (vui_parameters are not needed to decode samples)
-        if (br.bad() || s.mbw > 256 || s.mbh > 256) { fail("sequence parameter set damaged"); return false; }
-        if (s.max_refs > 3) { fail("max_num_ref_frames %d (up to 3)", s.max_refs); return false; }
+        if (br.bad()) { fail("sequence parameter set damaged"); return false; }
         s.valid = true;
         sps_[id] = s;
         return true;
@@ -257,15 +274,20 @@ private:
     {
         Pps p;
         const unsigned id = br.ue();
-        p.sps_id = (int)br.ue();
-        if (id > 255 || p.sps_id > 31) { fail("pic_parameter_set_id %d", (int)id); return false; }
+        const unsigned sid = br.ue();
+        if (id > 255 || sid > 31) { fail("pic_parameter_set_id %d", (int)id); return false; }
+        p.sps_id = (int)sid;
         if (br.u(1)) { fail("entropy_coding_mode_flag = 1 (CABAC)"); return false; }
         p.bottom_field_pic_order = br.u(1) != 0;
         if (br.ue() != 0) { fail("num_slice_groups_minus1 > 0 (FMO)"); return false; }
-        p.num_ref_default = (int)br.ue() + 1;
+        const unsigned nrd = br.ue();
+        if (nrd > 31) { fail("num_ref_idx_l0_default_active_minus1 %d", (int)nrd); return false; }
+        p.num_ref_default = (int)nrd + 1;
         br.ue();   // num_ref_idx_l1_default_active_minus1
         if (br.u(1) || br.u(2)) { fail("weighted prediction"); return false; }
-        p.pic_init_qp = 26 + br.se();
+        const int iq = br.se();
+        if (iq < -26 || iq > 25) { fail("pic_init_qp_minus26 %d", iq); return false; }
+        p.pic_init_qp = 26 + iq;
         br.se();   // pic_init_qs_minus26
         if (br.se() != 0) { fail("chroma_qp_index_offset != 0"); return false; }
         p.deblock_control = br.u(1) != 0;
@@ -424,8 +446,10 @@ private:
 
     bool parse_slice(BitReader& br, bool idr, int ref_idc, bool& have_pic, int& next_mb)
     {
-        const int first_mb = (int)br.ue();
-        int st = (int)br.ue();
+        const unsigned fm = br.ue(), stu = br.ue();
+        if (fm > 65535u || stu > 9u) { fail("slice header damaged (first_mb_in_slice / slice_type)"); return false; }
+        const int first_mb = (int)fm;
+        int st = (int)stu;
         if (st > 4) st -= 5;
         if (st != 0 && st != 2) { fail("slice_type %d (only I and P)", st); return false; }
         const unsigned pps_id = br.ue();
@@ -445,17 +469,19 @@ private:
         if (pps.redundant_pic_cnt) br.ue();
         int num_ref = pps.num_ref_default;
         if (st == 0) {
-            if (br.u(1)) num_ref = (int)br.ue() + 1;
+            if (br.u(1)) { const unsigned nr = br.ue(); num_ref = nr > 31 ? 99 : (int)nr + 1; }
             if (br.u(1)) { fail("ref_pic_list_modification"); return false; }
         }
         if (ref_idc != 0) {
             if (idr) { br.u(1); if (br.u(1)) { fail("long_term_reference_flag"); return false; } }
             else if (br.u(1)) { fail("adaptive_ref_pic_marking_mode_flag"); return false; }
         }
-        const int qp = pps.pic_init_qp + br.se();
+        const int qd = br.se();
+        const int qp = (qd < -64 || qd > 64) ? -1 : pps.pic_init_qp + qd;
         int idc = 0;
         if (pps.deblock_control) {
-            idc = (int)br.ue();
+            const unsigned di = br.ue();
+            idc = di > 2 ? 3 : (int)di;
             if (idc != 1 && (br.se() != 0 || br.se() != 0)) { fail("slice_alpha_c0 / beta offset != 0"); return false; }
         }
         if (br.bad() || qp < 0 || qp > 51 || idc > 2 || num_ref < 1 || num_ref > 3) { fail("slice header damaged"); return false; }
@@ -588,8 +614,9 @@ private:
             int ref = 0;
             if (num_ref_ > 1 && t != 4) {
                 for (int k = 0; k < nparts; k++) {
-                    const int r = num_ref_ == 2 ? (int)(1 - br.u(1)) : (int)br.ue();
-                    if (r >= num_ref_) { fail("ref_idx_l0 %d", r); return false; }
+                    const unsigned ru = num_ref_ == 2 ? 1u - br.u(1) : br.ue();
+                    if (ru >= (unsigned)num_ref_) { fail("ref_idx_l0 %d", (int)ru); return false; }
+                    const int r = (int)ru;
                     if (k && r != ref) { fail("partitions of one macroblock with different reference pictures"); return false; }
                     ref = r;
                 }
@@ -602,7 +629,10 @@ private:
                 else if (shape == 3) { x0 = k & 1; y0 = k >> 1; w = h = 1; }
                 int px, py;
                 predict(mx, my, x0, y0, w, h, ref, px, py);
-                const int vx = px + br.se(), vy = py + br.se();
+                const int dx = br.se(), dy = br.se();
+                if (dx < -8192 || dx > 8191 || dy < -8192 || dy > 8191) { fail("mvd_l0 out of range"); return false; }
+                const int vx = px + dx, vy = py + dy;
+                if (vx < -16384 || vx > 16383 || vy < -16384 || vy > 16383) { fail("motion vector out of range"); return false; }
                 for (int qy = y0; qy < y0 + h; qy++)
                     for (int qx = x0; qx < x0 + w; qx++) set_vectors(mx, my, 2 * qy + qx, vx, vy);
                 if (k == 0) { m.mvx = (int16_t)vx; m.mvy = (int16_t)vy; }
