@@ -115,9 +115,6 @@ def plugin_bench(streams, frames_per_stream, bitrate, device=0):
                 if rc != vc.SUCCESS:
                     fail[k] += 1
                 nbytes[k] += len(bs)
-                if k == 0 and i % 10 == 5:
-                    y = f[:WIDTH * HEIGHT].reshape(HEIGHT, WIDTH)
-                    psnr.append(synth.psnr(y, e.recon_y()[:HEIGHT, :WIDTH]))
 
         for k in range(S):   # warm-up outside the clock: first IDR, allocations
             encs[k].encode(frames[0])
@@ -128,6 +125,10 @@ def plugin_bench(streams, frames_per_stream, bitrate, device=0):
         for t in ths:
             t.join()
         dt = time.perf_counter() - t0
+        for j in range(3):   # quality, outside the clock: a few more pictures of stream 0 against its reconstruction
+            f = frames[(frames_per_stream + j + 1) % nsrc]
+            encs[0].encode(f)
+            psnr.append(synth.psnr(f[:WIDTH * HEIGHT].reshape(HEIGHT, WIDTH), encs[0].recon_y()[:HEIGHT, :WIDTH]))
         for e in encs:
             e.stop(); e.destroy(); e.delete()
         allat = np.sort(np.concatenate([np.asarray(x) for x in lat])) * 1e3

@@ -7,6 +7,7 @@
 // :408).  There is no CPU encode path here: without a HIP device create() fails.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <atomic>
 #include <cstdarg>
 #include <cmath>
 #include <cstdio>
@@ -162,7 +163,8 @@ struct mi355x_h264_encoder {
     int b_sl0 = 0, b_nsl = 1, b_row0 = 0, b_rows = 0, b_nmb = 0;
     size_t st_y = 0, st_c = 0, st_bitbuf_bytes = 0, st_au = 0, st_handoff = 0;  // per-item strides
     hipStream_t stream = nullptr;
-    hipStream_t stream_ec = nullptr;         // entropy coding runs here, beside the deblocking wavefront
+    hipStream_t stream_ec = nullptr;         // entropy coding runs here, beside the deblocking wavefront (= stream when the process holds many engines)
+    std::atomic<int>* counted_live = nullptr;
     enum { MAX_REFS = 3 };
     int nrefs = 1, nbuf = 2;                 // reference frames searched (config.refs) and reconstruction buffers (nrefs + 1)
     uint8_t* d_planes[MAX_REFS + 1][3] = {{nullptr}};  // ring: [index][plane]; `cur` is written, cur - 1 - r (mod nbuf) is ref_idx_l0 r
@@ -651,7 +653,18 @@ int mi355x_h264_create(const mi355x_h264_config* cfg, mi355x_h264_encoder** out)
     } while (0)
     CK(hipSetDevice(e->device));
     CK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
-    CK(hipStreamCreateWithFlags(&e->stream_ec, hipStreamNonBlocking));
+    // Entropy coding normally runs on a stream of its own beside the loop filter (shorter picture latency).  A process that
+    // holds many engines (the plugin surface with many streams: one engine per VideoEncoder object) would then ask for more
+    // hardware queues than the device has, and the runtime's multiplexing costs more than the overlap gains (16 plugin streams: 3.8 k -> 6.0 k fps; 4 streams: p99 8 -> 4 ms): from the third
+    // live engine on (or with MI355X_H264_ONE_STREAM=1) an engine uses its one stream for everything.
+    {
+        static std::atomic<int> live{0};
+        const char* one = getenv("MI355X_H264_ONE_STREAM");
+        const int n = live.fetch_add(1) + 1;
+        e->counted_live = &live;
+        if ((one && one[0] == '1') || (n > 2 && !(one && one[0] == '0'))) e->stream_ec = e->stream;
+        else CK(hipStreamCreateWithFlags(&e->stream_ec, hipStreamNonBlocking));
+    }
     const size_t ysz = (size_t)e->cw * e->ch;
     const size_t Gn = (size_t)e->G;
     e->st_y = ysz + 256; e->st_c = ysz / 4 + 256;
@@ -742,7 +755,8 @@ void mi355x_h264_destroy(mi355x_h264_encoder* e)
         for (auto& ev : S.evs) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
     }
     for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
-    if (e->stream_ec) { (void)hipStreamSynchronize(e->stream_ec); (void)hipStreamDestroy(e->stream_ec); }
+    if (e->stream_ec && e->stream_ec != e->stream) { (void)hipStreamSynchronize(e->stream_ec); (void)hipStreamDestroy(e->stream_ec); }
+    if (e->counted_live) e->counted_live->fetch_sub(1);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
