@@ -189,20 +189,41 @@ def decode_bench(frames_n, device=0):
         dec.decode(aus[0])            # engine creation + first launches are not timed
         dec.close()
         dec = h264dec.Decoder(device)
-        ok = True
         t0 = time.perf_counter()
-        for i, au in enumerate(aus):
+        for au in aus:
             dec.decode(au)
             if read:
                 dec.i420()
         dt = time.perf_counter() - t0
         n, parse_ms, gpu_ms = dec.timing()
-        for i in (0, len(aus) - 1):   # spot check outside the timed region
-            pass
         ok = bool(np.array_equal(dec.plane(0), recs[-1]))
         dec.close()
         out[label] = {"fps": round(frames_n / dt, 1), "ms_per_picture": round(dt / frames_n * 1e3, 3), "host_parse_ms_per_picture": round(parse_ms / n, 3),
                       "upload_and_gpu_ms_per_picture": round(gpu_ms / n, 3), "last_picture_equals_encoder_reconstruction": ok}
+    # several streams: S decoder objects on S host threads (each parses on its own core; the reconstructions share the GPU)
+    out["streams"] = []
+    for S in (4, 16):
+        decs = [h264dec.Decoder(device) for _ in range(S)]
+        for d in decs:
+            d.decode(aus[0])
+        good = [True] * S
+
+        def work(k):
+            for au in aus[1:]:
+                decs[k].decode(au)
+                decs[k].i420()
+            good[k] = bool(np.array_equal(decs[k].plane(0), recs[-1]))
+
+        ths = [threading.Thread(target=work, args=(k,)) for k in range(S)]
+        t0 = time.perf_counter()
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        dt = time.perf_counter() - t0
+        for d in decs:
+            d.close()
+        out["streams"].append({"streams": S, "fps_aggregate": round(S * (frames_n - 1) / dt, 1), "all_equal_encoder_reconstruction": all(good)})
     return out
 
 

@@ -100,7 +100,7 @@ def main():
             "ms_per_picture": round(dt / args.steps / gop * 1e3, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": "%dx%d I420 synthetic S1, baseline profile, fixed QP %d, closed GOP of %d, %d slice bands per picture "
-                                   "(disable_deblocking_filter_idc 2), 1 ref; band r of every picture on GPU r, halo swap per picture" % (w, h, qp, gop, args.slices),
+                                   "(disable_deblocking_filter_idc 2), %d reference picture(s); band r of every picture on GPU r, halo swap per picture" % (w, h, qp, gop, args.slices, max(1, args.refs)),
                        "bytes_per_gop": nbytes[0]}}))
     if dist is not None:
         dist.destroy_process_group()
