@@ -83,7 +83,10 @@ __device__ __forceinline__ uint32_t chroma_pred4(const uint8_t* cp, int cs2, int
     return o;
 }
 
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_me(FrameParams P0)
+#ifndef ME_WAVES_MIN
+#define ME_WAVES_MIN 6
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ME_WAVES_MIN, 8))) void k_me(FrameParams P0)
 {
     const FrameParams P = batch_view(P0, blockIdx.y);
     const int lane = threadIdx.x;
