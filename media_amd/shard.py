@@ -127,14 +127,36 @@ def gather_access_unit(part, rank, world, dist, device=None, cap=None, sizes_out
     return b"".join(parts[r][:sizes[r]].cpu().numpy().tobytes() for r in range(world))
 
 
-def encode_picture_bands(engine, frame, rank, world, dist, halo, device=None, rc=None):
+SCENE_CUT_COST_PER_MB = 3000   # = VideoEncoderMI355X::Rc::kSceneCutCostPerMb (media_amd/host/VideoEncoderMI355X.h)
+
+
+def encode_picture_bands(engine, frame, rank, world, dist, halo, device=None, rc=None, scene_detect=False, picture_mbs=None,
+                         cut_cost_per_mb=SCENE_CUT_COST_PER_MB):
     """one picture of a band-sharded stream: code this rank's slices, swap halos, gather the access unit on rank 0.
     rc (media_amd.ratecontrol.RateControl, the same initial state on every rank): bitrate mode.  Every rank sets the
     picture QP from its own copy of the controller and feeds it the picture's TOTAL size, which the gather's size
-    exchange already delivers to every rank - the copies stay identical without any further message."""
+    exchange already delivers to every rank - the copies stay identical without any further message.
+    scene_detect (the plugin class's rule, bEnableSceneChangeDetect of the reference preset): the bands' motion costs of a P
+    picture are summed over the ranks (one all_reduce of one integer); when the mean exceeds SCENE_CUT_COST_PER_MB per
+    macroblock of the PICTURE (picture_mbs) every rank drops its band of that P picture and codes it again as an IDR - the
+    same decision on every rank, before any halo is swapped."""
     if rc is not None:
         engine.set_qp(rc.qp)
     part, idr = engine.encode(frame)[:2]
+    if scene_detect and not (idr == 1 or idr is True):
+        import torch
+        cost = engine.me_cost()
+        cost = int(cost[0]) if hasattr(cost, "__len__") else int(cost)
+        if world > 1:
+            t = torch.tensor([cost], dtype=torch.int64, device=device)
+            dist.all_reduce(t)
+            cost = int(t.item())
+        if cost > cut_cost_per_mb * int(picture_mbs):
+            if hasattr(engine, "force_idr"):
+                engine.force_idr()
+                part, idr = engine.encode(frame)[:2]
+            else:
+                part, idr = engine.encode(frame, force_idr=True)[:2]
     exchange_band_halos(engine, rank, world, dist, halo)
     sizes = []
     au = gather_access_unit(part, rank, world, dist, device, sizes_out=sizes)

@@ -159,8 +159,12 @@ def _band_worker(rank, world, port, q):
     eng2 = OracleEncoder(w, h, qp=27, gop=4, slices=slices, band_index=rank, band_count=world)
     rc = RateControl(300000, 30)
     aus_rc = [shard.encode_picture_bands(eng2, f, rank, world, dist, halo, rc=rc) for f in synth.sequence("s1", w, h, n)]
+    # scene detection in band mode: the bands' motion costs are summed over the ranks, a cut re-codes the picture as an IDR
+    eng3 = OracleEncoder(w, h, qp=27, gop=30, slices=slices, band_index=rank, band_count=world)
+    aus_cut = [shard.encode_picture_bands(eng3, f, rank, world, dist, halo, scene_detect=True, picture_mbs=(w // 16) * (h // 16), cut_cost_per_mb=1500)
+               for f in synth.sequence("cut", w, h, 5)]
     if rank == 0:
-        q.put((aus, aus_rc, rc.state()))
+        q.put((aus, aus_rc, rc.state(), aus_cut))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -180,7 +184,7 @@ def test_slice_band_sharding_of_one_picture_swaps_halos():
     procs = [ctx.Process(target=_band_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    aus, aus_rc, rc_state = q.get(timeout=120)
+    aus, aus_rc, rc_state, aus_cut = q.get(timeout=180)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -200,3 +204,14 @@ def test_slice_band_sharding_of_one_picture_swaps_halos():
         rc.update(len(bs), idr)
         assert aus_rc[i] == bs, "bitrate mode, picture %d" % i
     assert rc.state() == tuple(rc_state) and len(qps) > 1      # (the controller did move the QP)
+    # scene detection: ONE encoder under the plugin class's rule (mean motion cost > 3000 per macroblock -> the P picture is
+    # dropped and coded again as IDR) makes the same stream; the cut of the "cut" content (picture 2) is found
+    one = OracleEncoder(w, h, qp=27, gop=30, slices=slices)
+    kinds = []
+    for i, f in enumerate(synth.sequence("cut", w, h, 5)):
+        bs, idr = one.encode(f)
+        if not idr and one.me_cost() > 1500 * (w // 16) * (h // 16):   # (the plugin class's rule with a threshold this small content reaches)
+            bs, idr = one.encode(f, force_idr=True)
+        assert aus_cut[i] == bs, "scene detection, picture %d" % i
+        kinds.append(bool(idr))
+    assert kinds == [True, False, True, False, False]
