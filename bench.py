@@ -487,8 +487,8 @@ def main():
         fps = total_frames / dt
         k = st["kernels"]
         nmb = (WIDTH // 16) * ((HEIGHT + 15) // 16)
-        pmb = k["pmb"]
-        pmb_ms = pmb["ms"] / max(1, pmb["launches"])
+        tq = k["tq"]
+        pmb_ms = tq["ms"] / max(1, tq["launches"])
         achieved = PMB_BYTES_PER_MB * nmb * B / (pmb_ms * 1e-3) / 1e9 if pmb_ms > 0 else 0.0
         per_kernel = {}
         for name, v in k.items():
@@ -527,7 +527,7 @@ def main():
             "single_gop_in_flight_fps": round(lat_steps * FRAMES_PER_STEP / lat_dt, 2),
         }
         if st_ex is not None:
-            pe = st_ex["kernels"]["pmb"]
+            pe = st_ex["kernels"]["tq"]
             ms_e = pe["ms"] / max(1, pe["launches"])
             a_e = PMB_BYTES_PER_MB * nmb * B / (ms_e * 1e-3) / 1e9
             res["roofline_exclusive"] = {"kernel": "k_tq, same launches with one instance running alone (no other stream's kernels "
@@ -535,7 +535,7 @@ def main():
                                          "unit": "GB/s", "frac": round(a_e / HBM_PEAK_GBS, 4), "avg_launch_ms": round(ms_e, 5)}
             res["kernels_exclusive"] = {name: {"ms_per_launch": round(v["ms"] / v["launches"], 4)}
                                         for name, v in st_ex["kernels"].items() if v["launches"]}
-        p1 = st1["kernels"]["pmb"]
+        p1 = st1["kernels"]["tq"]
         if p1["launches"]:
             ms1 = p1["ms"] / p1["launches"]
             a1 = PMB_BYTES_PER_MB * nmb / (ms1 * 1e-3) / 1e9

@@ -190,7 +190,7 @@ int64_t mi355x_h264_debug_read(mi355x_h264_encoder *enc, int what, void *dst, si
  * events on the encoder's own stream */
 enum {
     MI355X_H264_K_ME = 0,       /* motion search (SAD integer + SATD sub-pel)      */
-    MI355X_H264_K_PMB = 1,      /* MC + fDCT + quant + dequant + iDCT + recon      */
+    MI355X_H264_K_PMB = 1,      /* residual + fDCT + quant + dequant + iDCT + recon (k_tq / k_tq8; the MC moved into the search) */
     MI355X_H264_K_INTRA = 2,    /* Intra16x16 wavefront                            */
     MI355X_H264_K_CAVLC = 3,    /* entropy coding + packing                        */
     MI355X_H264_K_DEBLOCK = 4,  /* loop filter wavefront                           */

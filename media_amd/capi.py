@@ -16,7 +16,7 @@ MBINFO_DTYPE = np.dtype([("mvx", "<i2"), ("mvy", "<i2"), ("type", "u1"), ("i16_m
                          ("chroma_mode", "u1"), ("cbp", "u1"), ("tc", "u1", (24,))])
 FRAME_IDR, FRAME_P = 1, 3
 DBG_RECON_Y, DBG_RECON_U, DBG_RECON_V, DBG_MBINFO, DBG_LEVELS, DBG_PRE_Y, DBG_PRE_U, DBG_PRE_V, DBG_MBAUX, DBG_MVQ = range(10)
-K_NAMES = ["me", "pmb", "intra", "cavlc", "deblock"]
+K_NAMES = ["me", "tq", "intra", "cavlc", "deblock"]   # index = MI355X_H264_K_* (1: the id is still called K_PMB: k_tq / k_tq8 replaced k_pmb2)
 
 EXPORTS = [
     "mi355x_h264_abi_version", "mi355x_h264_default_config", "mi355x_h264_create", "mi355x_h264_destroy",
