@@ -137,9 +137,47 @@ def plugin_bench(streams, frames_per_stream, bitrate, device=0):
                     "latency_ms_p50": round(float(allat[len(allat) // 2]), 3), "latency_ms_p99": round(float(allat[min(len(allat) - 1, int(len(allat) * 0.99))]), 3),
                     "bytes_per_picture": round(sum(nbytes) / n, 1), "bitrate_target": bitrate, "bitrate_achieved": round(sum(nbytes) * 8 * 30 / n),
                     "psnr_y_db": round(float(np.mean(psnr)), 2) if psnr else None, "pictures": n, "encode_failures": sum(fail)})
-    return {"what": "VideoCodecApi plugin surface (CreateVideoEncoder / EncodeOneFrame), host I420 pictures over PCIe, bitrate mode, scene detection on, "
-                    "1080p30 S1, GOP 30, baseline; S encoder objects on S host threads of one process",
-            "results": out}
+    res = {"what": "VideoCodecApi plugin surface (CreateVideoEncoder / EncodeOneFrame), host I420 pictures over PCIe, bitrate mode, scene detection on, "
+                   "1080p30 S1, GOP 30, baseline; S encoder objects on S host threads of one process (Python threads over ctypes)",
+           "results": out}
+    try:
+        native = plugin_bench_native(streams, frames_per_stream, bitrate, device)
+        if native is not None:
+            res["native"] = native
+    except Exception as exc:   # the side measurement must not take the line down
+        res["native"] = {"error": str(exc)}
+    return res
+
+
+def plugin_bench_native(streams, frames_per_stream, bitrate, device=0):
+    """The same measurement with NO interpreter in the timed region: tools/plugin_bench.cpp (media_amd/lib/plugin_bench), S
+    std::threads on the C++ plugin surface.  None when the binary has not been built."""
+    import subprocess
+    import tempfile
+    import numpy as np
+    from media_amd import synth
+    exe = os.path.join(ROOT, "media_amd", "lib", "plugin_bench")
+    if not os.path.exists(exe):
+        return None
+    nsrc = 30
+    env = dict(os.environ)
+    env.update({"RO_VMI_DEMO_VIDEO_ENCODE_FORMAT": "3", "RO_SYS_VMI_CLOUDPHONE": "video", "RO_HARDWARE_WIDTH": str(WIDTH),
+                "RO_HARDWARE_HEIGHT": str(HEIGHT), "RO_HARDWARE_FPS": "30", "PERSIST_VMI_VIDEO_ENCODE_BITRATE": str(bitrate),
+                "PERSIST_VMI_VIDEO_ENCODE_GOPSIZE": str(GOP), "PERSIST_VMI_VIDEO_ENCODE_PROFILE": "baseline",
+                "PERSIST_VMI_VIDEO_ENCODE_PARAM_ADJUSTING": "0", "PERSIST_VMI_VIDEO_ENCODE_KEYFRAME": "0",
+                "PERSIST_VMI_VIDEO_ENCODE_SCENEDETECT": "1", "PERSIST_VMI_VIDEO_ENCODE_DEVICE": str(device), "MEDIA_LOG_QUIET": "1"})
+    env.pop("PERSIST_VMI_VIDEO_ENCODE_QP", None)
+    with tempfile.NamedTemporaryFile(suffix=".i420") as f:
+        for fr in synth.sequence("s1", WIDTH, HEIGHT, nsrc):
+            f.write(np.ascontiguousarray(fr).tobytes())
+        f.flush()
+        r = subprocess.run([exe, f.name, str(WIDTH), str(HEIGHT), str(nsrc), str(frames_per_stream), ",".join(str(s) for s in streams)],
+                           env=env, capture_output=True, text=True, timeout=600)
+    rows = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    if r.returncode != 0 or not rows:
+        return {"error": "plugin_bench exited %d: %s" % (r.returncode, r.stderr[-300:])}
+    return {"what": "the same through tools/plugin_bench.cpp: S std::threads on the C++ VideoEncoder surface (no interpreter in the timed region), "
+                    "host I420 pictures over PCIe, bitrate mode %d bit/s, scene detection on" % bitrate, "results": rows}
 
 
 def openh264_differential(frames, count):
