@@ -1067,8 +1067,6 @@ struct mi355x_h264_decoder {
     int width = 0, height = 0, crop_x = 0, crop_y = 0;
     uint64_t pictures = 0;
     double parse_ms = 0, gpu_ms = 0;
-    // the parser's arrays are page-locked once per picture size, so that their upload is one DMA each
-    const void* reg[4] = {nullptr, nullptr, nullptr, nullptr};
     char err[256] = {0};
 };
 
@@ -1103,16 +1101,6 @@ int dec_submit(mi355x_h264_decoder* d, const h264dec::Picture& pic)
     mi355x_h264_encoder* e = d->eng;
     const size_t nmb = (size_t)e->nmb;
     hipStream_t st = e->stream;
-    {
-        const void* ptr[4] = {pic.mb.data(), pic.mvq.data(), pic.aux.data(), pic.levels.data()};
-        const size_t bytes[4] = {nmb * sizeof(MbInfo), nmb * 16, nmb * 16, nmb * LV_STRIDE * sizeof(int16_t)};
-        for (int i = 0; i < 4; i++)
-            if (d->reg[i] != ptr[i]) {   // (the vectors keep their storage while the picture size stays the same)
-                if (d->reg[i]) (void)hipHostUnregister(const_cast<void*>(d->reg[i]));
-                d->reg[i] = hipHostRegister(const_cast<void*>(ptr[i]), bytes[i], hipHostRegisterDefault) == hipSuccess ? ptr[i] : nullptr;
-                (void)hipGetLastError();
-            }
-    }
     DHIP(d, hipMemcpyAsync(e->d_mb, pic.mb.data(), nmb * sizeof(MbInfo), hipMemcpyHostToDevice, st));
     DHIP(d, hipMemcpyAsync(e->d_mvq, pic.mvq.data(), nmb * 16, hipMemcpyHostToDevice, st));
     DHIP(d, hipMemcpyAsync(e->d_aux, pic.aux.data(), nmb * 16, hipMemcpyHostToDevice, st));
@@ -1210,8 +1198,6 @@ int mi355x_h264_dec_create(int device, mi355x_h264_decoder** out)
 void mi355x_h264_dec_destroy(mi355x_h264_decoder* d)
 {
     if (!d) return;
-    for (int i = 0; i < 4; i++)
-        if (d->reg[i]) (void)hipHostUnregister(const_cast<void*>(d->reg[i]));
     if (d->eng) mi355x_h264_destroy(d->eng);
     delete d;
 }
