@@ -5,7 +5,7 @@ indices, coded_block_pattern, TotalCoeff, the quadrant vectors (mvd + its own st
 import numpy as np
 import pytest
 from media_amd import synth, h264dec
-from oracle_lib import OracleEncoder
+from oracle_lib import OracleEncoder, OracleDecoder
 
 CASES = [("s1", 176, 144, 26, 66, 0, 0), ("cut", 208, 160, 28, 66, 0, 0), ("split", 176, 144, 26, 66, 0, 0), ("s3", 96, 80, 30, 66, 0, 0),
          ("s3", 64, 48, 10, 66, 0, 0), ("split", 208, 160, 30, 100, 2, 0), ("cut", 176, 144, 22, 77, 3, 3), ("scroll", 130, 98, 30, 100, 0, 2),
@@ -109,3 +109,45 @@ def test_parser_survives_damaged_streams():
     for au in streams[0]:
         assert par.parse(au)
     par.close()
+
+
+def test_two_independent_parsers_agree_on_damaged_streams():
+    """Differential check between the product's host parser (media_amd/csrc/h264_parse.h) and the oracle's independent decoder
+    (oracle/h264_dec.c), which share no code: 2 000 damaged P-picture access units are given to both after the same intact IDR
+    picture.  Each may refuse a unit (the oracle decoder supports more syntax than the product parser, so it accepts more), but
+    whenever BOTH accept one they must have read the same macroblock kinds and the same quadrant vectors out of the same bits."""
+    import random
+    rng = random.Random(99)
+    kind_of = {0: 2, 4: 1, 3: 3, 1: 4, 5: 4, 6: 4, 7: 4, 2: 5}   # product type -> oracle decoder kind (I16, I4, I_PCM, inter, skip)
+    both = 0
+    for (content, w, h, qp, prof, refs) in (("cut", 96, 80, 28, 66, 0), ("split", 96, 80, 26, 100, 2), ("s1", 64, 48, 34, 77, 0)):
+        enc = OracleEncoder(w, h, qp=qp, gop=30, profile_idc=prof, refs=refs)
+        aus = [enc.encode(f)[0] for f in synth.sequence(content, w, h, 3)]
+        for case in range(700):
+            au = bytearray(aus[1 + case % 2])
+            for _ in range(rng.randint(1, 3)):
+                k = rng.randrange(6, len(au))          # (leave the NAL header alone)
+                au[k] ^= 1 << rng.randrange(8)
+            dec, par = OracleDecoder(), h264dec.Parser()
+            assert dec.decode(aus[0]) == 1 and par.parse(aus[0])
+            if case % 2:
+                assert dec.decode(aus[1]) == 1 and par.parse(aus[1])
+            try:
+                ok_dec = dec.decode(bytes(au)) == 1
+            except Exception:
+                ok_dec = False
+            try:
+                ok_par = par.parse(bytes(au))
+            except h264dec.StreamError:
+                ok_par = False
+            if ok_dec and ok_par:
+                both += 1
+                mb, mvq, _, _ = par.arrays()
+                kinds = dec.mb_kinds()
+                assert [kind_of[t] for t in mb["type"]] == list(kinds), (content, case)
+                for a in np.where(np.isin(mb["type"], (1, 2, 5, 6, 7)))[0][::5]:
+                    for q in range(4):
+                        x, y, r = dec.mb_mv(int(a), (q >> 1) * 8 + (q & 1) * 2)
+                        assert (x, y, r) == (mvq[a, 2 * q], mvq[a, 2 * q + 1], mb["chroma_mode"][a]), (content, case, a, q)
+            par.close()
+    assert both > 150, both
