@@ -125,7 +125,7 @@ struct IntraLds {
     __attribute__((aligned(16))) uint8_t rec_c[128];   // Cb 8x8, Cr 8x8 (pitch 8)
     __attribute__((aligned(16))) int16_t lv[LV_STRIDE];
     int dc[16];
-    uint8_t top[20], left[16];        // luma neighbours; top[0] = top-left
+    uint8_t top[24], left[16];        // luma neighbours; top[0] = top-left, top[1..16] above, top[17..20] above-right (decoder only)
     uint8_t ctop[2][12], cleft[2][8];
     I4Lds i4;                         // Intra4x4 macroblocks (k_intra4.h)
 };
@@ -171,7 +171,7 @@ __device__ __forceinline__ void intra_mb_core(const FrameParams& P, int mx, int 
     if (use_i4) {
         const uint32_t m0 = (uint32_t)__builtin_amdgcn_readlane((int)auxw, 0), m1 = (uint32_t)__builtin_amdgcn_readlane((int)auxw, 1);
         const uint32_t m2 = (uint32_t)__builtin_amdgcn_readlane((int)auxw, 2), m3 = (uint32_t)__builtin_amdgcn_readlane((int)auxw, 3);
-        cbp_luma_i4 = i4_code_luma<DEC>(P.qy, S.i4, S.top, S.left, S.src, m0, m1, m2, m3, S.lv, S.dc, mx, top, lane);   // (S.dc: TotalCoeff of the 16 blocks)
+        cbp_luma_i4 = i4_code_luma<DEC>(P.qy, S.i4, S.top, S.left, S.src, m0, m1, m2, m3, S.lv, S.dc, mx, top, top && mx + 1 < P.mbw, lane);   // (S.dc: TotalCoeff of the 16 blocks)
         const uint32_t o = *(const uint32_t*)(S.i4.rb + (1 + (lane >> 2)) * 32 + 4 + (lane & 3) * 4);
         *(uint32_t*)(S.rec_y + (lane >> 2) * 16 + (lane & 3) * 4) = o;
         *(uint32_t*)(P.rec[0] + (size_t)(by + (lane >> 2)) * P.cw + bx + (lane & 3) * 4) = o;
@@ -654,6 +654,17 @@ __global__ __launch_bounds__(64) void k_pintra_rows(IntraRowParams R)
                 } else {
                     if (lane < 16) S.top[1 + lane] = P.rec[0][(size_t)(16 * my - 1) * P.cw + 16 * mx + lane];
                     else if (lane < 32) S.ctop[(lane >> 3) & 1][1 + (lane & 7)] = rec_chroma(P, lane & 8)[(size_t)(8 * my - 1) * cs + 8 * mx + (lane & 7)];
+                }
+                if (DEC && mx + 1 < P.mbw) {   // the decoder also needs the four samples above-right (Intra4x4 modes 3 / 7 of block (3, 0))
+                    if (marked(mx + 1, my - 1)) {
+                        unsigned long long g;
+                        wait_granules(mx + 1, 1, g);
+                        if (lane == 0) {
+                            const uint32_t v = (uint32_t)g;
+#pragma unroll
+                            for (int k = 0; k < 4; k++) S.top[17 + k] = (uint8_t)(v >> (8 * k));
+                        }
+                    } else if (lane < 4) S.top[17 + lane] = P.rec[0][(size_t)(16 * my - 1) * P.cw + 16 * (mx + 1) + lane];
                 }
                 if (mx > 0) {
                     if (dI) {   // last samples of the bottom rows of the macroblock above-left: granules 3 (luma), 5 (Cb), 7 (Cr)

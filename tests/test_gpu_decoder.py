@@ -56,3 +56,18 @@ def test_decoder_on_the_hip_encoders_streams_and_size_change():
     assert fresh.decode(aus[0]) and fresh.decode(aus[1])
     fresh.close()
     dec.close()
+
+
+def test_intra4x4_block_3_0_reads_the_macroblock_above_right():
+    """tests/golden/dec_damaged_i4_topright.h264: an IDR picture of the oracle encoder with a few flipped bits, found by
+    tools/soak_decoder.py's differential run.  It is still a conforming picture, and one of its Intra4x4 macroblocks predicts
+    block (3, 0) with mode 7 (vertical-left), which reads four samples of the macroblock ABOVE-RIGHT - something this
+    repository's encoder never produces (its row wavefront lags one macroblock, so it does not offer that block the two modes).
+    The decoder must follow the standard, not the encoder: its intra row wavefront waits for the macroblock above-right too."""
+    import os
+    au = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dec_damaged_i4_topright.h264"), "rb").read()
+    ref, dec = OracleDecoder(), h264dec.Decoder()
+    assert ref.decode(au) == 1 and dec.decode(au)
+    for p in range(3):
+        assert np.array_equal(dec.plane(p), ref.plane(p)), "plane %d" % p
+    dec.close()
