@@ -2,12 +2,13 @@
 GOP, profile, loop filter, NV12 / I420, slices, content (pan, scroll, static, noise, local uncovered areas): every access
 unit of the HIP path against the CPU oracle.  Round 1: seeds 1 and 2, 17 000 cases, 0 mismatches (about 17 ms a case).
 Round 2 adds 1..3 reference pictures, the 'split' (partitions) and 'cut' (intra in P) contents; no exception is tolerated
-(the I_PCM fallback makes a payload overflow impossible)."""
+(the I_PCM fallback makes a payload overflow impossible); every other case also sends the stream through the oracle's
+independent decoder (reconstruction equal, no macroblock above 3 200 bits, no level_prefix above 15)."""
 import sys, time; sys.path.insert(0,'.'); sys.path.insert(0,'tests')
 import numpy as np, random, torch
 torch.cuda.init()
 from media_amd import capi, synth
-from oracle_lib import OracleEncoder
+from oracle_lib import OracleEncoder, OracleDecoder
 seed = int(sys.argv[1]); ncase = int(sys.argv[2])
 rng = random.Random(seed)
 bad = 0; t0 = time.time()
@@ -45,10 +46,14 @@ for case in range(ncase):
     try:
         enc = capi.Encoder(w, h, qp=qp, gop=gop, profile_idc=prof, disable_deblock=int(nodb), input_format=int(nv12), slices=sl, refs=refs)
         orc = OracleEncoder(w, h, qp=qp, gop=gop, profile_idc=prof, disable_deblock=int(nodb), slices=sl, refs=refs)
+        odec = OracleDecoder() if case % 2 == 0 else None   # every other case: the stream through the independent decoder too
         for i, f in enumerate(frames):
             if rng.random() < 0.15:
                 q2 = rng.randint(10, 51); enc.set_qp(q2); orc.set_qp(q2)
             want = orc.encode(f)[0]
+            if odec is not None:
+                if odec.decode(want) != 1 or any(not np.array_equal(odec.plane(p), orc.recon(p)) for p in range(3)) or odec.max_mb_bits > 3200 or odec.max_level_prefix > 15:
+                    bad += 1; print("ROUNDTRIP", tag, "frame", i, flush=True); break
             if nv12:
                 d = torch.from_numpy(to_nv12(f, w, h)).cuda(); got = enc.encode_device(d.data_ptr())[0]
             else:
