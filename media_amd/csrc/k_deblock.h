@@ -417,4 +417,205 @@ __global__ __launch_bounds__(64) void k_deblock_rows(DbRowParams R)
 #undef SC
 }
 
+
+// ===========================================================================
+// Pair form of the persistent loop filter: ONE wave filters TWO macroblock rows - lanes 0..31 row 2p
+// (macroblock t in iteration t), lanes 32..63 row 2p + 1 two macroblocks behind (macroblock t - 2), which is exactly the lag
+// 8.7 demands (left, top, top-right).  Both rows run the SAME instruction stream: every phase of the row form used lanes
+// 0..31 only for the filter arithmetic, so a lockstep batch needs half the waves and half the filter instructions per
+// macroblock, and the upper row hands its bottom sample rows to the lower one through LDS (a two-slot ring: written in
+// iteration t - 1, read in iteration t) instead of 24 global granules and their latency.  Between pairs the hand-off is
+// the row form's ({tag, 4 samples} granules in global memory), and so is everything else: tile layout, the branch-free
+// filter, prefetch one macroblock ahead, one writer per picture sample, bounded spins.
+// MEASURED (bench workload, 32 pictures per launch): the launch gets 7 % shorter (0.787 -> 0.728 ms alone, 0.893 -> 0.845 ms beside
+// the other instance), the pipeline 1 % slower (23.5 -> 23.3 k fps): each step of the 254-step critical path now carries the data
+// movement of two macroblocks (32 lanes per row instead of 64), and the waves the row form had too many of were asleep in their
+// hand-off spins, not contending for issue.  So this form is an option (MI355X_H264_PAIR_FILTER=N: batches of N pictures or
+// more, pictures of one slice), kept correct by tests/test_gpu_parity.py, and the row form stays the default.
+// ===========================================================================
+template <bool BS4>
+__global__ __launch_bounds__(64) void k_deblock_pairs(DbRowParams R)
+{
+    __builtin_amdgcn_s_setprio(3);
+    if (R.anybs[blockIdx.y] != R.serial) return;
+    if (R.anypcm[blockIdx.y] == R.pic_serial) return;
+    if (R.need_intra != 0 && (R.anyintra[blockIdx.y] == R.pic_serial) != (R.need_intra > 0)) return;
+    DbParams D = R.d;
+    {
+        const size_t g = blockIdx.y;
+        D.pl[0] += g * R.st_y; D.pl[1] += g * R.st_c; D.pl[2] += g * R.st_c; D.mb += g * R.st_mb;
+    }
+    u64* const handoff = R.handoff + (size_t)blockIdx.y * R.st_handoff;
+    const uint32_t* const bsw = R.bs + (size_t)blockIdx.y * R.st_mb * 8;
+    const int lane = threadIdx.x, half = lane >> 5, hl = lane & 31, cs = D.cw / 2;
+    const int rowA = R.row0 + 2 * (int)blockIdx.x, rowB = rowA + 1;
+    const bool hasB = rowB < D.mbh;                 // (an odd number of rows: the last wave has an upper row only)
+    const int my = half ? (hasB ? rowB : rowA) : rowA;
+    const bool live = half == 0 || hasB;            // lanes 32..63 of a wave without a lower row idle along on row A's addresses and store nothing
+    const bool first_row = half == 0 && rowA == 0;  // (one slice: only picture row 0 has nothing above)
+    const bool last_row = my == D.mbh - 1;
+    const bool from_lds = half == 1;                // the lower row's top apron comes from the upper row through LDS
+    __shared__ __attribute__((aligned(16))) uint8_t s_yy[2][20 * DR_LP];
+    __shared__ __attribute__((aligned(16))) uint8_t s_cc[2][2][20 * DR_CP];
+    __shared__ __attribute__((aligned(16))) uint32_t s_ring[2][24];   // bottom rows of the upper row's macroblock (parity of its index): 16 luma + 8 chroma dwords
+    uint8_t* const s_y = s_yy[half];
+#define SY(r, c) s_y[((r) + 4) * DR_LP + (c) + 16]
+#define SC(pl, r, c) s_cc[half][pl][((r) + 4) * DR_CP + (c) + 8]
+    bool timed_out = false;
+    // luma dwords owned by this lane: two of the 64 of a macroblock (rows yr0 and yr0 + 8); chroma dword as in the row form
+    const int yr0 = hl >> 2, yc4 = (hl & 3) * 4;
+    const int cpl_l = (hl >> 4) & 1, cr_l = (hl >> 1) & 7, cc4 = (hl & 1) * 4;
+    const int gk = hl;   // granule index (hl < 24)
+    const bool isC = hl >= 16;
+    const int fpl = (hl >> 3) & 1, fln = isC ? (hl & 7) : hl;
+    const int seg8 = 8 * (isC ? (fln >> 1) : (fln >> 2));
+    const int al = isC ? D.alpha_c : D.alpha_y, be = isC ? D.beta_c : D.beta_y;
+    const int t1 = isC ? D.tc0_c[0] : D.tc0_y[0], t2 = isC ? D.tc0_c[1] : D.tc0_y[1], t3 = isC ? D.tc0_c[2] : D.tc0_y[2];
+    uint8_t* vrow = isC ? &SC(fpl, fln, -4) : &SY(fln, -4);
+    uint8_t* hcol = isC ? &SC(fpl, -4, fln) : &SY(-4, fln);
+    const int hstride = isC ? DR_CP : DR_LP;
+
+    uint32_t pf_y0 = 0, pf_y1 = 0, pf_c = 0;
+    uint4 pf_b0 = {0, 0, 0, 0}, pf_b1 = pf_b0;
+    u64 pf_g = 0;
+    // only the upper row reads global granules (those of the row above it); a first row and the lanes of the lower row read
+    // and ignore row A's own slots - never row -1
+    const int grow = (first_row || half == 1) ? rowA : rowA - 1;
+    const int glane = hl < 24 ? hl : hl - 24;
+    const int last_mx = D.mbw - 1;
+    auto prefetch = [&](int mx) {   // mx clamped by the caller into 0 .. mbw - 1
+        pf_y0 = *(const uint32_t*)(D.pl[0] + (size_t)(16 * my + yr0) * D.cw + 16 * mx + yc4);
+        pf_y1 = *(const uint32_t*)(D.pl[0] + (size_t)(16 * my + yr0 + 8) * D.cw + 16 * mx + yc4);
+        pf_c = *(const uint32_t*)((cpl_l ? D.pl[2] : D.pl[1]) + (size_t)(8 * my + cr_l) * cs + 8 * mx + cc4);
+        const uint4* b = (const uint4*)(bsw + ((size_t)my * D.mbw + mx) * 8);
+        pf_b0 = b[0]; pf_b1 = b[1];
+        pf_g = AT_LOAD(handoff + ((size_t)grow * D.mbw + mx) * 24 + glane);
+    };
+    auto consume = [&]() {
+        asm volatile("" : "+v"(pf_y0), "+v"(pf_y1), "+v"(pf_c), "+v"(pf_g));
+        asm volatile("" : "+v"(pf_b0.x), "+v"(pf_b0.y), "+v"(pf_b0.z), "+v"(pf_b0.w));
+        asm volatile("" : "+v"(pf_b1.x), "+v"(pf_b1.y), "+v"(pf_b1.z), "+v"(pf_b1.w));
+    };
+    prefetch(0);
+    consume();
+    uint32_t cur_y0 = pf_y0, cur_y1 = pf_y1, cur_c = pf_c;
+    uint4 b0 = pf_b0, b1 = pf_b1;
+    u64 g = pf_g;
+
+    // the previous macroblock of this lane's row is final for the row: rows 0..11 (all 16 of a last row) to the picture, rows
+    // 12..15 handed down - the upper row into the LDS ring, the lower row as global granules for the next pair
+    auto store_prev = [&](const int mx, const bool have_cur) {
+        if (mx > 0 && live) {
+            const int pmx = mx - 1;
+            const int co = have_cur ? -16 : 0, cco = have_cur ? -8 : 0;
+            const int nrow = last_row ? 16 : 12, ncrow = last_row ? 8 : 6;
+            *(uint32_t*)(D.pl[0] + (size_t)(16 * my + yr0) * D.cw + 16 * pmx + yc4) = *(const uint32_t*)&SY(yr0, co + yc4);
+            if (yr0 + 8 < nrow) *(uint32_t*)(D.pl[0] + (size_t)(16 * my + yr0 + 8) * D.cw + 16 * pmx + yc4) = *(const uint32_t*)&SY(yr0 + 8, co + yc4);
+            if (cr_l < ncrow)
+                *(uint32_t*)((cpl_l ? D.pl[2] : D.pl[1]) + (size_t)(8 * my + cr_l) * cs + 8 * pmx + cc4) = *(const uint32_t*)&SC(cpl_l, cr_l, cco + cc4);
+            if (!last_row && hl < 24) {
+                uint32_t v;
+                if (hl < 16) v = *(const uint32_t*)&SY(12 + (gk >> 2), co + (gk & 3) * 4);
+                else v = *(const uint32_t*)&SC((gk - 16) >> 2, 6 + (((gk - 16) >> 1) & 1), cco + ((gk - 16) & 1) * 4);
+                if (half == 0) s_ring[pmx & 1][gk] = v;
+                else AT_STORE(handoff + ((size_t)my * D.mbw + pmx) * 24 + gk, ((u64)R.serial << 32) | v);
+            }
+        }
+    };
+    for (int t = 0; t <= D.mbw + 2; t++) {
+        const int mx = t - 2 * half;                              // this lane's macroblock
+        const bool in_range = mx >= 0 && mx <= D.mbw && live;     // (mx == mbw: the closing store of the row)
+        const bool have_cur = in_range && mx < D.mbw;
+        if (have_cur) {
+            if (mx > 0) {
+                *(uint32_t*)&SY(yr0, yc4 - 16) = *(const uint32_t*)&SY(yr0, yc4);
+                *(uint32_t*)&SY(yr0 + 8, yc4 - 16) = *(const uint32_t*)&SY(yr0 + 8, yc4);
+                *(uint32_t*)&SC(cpl_l, cr_l, cc4 - 8) = *(const uint32_t*)&SC(cpl_l, cr_l, cc4);
+            }
+        }
+        wave_sync();
+        if (have_cur) {
+            *(uint32_t*)&SY(yr0, yc4) = cur_y0;
+            *(uint32_t*)&SY(yr0 + 8, yc4) = cur_y1;
+            *(uint32_t*)&SC(cpl_l, cr_l, cc4) = cur_c;
+        }
+        // top apron: the upper row waits for the previous pair's granules, the lower row takes the ring slot of its macroblock
+        {
+            const bool need_g = have_cur && !from_lds && !first_row;   // lanes of the upper half
+            unsigned spins = 0;
+            while (!timed_out) {
+                const bool bad = need_g && hl < 24 && (unsigned)(g >> 32) != R.serial;
+                if (__ballot(bad) == 0ull) break;
+                if (++spins > (1u << 20)) { timed_out = true; break; }
+                __builtin_amdgcn_s_sleep(1);
+                if (need_g) g = AT_LOAD(handoff + ((size_t)grow * D.mbw + mx) * 24 + glane);
+            }
+            if (have_cur && !first_row && hl < 24) {
+                const uint32_t v = from_lds ? s_ring[mx & 1][gk] : (uint32_t)g;
+                if (hl < 16) *(uint32_t*)&SY(-4 + (gk >> 2), (gk & 3) * 4) = v;
+                else *(uint32_t*)&SC((gk - 16) >> 2, -2 + (((gk - 16) >> 1) & 1), ((gk - 16) & 1) * 4) = v;
+            }
+        }
+        {   // requests for this lane's next macroblock (clamped: the loads of a finished or not yet started row are harmless)
+            const int nx = mx + 1 < 0 ? 0 : (mx + 1 > last_mx ? last_mx : mx + 1);
+            prefetch(nx);
+        }
+        wave_sync();
+        const bool any_v = have_cur && (b0.x | b0.y | b0.z | b0.w) != 0, any_h = have_cur && (b1.x | b1.y | b1.z | b1.w) != 0;
+        if (any_v) {
+            int px[20];
+#pragma unroll
+            for (int w = 0; w < 5; w++) {
+                const uint32_t v = *(const uint32_t*)(vrow + 4 * w);
+#pragma unroll
+                for (int b = 0; b < 4; b++) px[4 * w + b] = (int)((v >> (8 * b)) & 255);
+            }
+            const int e0 = (int)((b0.x >> seg8) & 255), e1 = (int)(((isC ? b0.z : b0.y) >> seg8) & 255);
+            const int e2 = isC ? 0 : (int)((b0.z >> seg8) & 255), e3 = isC ? 0 : (int)((b0.w >> seg8) & 255);
+            filt_uni<BS4>(px[0], px[1], px[2], px[3], px[4], px[5], px[6], px[7], e0, isC, al, be, t1, t2, t3);
+            filt_uni<BS4>(px[4], px[5], px[6], px[7], px[8], px[9], px[10], px[11], e1, isC, al, be, t1, t2, t3);
+            filt_uni<BS4>(px[8], px[9], px[10], px[11], px[12], px[13], px[14], px[15], e2, isC, al, be, t1, t2, t3);
+            filt_uni<BS4>(px[12], px[13], px[14], px[15], px[16], px[17], px[18], px[19], e3, isC, al, be, t1, t2, t3);
+#pragma unroll
+            for (int w = 0; w < 5; w++)
+                if (w < 3 || !isC)
+                    *(uint32_t*)(vrow + 4 * w) = (uint32_t)px[4 * w] | ((uint32_t)px[4 * w + 1] << 8) | ((uint32_t)px[4 * w + 2] << 16) | ((uint32_t)px[4 * w + 3] << 24);
+        }
+        wave_sync();
+        if (have_cur) store_prev(mx, true);
+        if (any_h) {
+            int px[20];
+#pragma unroll
+            for (int r = 0; r < 20; r++) px[r] = hcol[r * hstride];
+            const int e0 = (int)((b1.x >> seg8) & 255), e1 = (int)(((isC ? b1.z : b1.y) >> seg8) & 255);
+            const int e2 = isC ? 0 : (int)((b1.z >> seg8) & 255), e3 = isC ? 0 : (int)((b1.w >> seg8) & 255);
+            filt_uni<BS4>(px[0], px[1], px[2], px[3], px[4], px[5], px[6], px[7], e0, isC, al, be, t1, t2, t3);
+            filt_uni<BS4>(px[4], px[5], px[6], px[7], px[8], px[9], px[10], px[11], e1, isC, al, be, t1, t2, t3);
+            filt_uni<BS4>(px[8], px[9], px[10], px[11], px[12], px[13], px[14], px[15], e2, isC, al, be, t1, t2, t3);
+            filt_uni<BS4>(px[12], px[13], px[14], px[15], px[16], px[17], px[18], px[19], e3, isC, al, be, t1, t2, t3);
+#pragma unroll
+            for (int r = 1; r < 19; r++) {
+                const bool both = r == 3 || r == 4 || r == 7 || r == 8;
+                if (both || !isC) hcol[r * hstride] = (uint8_t)px[r];
+            }
+        }
+        wave_sync();
+        consume();
+        // the top apron (rows 12..15 / 6..7 of the macroblock above) is final: store it
+        if (have_cur && !first_row) {
+            if (hl < 16) *(uint32_t*)(D.pl[0] + (size_t)(16 * my - 4 + (gk >> 2)) * D.cw + 16 * mx + (gk & 3) * 4) = *(const uint32_t*)&SY(-4 + (gk >> 2), (gk & 3) * 4);
+            else if (hl < 24) {
+                const int k = gk - 16, pl = k >> 2, r = (k >> 1) & 1, c4 = (k & 1) * 4;
+                *(uint32_t*)((pl ? D.pl[2] : D.pl[1]) + (size_t)(8 * my - 2 + r) * cs + 8 * mx + c4) = *(const uint32_t*)&SC(pl, -2 + r, c4);
+            }
+        }
+        if (in_range && !have_cur) store_prev(mx, false);   // after the last macroblock of this lane's row
+        if (mx + 1 >= 0 && mx + 1 <= last_mx) { cur_y0 = pf_y0; cur_y1 = pf_y1; cur_c = pf_c; b0 = pf_b0; b1 = pf_b1; g = pf_g; }
+        wave_sync();
+    }
+    if (timed_out && lane == 0) *R.err = 1u;
+#undef SY
+#undef SC
+}
+
 }  // namespace h264

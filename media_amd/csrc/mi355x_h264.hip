@@ -170,6 +170,8 @@ struct mi355x_h264_encoder {
     uint8_t* d_planes[MAX_REFS + 1][3] = {{nullptr}};  // ring: [index][plane]; `cur` is written, cur - 1 - r (mod nbuf) is ref_idx_l0 r
     uint8_t* d_pre[3] = {nullptr};           // copy of the reconstruction before the loop filter (debug)
     int cur = 0;                             // index written by the picture being encoded
+    bool pair_filter = false;                // MI355X_H264_PAIR_FILTER=N: two macroblock rows per wave in the loop filter for batches of N pictures or more
+    int pair_min_batch = 16;
     MbInfo* d_mb = nullptr;
     int16_t* d_levels = nullptr;
     int16_t* d_mvd = nullptr;
@@ -461,10 +463,20 @@ int submit(mi355x_h264_encoder* e, const uint8_t* d_src, size_t src_item_stride,
             R.serial = db_serial; R.row0 = e->b_row0;
             R.bs = e->d_bs; R.anybs = e->d_anybs;
             R.anypcm = e->d_anypcm; R.anyintra = e->d_anyintra; R.pic_serial = e->pic_serial;
-            if (idr) { R.need_intra = 0; hipLaunchKernelGGL(k_deblock_rows<true>, dim3(e->b_rows, G), dim3(64), 0, st, R); }
-            else {   // P pictures: the form without the bS 4 filter, or - when the picture has intra macroblocks - the one with it
-                R.need_intra = -1; hipLaunchKernelGGL(k_deblock_rows<false>, dim3(e->b_rows, G), dim3(64), 0, st, R);
-                R.need_intra = 1; hipLaunchKernelGGL(k_deblock_rows<true>, dim3(e->b_rows, G), dim3(64), 0, st, R);
+            // optional (MI355X_H264_PAIR_FILTER): two macroblock rows per wave (k_deblock_pairs) for pictures of one slice; else one row per wave
+            const bool pairs = e->pair_filter && e->G >= e->pair_min_batch && e->nsl == 1 && e->b_rows == e->mbh;
+            const dim3 grid(pairs ? (unsigned)((e->b_rows + 1) / 2) : (unsigned)e->b_rows, G);
+            if (idr) {
+                R.need_intra = 0;
+                if (pairs) hipLaunchKernelGGL(k_deblock_pairs<true>, grid, dim3(64), 0, st, R);
+                else hipLaunchKernelGGL(k_deblock_rows<true>, grid, dim3(64), 0, st, R);
+            } else {   // P pictures: the form without the bS 4 filter, or - when the picture has intra macroblocks - the one with it
+                R.need_intra = -1;
+                if (pairs) hipLaunchKernelGGL(k_deblock_pairs<false>, grid, dim3(64), 0, st, R);
+                else hipLaunchKernelGGL(k_deblock_rows<false>, grid, dim3(64), 0, st, R);
+                R.need_intra = 1;
+                if (pairs) hipLaunchKernelGGL(k_deblock_pairs<true>, grid, dim3(64), 0, st, R);
+                else hipLaunchKernelGGL(k_deblock_rows<true>, grid, dim3(64), 0, st, R);
             }
         }
     }
@@ -702,6 +714,14 @@ int mi355x_h264_create(const mi355x_h264_config* cfg, mi355x_h264_encoder** out)
     CK(hipMemset(e->d_me_cost, 0, Gn * e->nmb * sizeof(uint16_t)));
     e->last_me_cost.assign(Gn, 0);
     e->diag_mode = getenv("MI355X_H264_DIAG") != nullptr && e->G == 1 && e->b_nsl == e->nsl;
+    {
+        // MI355X_H264_PAIR_FILTER=N (1..64): the loop filter takes two macroblock rows per wave (k_deblock_pairs) from a lockstep batch
+        // of N pictures on.  Off by default: measured on the bench workload it shortens the filter launch by 7 % (0.787 -> 0.728 ms
+        // per 32 pictures) and costs the pipeline 1 %.
+        const char* pf = getenv("MI355X_H264_PAIR_FILTER");
+        e->pair_filter = pf && pf[0] >= '1' && pf[0] <= '9';
+        e->pair_min_batch = e->pair_filter ? atoi(pf) : 1 << 30;
+    }
     e->frame_bytes = (size_t)cfg->width * cfg->height * 3 / 2;
     CK(hipMalloc((void**)&e->d_stage, e->frame_bytes + 256));
     CK(hipHostMalloc((void**)&e->h_stage, e->frame_bytes + 256, hipHostMallocDefault));

@@ -189,6 +189,37 @@ def test_nv12_device_pictures_in_lockstep_batch():
     enc.close()
 
 
+@pytest.mark.parametrize("kind,w,h,qp,prof,refs,G", [("s1", 352, 288, 20, 66, 0, 1), ("cut", 320, 240, 28, 100, 2, 1), ("split", 208, 160, 26, 66, 0, 3),
+                                                     ("s3", 130, 98, 34, 77, 0, 2), ("s1", 720, 720, 30, 66, 0, 1), ("scroll", 16, 48, 30, 66, 0, 1)])
+def test_loop_filter_with_two_rows_per_wave(monkeypatch, kind, w, h, qp, prof, refs, G):
+    """MI355X_H264_PAIR_FILTER: k_deblock_pairs (two macroblock rows per wave, the lower row two macroblocks behind, hand-off
+    through LDS inside the pair and through global granules between pairs) must give the stream and reconstruction of the
+    one-row-per-wave form: even and odd numbers of macroblock rows, IDR and P pictures, intra macroblocks in P pictures,
+    single pictures and lockstep batches."""
+    monkeypatch.setenv("MI355X_H264_PAIR_FILTER", "1")
+    frames = synth.sequence(kind, w, h, 3 * max(G, 2))
+    orc = OracleEncoder(w, h, qp=qp, gop=3, profile_idc=prof, refs=refs)
+    want = [orc.encode(f)[0] for f in frames]
+    if G == 1:
+        enc = capi.Encoder(w, h, qp=qp, gop=3, profile_idc=prof, refs=refs)
+        orc = OracleEncoder(w, h, qp=qp, gop=3, profile_idc=prof, refs=refs)
+        for i, f in enumerate(frames):
+            assert enc.encode(f)[0] == orc.encode(f)[0], "picture %d" % i
+            for p in range(3):
+                assert np.array_equal(enc.debug_read(capi.DBG_RECON_Y + p), orc.recon(p)), "picture %d plane %d" % (i, p)
+    else:
+        import torch
+        fbytes, gop = w * h * 3 // 2, 3
+        dev = torch.from_numpy(np.stack(frames[: G * gop])).cuda()
+        enc = capi.Encoder(w, h, qp=qp, gop=gop, profile_idc=prof, refs=refs, batch=G)
+        cap = 2 * gop * fbytes
+        out, szs, gb = np.zeros(G * cap, np.uint8), np.zeros(G * gop, np.uint32), np.zeros(G, np.uint64)
+        enc.encode_gops_device(dev.data_ptr(), fbytes, gop * fbytes, gop, out, cap, szs, gb)
+        for g in range(G):
+            assert out[g * cap: g * cap + int(gb[g])].tobytes() == b"".join(want[g * gop:(g + 1) * gop]), "GOP %d" % g
+    enc.close()
+
+
 def test_reference_forms_of_the_kernels(monkeypatch):
     """the simpler first forms of the two row-wavefront kernels (one launch per wavefront step) stay selectable for
     debugging and must give the same stream"""
