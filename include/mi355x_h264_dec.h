@@ -56,10 +56,13 @@ mi355x_h264_parser *mi355x_h264_parser_create(void);
 void mi355x_h264_parser_destroy(mi355x_h264_parser *p);
 int mi355x_h264_parser_parse(mi355x_h264_parser *p, const uint8_t *au, size_t len);   /* 1 picture, 0 none, -1 error */
 const char *mi355x_h264_parser_error(const mi355x_h264_parser *p);
-/* out[12]: mbw, mbh, width, height, idr, qp, slice_rows (0 = one slice), deblocking idc, num_ref_idx_active, transform_8x8_mode,
- * has I_PCM, bit 0 has intra | bit 1 has inter */
+/* out[12]: mbw, mbh, width, height, idr, qp (of the first slice), slice_rows (0 = one slice), deblocking idc, num_ref_idx_active,
+ * transform_8x8_mode, has I_PCM, bit 0 has intra | bit 1 has inter; with n >= 17 also: chroma_qp_index_offset,
+ * second_chroma_qp_index_offset, FilterOffsetA, FilterOffsetB, 1 = every macroblock has that one QP and no offset applies.
+ * Returns the number of values written */
 int mi355x_h264_parser_info(const mi355x_h264_parser *p, int32_t *out, int n);
-/* what: 0 MbInfo (32 B / macroblock, layout of mi355x_h264.h), 1 quadrant vectors (8 int16), 2 Intra4x4 modes (16 B), 3 levels (416 int16) */
+/* what: 0 MbInfo (32 B / macroblock, layout of mi355x_h264.h), 1 quadrant vectors (8 int16), 2 Intra4x4 modes (16 B), 3 levels (416 int16),
+ * 4 QP_Y (1 B / macroblock; 0 for I_PCM) */
 int64_t mi355x_h264_parser_read(const mi355x_h264_parser *p, int what, void *dst, size_t cap);
 
 #ifdef __cplusplus

@@ -95,6 +95,9 @@ struct FrameParams {
     SliceRows sl;        // slices of the picture: bands of sl.rows macroblock rows (sl.rows = mbh: one slice)
     Band band;           // the rows this instance encodes; grids cover the band, coordinates stay those of the picture
     MbDiv mbdiv;         // macroblock index / mbw
+    // decoder peer only (the encoder's pictures have one QP: qy, qc above; it leaves these 0):
+    const uint8_t* mbqp; // QP_Y of every macroblock (7.4.5: slice_qp_delta, mb_qp_delta); 0 for I_PCM
+    int cqo_cb, cqo_cr;  // chroma_qp_index_offset, second_chroma_qp_index_offset
 };
 
 // the parameter block of batch item g (pointers advanced by g strides)
@@ -380,6 +383,26 @@ __device__ __forceinline__ uint32_t src_chroma4(const FrameParams& P, int pl, in
 #pragma unroll
     for (int k = 0; k < 4; k++) v |= (uint32_t)src_px(C, pw, ph, gx + k, gy) << (8 * k);
     return v;
+}
+
+// ---- decoder peer: the scaling constants of a macroblock's own QP (the encoder has them host-prepared in Quant) ----
+__constant__ const uint8_t c_dequant_v[6][3] = {{10, 16, 13}, {11, 18, 14}, {13, 20, 16}, {14, 23, 18}, {16, 25, 20}, {18, 29, 23}};   // Table in 8.5.9 by position class
+__constant__ const uint8_t c_dequant8_v[6][6] = {{20, 18, 32, 19, 25, 24}, {22, 19, 35, 21, 28, 26}, {26, 23, 42, 24, 33, 31},
+                                                 {28, 25, 45, 26, 35, 33}, {32, 28, 51, 30, 40, 38}, {36, 32, 58, 34, 46, 43}};
+__constant__ const uint8_t c_chroma_qp[52] = {0,  1,  2,  3,  4,  5,  6,  7,  8,  9,  10, 11, 12, 13, 14, 15, 16, 17,
+                                              18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 29, 30, 31, 32, 32, 33,
+                                              34, 34, 35, 35, 36, 36, 37, 37, 37, 38, 38, 38, 39, 39, 39, 39};   // Table 8-15
+// dq[class] = v << (qp / 6), the form Quant::dq has
+__device__ __forceinline__ void dec_dq(int qp, int dq[3])
+{
+    const int m = qp % 6, s = qp / 6;
+#pragma unroll
+    for (int c = 0; c < 3; c++) dq[c] = (int)c_dequant_v[m][c] << s;
+}
+// QP_C of chroma component pl (0 Cb, 1 Cr) of a macroblock with luma QP qp (8.5.8 -> Table 8-15 at the offset index)
+__device__ __forceinline__ int dec_qpc(const FrameParams& P, int qp, int pl)
+{
+    return (int)c_chroma_qp[clip3(0, 51, qp + (pl ? P.cqo_cr : P.cqo_cb))];
 }
 
 // Load the source macroblock (mx,my) into LDS: y[256] (pitch 16), c[128] (Cb 8x8 then Cr 8x8).

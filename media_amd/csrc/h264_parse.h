@@ -8,11 +8,13 @@
 // transforms, intra prediction in row-wavefront order, the loop filter - then runs on the GPU (k_dec.h and the encoder's own
 // k_bs / k_deblock_rows).  Nothing here touches samples except I_PCM's raw bytes.
 //
-// Supported streams = what this repository's encoder can produce, which is also what the reference preset asks of OpenH264
-// minus CABAC: baseline / main / high with CAVLC, frame macroblocks, I and P slices; Intra16x16, Intra4x4, I_PCM;
-// P_L0_16x16, 16x8, 8x16, P_8x8 / P_8x8ref0 with 8x8 sub-macroblocks, P_Skip; up to 3 reference pictures by sliding window,
-// no reordering, one reference per macroblock; 4x4 transform, 8x8 transform on inter macroblocks; one QP per picture;
-// slices = bands of whole macroblock rows of equal height; loop filter idc 0 / 1 (one slice) or 1 / 2 (several).
+// Supported streams = a superset of what this repository's encoder produces (which is what the reference preset asks of
+// OpenH264 minus CABAC): baseline / main / high with CAVLC, frame macroblocks, I and P slices; Intra16x16, Intra4x4, I_PCM
+// (also in loop-filtered pictures); P_L0_16x16, 16x8, 8x16, P_8x8 / P_8x8ref0 with 8x8 sub-macroblocks, P_Skip; up to 3
+// reference pictures by sliding window, no reordering, one reference per macroblock; 4x4 transform, 8x8 transform on inter
+// macroblocks; QP per macroblock (slice_qp_delta per slice, mb_qp_delta), chroma_qp_index_offset and
+// second_chroma_qp_index_offset, slice_alpha_c0_offset_div2 / slice_beta_offset_div2 (one pair per picture);
+// slices = bands of whole macroblock rows of equal height; disable_deblocking_filter_idc 0 / 1 / 2 (one value per picture).
 // Anything else is refused with a message naming the syntax element (never decoded wrongly).
 #pragma once
 #include <stdint.h>
@@ -43,6 +45,7 @@ struct Sps {
 struct Pps {
     bool valid = false;
     int sps_id = 0, num_ref_default = 1, pic_init_qp = 26;
+    int cqo[2] = {0, 0};   // chroma_qp_index_offset, second_chroma_qp_index_offset (Cb, Cr)
     bool deblock_control = false, t8x8 = false, bottom_field_pic_order = false, redundant_pic_cnt = false;
 };
 
@@ -143,6 +146,11 @@ struct Picture {
     bool idr = false, is_ref = true;
     int qp = 26, slice_rows = 0, deblock_idc = 0, num_ref_active = 0, t8x8_mode = 0, profile_idc = 66;
     bool has_pcm = false, has_intra = false, has_inter = false;
+    int cqo[2] = {0, 0};             // chroma QP index offsets (Cb, Cr) of the picture parameter set
+    int filter_oa = 0, filter_ob = 0;   // FilterOffsetA / FilterOffsetB (2 * slice_alpha_c0_offset_div2, 2 * slice_beta_offset_div2)
+    bool one_qp = true;              // every macroblock has QP_Y = qp, no chroma / filter offset, no I_PCM macroblock: the picture
+                                     // reconstructs with the per-picture constants the encoder's kernels use
+    std::vector<uint8_t> mbqp;       // QP_Y of every macroblock (7.4.5); 0 for I_PCM, the value its edges filter with (8.7.2.2)
     std::vector<MbRec> mb;
     std::vector<int16_t> mvq;      // 8 per macroblock
     std::vector<uint8_t> aux;      // 16 per macroblock
@@ -186,6 +194,7 @@ private:
     std::vector<uint8_t> rbsp_;
     // state of the slice being parsed
     int slice_first_ = 0, slice_type_ = 0, slice_qp_ = 26, num_ref_ = 1;
+    int qp_ = 26;   // QP_Y of the previous macroblock of the slice in decoding order
 
     int fail(const char* fmt, int a = 0, int b = 0)
     {
@@ -289,14 +298,18 @@ private:
         if (iq < -26 || iq > 25) { fail("pic_init_qp_minus26 %d", iq); return false; }
         p.pic_init_qp = 26 + iq;
         br.se();   // pic_init_qs_minus26
-        if (br.se() != 0) { fail("chroma_qp_index_offset != 0"); return false; }
+        const int cq = br.se();
+        if (cq < -12 || cq > 12) { fail("chroma_qp_index_offset %d", cq); return false; }
+        p.cqo[0] = p.cqo[1] = cq;
         p.deblock_control = br.u(1) != 0;
         if (br.u(1)) { fail("constrained_intra_pred_flag = 1"); return false; }
         p.redundant_pic_cnt = br.u(1) != 0;
         if (br.more_data()) {
             p.t8x8 = br.u(1) != 0;
             if (br.u(1)) { fail("pic_scaling_matrix_present_flag"); return false; }
-            if (br.se() != 0) { fail("second_chroma_qp_index_offset != 0"); return false; }
+            const int cq2 = br.se();
+            if (cq2 < -12 || cq2 > 12) { fail("second_chroma_qp_index_offset %d", cq2); return false; }
+            p.cqo[1] = cq2;
         }
         if (br.bad()) { fail("picture parameter set damaged"); return false; }
         p.valid = true;
@@ -478,11 +491,15 @@ private:
         }
         const int qd = br.se();
         const int qp = (qd < -64 || qd > 64) ? -1 : pps.pic_init_qp + qd;
-        int idc = 0;
+        int idc = 0, oa = 0, ob = 0;
         if (pps.deblock_control) {
             const unsigned di = br.ue();
             idc = di > 2 ? 3 : (int)di;
-            if (idc != 1 && (br.se() != 0 || br.se() != 0)) { fail("slice_alpha_c0 / beta offset != 0"); return false; }
+            if (idc != 1) {
+                oa = br.se(); ob = br.se();
+                if (oa < -6 || oa > 6 || ob < -6 || ob > 6) { fail("slice_alpha_c0_offset_div2 / slice_beta_offset_div2 out of range"); return false; }
+                oa *= 2; ob *= 2;
+            }
         }
         if (br.bad() || qp < 0 || qp > 51 || idc > 2 || num_ref < 1 || num_ref > 3) { fail("slice header damaged"); return false; }
 
@@ -493,7 +510,10 @@ private:
             pic_.idr = idr; pic_.is_ref = ref_idc != 0; pic_.qp = qp; pic_.deblock_idc = idc; pic_.slice_rows = 0;
             pic_.num_ref_active = st == 0 ? num_ref : 0; pic_.t8x8_mode = pps.t8x8 ? 1 : 0; pic_.profile_idc = sps.profile_idc;
             pic_.has_pcm = pic_.has_intra = pic_.has_inter = false;
+            pic_.cqo[0] = pps.cqo[0]; pic_.cqo[1] = pps.cqo[1]; pic_.filter_oa = oa; pic_.filter_ob = ob;
+            pic_.one_qp = pps.cqo[0] == 0 && pps.cqo[1] == 0 && oa == 0 && ob == 0;
             const size_t n = (size_t)sps.mbw * sps.mbh;
+            pic_.mbqp.assign(n, (uint8_t)qp);
             pic_.mb.assign(n, MbRec{});
             pic_.mvq.assign(n * 8, 0);
             pic_.aux.assign(n * 16, 0);
@@ -504,13 +524,15 @@ private:
             if (first_mb % pic_.mbw) { fail("slice starts inside a macroblock row (first_mb_in_slice %d)", first_mb); return false; }
             if (pic_.slice_rows == 0) pic_.slice_rows = first_mb / pic_.mbw;
             else if ((first_mb / pic_.mbw) % pic_.slice_rows) { fail("slices are not bands of equal height"); return false; }
-            if (qp != pic_.qp) { fail("slice QP %d differs from the picture's %d", qp, pic_.qp); return false; }
+            if (qp != pic_.qp) pic_.one_qp = false;
             if (idc != pic_.deblock_idc) { fail("disable_deblocking_filter_idc differs between slices"); return false; }
+            if (oa != pic_.filter_oa || ob != pic_.filter_ob) { fail("deblocking filter offsets differ between slices"); return false; }
+            if (pps.cqo[0] != pic_.cqo[0] || pps.cqo[1] != pic_.cqo[1]) { fail("chroma QP offsets differ between slices"); return false; }
             if (st == 0 && pic_.num_ref_active && num_ref != pic_.num_ref_active) { fail("num_ref_idx_active differs between slices"); return false; }
             if (st == 0 && !pic_.num_ref_active) pic_.num_ref_active = num_ref;
-            if (idc == 0) { fail("several slices with disable_deblocking_filter_idc 0 (filtering across slice edges)"); return false; }
         }
         slice_first_ = first_mb; slice_type_ = st; slice_qp_ = qp; num_ref_ = num_ref;
+        qp_ = qp;   // QP_Y,PRED of the slice's first macroblock (7.4.5)
 
         // ---- slice_data (7.3.4) ----
         int addr = first_mb;
@@ -539,12 +561,18 @@ private:
         int16_t* v = &pic_.mvq[((size_t)my * pic_.mbw + mx) * 8 + 2 * q];
         v[0] = (int16_t)x; v[1] = (int16_t)y;
     }
+    void set_qp(int mx, int my, int qp)
+    {
+        pic_.mbqp[(size_t)my * pic_.mbw + mx] = (uint8_t)qp;
+        if (qp != pic_.qp) pic_.one_qp = false;
+    }
     void skip_mb(int mx, int my)
     {
         MbRec& m = M(mx, my);
         m = MbRec{};
         m.type = T_PSKIP;
         m.chroma_mode = 0;   // ref_idx_l0 = 0
+        set_qp(mx, my, qp_);
         int px, py;
         predict(mx, my, 0, 0, 2, 2, 0, px, py, true);
         m.mvx = (int16_t)px; m.mvy = (int16_t)py;
@@ -572,6 +600,8 @@ private:
             m.type = T_IPCM; m.cbp = 0x2F;
             memset(m.tc, 16, 24);
             pic_.has_pcm = pic_.has_intra = true;
+            set_qp(mx, my, 0);        // its edges filter with qP 0; QP_Y,PRED of the next macroblock stays
+            pic_.one_qp = false;
             return true;
         }
         if (is_intra) {
@@ -647,7 +677,9 @@ private:
         m.cbp = (uint8_t)cbp;
         if (!is_intra) m.i16_mode = t8flag ? 1 : 0;
         if (cbp > 0 || i16) {
-            if (br.se() != 0) { fail("mb_qp_delta != 0 (one QP per picture)"); return false; }
+            const int dq = br.se();
+            if (dq < -26 || dq > 25) { fail("mb_qp_delta %d", dq); return false; }
+            qp_ = (qp_ + dq + 52) % 52;
             // residual (7.3.5.3)
             if (i16) {
                 int16_t dc[16] = {0};
@@ -675,6 +707,7 @@ private:
             }
         }
         if (br.bad()) { fail("macroblock %d runs past the slice", my * pic_.mbw + mx); return false; }
+        set_qp(mx, my, qp_);
         return true;
     }
 };

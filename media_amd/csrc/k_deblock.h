@@ -39,6 +39,10 @@ struct DbParams {
     int tc0_y[3], tc0_c[3];  // by bS-1
     SliceRows sl;        // several slices: disable_deblocking_filter_idc 2, the edge between two slices is left alone
     const uint8_t* bs;   // k_bs's boundary strengths, 32 per macroblock: [dir][edge][segment] (the diagonal form reads them here)
+    // k_deblock_rows<.., PERMB = true> (decoder peer): thresholds per edge from the two macroblocks' own QPs (8.7.2.2)
+    const uint8_t* mbqp; // QP_Y per macroblock (0 for I_PCM)
+    int oa, ob;          // FilterOffsetA, FilterOffsetB
+    int cqo_cb, cqo_cr;  // chroma_qp_index_offset, second_chroma_qp_index_offset
 };
 
 // filter one line across an edge; p points at q0 inside LDS, xs = distance between samples across the edge
@@ -241,7 +245,11 @@ __device__ __forceinline__ void filt_uni(const int p3, int& p2, int& p1, int& p0
 
 enum { DR_LP = 40, DR_CP = 24 };  // LDS pitches; luma tile cols -16..15 (+4 pad), rows -4..15; chroma cols -8..7, rows -4..15
 
-template <bool BS4>
+// PERMB (the decoder peer, streams of other encoders): qPp / qPq are the two macroblocks' own QPs (mb_qp_delta, I_PCM = 0),
+// the chroma QPs go through chroma_qp_index_offset, indexA / indexB through the slice's filter offsets - three threshold
+// sets per macroblock (left edge, top edge, inner edges), looked up in LDS copies of Tables 8-15 / 8-16.  PERMB = false is
+// the encoder's form: one set per picture, prepared on the host.
+template <bool BS4, bool PERMB = false>
 __global__ __launch_bounds__(64) void k_deblock_rows(DbRowParams R)
 {
     // dependency-bound: when a throughput kernel of another stream shares the SIMD, this wave issues first
@@ -253,6 +261,7 @@ __global__ __launch_bounds__(64) void k_deblock_rows(DbRowParams R)
     {
         const size_t g = blockIdx.y;
         D.pl[0] += g * R.st_y; D.pl[1] += g * R.st_c; D.pl[2] += g * R.st_c; D.mb += g * R.st_mb;
+        if (PERMB) D.mbqp += g * R.st_mb;
     }
     u64* const handoff = R.handoff + (size_t)blockIdx.y * R.st_handoff;
     const uint32_t* const bsw = R.bs + (size_t)blockIdx.y * R.st_mb * 8;
@@ -274,8 +283,30 @@ __global__ __launch_bounds__(64) void k_deblock_rows(DbRowParams R)
     const bool isC = lane >= 16;
     const int fpl = (lane >> 3) & 1, fln = isC ? (lane & 7) : lane;
     const int seg8 = 8 * (isC ? (fln >> 1) : (fln >> 2));
-    const int al = isC ? D.alpha_c : D.alpha_y, be = isC ? D.beta_c : D.beta_y;
-    const int t1 = isC ? D.tc0_c[0] : D.tc0_y[0], t2 = isC ? D.tc0_c[1] : D.tc0_y[1], t3 = isC ? D.tc0_c[2] : D.tc0_y[2];
+    // thresholds of the inner edges, of the left edge (L) and of the top edge (T); one set unless PERMB
+    int al = isC ? D.alpha_c : D.alpha_y, be = isC ? D.beta_c : D.beta_y;
+    int t1 = isC ? D.tc0_c[0] : D.tc0_y[0], t2 = isC ? D.tc0_c[1] : D.tc0_y[1], t3 = isC ? D.tc0_c[2] : D.tc0_y[2];
+    int alL = al, beL = be, t1L = t1, t2L = t2, t3L = t3, alT = al, beT = be, t1T = t1, t2T = t2, t3T = t3;
+    __shared__ uint32_t s_tA[PERMB ? 52 : 1];   // by indexA: alpha << 24 | tc0(bS 3) << 16 | tc0(bS 2) << 8 | tc0(bS 1)
+    __shared__ uint8_t s_tB[PERMB ? 52 : 1], s_cq[PERMB ? 52 : 1];   // beta by indexB; QP_C by the offset luma QP
+    if (PERMB) {
+        if (lane < 52) {
+            s_tA[lane] = ((uint32_t)c_alpha[lane] << 24) | ((uint32_t)c_tc0[lane][2] << 16) | ((uint32_t)c_tc0[lane][1] << 8) | (uint32_t)c_tc0[lane][0];
+            s_tB[lane] = c_beta[lane];
+            s_cq[lane] = c_chroma_qp[lane];
+        }
+        wave_sync();
+    }
+    const int cqo = fpl ? D.cqo_cr : D.cqo_cb;
+    auto thresholds = [&](const int qa, const int qb, int& A, int& B, int& T1, int& T2, int& T3) {
+        const int ca = (int)s_cq[clip3(0, 51, qa + cqo)], cb = (int)s_cq[clip3(0, 51, qb + cqo)];
+        const int av = ((isC ? ca : qa) + (isC ? cb : qb) + 1) >> 1;           // qPav (8-461)
+        const uint32_t w = s_tA[clip3(0, 51, av + D.oa)];
+        A = (int)(w >> 24); T1 = (int)(w & 255u); T2 = (int)((w >> 8) & 255u); T3 = (int)((w >> 16) & 255u);
+        B = (int)s_tB[clip3(0, 51, av + D.ob)];
+    };
+    uint32_t pf_q = 0;   // QP_Y of the macroblock | of the one above << 8
+    int qp_left = 0;
     uint8_t* vrow = isC ? &SC(fpl, fln, -4) : &SY(fln, -4);                 // V phase: this lane's line, 4-byte aligned
     uint8_t* hcol = isC ? &SC(fpl, -4, fln) : &SY(-4, fln);                 // H phase: top of this lane's column
     const int hstride = isC ? DR_CP : DR_LP;
@@ -295,15 +326,17 @@ __global__ __launch_bounds__(64) void k_deblock_rows(DbRowParams R)
         const uint4* b = (const uint4*)(bsw + ((size_t)my * D.mbw + mx) * 8);
         pf_b0 = b[0]; pf_b1 = b[1];
         pf_g = AT_LOAD(handoff + ((size_t)grow * D.mbw + mx) * 24 + glane);
+        if (PERMB) pf_q = (uint32_t)D.mbqp[(size_t)my * D.mbw + mx] | ((uint32_t)D.mbqp[(size_t)grow * D.mbw + mx] << 8);
     };
     auto consume = [&]() {   // forces the waits for the prefetched registers to sit here
         asm volatile("" : "+v"(pf_y), "+v"(pf_c), "+v"(pf_g));
         asm volatile("" : "+v"(pf_b0.x), "+v"(pf_b0.y), "+v"(pf_b0.z), "+v"(pf_b0.w));
         asm volatile("" : "+v"(pf_b1.x), "+v"(pf_b1.y), "+v"(pf_b1.z), "+v"(pf_b1.w));
+        if (PERMB) asm volatile("" : "+v"(pf_q));
     };
     prefetch(0);
     consume();
-    uint32_t cur_y = pf_y, cur_c = pf_c;
+    uint32_t cur_y = pf_y, cur_c = pf_c, cur_q = pf_q;
     uint4 b0 = pf_b0, b1 = pf_b1;
     u64 g = pf_g;
 
@@ -354,6 +387,13 @@ __global__ __launch_bounds__(64) void k_deblock_rows(DbRowParams R)
             }
             // requests for the next macroblock leave now and are collected after the filter
             if (mx + 1 < D.mbw) prefetch(mx + 1);
+            if (PERMB) {
+                const int qc = (int)(cur_q & 255u), qt = (int)(cur_q >> 8);
+                thresholds(qc, qc, al, be, t1, t2, t3);
+                thresholds(mx > 0 ? qp_left : qc, qc, alL, beL, t1L, t2L, t3L);
+                thresholds(qt, qc, alT, beT, t1T, t2T, t3T);
+                qp_left = qc;
+            }
             wave_sync();
             const bool any_v = (b0.x | b0.y | b0.z | b0.w) != 0, any_h = (b1.x | b1.y | b1.z | b1.w) != 0;
             // 4. vertical edges: lane = one line of samples, four edges in registers.
@@ -368,7 +408,7 @@ __global__ __launch_bounds__(64) void k_deblock_rows(DbRowParams R)
                 }
                 const int e0 = (int)(((isC ? b0.x : b0.x) >> seg8) & 255), e1 = (int)(((isC ? b0.z : b0.y) >> seg8) & 255);
                 const int e2 = isC ? 0 : (int)((b0.z >> seg8) & 255), e3 = isC ? 0 : (int)((b0.w >> seg8) & 255);
-                filt_uni<BS4>(px[0], px[1], px[2], px[3], px[4], px[5], px[6], px[7], e0, isC, al, be, t1, t2, t3);
+                filt_uni<BS4>(px[0], px[1], px[2], px[3], px[4], px[5], px[6], px[7], e0, isC, alL, beL, t1L, t2L, t3L);
                 filt_uni<BS4>(px[4], px[5], px[6], px[7], px[8], px[9], px[10], px[11], e1, isC, al, be, t1, t2, t3);
                 filt_uni<BS4>(px[8], px[9], px[10], px[11], px[12], px[13], px[14], px[15], e2, isC, al, be, t1, t2, t3);
                 filt_uni<BS4>(px[12], px[13], px[14], px[15], px[16], px[17], px[18], px[19], e3, isC, al, be, t1, t2, t3);
@@ -386,7 +426,7 @@ __global__ __launch_bounds__(64) void k_deblock_rows(DbRowParams R)
                 for (int r = 0; r < 20; r++) px[r] = hcol[r * hstride];
                 const int e0 = (int)((b1.x >> seg8) & 255), e1 = (int)(((isC ? b1.z : b1.y) >> seg8) & 255);
                 const int e2 = isC ? 0 : (int)((b1.z >> seg8) & 255), e3 = isC ? 0 : (int)((b1.w >> seg8) & 255);
-                filt_uni<BS4>(px[0], px[1], px[2], px[3], px[4], px[5], px[6], px[7], e0, isC, al, be, t1, t2, t3);
+                filt_uni<BS4>(px[0], px[1], px[2], px[3], px[4], px[5], px[6], px[7], e0, isC, alT, beT, t1T, t2T, t3T);
                 filt_uni<BS4>(px[4], px[5], px[6], px[7], px[8], px[9], px[10], px[11], e1, isC, al, be, t1, t2, t3);
                 filt_uni<BS4>(px[8], px[9], px[10], px[11], px[12], px[13], px[14], px[15], e2, isC, al, be, t1, t2, t3);
                 filt_uni<BS4>(px[12], px[13], px[14], px[15], px[16], px[17], px[18], px[19], e3, isC, al, be, t1, t2, t3);
@@ -409,7 +449,7 @@ __global__ __launch_bounds__(64) void k_deblock_rows(DbRowParams R)
             }
         }
         if (!have_cur) store_prev(mx, false);   // after the last macroblock of the row
-        cur_y = pf_y; cur_c = pf_c; b0 = pf_b0; b1 = pf_b1; g = pf_g;
+        cur_y = pf_y; cur_c = pf_c; b0 = pf_b0; b1 = pf_b1; g = pf_g; cur_q = pf_q;
         wave_sync();
     }
     if (timed_out && lane == 0) *R.err = 1u;  // pinned host word, read after the picture's event

@@ -54,13 +54,14 @@ __device__ __forceinline__ uint32_t mc_luma4(const uint8_t* R, int cw, int ch, i
             const int h = clip255((h1(i + 2) + 16) >> 5);
             v = fy == 2 ? h : ((fy == 1 ? g0 : G[3][i + 2]) + h + 1) >> 1;
         } else if (fx != 2 && fy != 2) {   // e, g, p, r: a horizontal and a vertical half sample
-            const int b = clip255((b1(fy == 1 ? 2 : 3) + 16) >> 5), h = clip255((h1(fx == 1 ? i + 2 : i + 3) + 16) >> 5);
+            // (both candidates are evaluated and one is selected: an index that depends on the vector would put G into scratch memory)
+            const int b = clip255(((fy == 1 ? b1(2) : b1(3)) + 16) >> 5), h = clip255(((fx == 1 ? h1(i + 2) : h1(i + 3)) + 16) >> 5);
             v = (b + h + 1) >> 1;
         } else {
             const int j = clip255((b1(0) - 5 * b1(1) + 20 * b1(2) + 20 * b1(3) - 5 * b1(4) + b1(5) + 512) >> 10);
             if (fx == 2 && fy == 2) v = j;
-            else if (fx == 2) v = (clip255((b1(fy == 1 ? 2 : 3) + 16) >> 5) + j + 1) >> 1;     // f, q
-            else v = (clip255((h1(fx == 1 ? i + 2 : i + 3) + 16) >> 5) + j + 1) >> 1;           // i, k
+            else if (fx == 2) v = (clip255(((fy == 1 ? b1(2) : b1(3)) + 16) >> 5) + j + 1) >> 1;     // f, q
+            else v = (clip255(((fx == 1 ? h1(i + 2) : h1(i + 3)) + 16) >> 5) + j + 1) >> 1;           // i, k
         }
         out |= (uint32_t)v << (8 * i);
     }
@@ -122,11 +123,17 @@ __global__ __launch_bounds__(64) void k_dec_resid(FrameParams P0)
     const bool t8 = ((w1 >> 8) & 1u) != 0;
     const int my = P.mbdiv.row(mbi), mx = mbi - my * P.mbw, cs = P.cw / 2;
     const int16_t* lv = P.levels + (size_t)mbi * LV_STRIDE;
+    const int qp = (int)P.mbqp[mbi];   // the macroblock's own QP_Y (lanes of four macroblocks: a per-lane value)
     if (cbp & (1 << (blk >> 2))) {
         if (!t8) {
+            int dq[3];
+            dec_dq(qp, dq);
             int d[16];
 #pragma unroll
-            for (int i = 0; i < 16; i++) d[i] = (int)lv[LV_LUMA + blk * 16 + c_zigzag_inv[i]] * P.qy.dq[pos_class(i)];
+            for (int i = 0; i < 16; i++) {
+                const int k = pos_class(i);
+                d[i] = (int)lv[LV_LUMA + blk * 16 + c_zigzag_inv[i]] * (k == 0 ? dq[0] : (k == 1 ? dq[1] : dq[2]));
+            }
             idct4x4(d);
             uint8_t* dst = P.rec[0] + (size_t)(16 * my + 4 * blk_y(blk)) * P.cw + 16 * mx + 4 * blk_x(blk);
 #pragma unroll
@@ -138,10 +145,10 @@ __global__ __launch_bounds__(64) void k_dec_resid(FrameParams P0)
             // 8x8 block blk >> 2: coefficient k of the 8x8 zig-zag scan is element k >> 2 of the quadrant's list k & 3 (7.3.5.3.2)
             constexpr int ZZ8[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6,  7,  14, 21, 28,
                                      35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
-            const int b8 = blk >> 2, qp6 = P.qy.qp / 6;
+            const int b8 = blk >> 2, qp6 = qp / 6, qm = qp % 6;
             int ls[6];
 #pragma unroll
-            for (int c = 0; c < 6; c++) ls[c] = vreg(P.qy.ls8[c]);
+            for (int c = 0; c < 6; c++) ls[c] = 16 * (int)c_dequant8_v[qm][c];
             int d[64];
 #pragma unroll
             for (int k = 0; k < 64; k++) {
@@ -169,10 +176,15 @@ __global__ __launch_bounds__(64) void k_dec_resid(FrameParams P0)
 #pragma unroll
         for (int i = 0; i < 4; i++) dc[i] = (int)lv[LV_CHROMA_DC + 4 * pl + i];
         const int fi[4] = {dc[0] + dc[1] + dc[2] + dc[3], dc[0] - dc[1] + dc[2] - dc[3], dc[0] + dc[1] - dc[2] - dc[3], dc[0] - dc[1] - dc[2] + dc[3]};
+        int dq[3];
+        dec_dq(dec_qpc(P, qp, pl), dq);
         int d[16];
 #pragma unroll
-        for (int i = 1; i < 16; i++) d[i] = (int)lv[LV_CHROMA_AC + (4 * pl + cb) * 16 + c_zigzag_inv[i]] * P.qc.dq[pos_class(i)];
-        d[0] = ((cb == 0 ? fi[0] : (cb == 1 ? fi[1] : (cb == 2 ? fi[2] : fi[3]))) * 16 * P.qc.dq[0]) >> 5;
+        for (int i = 1; i < 16; i++) {
+            const int k = pos_class(i);
+            d[i] = (int)lv[LV_CHROMA_AC + (4 * pl + cb) * 16 + c_zigzag_inv[i]] * (k == 0 ? dq[0] : (k == 1 ? dq[1] : dq[2]));
+        }
+        d[0] = ((cb == 0 ? fi[0] : (cb == 1 ? fi[1] : (cb == 2 ? fi[2] : fi[3]))) * 16 * dq[0]) >> 5;
         idct4x4(d);
         uint8_t* dst = rec_chroma(P, pl) + (size_t)(8 * my + 4 * (cb >> 1)) * cs + 8 * mx + 4 * (cb & 1);
 #pragma unroll

@@ -143,6 +143,16 @@ __device__ __forceinline__ void intra_mb_core(const FrameParams& P, int mx, int 
     const bool top = P.sl.has_top(my);   // the row above belongs to this slice
     const int avail = (mx > 0 ? 1 : 0) | (top ? 2 : 0) | ((mx > 0 && top) ? 4 : 0);
     MbInfo* const mbp = P.mb + mbi;
+    // DEC: the macroblock's own QP (mb_qp_delta) - of Quant only qp and dq[] are read on the decoding paths; chroma per component
+    Quant dqy = {};
+    int dqc[2][3] = {{0, 0, 0}, {0, 0, 0}};
+    if (DEC) {
+        dqy.qp = __builtin_amdgcn_readfirstlane((int)P.mbqp[mbi]);
+        dec_dq(dqy.qp, dqy.dq);
+        dec_dq(dec_qpc(P, dqy.qp, 0), dqc[0]);
+        dec_dq(dec_qpc(P, dqy.qp, 1), dqc[1]);
+    }
+    const Quant& QY = DEC ? dqy : P.qy;
     if (DEC) {
         if (lane < LV_STRIDE * 2 / 16) ((uint4*)S.lv)[lane] = ((const uint4*)(P.levels + (size_t)mbi * LV_STRIDE))[lane];
         wave_sync();
@@ -171,7 +181,7 @@ __device__ __forceinline__ void intra_mb_core(const FrameParams& P, int mx, int 
     if (use_i4) {
         const uint32_t m0 = (uint32_t)__builtin_amdgcn_readlane((int)auxw, 0), m1 = (uint32_t)__builtin_amdgcn_readlane((int)auxw, 1);
         const uint32_t m2 = (uint32_t)__builtin_amdgcn_readlane((int)auxw, 2), m3 = (uint32_t)__builtin_amdgcn_readlane((int)auxw, 3);
-        cbp_luma_i4 = i4_code_luma<DEC>(P.qy, S.i4, S.top, S.left, S.src, m0, m1, m2, m3, S.lv, S.dc, mx, top, top && mx + 1 < P.mbw, lane);   // (S.dc: TotalCoeff of the 16 blocks)
+        cbp_luma_i4 = i4_code_luma<DEC>(QY, S.i4, S.top, S.left, S.src, m0, m1, m2, m3, S.lv, S.dc, mx, top, top && mx + 1 < P.mbw, lane);   // (S.dc: TotalCoeff of the 16 blocks)
         const uint32_t o = *(const uint32_t*)(S.i4.rb + (1 + (lane >> 2)) * 32 + 4 + (lane & 3) * 4);
         *(uint32_t*)(S.rec_y + (lane >> 2) * 16 + (lane & 3) * 4) = o;
         *(uint32_t*)(P.rec[0] + (size_t)(by + (lane >> 2)) * P.cw + bx + (lane & 3) * 4) = o;
@@ -282,7 +292,7 @@ __device__ __forceinline__ void intra_mb_core(const FrameParams& P, int mx, int 
         }
         if (DEC) {   // scaled coefficients from the given levels (the DC position comes through the Hadamard path below)
 #pragma unroll
-            for (int i = 1; i < 16; i++) d[i] = (int)S.lv[LV_LUMA + lane * 16 + c_zigzag_inv[i]] * P.qy.dq[pos_class(i)];
+            for (int i = 1; i < 16; i++) d[i] = (int)S.lv[LV_LUMA + lane * 16 + c_zigzag_inv[i]] * QY.dq[pos_class(i)];
             d[0] = 0;
         } else {
             nnz = tq4x4(d, P.qy, P.qy.f_intra, 1, S.lv + LV_LUMA + lane * 16, &dcw, 0, false);
@@ -297,8 +307,12 @@ __device__ __forceinline__ void intra_mb_core(const FrameParams& P, int mx, int 
             for (int c = 0; c < 4; c++) d[4 * r + c] = (int)((sw >> (8 * c)) & 255) - (int)((pw >> (8 * c)) & 255);
         }
         if (DEC) {
+            const int ca = cpl ? dqc[1][0] : dqc[0][0], cbq = cpl ? dqc[1][1] : dqc[0][1], cc = cpl ? dqc[1][2] : dqc[0][2];
 #pragma unroll
-            for (int i = 1; i < 16; i++) d[i] = (int)S.lv[LV_CHROMA_AC + (cpl * 4 + cb) * 16 + c_zigzag_inv[i]] * P.qc.dq[pos_class(i)];
+            for (int i = 1; i < 16; i++) {
+                const int k = pos_class(i);
+                d[i] = (int)S.lv[LV_CHROMA_AC + (cpl * 4 + cb) * 16 + c_zigzag_inv[i]] * (k == 0 ? ca : (k == 1 ? cbq : cc));
+            }
             d[0] = 0;
         } else
             nnz = tq4x4(d, P.qc, P.qc.f_intra, 1, S.lv + LV_CHROMA_AC + (cpl * 4 + cb) * 16, &dcw, 0, false);
@@ -337,7 +351,7 @@ __device__ __forceinline__ void intra_mb_core(const FrameParams& P, int mx, int 
         wave_sync();
         if (is_luma) {
             const int fi = S.dc[blk_y(lane) * 4 + blk_x(lane)];
-            const int qp = P.qy.qp, ls = 16 * (P.qy.dq[0] >> (qp / 6));
+            const int qp = QY.qp, ls = 16 * (QY.dq[0] >> (qp / 6));
             d[0] = qp >= 36 ? (fi * ls) << (qp / 6 - 6) : (fi * ls + (1 << (5 - qp / 6))) >> (6 - qp / 6);
         }
     }
@@ -351,7 +365,7 @@ __device__ __forceinline__ void intra_mb_core(const FrameParams& P, int mx, int 
             for (int i = 0; i < 4; i++) lv[i] = (int)S.lv[LV_CHROMA_DC + pl * 4 + i];
             const int fi[4] = {lv[0] + lv[1] + lv[2] + lv[3], lv[0] - lv[1] + lv[2] - lv[3], lv[0] + lv[1] - lv[2] - lv[3], lv[0] - lv[1] - lv[2] + lv[3]};
 #pragma unroll
-            for (int i = 0; i < 4; i++) deq[i] = (fi[i] * 16 * P.qc.dq[0]) >> 5;
+            for (int i = 0; i < 4; i++) deq[i] = (fi[i] * 16 * (pl ? dqc[1][0] : dqc[0][0])) >> 5;
             if (is_chroma) d[0] = pick4(deq, cb);
         } else {
             chroma_dc(w4, P.qc, P.qc.f_intra, lv, deq);

@@ -1087,6 +1087,7 @@ struct mi355x_h264_decoder {
     int width = 0, height = 0, crop_x = 0, crop_y = 0;
     uint64_t pictures = 0;
     double parse_ms = 0, gpu_ms = 0;
+    uint8_t* d_mbqp = nullptr;   // QP_Y per macroblock of the picture being reconstructed
     char err[256] = {0};
 };
 
@@ -1125,6 +1126,7 @@ int dec_submit(mi355x_h264_decoder* d, const h264dec::Picture& pic)
     DHIP(d, hipMemcpyAsync(e->d_mvq, pic.mvq.data(), nmb * 16, hipMemcpyHostToDevice, st));
     DHIP(d, hipMemcpyAsync(e->d_aux, pic.aux.data(), nmb * 16, hipMemcpyHostToDevice, st));
     DHIP(d, hipMemcpyAsync(e->d_levels, pic.levels.data(), nmb * LV_STRIDE * sizeof(int16_t), hipMemcpyHostToDevice, st));
+    DHIP(d, hipMemcpyAsync(d->d_mbqp, pic.mbqp.data(), nmb, hipMemcpyHostToDevice, st));
     const int cur = e->cur;
     FrameParams P{};
     P.w = e->cw; P.h = e->ch; P.cw = e->cw; P.ch = e->ch; P.mbw = e->mbw; P.mbh = e->mbh;
@@ -1143,8 +1145,9 @@ int dec_submit(mi355x_h264_decoder* d, const h264dec::Picture& pic)
     P.mbdiv.inv = e->mbw > 1 ? (unsigned)(0x100000000ull / (unsigned)e->mbw) + 1u : 0u;
     e->pic_serial = e->pic_serial == 0xFFFFFFFFu ? 1u : e->pic_serial + 1u;
     P.anypcm = e->d_anypcm; P.anyintra = e->d_anyintra; P.pic_serial = e->pic_serial;
-    fill_quant(P.qy, pic.qp);
+    fill_quant(P.qy, pic.qp);                 // (the reconstruction kernels scale with the macroblock's own QP: mbqp)
     fill_quant(P.qc, h_chroma_qp[pic.qp]);
+    P.mbqp = d->d_mbqp; P.cqo_cb = pic.cqo[0]; P.cqo_cr = pic.cqo[1];
     {   // the flags the loop filter launches look at: intra macroblocks present (bS 3 / 4 form); I_PCM never switches the filter off here
         const unsigned flags[2] = {0u, pic.has_intra ? e->pic_serial : 0u};
         DHIP(d, hipMemcpyAsync(e->d_anypcm, &flags[0], sizeof(unsigned), hipMemcpyHostToDevice, st));
@@ -1164,7 +1167,10 @@ int dec_submit(mi355x_h264_decoder* d, const h264dec::Picture& pic)
     }
     if (pic.deblock_idc != 1) {
         CavlcParams C{};
-        C.mb = e->d_mb; C.levels = e->d_levels; C.mvd = e->d_mvd; C.mvq = e->d_mvq; C.mbw = e->mbw; C.nmb = e->nmb; C.sl = P.sl;
+        // disable_deblocking_filter_idc 0 filters the edges between slices too: the filter then sees one slice
+        SliceRows dsl = P.sl;
+        if (pic.deblock_idc == 0) { dsl.rows = e->mbh; dsl.inv = e->mbh > 1 ? (unsigned)(0x100000000ull / (unsigned)e->mbh) + 1u : 0u; }
+        C.mb = e->d_mb; C.levels = e->d_levels; C.mvd = e->d_mvd; C.mvq = e->d_mvq; C.mbw = e->mbw; C.nmb = e->nmb; C.sl = dsl;
         C.mb_first = 0; C.mb_end = e->nmb; C.mbdiv = P.mbdiv; C.bs = (uint8_t*)e->d_bs; C.st_mb = e->nmb; C.aux = e->d_aux;
         C.slotbits = e->d_slotbits; C.slotcode = e->d_slotcode; C.mbbits = e->d_mbbits; C.prevcoded = e->d_prevcoded;
         e->serial = e->serial == 0xFFFFFFFFu ? 1 : e->serial + 1;
@@ -1172,7 +1178,8 @@ int dec_submit(mi355x_h264_decoder* d, const h264dec::Picture& pic)
         hipLaunchKernelGGL(k_bs, dim3((e->nmb + 1) / 2, 1), dim3(64), 0, st, C, e->d_anybs, db_serial);
         DbParams D{};
         for (int p = 0; p < 3; p++) D.pl[p] = e->d_planes[cur][p];
-        D.mb = e->d_mb; D.cw = e->cw; D.ch = e->ch; D.mbw = e->mbw; D.mbh = e->mbh; D.sl = P.sl; D.bs = (const uint8_t*)e->d_bs;
+        D.mb = e->d_mb; D.cw = e->cw; D.ch = e->ch; D.mbw = e->mbw; D.mbh = e->mbh; D.sl = dsl; D.bs = (const uint8_t*)e->d_bs;
+        D.mbqp = d->d_mbqp; D.oa = pic.filter_oa; D.ob = pic.filter_ob; D.cqo_cb = pic.cqo[0]; D.cqo_cr = pic.cqo[1];
         const int qp = pic.qp, qpc = h_chroma_qp[qp];
         D.alpha_y = h_alpha[qp]; D.beta_y = h_beta[qp]; D.alpha_c = h_alpha[qpc]; D.beta_c = h_beta[qpc];
         for (int i = 0; i < 3; i++) { D.tc0_y[i] = h_tc0[qp][i]; D.tc0_c[i] = h_tc0[qpc][i]; }
@@ -1182,7 +1189,12 @@ int dec_submit(mi355x_h264_decoder* d, const h264dec::Picture& pic)
         R.serial = db_serial; R.row0 = 0;
         R.bs = e->d_bs; R.anybs = e->d_anybs;
         R.anypcm = e->d_anypcm; R.anyintra = e->d_anyintra; R.pic_serial = e->pic_serial;
-        if (!pic.has_inter) { R.need_intra = 0; hipLaunchKernelGGL(k_deblock_rows<true>, dim3(e->mbh, 1), dim3(64), 0, st, R); }
+        // one_qp: the per-picture thresholds above are every edge's (the encoder's own streams); else per edge from mbqp
+        if (!pic.one_qp) {
+            R.need_intra = 0;
+            if (pic.has_intra) hipLaunchKernelGGL((k_deblock_rows<true, true>), dim3(e->mbh, 1), dim3(64), 0, st, R);
+            else hipLaunchKernelGGL((k_deblock_rows<false, true>), dim3(e->mbh, 1), dim3(64), 0, st, R);
+        } else if (!pic.has_inter) { R.need_intra = 0; hipLaunchKernelGGL(k_deblock_rows<true>, dim3(e->mbh, 1), dim3(64), 0, st, R); }
         else {
             R.need_intra = -1; hipLaunchKernelGGL(k_deblock_rows<false>, dim3(e->mbh, 1), dim3(64), 0, st, R);
             R.need_intra = 1; hipLaunchKernelGGL(k_deblock_rows<true>, dim3(e->mbh, 1), dim3(64), 0, st, R);
@@ -1219,6 +1231,7 @@ void mi355x_h264_dec_destroy(mi355x_h264_decoder* d)
 {
     if (!d) return;
     if (d->eng) mi355x_h264_destroy(d->eng);
+    if (d->d_mbqp) (void)hipFree(d->d_mbqp);
     delete d;
 }
 
@@ -1237,8 +1250,6 @@ int mi355x_h264_dec_decode(mi355x_h264_decoder* d, const uint8_t* au, size_t len
     if (rc == 0) return MI355X_H264_OK;
     const h264dec::Picture& pic = d->parser.picture();
     const h264dec::Sps& sps = d->parser.sps();
-    if (pic.has_pcm && pic.deblock_idc != 1)
-        return dfail(d, MI355X_H264_E_STREAM, "I_PCM macroblock in a loop-filtered picture (qP 0 edges are not supported)");
     if (!d->eng || d->mbw != pic.mbw || d->mbh != pic.mbh) {
         if (!pic.idr) return dfail(d, MI355X_H264_E_STREAM, "the stream must start with an IDR picture");
         if (d->eng) { mi355x_h264_destroy(d->eng); d->eng = nullptr; }
@@ -1248,6 +1259,8 @@ int mi355x_h264_dec_decode(mi355x_h264_decoder* d, const uint8_t* au, size_t len
         const int crc = mi355x_h264_create(&cfg, &d->eng);
         if (crc != MI355X_H264_OK) return dfail(d, crc, "engine for %dx%d macroblocks could not be created", pic.mbw, pic.mbh);
         d->mbw = pic.mbw; d->mbh = pic.mbh; d->have_refs = 0; d->last = -1;
+        if (d->d_mbqp) { (void)hipFree(d->d_mbqp); d->d_mbqp = nullptr; }
+        if (hipMalloc((void**)&d->d_mbqp, (size_t)pic.mbw * pic.mbh) != hipSuccess) return dfail(d, MI355X_H264_E_NOMEM, "hipMalloc (macroblock QPs)");
     }
     if (hipSetDevice(d->device) != hipSuccess) return dfail(d, MI355X_H264_E_HIP, "hipSetDevice");
     d->width = pic.width; d->height = pic.height; d->crop_x = 2 * sps.crop_l; d->crop_y = 2 * sps.crop_t;
@@ -1328,9 +1341,11 @@ int mi355x_h264_parser_info(const mi355x_h264_parser* p, int32_t* out, int n)
 {
     if (!p || !out || n < 12) return -1;
     const h264dec::Picture& c = p->p.picture();
-    const int32_t v[12] = {c.mbw, c.mbh, c.width, c.height, c.idr, c.qp, c.slice_rows, c.deblock_idc, c.num_ref_active, c.t8x8_mode, c.has_pcm, c.has_intra | (c.has_inter << 1)};
-    memcpy(out, v, sizeof(v));
-    return 12;
+    const int32_t v[17] = {c.mbw, c.mbh, c.width, c.height, c.idr, c.qp, c.slice_rows, c.deblock_idc, c.num_ref_active, c.t8x8_mode, c.has_pcm, c.has_intra | (c.has_inter << 1),
+                           c.cqo[0], c.cqo[1], c.filter_oa, c.filter_ob, c.one_qp};
+    const int m = n < 17 ? 12 : 17;   // (a caller with the first layout's 12 slots gets those)
+    memcpy(out, v, (size_t)m * sizeof(int32_t));
+    return m;
 }
 // what: 0 MbInfo (32 B / macroblock), 1 quadrant vectors (16 B), 2 Intra4x4 modes (16 B), 3 levels (832 B)
 int64_t mi355x_h264_parser_read(const mi355x_h264_parser* p, int what, void* dst, size_t cap)
@@ -1344,6 +1359,7 @@ int64_t mi355x_h264_parser_read(const mi355x_h264_parser* p, int what, void* dst
         case 1: src = c.mvq.data(); n = c.mvq.size() * sizeof(int16_t); break;
         case 2: src = c.aux.data(); n = c.aux.size(); break;
         case 3: src = c.levels.data(); n = c.levels.size() * sizeof(int16_t); break;
+        case 4: src = c.mbqp.data(); n = c.mbqp.size(); break;
         default: return -1;
     }
     if (cap < n) return -1;

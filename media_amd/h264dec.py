@@ -100,7 +100,8 @@ class Decoder:
 
 
 class Parser:
-    INFO = ("mbw", "mbh", "width", "height", "idr", "qp", "slice_rows", "deblock_idc", "num_ref_active", "t8x8_mode", "has_pcm", "kinds")
+    INFO = ("mbw", "mbh", "width", "height", "idr", "qp", "slice_rows", "deblock_idc", "num_ref_active", "t8x8_mode", "has_pcm", "kinds",
+            "cqo_cb", "cqo_cr", "filter_oa", "filter_ob", "one_qp")
 
     def __init__(self):
         self.h = C.c_void_p(_bind().mi355x_h264_parser_create())
@@ -124,9 +125,14 @@ class Parser:
         return rc == 1
 
     def info(self):
-        v = (C.c_int32 * 12)()
-        lib().mi355x_h264_parser_info(self.h, v, 12)
+        v = (C.c_int32 * 17)()
+        lib().mi355x_h264_parser_info(self.h, v, 17)
         return dict(zip(self.INFO, list(v)))
+
+    def mbqp(self):
+        """QP_Y of every macroblock of the last picture (0 for I_PCM)"""
+        i = self.info()
+        return self._read(4, np.empty(i["mbw"] * i["mbh"], np.uint8))
 
     def _read(self, what, arr):
         n = lib().mi355x_h264_parser_read(self.h, what, arr.ctypes.data, arr.nbytes)

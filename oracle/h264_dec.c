@@ -290,6 +290,7 @@ int h264o_dec_last_nal_type(const h264o_dec *d) { return d->nal_type; }
 /* statistics of the last decoded picture, for tests: kind of macroblock `addr` (DMB_*), the largest
  * macroblock_layer() in bits (A.3.1: <= 3200), the largest level_prefix met (A.2: <= 15 outside the High profiles) */
 int h264o_dec_mb_kind(const h264o_dec *d, int addr) { return addr >= 0 && addr < d->mbw * d->mbh ? d->mb[addr].kind : -1; }
+int h264o_dec_mb_qp(const h264o_dec *d, int addr) { return addr >= 0 && addr < d->mbw * d->mbh ? d->mb[addr].qp : -1; }   /* QP_Y (0 for I_PCM) */
 int h264o_dec_max_mb_bits(const h264o_dec *d) { return d->max_mb_bits; }
 int h264o_dec_max_level_prefix(const h264o_dec *d) { return d->max_level_prefix; }
 int h264o_dec_mb_mv(const h264o_dec *d, int addr, int blk4, int *mvx, int *mvy, int *ref)

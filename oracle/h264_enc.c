@@ -157,6 +157,13 @@ int h264o_cavlc_block(const int16_t *lv, int max_coeff, int nC, uint8_t *buf)
 }
 
 /* ------------------------------------------------------------ encoder state */
+/* syntax elements only the random-stream generator (end of this file) sets; the encoder writes 0 / its fixed choice for each */
+struct randsyn {
+    int cqo[2];          /* chroma_qp_index_offset, second_chroma_qp_index_offset */
+    int idc, oa, ob;     /* disable_deblocking_filter_idc, slice_alpha_c0_offset_div2, slice_beta_offset_div2 */
+    int slice_qp[256];   /* SliceQP_Y per slice */
+    int8_t *qpd;         /* mb_qp_delta per macroblock (written where the syntax carries one) */
+};
 struct h264o_enc {
     h264o_config cfg;
     int mbw, mbh, cw, ch, level_idc;
@@ -178,6 +185,7 @@ struct h264o_enc {
     uint8_t *aux;          /* 16 bytes per macroblock: Intra4x4PredMode of the 16 blocks (blkIdx order) */
     int16_t *mvq;          /* 8 int16 per macroblock: vectors of the four 8x8 quadrants of an inter macroblock */
     uint8_t *pshape;       /* P pictures: partition shape the motion search chose (0 16x16, 1 16x8, 2 8x16, 3 8x8) */
+    const struct randsyn *rs;   /* h264o_enc_random_picture (decoder-peer tests): syntax the encoder itself never uses; NULL while encoding */
     uint8_t *want_intra;   /* P pictures: 1 = the motion search handed the macroblock to the intra pass; 2 = one of the "nothing
                             * left to code" tests hit: the prediction is the reconstruction, no transform is run (the tests use
                             * the 4x4 transform whatever transform the profile codes with) */
@@ -360,14 +368,14 @@ static void write_pps(h264o_enc *e, bitw *b)
     bw_put(b, 2, 0); /* weighted_bipred_idc */
     bw_se(b, 0);     /* pic_init_qp_minus26 */
     bw_se(b, 0);     /* pic_init_qs_minus26 */
-    bw_se(b, 0);     /* chroma_qp_index_offset */
+    bw_se(b, e->rs ? e->rs->cqo[0] : 0);     /* chroma_qp_index_offset */
     bw_put(b, 1, 1); /* deblocking_filter_control_present_flag */
     bw_put(b, 1, 0); /* constrained_intra_pred_flag */
     bw_put(b, 1, 0); /* redundant_pic_cnt_present_flag */
     if (e->cfg.profile_idc == 100) {
         bw_put(b, 1, 1); /* transform_8x8_mode_flag: inter macroblocks use the 8x8 transform */
         bw_put(b, 1, 0); /* pic_scaling_matrix_present_flag */
-        bw_se(b, 0);     /* second_chroma_qp_index_offset */
+        bw_se(b, e->rs ? e->rs->cqo[1] : 0);     /* second_chroma_qp_index_offset */
     }
     bw_trailing(b);
 }
@@ -390,6 +398,12 @@ static void write_slice_header(h264o_enc *e, bitw *b, int idr, int first_mb)
         bw_put(b, 1, 0); /* long_term_reference_flag */
     } else {
         bw_put(b, 1, 0); /* adaptive_ref_pic_marking_mode_flag */
+    }
+    if (e->rs) {   /* random-stream generator: its own QP and filter parameters */
+        bw_se(b, e->rs->slice_qp[(first_mb / e->mbw / e->slice_rows) & 255] - 26);
+        bw_ue(b, (uint32_t)e->rs->idc);
+        if (e->rs->idc != 1) { bw_se(b, e->rs->oa); bw_se(b, e->rs->ob); }
+        return;
     }
     bw_se(b, e->cfg.qp - 26); /* slice_qp_delta */
     /* several slices: 2 = no filtering across slice edges, so that the bands stay independent of one another */
@@ -1091,6 +1105,7 @@ static void write_mb(h264o_enc *e, bitw *b, int mx, int my, int p_slice)
     const h264o_mbinfo *mb = &e->mb[my * e->mbw + mx];
     const int16_t *lv = e->levels + (size_t)(my * e->mbw + mx) * H264O_LV_STRIDE;
     int cbpl = mb->cbp & 15, cbpc = mb->cbp >> 4;
+    const int qpd = e->rs ? e->rs->qpd[my * e->mbw + mx] : 0;   /* mb_qp_delta: 0 for every macroblock the encoder codes */
     if (mb->type == H264O_MB_IPCM) {   /* 7.3.5: mb_type I_PCM, alignment, 256 + 2 x 64 samples */
         int cw = e->cw, cs = cw / 2;
         bw_ue(b, (uint32_t)(p_slice ? 5 + 25 : 25));
@@ -1122,13 +1137,13 @@ static void write_mb(h264o_enc *e, bitw *b, int mx, int my, int p_slice)
         int code = 0;
         while (o_cbp_code2intra[code] != mb->cbp) code++;
         bw_ue(b, (uint32_t)code);
-        if (mb->cbp) bw_se(b, 0); /* mb_qp_delta */
+        if (mb->cbp) bw_se(b, qpd); /* mb_qp_delta */
     } else
     if (mb->type == H264O_MB_I16) {
         int t = 1 + mb->i16_mode + 4 * cbpc + (cbpl ? 12 : 0);
         bw_ue(b, (uint32_t)(p_slice ? 5 + t : t));
         bw_ue(b, mb->chroma_mode);
-        bw_se(b, 0); /* mb_qp_delta */
+        bw_se(b, qpd); /* mb_qp_delta */
         cavlc_block(b, lv + H264O_LV_LUMA_DC, 16, nc_luma(e, mx, my, 0));
     } else {
         /* 7.3.5.1 / 7.3.5.2: mb_type (P_L0_16x16, P_L0_L0_16x8, P_L0_L0_8x16, P_8x8 with four sub_mb_type P_L0_8x8), then
@@ -1152,7 +1167,7 @@ static void write_mb(h264o_enc *e, bitw *b, int mx, int my, int p_slice)
         while (o_cbp_code2inter[code] != mb->cbp) code++;
         bw_ue(b, (uint32_t)code);
         if (e->cfg.profile_idc == 100 && (mb->cbp & 15)) bw_put(b, 1, mb->i16_mode); /* transform_size_8x8_flag */
-        if (mb->cbp) bw_se(b, 0); /* mb_qp_delta */
+        if (mb->cbp) bw_se(b, qpd); /* mb_qp_delta */
     }
     for (int b8 = 0; b8 < 4; b8++)
         if (cbpl & (1 << b8))
@@ -1319,6 +1334,224 @@ int64_t h264o_enc_encode(h264o_enc *e, const uint8_t *y, int ys, const uint8_t *
         e->ref[p] = e->cur[p];
         e->cur[p] = oldest;
     }
+    if (idr) e->idr_id = (e->idr_id + e->idr_step) & 0xFF;
+    e->frame_num = (e->frame_num + 1) & 255;
+    e->frame_in_gop++;
+    e->frames++;
+    return (int64_t)pos;
+}
+
+/* ------------------------------------------------------------ random conforming streams (decoder-peer tests)
+ * One picture of RANDOM syntax written with the writers above: macroblock types, prediction modes, vectors, reference
+ * indices, coded_block_patterns, levels, I_PCM samples, and - what the encoder never produces - mb_qp_delta, slice QPs,
+ * chroma_qp_index_offsets, filter offsets and every disable_deblocking_filter_idc.  Nothing is reconstructed here: the
+ * stream is the test vector, oracle/h264_dec.c says what it decodes to, and the decoder peer (media_amd/csrc/h264_parse.h +
+ * k_dec.h) has to produce the same samples.  Stays inside what that peer accepts (its header lists the limits): I / P
+ * slices in bands of whole rows, one reference index per macroblock, sub_mb_type P_L0_8x8, no Intra8x8.
+ * Conformance: a prediction mode is only chosen where its neighbours are available (8.3.1.2, 8.3.3, 8.3.4), QP_Y stays in
+ * 0..51, levels are small enough for every intermediate of 8.5 to fit 16 bits at the QPs drawn (bounded below). */
+static uint32_t rs_next(uint32_t *s)
+{
+    uint32_t x = *s;
+    x ^= x << 13; x ^= x >> 17; x ^= x << 5;
+    return *s = x ? x : 0x9E3779B9u;
+}
+static int rs_below(uint32_t *s, int n) { return (int)(rs_next(s) % (uint32_t)n); }   /* 0 .. n - 1 */
+
+/* n levels (zig-zag order) of one residual block: `density` in 1/16 of the positions non-zero, magnitudes 1 .. mag */
+static int rs_levels(uint32_t *s, int16_t *lv, int first, int n, int density, int mag)
+{
+    int tc = 0;
+    for (int i = first; i < n; i++) {
+        lv[i] = 0;
+        if (rs_below(s, 16) < density) {
+            int a = 1 + (rs_below(s, 4) == 0 ? rs_below(s, mag) : 0);
+            lv[i] = (int16_t)(rs_below(s, 2) ? -a : a);
+            tc++;
+        }
+    }
+    return tc;
+}
+
+int64_t h264o_enc_random_picture(h264o_enc *e, uint32_t seed, int force_idr, int features, uint8_t *out, size_t out_cap,
+                                 int *is_idr, uint8_t *mbqp_out)
+{
+    if (!e || !out) return -1;
+    uint32_t rng = seed * 2654435761u + 12345u;
+    rs_next(&rng);
+    const int nmb = e->mbw * e->mbh, high = e->cfg.profile_idc == 100;
+    static struct randsyn rs;   /* (one generator at a time: test infrastructure) */
+    static int cqo_sticky[2];   /* the PPS travels with IDR pictures only: its offsets hold until the next one */
+    int idr = force_idr || e->frames == 0 || e->frame_in_gop >= e->cfg.gop;
+    if (idr) { e->frame_in_gop = 0; e->frame_num = 0; }
+    if (is_idr) *is_idr = idr;
+    e->avail_refs = idr ? 0 : (e->frame_in_gop < e->nrefs ? e->frame_in_gop : e->nrefs);
+    rs.qpd = (int8_t *)calloc((size_t)nmb, 1);
+    if (idr) {
+        cqo_sticky[0] = (features & 2) ? rs_below(&rng, 25) - 12 : 0;
+        cqo_sticky[1] = (features & 2) && high ? rs_below(&rng, 25) - 12 : cqo_sticky[0];
+    }
+    rs.cqo[0] = cqo_sticky[0]; rs.cqo[1] = cqo_sticky[1];
+    rs.idc = (features & 16) ? rs_below(&rng, 3) : (e->cfg.disable_deblock ? 1 : e->slice_rows < e->mbh ? 2 : 0);
+    rs.oa = (features & 4) ? rs_below(&rng, 13) - 6 : 0;
+    rs.ob = (features & 4) ? rs_below(&rng, 13) - 6 : 0;
+    const int qlo = 4, qhi = 48;   /* QP_Y range drawn from: wide enough for every row of Tables 8-15 / 8-16 that filters */
+    for (int i = 0; i < 256; i++) rs.slice_qp[i] = (features & 1) ? qlo + rs_below(&rng, qhi - qlo + 1) : e->cfg.qp;
+    /* samples of the I_PCM macroblocks */
+    for (int p = 0; p < 3; p++) {
+        size_t n = (size_t)e->cw * e->ch / (p ? 4 : 1);
+        for (size_t i = 0; i < n; i++) e->src[p][i] = (uint8_t)(rs_next(&rng) >> 11);
+    }
+    memset(e->levels, 0, (size_t)nmb * H264O_LV_STRIDE * sizeof(int16_t));
+    memset(e->aux, 0, (size_t)nmb * 16);
+    memset(e->mvq, 0, (size_t)nmb * 8 * sizeof(int16_t));
+    int qp = 26;
+    for (int my = 0; my < e->mbh; my++)
+        for (int mx = 0; mx < e->mbw; mx++) {
+            const int mbi = my * e->mbw + mx;
+            h264o_mbinfo *mb = &e->mb[mbi];
+            int16_t *lv = e->levels + (size_t)mbi * H264O_LV_STRIDE, *qv = e->mvq + (size_t)mbi * 8;
+            uint8_t *am = e->aux + (size_t)mbi * 16;
+            memset(mb, 0, sizeof(*mb));
+            if (mx == 0 && my % e->slice_rows == 0) qp = rs.slice_qp[(my / e->slice_rows) & 255];   /* QP_Y,PRED at a slice start */
+            const int left = mx > 0, top = top_in_slice(e, my);
+            int kind = rs_below(&rng, 100);
+            /* I picture: I4 45 %, I16 45 %, I_PCM 10 %; P picture: skip 22, 16x16 22, 16x8 10, 8x16 10, 8x8 12, I16 9, I4 9, PCM 6 */
+            int type;
+            if (idr) type = kind < 45 ? H264O_MB_I4 : kind < 90 ? H264O_MB_I16 : H264O_MB_IPCM;
+            else type = kind < 22 ? H264O_MB_PSKIP : kind < 44 ? H264O_MB_P16 : kind < 54 ? H264O_MB_P16X8 : kind < 64 ? H264O_MB_P8X16
+                      : kind < 76 ? H264O_MB_P8X8 : kind < 85 ? H264O_MB_I16 : kind < 94 ? H264O_MB_I4 : H264O_MB_IPCM;
+            if (type == H264O_MB_IPCM && !(features & 8)) type = H264O_MB_I16;
+            mb->type = (uint8_t)type;
+            /* residual density / magnitude of this macroblock (kept small at high QP: 16-bit intermediates of 8.5) */
+            const int dens = 1 + rs_below(&rng, 6), mag = qp > 40 ? 2 : qp > 30 ? 4 : 9;
+            if (type == H264O_MB_IPCM) {
+                mb->cbp = 0x2F;
+                memset(mb->tc, 16, 24);
+                if (mbqp_out) mbqp_out[mbi] = 0;   /* 8.7.2.2: qP of an I_PCM macroblock */
+                continue;
+            }
+            if (type == H264O_MB_PSKIP) {
+                mv_t skip;
+                predict_mv_part(e, mx, my, 0, 0, 2, 2, 0, &skip);
+                mb->mvx = skip.x; mb->mvy = skip.y;
+                for (int q = 0; q < 4; q++) { qv[2 * q] = skip.x; qv[2 * q + 1] = skip.y; }
+                if (mbqp_out) mbqp_out[mbi] = (uint8_t)qp;
+                continue;
+            }
+            int carries_delta = 0;
+            if (type == H264O_MB_I16 || type == H264O_MB_I4) {
+                /* chroma: 0 DC, 1 horizontal (left), 2 vertical (top), 3 plane (left, top, top-left) */
+                int cm;
+                do cm = rs_below(&rng, 4); while ((cm == 1 && !left) || (cm == 2 && !top) || (cm == 3 && !(left && top)));
+                mb->chroma_mode = (uint8_t)cm;
+            }
+            if (type == H264O_MB_I16) {
+                int m;
+                do m = rs_below(&rng, 4); while ((m == 0 && !top) || (m == 1 && !left) || (m == 3 && !(left && top)));
+                mb->i16_mode = (uint8_t)m;
+                const int cbpl = rs_below(&rng, 2) ? 15 : 0, cbpc = rs_below(&rng, 3);
+                mb->cbp = (uint8_t)(cbpl | (cbpc << 4));
+                rs_levels(&rng, lv + H264O_LV_LUMA_DC, 0, 16, dens + 2, mag);
+                if (cbpl)
+                    for (int b = 0; b < 16; b++) mb->tc[b] = (uint8_t)rs_levels(&rng, lv + H264O_LV_LUMA + b * 16, 1, 16, dens, mag);
+                carries_delta = 1;
+            } else if (type == H264O_MB_I4) {
+                for (int k = 0; k < 16; k++) {
+                    const int x = o_blk_x[k], y = o_blk_y[k];
+                    const int aL = x > 0 || left, aT = y > 0 || top;
+                    const int aTL = (x > 0 && y > 0) || (x > 0 && y == 0 && top) || (x == 0 && y > 0 && left) || (x == 0 && y == 0 && left && top);
+                    int m;
+                    for (;;) {
+                        m = rs_below(&rng, 9);
+                        const int need_t = m == 0 || m == 3 || m == 7, need_l = m == 1 || m == 8, need_all = m == 4 || m == 5 || m == 6;
+                        if ((need_t && !aT) || (need_l && !aL) || (need_all && !(aL && aT && aTL))) continue;
+                        break;
+                    }
+                    am[k] = (uint8_t)m;
+                }
+                mb->cbp = (uint8_t)(rs_below(&rng, 16) | (rs_below(&rng, 3) << 4));
+            } else {
+                const int shape = type == H264O_MB_P16 ? 0 : type - H264O_MB_P16X8 + 1, nparts = shape == 0 ? 1 : shape == 3 ? 4 : 2;
+                mb->chroma_mode = (uint8_t)rs_below(&rng, e->avail_refs);   /* ref_idx_l0 of all its partitions */
+                for (int k = 0; k < nparts; k++) {
+                    int x0 = 0, y0 = 0, w = 2, h = 2;
+                    if (shape) part_rect(shape, k, &x0, &y0, &w, &h);
+                    /* mostly near the predictor (short mvd codes), sometimes anywhere within +-40 samples, rarely far outside */
+                    mv_t p = predict_mv_part(e, mx, my, x0, y0, w, h, mb->chroma_mode, NULL);
+                    int vx, vy, r = rs_below(&rng, 10);
+                    if (r < 5) { vx = p.x + rs_below(&rng, 9) - 4; vy = p.y + rs_below(&rng, 9) - 4; }
+                    else if (r < 9) { vx = rs_below(&rng, 321) - 160; vy = rs_below(&rng, 321) - 160; }
+                    else { vx = rs_below(&rng, 1601) - 800; vy = rs_below(&rng, 1601) - 800; }
+                    vx = clip3(-2000, 2000, vx); vy = clip3(-2000, 2000, vy);
+                    for (int qy = y0; qy < y0 + h; qy++)
+                        for (int qx = x0; qx < x0 + w; qx++) { qv[2 * (2 * qy + qx)] = (int16_t)vx; qv[2 * (2 * qy + qx) + 1] = (int16_t)vy; }
+                }
+                mb->mvx = qv[0]; mb->mvy = qv[1];
+                mb->cbp = (uint8_t)(rs_below(&rng, 3) == 0 ? 0 : (rs_below(&rng, 16) | (rs_below(&rng, 3) << 4)));
+                mb->i16_mode = (uint8_t)(high && (mb->cbp & 15) ? rs_below(&rng, 2) : 0);   /* transform_size_8x8_flag */
+            }
+            if (type != H264O_MB_I16) {
+                for (int b = 0; b < 16; b++)
+                    if (mb->cbp & (1 << (b >> 2))) mb->tc[b] = (uint8_t)rs_levels(&rng, lv + H264O_LV_LUMA + b * 16, 0, 16, dens, mag);
+                carries_delta = mb->cbp != 0;
+            }
+            if (mb->cbp >> 4) {
+                rs_levels(&rng, lv + H264O_LV_CHROMA_DC, 0, 8, dens + 3, mag);
+                if ((mb->cbp >> 4) == 2)
+                    for (int b = 0; b < 8; b++) mb->tc[16 + b] = (uint8_t)rs_levels(&rng, lv + H264O_LV_CHROMA_AC + b * 16, 1, 16, dens, mag);
+            }
+            if (carries_delta && (features & 1) && rs_below(&rng, 2)) {
+                int d = rs_below(&rng, 4) ? rs_below(&rng, 9) - 4 : rs_below(&rng, 52) - 26;
+                const int nq = clip3(qlo, qhi, qp + d);
+                d = nq - qp;
+                if (d < -26) d += 52;
+                if (d > 25) d -= 52;
+                rs.qpd[mbi] = (int8_t)d;
+                qp = nq;
+            }
+            if (mbqp_out) mbqp_out[mbi] = (uint8_t)qp;
+        }
+    /* headers and slices, as h264o_enc_encode writes them */
+    size_t pos = 0;
+    bitw b;
+    e->rs = &rs;
+    if (idr) {
+        memset(e->rbsp, 0, 256);
+        b = (bitw){e->rbsp, e->rbsp_cap, 0};
+        write_sps(e, &b);
+        pos = emit_nal(out, out_cap, pos, 3, 7, e->rbsp, (size_t)(b.bits >> 3));
+        memset(e->rbsp, 0, 256);
+        b = (bitw){e->rbsp, e->rbsp_cap, 0};
+        write_pps(e, &b);
+        if (pos != (size_t)-1) pos = emit_nal(out, out_cap, pos, 3, 8, e->rbsp, (size_t)(b.bits >> 3));
+    }
+    memset(e->rbsp, 0, e->rbsp_cap);
+    for (int row0 = 0; row0 < e->mbh && pos != (size_t)-1; row0 += e->slice_rows) {
+        int row1 = row0 + e->slice_rows < e->mbh ? row0 + e->slice_rows : e->mbh;
+        b = (bitw){e->rbsp, e->rbsp_cap, 0};
+        write_slice_header(e, &b, idr, row0 * e->mbw);
+        int skip_run = 0;
+        for (int my = row0; my < row1; my++)
+            for (int mx = 0; mx < e->mbw; mx++) {
+                const h264o_mbinfo *mb = &e->mb[my * e->mbw + mx];
+                if (!idr) {
+                    if (mb->type == H264O_MB_PSKIP) { skip_run++; continue; }
+                    bw_ue(&b, (uint32_t)skip_run);
+                    skip_run = 0;
+                }
+                write_mb(e, &b, mx, my, !idr);
+            }
+        if (skip_run) bw_ue(&b, (uint32_t)skip_run);
+        bw_trailing(&b);
+        if ((b.bits >> 3) > e->rbsp_cap) { pos = (size_t)-1; break; }
+        pos = emit_nal(out, out_cap, pos, idr ? 3 : 2, idr ? 5 : 1, e->rbsp, (size_t)(b.bits >> 3));
+        memset(e->rbsp, 0, (size_t)(b.bits >> 3) + 8);
+    }
+    e->rs = NULL;
+    free(rs.qpd);
+    rs.qpd = NULL;
+    if (pos == (size_t)-1) return -2;
     if (idr) e->idr_id = (e->idr_id + e->idr_step) & 0xFF;
     e->frame_num = (e->frame_num + 1) & 255;
     e->frame_in_gop++;

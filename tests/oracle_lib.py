@@ -66,6 +66,8 @@ def lib():
         L.h264o_enc_halo_export.restype = None
         L.h264o_enc_halo_import.argtypes = [vp, C.c_int, vp]
         L.h264o_enc_halo_import.restype = None
+        L.h264o_enc_random_picture.restype = C.c_int64
+        L.h264o_enc_random_picture.argtypes = [vp, C.c_uint32, C.c_int, C.c_int, vp, C.c_size_t, C.POINTER(C.c_int), vp]
         L.h264o_enc_last_slice_bits.restype = C.c_int64
         L.h264o_enc_last_slice_bits.argtypes = [vp]
         L.h264o_dec_create.restype = vp
@@ -81,6 +83,7 @@ def lib():
         for n in ("h264o_dec_max_mb_bits", "h264o_dec_max_level_prefix"):
             getattr(L, n).argtypes = [vp]
         L.h264o_dec_mb_kind.argtypes = [vp, C.c_int]
+        L.h264o_dec_mb_qp.argtypes = [vp, C.c_int]
         L.h264o_dec_mb_mv.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         ip, up = C.POINTER(C.c_int), C.POINTER(C.c_uint)
         L.h264o_dec_table_coeff_token.argtypes = [C.c_int, C.c_int, C.c_int, ip, up]
@@ -133,6 +136,20 @@ class OracleEncoder:
         if n < 0:
             raise RuntimeError("oracle encode failed %d" % n)
         return bytes(self.out[:n]), bool(idr.value)
+
+    RAND_QP, RAND_CHROMA_OFF, RAND_FILTER_OFF, RAND_PCM, RAND_IDC, RAND_ALL = 1, 2, 4, 8, 16, 31
+
+    def random_picture(self, seed, force_idr=False, features=31):
+        """one picture of random conforming syntax (h264o_enc_random_picture): (access unit, is_idr, QP_Y per macroblock);
+        mbinfo() / mvq() / mbaux() / levels() then hold what was written"""
+        idr = C.c_int(0)
+        n_mb = (self.cw // 16) * (self.ch // 16)
+        mbqp = np.zeros(n_mb, dtype=np.uint8)
+        n = lib().h264o_enc_random_picture(self.h, int(seed) & 0xFFFFFFFF, int(force_idr), int(features), _ptr(self.out), self.out.size,
+                                           C.byref(idr), _ptr(mbqp))
+        if n < 0:
+            raise RuntimeError("oracle random picture failed %d" % n)
+        return bytes(self.out[:n]), bool(idr.value), mbqp
 
     def _plane(self, fn, p):
         cw, ch = (self.cw, self.ch) if p == 0 else (self.cw // 2, self.ch // 2)
@@ -227,6 +244,10 @@ class OracleDecoder:
     def mb_kinds(self):
         n = (lib().h264o_dec_coded_width(self.h) // 16) * (lib().h264o_dec_coded_height(self.h) // 16)
         return np.array([lib().h264o_dec_mb_kind(self.h, i) for i in range(n)], dtype=np.int32)
+
+    def mb_qps(self):
+        n = (lib().h264o_dec_coded_width(self.h) // 16) * (lib().h264o_dec_coded_height(self.h) // 16)
+        return np.array([lib().h264o_dec_mb_qp(self.h, i) for i in range(n)], dtype=np.int32)
 
     def mb_mv(self, addr, blk4=0):
         x, y, r = C.c_int(0), C.c_int(0), C.c_int(0)

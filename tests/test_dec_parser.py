@@ -151,3 +151,54 @@ def test_two_independent_parsers_agree_on_damaged_streams():
                         assert (x, y, r) == (mvq[a, 2 * q], mvq[a, 2 * q + 1], mb["chroma_mode"][a]), (content, case, a, q)
             par.close()
     assert both > 150, both
+
+
+def _compare_side_information(par, enc, label):
+    mb, mvq, aux, lv = par.arrays()
+    omb, omvq, oaux, olv = enc.mbinfo(), enc.mvq(), enc.mbaux(), enc.levels()
+    for fld in ("type", "cbp", "chroma_mode", "tc", "mvx", "mvy"):
+        assert np.array_equal(mb[fld], omb[fld]), "%s: %s" % (label, fld)
+    i16 = omb["type"] == 0
+    inter = np.isin(omb["type"], (1, 2, 5, 6, 7))
+    assert np.array_equal(mb["i16_mode"][i16 | inter], omb["i16_mode"][i16 | inter]), label
+    assert np.array_equal(mvq[inter], omvq[inter]), "%s: quadrant vectors" % label
+    i4 = omb["type"] == 4
+    assert np.array_equal(aux[i4], oaux[i4]), "%s: Intra4x4 modes" % label
+    read = np.zeros(olv.shape, bool)
+    cbp = omb["cbp"].astype(np.int32)
+    read[i16, 0:16] = True
+    for q in range(4):
+        read[(cbp >> q) & 1 == 1, 16 + 64 * q: 16 + 64 * (q + 1)] = True
+    read[(cbp >> 4) >= 1, 272:280] = True
+    read[(cbp >> 4) == 2, 280:408] = True
+    read[np.isin(omb["type"], (2, 3)), :] = False
+    assert np.array_equal(np.where(read, lv, 0), np.where(read, olv, 0)), "%s: levels" % label
+
+
+RANDOM_CASES = [(96, 80, 66, 0, 1, 31), (96, 80, 77, 3, 3, 31), (112, 64, 100, 2, 2, 31), (16, 16, 66, 0, 1, 31), (48, 160, 100, 4, 3, 31),
+                (96, 80, 100, 0, 3, 1), (96, 80, 66, 2, 1, 2 | 4), (64, 64, 77, 0, 2, 8 | 16)]
+
+
+@pytest.mark.parametrize("w,h,prof,slices,refs,features", RANDOM_CASES)
+def test_parser_reads_random_streams(w, h, prof, slices, refs, features):
+    """Streams of RANDOM syntax (oracle/h264_enc.c h264o_enc_random_picture: every macroblock type, prediction mode and
+    partition shape, random vectors, reference indices, levels, I_PCM, and what this repository's encoder never writes -
+    mb_qp_delta, slice QPs, chroma_qp_index_offsets, filter offsets, every deblocking idc): the product parser must read back
+    exactly what was written, QP_Y of every macroblock included, and the oracle's independent decoder must agree on the QPs."""
+    enc = OracleEncoder(w, h, qp=30, gop=4, profile_idc=prof, slices=slices, refs=refs)
+    par, dec = h264dec.Parser(), OracleDecoder()
+    seen = set()
+    for i in range(10):
+        au, idr, mbqp = enc.random_picture(7919 * i + w + 3 * prof + features, features=features)
+        assert dec.decode(au) == 1, "the oracle decoder accepts the stream"
+        assert par.parse(au), "picture %d" % i
+        _compare_side_information(par, enc, "picture %d" % i)
+        assert np.array_equal(par.mbqp(), mbqp), "picture %d: QP_Y" % i
+        assert np.array_equal(dec.mb_qps(), mbqp.astype(np.int32)), "picture %d: QP_Y (oracle decoder)" % i
+        info = par.info()
+        assert bool(info["idr"]) == idr
+        seen |= set(int(t) for t in enc.mbinfo()["type"])
+        if features & 1:
+            assert not info["one_qp"] or len(set(mbqp)) == 1
+    assert seen >= ({0, 1, 2, 4, 5, 6, 7} | ({3} if features & 8 else set())) or w * h <= 256
+    par.close()

@@ -71,3 +71,32 @@ def test_intra4x4_block_3_0_reads_the_macroblock_above_right():
     for p in range(3):
         assert np.array_equal(dec.plane(p), ref.plane(p)), "plane %d" % p
     dec.close()
+
+
+RANDOM_CASES = [(96, 80, 66, 0, 1, 31), (96, 80, 77, 3, 3, 31), (112, 64, 100, 2, 2, 31), (16, 16, 66, 0, 1, 31), (48, 160, 100, 4, 3, 31),
+                (96, 80, 100, 0, 3, 1), (96, 80, 66, 2, 1, 2 | 4), (64, 64, 77, 0, 2, 8 | 16), (96, 80, 66, 0, 1, 0), (352, 288, 100, 3, 3, 31),
+                (640, 368, 100, 0, 2, 31)]
+
+
+@pytest.mark.parametrize("w,h,prof,slices,refs,features", RANDOM_CASES)
+def test_decoder_equals_the_independent_decoder_on_random_streams(w, h, prof, slices, refs, features):
+    """Streams of RANDOM syntax (oracle/h264_enc.c h264o_enc_random_picture; tests/test_dec_parser.py lists what they hold):
+    every macroblock type / mode / partition shape next to every other, QP changing per slice and per macroblock, chroma QP
+    offsets (Cb and Cr apart under High), filter offsets, I_PCM inside filtered pictures, filtering across slice edges.  No
+    encoder reconstruction exists for these; the oracle's spec-literal decoder says what they decode to, and the GPU decoder
+    must produce the same samples in every picture (errors would also propagate through the P pictures' references)."""
+    enc = OracleEncoder(w, h, qp=30, gop=5, profile_idc=prof, slices=slices, refs=refs)
+    ref_dec, dec = OracleDecoder(), h264dec.Decoder()
+    for i in range(12):
+        au, idr, mbqp = enc.random_picture(104729 * i + w + 3 * prof + features, features=features)
+        assert ref_dec.decode(au) == 1
+        assert dec.decode(au), "picture %d" % i
+        for p in range(3):
+            got, want = dec.plane(p), ref_dec.plane(p)
+            if not np.array_equal(got, want):
+                ys, xs = np.nonzero(got != want)
+                s = 16 if p == 0 else 8
+                k = (int(ys[0]) // s) * ((w + 15) // 16) + int(xs[0]) // s
+                raise AssertionError("picture %d (%s) plane %d: %d samples differ, first in macroblock %d (type %d, QP %d)"
+                                     % (i, "IDR" if idr else "P", p, ys.size, k, int(enc.mbinfo()["type"][k]), int(mbqp[k])))
+    dec.close()
