@@ -63,7 +63,7 @@ const char *mi355x_h264_parser_error(const mi355x_h264_parser *p);
  * Returns the number of values written */
 int mi355x_h264_parser_info(const mi355x_h264_parser *p, int32_t *out, int n);
 /* what: 0 MbInfo (32 B / macroblock, layout of mi355x_h264.h), 1 quadrant vectors (8 int16), 2 Intra4x4 modes (16 B), 3 levels (416 int16),
- * 4 QP_Y (1 B / macroblock; 0 for I_PCM) */
+ * 4 QP_Y (1 B / macroblock; 0 for I_PCM), 5 vectors per 4x4 block (32 int16, raster order), 6 ref_idx_l0 per 8x8 quadrant (4 B; 255 intra) */
 int64_t mi355x_h264_parser_read(const mi355x_h264_parser *p, int what, void *dst, size_t cap);
 
 #ifdef __cplusplus

@@ -98,6 +98,8 @@ struct FrameParams {
     // decoder peer only (the encoder's pictures have one QP: qy, qc above; it leaves these 0):
     const uint8_t* mbqp; // QP_Y of every macroblock (7.4.5: slice_qp_delta, mb_qp_delta); 0 for I_PCM
     int cqo_cb, cqo_cr;  // chroma_qp_index_offset, second_chroma_qp_index_offset
+    const int16_t* mv4;  // 32 int16 per macroblock: the vector (x, y) of every 4x4 block, raster order (sub-macroblock partitions)
+    const uint8_t* refq; // 4 per macroblock: ref_idx_l0 of the four 8x8 quadrants
 };
 
 // the parameter block of batch item g (pointers advanced by g strides)

@@ -152,7 +152,9 @@ struct Picture {
                                      // reconstructs with the per-picture constants the encoder's kernels use
     std::vector<uint8_t> mbqp;       // QP_Y of every macroblock (7.4.5); 0 for I_PCM, the value its edges filter with (8.7.2.2)
     std::vector<MbRec> mb;
-    std::vector<int16_t> mvq;      // 8 per macroblock
+    std::vector<int16_t> mvq;      // 8 per macroblock: the vectors of the four 8x8 quadrants' first blocks (the encoder's layout)
+    std::vector<int16_t> mv4;      // 32 per macroblock: the vector (x, y) of every 4x4 block, raster order (sub-macroblock partitions)
+    std::vector<uint8_t> refq;     // 4 per macroblock: ref_idx_l0 of the four quadrants (0xFF: intra)
     std::vector<uint8_t> aux;      // 16 per macroblock
     std::vector<int16_t> levels;   // L_STRIDE per macroblock (I_PCM: its 384 samples as bytes at the start)
 };
@@ -413,42 +415,45 @@ private:
         return br.bad() ? -1 : tc;
     }
 
-    // ---- 8.4.1.3 with vectors per 8x8 quadrant (all partitions here are 8x8 or larger) ----
+    // ---- 8.4.1.3 on the 4x4 grid (sub-macroblock partitions go down to 4x4): neighbours A (left of the partition's first block),
+    // B (above it), C (above-right of its top-right block; D above-left when C is not available - outside, or later in decoding
+    // order, 6.4.11.7) ----
     struct Cand { bool av; int ref, x, y; };
-    Cand quadrant(int mx, int my, int q, bool self = false)
+    Cand block(int mx, int my, int bx, int by, bool self = false)
     {
         Cand c{false, -1, 0, 0};
         if (!self && !avail(mx, my)) return c;
         c.av = true;
-        const MbRec& m = M(mx, my);
-        if (!intra(m.type)) {
-            c.ref = m.chroma_mode;
-            c.x = pic_.mvq[((size_t)my * pic_.mbw + mx) * 8 + 2 * q];
-            c.y = pic_.mvq[((size_t)my * pic_.mbw + mx) * 8 + 2 * q + 1];
+        const size_t i = (size_t)my * pic_.mbw + mx;
+        if (!intra(pic_.mb[i].type)) {
+            c.ref = pic_.refq[i * 4 + 2 * (by >> 1) + (bx >> 1)];
+            c.x = pic_.mv4[i * 32 + 2 * (4 * by + bx)];
+            c.y = pic_.mv4[i * 32 + 2 * (4 * by + bx) + 1];
         }
         return c;
     }
     static int med3(int a, int b, int c) { return a > b ? (b > c ? b : (a > c ? c : a)) : (a > c ? a : (b > c ? c : b)); }
-    void predict(int mx, int my, int x0, int y0, int w, int h, int ref, int& px, int& py, bool skip_rule = false)
+    // partition of w4 x h4 blocks at (x4, y4); mbpart: a macroblock partition (the directional rules of 16x8 / 8x16 apply)
+    void predict(int mx, int my, int x4, int y4, int w4, int h4, int ref, int& px, int& py, bool mbpart, bool skip_rule = false)
     {
-        const Cand A = x0 == 0 ? quadrant(mx - 1, my, 2 * y0 + 1) : quadrant(mx, my, 2 * y0, true);
-        const Cand B = y0 == 0 ? quadrant(mx, my - 1, 2 + x0) : quadrant(mx, my, x0, true);
+        const Cand A = x4 == 0 ? block(mx - 1, my, 3, y4) : block(mx, my, x4 - 1, y4, true);
+        const Cand B = y4 == 0 ? block(mx, my - 1, x4, 3) : block(mx, my, x4, y4 - 1, true);
         Cand C{false, -1, 0, 0};
-        if (y0 == 0) C = x0 + w <= 1 ? quadrant(mx, my - 1, 2 + x0 + w) : quadrant(mx + 1, my - 1, 2);
-        else if (x0 + w <= 1) C = quadrant(mx, my, x0 + w, true);
+        if (y4 == 0) C = x4 + w4 < 4 ? block(mx, my - 1, x4 + w4, 3) : block(mx + 1, my - 1, 0, 3);
+        else if (x4 + w4 < 4 && blk_idx(x4 + w4, y4 - 1) < blk_idx(x4, y4)) C = block(mx, my, x4 + w4, y4 - 1, true);   // decoded before this partition
         if (!C.av) {
-            if (x0 == 0 && y0 == 0) C = quadrant(mx - 1, my - 1, 3);
-            else if (y0 == 0) C = quadrant(mx, my - 1, 2);
-            else if (x0 == 0) C = quadrant(mx - 1, my, 1);
-            else C = quadrant(mx, my, 0, true);
+            if (x4 == 0 && y4 == 0) C = block(mx - 1, my - 1, 3, 3);
+            else if (y4 == 0) C = block(mx, my - 1, x4 - 1, 3);
+            else if (x4 == 0) C = block(mx - 1, my, 3, y4 - 1);
+            else C = block(mx, my, x4 - 1, y4 - 1, true);
         }
         if (skip_rule && (!A.av || !B.av || (A.ref == 0 && A.x == 0 && A.y == 0) || (B.ref == 0 && B.x == 0 && B.y == 0))) { px = py = 0; return; }
-        if (w == 2 && h == 1) {
-            if (y0 == 0 && B.ref == ref) { px = B.x; py = B.y; return; }
-            if (y0 == 1 && A.ref == ref) { px = A.x; py = A.y; return; }
-        } else if (w == 1 && h == 2) {
-            if (x0 == 0 && A.ref == ref) { px = A.x; py = A.y; return; }
-            if (x0 == 1 && C.ref == ref) { px = C.x; py = C.y; return; }
+        if (mbpart && w4 == 4 && h4 == 2) {
+            if (y4 == 0 && B.ref == ref) { px = B.x; py = B.y; return; }
+            if (y4 == 2 && A.ref == ref) { px = A.x; py = A.y; return; }
+        } else if (mbpart && w4 == 2 && h4 == 4) {
+            if (x4 == 0 && A.ref == ref) { px = A.x; py = A.y; return; }
+            if (x4 == 2 && C.ref == ref) { px = C.x; py = C.y; return; }
         }
         Cand a = A, b = B, c = C;
         if (!b.av && !c.av && a.av) { b = a; c = a; }
@@ -516,6 +521,8 @@ private:
             pic_.mbqp.assign(n, (uint8_t)qp);
             pic_.mb.assign(n, MbRec{});
             pic_.mvq.assign(n * 8, 0);
+            pic_.mv4.assign(n * 32, 0);
+            pic_.refq.assign(n * 4, 0xFF);
             pic_.aux.assign(n * 16, 0);
             pic_.levels.assign(n * L_STRIDE, 0);
             have_pic = true;
@@ -556,10 +563,21 @@ private:
         return true;
     }
 
-    void set_vectors(int mx, int my, int q, int x, int y)
+    // the vector of the w4 x h4 blocks at (x4, y4); a quadrant's entry of mvq is its first block's
+    void set_vectors(int mx, int my, int x4, int y4, int w4, int h4, int x, int y)
     {
-        int16_t* v = &pic_.mvq[((size_t)my * pic_.mbw + mx) * 8 + 2 * q];
-        v[0] = (int16_t)x; v[1] = (int16_t)y;
+        const size_t i = (size_t)my * pic_.mbw + mx;
+        for (int by = y4; by < y4 + h4; by++)
+            for (int bx = x4; bx < x4 + w4; bx++) {
+                int16_t* v = &pic_.mv4[i * 32 + 2 * (4 * by + bx)];
+                v[0] = (int16_t)x; v[1] = (int16_t)y;
+                if (!(bx & 1) && !(by & 1)) { int16_t* q = &pic_.mvq[i * 8 + 2 * (2 * (by >> 1) + (bx >> 1))]; q[0] = (int16_t)x; q[1] = (int16_t)y; }
+            }
+    }
+    void set_refs(int mx, int my, int r0, int r1, int r2, int r3)
+    {
+        uint8_t* r = &pic_.refq[((size_t)my * pic_.mbw + mx) * 4];
+        r[0] = (uint8_t)r0; r[1] = (uint8_t)r1; r[2] = (uint8_t)r2; r[3] = (uint8_t)r3;
     }
     void set_qp(int mx, int my, int qp)
     {
@@ -574,9 +592,10 @@ private:
         m.chroma_mode = 0;   // ref_idx_l0 = 0
         set_qp(mx, my, qp_);
         int px, py;
-        predict(mx, my, 0, 0, 2, 2, 0, px, py, true);
+        set_refs(mx, my, 0, 0, 0, 0);
+        predict(mx, my, 0, 0, 4, 4, 0, px, py, true, true);
         m.mvx = (int16_t)px; m.mvy = (int16_t)py;
-        for (int q = 0; q < 4; q++) set_vectors(mx, my, q, px, py);
+        set_vectors(mx, my, 0, 0, 4, 4, px, py);
         pic_.has_inter = true;
     }
 
@@ -592,6 +611,8 @@ private:
         if (br.bad() || (is_intra && t > 25) || (!is_intra && t > 4)) { fail("mb_type %d", (int)t); return false; }
         int cbp = 0;
         bool i16 = false, t8flag = false;
+        if (is_intra) set_refs(mx, my, 0xFF, 0xFF, 0xFF, 0xFF);
+        bool all8x8 = true;   // NoSubMbPartSizeLessThan8x8Flag
         if (is_intra && t == 25) {   // I_PCM
             while (!br.aligned()) br.u(1);
             uint8_t* raw = (uint8_t*)lv;
@@ -638,41 +659,60 @@ private:
             const int shape = t == 4 ? 3 : (int)t;
             m.type = (uint8_t)(shape == 0 ? T_P16 : T_P16X8 + shape - 1);
             const int nparts = shape == 0 ? 1 : (shape == 3 ? 4 : 2);
+            int sub[4] = {0, 0, 0, 0};   // sub_mb_type: 0 8x8, 1 8x4, 2 4x8, 3 4x4
             if (shape == 3)
-                for (int k = 0; k < 4; k++)
-                    if (br.ue() != 0) { fail("sub_mb_type other than P_L0_8x8"); return false; }
-            int ref = 0;
-            if (num_ref_ > 1 && t != 4) {
+                for (int k = 0; k < 4; k++) {
+                    const unsigned su = br.ue();
+                    if (su > 3) { fail("sub_mb_type %d", (int)su); return false; }
+                    sub[k] = (int)su;
+                    if (su) all8x8 = false;
+                }
+            int ref[4] = {0, 0, 0, 0};
+            if (num_ref_ > 1 && t != 4)
                 for (int k = 0; k < nparts; k++) {
                     const unsigned ru = num_ref_ == 2 ? 1u - br.u(1) : br.ue();
                     if (ru >= (unsigned)num_ref_) { fail("ref_idx_l0 %d", (int)ru); return false; }
-                    const int r = (int)ru;
-                    if (k && r != ref) { fail("partitions of one macroblock with different reference pictures"); return false; }
-                    ref = r;
+                    ref[k] = (int)ru;
                 }
-            }
-            m.chroma_mode = (uint8_t)ref;
-            for (int k = 0; k < nparts; k++) {
-                int x0 = 0, y0 = 0, w = 2, h = 2;
-                if (shape == 1) { y0 = k; h = 1; }
-                else if (shape == 2) { x0 = k; w = 1; }
-                else if (shape == 3) { x0 = k & 1; y0 = k >> 1; w = h = 1; }
+            // refs of the four quadrants, known before the first vector is predicted
+            if (shape == 0) set_refs(mx, my, ref[0], ref[0], ref[0], ref[0]);
+            else if (shape == 1) set_refs(mx, my, ref[0], ref[0], ref[1], ref[1]);
+            else if (shape == 2) set_refs(mx, my, ref[0], ref[1], ref[0], ref[1]);
+            else set_refs(mx, my, ref[0], ref[1], ref[2], ref[3]);
+            m.chroma_mode = (uint8_t)ref[0];
+            auto one_vector = [&](int x4, int y4, int w4, int h4, int r, bool mbpart, bool first) -> bool {
                 int px, py;
-                predict(mx, my, x0, y0, w, h, ref, px, py);
+                predict(mx, my, x4, y4, w4, h4, r, px, py, mbpart);
                 const int dx = br.se(), dy = br.se();
                 if (dx < -8192 || dx > 8191 || dy < -8192 || dy > 8191) { fail("mvd_l0 out of range"); return false; }
                 const int vx = px + dx, vy = py + dy;
                 if (vx < -16384 || vx > 16383 || vy < -16384 || vy > 16383) { fail("motion vector out of range"); return false; }
-                for (int qy = y0; qy < y0 + h; qy++)
-                    for (int qx = x0; qx < x0 + w; qx++) set_vectors(mx, my, 2 * qy + qx, vx, vy);
-                if (k == 0) { m.mvx = (int16_t)vx; m.mvy = (int16_t)vy; }
+                set_vectors(mx, my, x4, y4, w4, h4, vx, vy);
+                if (first) { m.mvx = (int16_t)vx; m.mvy = (int16_t)vy; }
+                return true;
+            };
+            for (int k = 0; k < nparts; k++) {
+                if (shape == 0) { if (!one_vector(0, 0, 4, 4, ref[0], true, true)) return false; }
+                else if (shape == 1) { if (!one_vector(0, 2 * k, 4, 2, ref[k], true, k == 0)) return false; }
+                else if (shape == 2) { if (!one_vector(2 * k, 0, 2, 4, ref[k], true, k == 0)) return false; }
+                else {
+                    const int qx = 2 * (k & 1), qy = 2 * (k >> 1);
+                    const int nsub = sub[k] == 0 ? 1 : (sub[k] == 3 ? 4 : 2);
+                    for (int j = 0; j < nsub; j++) {
+                        int x4 = qx, y4 = qy, w4 = 2, h4 = 2;
+                        if (sub[k] == 1) { y4 += j; h4 = 1; }
+                        else if (sub[k] == 2) { x4 += j; w4 = 1; }
+                        else if (sub[k] == 3) { x4 += j & 1; y4 += j >> 1; w4 = h4 = 1; }
+                        if (!one_vector(x4, y4, w4, h4, ref[k], false, k == 0 && j == 0)) return false;
+                    }
+                }
             }
         }
         if (!i16) {
             const unsigned code = br.ue();
             if (code > 47) { fail("coded_block_pattern code %d", (int)code); return false; }
             cbp = is_intra ? vlc().code2cbp_intra[code] : vlc().code2cbp_inter[code];
-            if ((cbp & 15) && pps.t8x8 && !is_intra) t8flag = br.u(1) != 0;
+            if ((cbp & 15) && pps.t8x8 && !is_intra && all8x8) t8flag = br.u(1) != 0;
         }
         m.cbp = (uint8_t)cbp;
         if (!is_intra) m.i16_mode = t8flag ? 1 : 0;

@@ -4,7 +4,9 @@
 // encoder's own reconstruction path run from given decisions:
 //   k_dec_inter   motion-compensated prediction of every inter macroblock (8.4.2.2: luma by the 6-tap / bilinear quarter-
 //                 sample rules straight from the reference plane, chroma by the 1/8-sample bilinear rule), written into the
-//                 picture; lane = (row, four samples), one wave per macroblock
+//                 picture; lane = (row, four samples), one wave per macroblock; a vector per 4x4 block and a reference
+//                 picture per 8x8 quadrant (the parser's mv4 / refq: partitions down to 4x4, 7.3.5.2)
+//   k_dec_bs      boundary strengths (8.7.2.1) from those arrays - the encoder's k_bs knows vectors per quadrant only
 //   k_dec_resid   scaling + inverse transform (4x4: 8.5.12, 8x8: 8.5.13, chroma DC: 8.5.11) of the inter macroblocks' levels,
 //                 added to the prediction in place; lane = one 4x4 block, four macroblocks per wave
 //   k_pintra_rows<true> (k_intra.h)  the intra macroblocks in row-wavefront order, intra_mb_core<true>
@@ -89,25 +91,75 @@ __global__ __launch_bounds__(64) void k_dec_inter(FrameParams P0)
     const int mbi = P.band.row0 * P.mbw + (int)blockIdx.x, my = P.mbdiv.row(mbi), mx = mbi - my * P.mbw;
     const uint32_t w1 = *(const uint32_t*)((const uint8_t*)(P.mb + mbi) + 4);
     if (mb_is_intra((int)(w1 & 255u))) return;
-    const int ref = (int)((w1 >> 16) & 255u);
-    const uint4 qv = *(const uint4*)(P.mvq + (size_t)mbi * 8);
-    auto vec = [&](bool low, bool left, int& vx, int& vy) {
-        const uint32_t v = low ? (left ? qv.x : qv.y) : (left ? qv.z : qv.w);
-        vx = (int)(int16_t)(v & 0xFFFFu); vy = (int)(int16_t)(v >> 16);
-    };
+    const uint32_t* mv = (const uint32_t*)(P.mv4 + (size_t)mbi * 32);   // [4 * by + bx] = x | y << 16
+    const uint32_t refs = *(const uint32_t*)(P.refq + (size_t)mbi * 4);
     {
         const int y = lane >> 2, seg = (lane & 3) * 4;
-        int vx, vy;
-        vec(y < 8, seg < 8, vx, vy);
-        *(uint32_t*)(P.rec[0] + (size_t)(16 * my + y) * P.cw + 16 * mx + seg) = mc_luma4(ref_plane(P, ref, 0), P.cw, P.ch, 16 * mx + seg, 16 * my + y, vx, vy);
+        const uint32_t v = mv[4 * (y >> 2) + (seg >> 2)];
+        const int ref = (int)((refs >> (8 * (2 * (y >> 3) + (seg >> 3)))) & 255u);
+        *(uint32_t*)(P.rec[0] + (size_t)(16 * my + y) * P.cw + 16 * mx + seg) =
+            mc_luma4(ref_plane(P, ref, 0), P.cw, P.ch, 16 * mx + seg, 16 * my + y, (int)(int16_t)(v & 0xFFFFu), (int)(int16_t)(v >> 16));
     }
     if (lane < 32) {
+        // four chroma samples of one row = the chroma of two 4x4 luma blocks (2 x 2 samples each), which may move differently
         const int pl = lane >> 4, cyy = (lane >> 1) & 7, cxx = (lane & 1) * 4;
-        int vx, vy;
-        vec(cyy < 4, cxx < 4, vx, vy);
-        *(uint32_t*)(rec_chroma(P, pl) + (size_t)(8 * my + cyy) * (P.cw / 2) + 8 * mx + cxx) =
-            chroma_pred4(ref_plane(P, ref, 1 + pl), P.cw / 2, P.ch / 2, 8 * mx + cxx + (vx >> 3), 8 * my + cyy + (vy >> 3), vx & 7, vy & 7);
+        const int b = 4 * (cyy >> 1) + (cxx >> 1);
+        const uint32_t va = mv[b], vb = mv[b + 1];
+        const int ref = (int)((refs >> (8 * (2 * (cyy >> 2) + (cxx >> 2)))) & 255u);
+        const uint8_t* R = ref_plane(P, ref, 1 + pl);
+        auto pred = [&](uint32_t v) {
+            const int vx = (int)(int16_t)(v & 0xFFFFu), vy = (int)(int16_t)(v >> 16);
+            return chroma_pred4(R, P.cw / 2, P.ch / 2, 8 * mx + cxx + (vx >> 3), 8 * my + cyy + (vy >> 3), vx & 7, vy & 7);
+        };
+        uint32_t o = pred(va);
+        if (vb != va) o = (o & 0xFFFFu) | (pred(vb) & 0xFFFF0000u);
+        *(uint32_t*)(rec_chroma(P, pl) + (size_t)(8 * my + cyy) * (P.cw / 2) + 8 * mx + cxx) = o;
     }
+}
+
+// 8.7.2.1 for the decoder: lane = (macroblock of the pair, direction, edge, segment); vectors per 4x4 block, references per
+// quadrant (one list, never reordered: equal indices = the same picture).  Writes the layout k_bs writes.
+struct DecBsParams {
+    const MbInfo* mb;
+    const int16_t* mv4;
+    const uint8_t* refq;
+    uint8_t* bs;
+    int mbw, nmb;
+    SliceRows sl;      // the slices the FILTER sees (idc 0: one)
+    MbDiv mbdiv;
+};
+__global__ __launch_bounds__(64) void k_dec_bs(DecBsParams C, unsigned* anybs, unsigned serial)
+{
+    const int lane = threadIdx.x, l = lane & 31, mbi = 2 * (int)blockIdx.x + (lane >> 5);
+    int bs = 0;
+    if (mbi < C.nmb) {
+        const int my = C.mbdiv.row(mbi), mx = mbi - my * C.mbw;
+        const int dir = l >> 4, e = (l >> 2) & 3, k = l & 3;
+        const bool edge_ok = !(e == 0 && (dir == 0 ? mx == 0 : !C.sl.has_top(my)));
+        if (edge_ok) {
+            const int pi = e == 0 ? (dir == 0 ? mbi - 1 : mbi - C.mbw) : mbi;
+            const MbInfo *q = C.mb + mbi, *p = C.mb + pi;
+            const int qx = dir == 0 ? e : k, qy = dir == 0 ? k : e;                                  // 4x4 raster position of q's block
+            const int px = dir == 0 ? (e == 0 ? 3 : e - 1) : k, py = dir == 0 ? k : (e == 0 ? 3 : e - 1);
+            const int bq = xy2blk(qx, qy), bp = xy2blk(px, py);
+            if (mb_is_intra(p->type) || mb_is_intra(q->type)) bs = e == 0 ? 4 : 3;
+            else {
+                const bool q8 = (q->type == MB_P16 || q->type >= MB_P16X8) && q->i16_mode == 1, p8 = (p->type == MB_P16 || p->type >= MB_P16X8) && p->i16_mode == 1;
+                if (!(q8 && (e & 1))) {
+                    const bool nzq = q8 ? (*(const uint32_t*)(q->tc + (bq & ~3)) != 0) : q->tc[bq] != 0;
+                    const bool nzp = p8 ? (*(const uint32_t*)(p->tc + (bp & ~3)) != 0) : p->tc[bp] != 0;
+                    if (nzp || nzq) bs = 2;
+                    else if (C.refq[(size_t)pi * 4 + 2 * (py >> 1) + (px >> 1)] != C.refq[(size_t)mbi * 4 + 2 * (qy >> 1) + (qx >> 1)]) bs = 1;
+                    else {
+                        const uint32_t vp = *(const uint32_t*)(C.mv4 + (size_t)pi * 32 + 2 * (4 * py + px)), vq = *(const uint32_t*)(C.mv4 + (size_t)mbi * 32 + 2 * (4 * qy + qx));
+                        bs = (iabs((int)(int16_t)(vp & 0xFFFFu) - (int)(int16_t)(vq & 0xFFFFu)) >= 4 || iabs((int)(int16_t)(vp >> 16) - (int)(int16_t)(vq >> 16)) >= 4) ? 1 : 0;
+                    }
+                }
+            }
+        }
+        C.bs[(size_t)mbi * 32 + l] = (uint8_t)bs;
+    }
+    if (__ballot(bs != 0) != 0ull && lane == 0) anybs[blockIdx.y] = serial;
 }
 
 __global__ __launch_bounds__(64) void k_dec_resid(FrameParams P0)

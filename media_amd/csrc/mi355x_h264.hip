@@ -1088,6 +1088,8 @@ struct mi355x_h264_decoder {
     uint64_t pictures = 0;
     double parse_ms = 0, gpu_ms = 0;
     uint8_t* d_mbqp = nullptr;   // QP_Y per macroblock of the picture being reconstructed
+    int16_t* d_mv4 = nullptr;    // its vectors per 4x4 block (32 int16 per macroblock)
+    uint8_t* d_refq = nullptr;   // and reference indices per quadrant (4 per macroblock)
     char err[256] = {0};
 };
 
@@ -1127,6 +1129,10 @@ int dec_submit(mi355x_h264_decoder* d, const h264dec::Picture& pic)
     DHIP(d, hipMemcpyAsync(e->d_aux, pic.aux.data(), nmb * 16, hipMemcpyHostToDevice, st));
     DHIP(d, hipMemcpyAsync(e->d_levels, pic.levels.data(), nmb * LV_STRIDE * sizeof(int16_t), hipMemcpyHostToDevice, st));
     DHIP(d, hipMemcpyAsync(d->d_mbqp, pic.mbqp.data(), nmb, hipMemcpyHostToDevice, st));
+    if (pic.has_inter) {
+        DHIP(d, hipMemcpyAsync(d->d_mv4, pic.mv4.data(), nmb * 64, hipMemcpyHostToDevice, st));
+        DHIP(d, hipMemcpyAsync(d->d_refq, pic.refq.data(), nmb * 4, hipMemcpyHostToDevice, st));
+    }
     const int cur = e->cur;
     FrameParams P{};
     P.w = e->cw; P.h = e->ch; P.cw = e->cw; P.ch = e->ch; P.mbw = e->mbw; P.mbh = e->mbh;
@@ -1147,7 +1153,7 @@ int dec_submit(mi355x_h264_decoder* d, const h264dec::Picture& pic)
     P.anypcm = e->d_anypcm; P.anyintra = e->d_anyintra; P.pic_serial = e->pic_serial;
     fill_quant(P.qy, pic.qp);                 // (the reconstruction kernels scale with the macroblock's own QP: mbqp)
     fill_quant(P.qc, h_chroma_qp[pic.qp]);
-    P.mbqp = d->d_mbqp; P.cqo_cb = pic.cqo[0]; P.cqo_cr = pic.cqo[1];
+    P.mbqp = d->d_mbqp; P.cqo_cb = pic.cqo[0]; P.cqo_cr = pic.cqo[1]; P.mv4 = d->d_mv4; P.refq = d->d_refq;
     {   // the flags the loop filter launches look at: intra macroblocks present (bS 3 / 4 form); I_PCM never switches the filter off here
         const unsigned flags[2] = {0u, pic.has_intra ? e->pic_serial : 0u};
         DHIP(d, hipMemcpyAsync(e->d_anypcm, &flags[0], sizeof(unsigned), hipMemcpyHostToDevice, st));
@@ -1175,7 +1181,12 @@ int dec_submit(mi355x_h264_decoder* d, const h264dec::Picture& pic)
         C.slotbits = e->d_slotbits; C.slotcode = e->d_slotcode; C.mbbits = e->d_mbbits; C.prevcoded = e->d_prevcoded;
         e->serial = e->serial == 0xFFFFFFFFu ? 1 : e->serial + 1;
         const unsigned db_serial = e->serial;
-        hipLaunchKernelGGL(k_bs, dim3((e->nmb + 1) / 2, 1), dim3(64), 0, st, C, e->d_anybs, db_serial);
+        if (pic.has_inter) {   // vectors per 4x4 block, references per quadrant
+            DecBsParams B{};
+            B.mb = e->d_mb; B.mv4 = d->d_mv4; B.refq = d->d_refq; B.bs = (uint8_t*)e->d_bs; B.mbw = e->mbw; B.nmb = e->nmb; B.sl = dsl; B.mbdiv = P.mbdiv;
+            hipLaunchKernelGGL(k_dec_bs, dim3((e->nmb + 1) / 2, 1), dim3(64), 0, st, B, e->d_anybs, db_serial);
+        } else
+            hipLaunchKernelGGL(k_bs, dim3((e->nmb + 1) / 2, 1), dim3(64), 0, st, C, e->d_anybs, db_serial);
         DbParams D{};
         for (int p = 0; p < 3; p++) D.pl[p] = e->d_planes[cur][p];
         D.mb = e->d_mb; D.cw = e->cw; D.ch = e->ch; D.mbw = e->mbw; D.mbh = e->mbh; D.sl = dsl; D.bs = (const uint8_t*)e->d_bs;
@@ -1232,6 +1243,8 @@ void mi355x_h264_dec_destroy(mi355x_h264_decoder* d)
     if (!d) return;
     if (d->eng) mi355x_h264_destroy(d->eng);
     if (d->d_mbqp) (void)hipFree(d->d_mbqp);
+    if (d->d_mv4) (void)hipFree(d->d_mv4);
+    if (d->d_refq) (void)hipFree(d->d_refq);
     delete d;
 }
 
@@ -1260,7 +1273,11 @@ int mi355x_h264_dec_decode(mi355x_h264_decoder* d, const uint8_t* au, size_t len
         if (crc != MI355X_H264_OK) return dfail(d, crc, "engine for %dx%d macroblocks could not be created", pic.mbw, pic.mbh);
         d->mbw = pic.mbw; d->mbh = pic.mbh; d->have_refs = 0; d->last = -1;
         if (d->d_mbqp) { (void)hipFree(d->d_mbqp); d->d_mbqp = nullptr; }
-        if (hipMalloc((void**)&d->d_mbqp, (size_t)pic.mbw * pic.mbh) != hipSuccess) return dfail(d, MI355X_H264_E_NOMEM, "hipMalloc (macroblock QPs)");
+        if (d->d_mv4) { (void)hipFree(d->d_mv4); d->d_mv4 = nullptr; }
+        if (d->d_refq) { (void)hipFree(d->d_refq); d->d_refq = nullptr; }
+        const size_t n = (size_t)pic.mbw * pic.mbh;
+        if (hipMalloc((void**)&d->d_mbqp, n) != hipSuccess || hipMalloc((void**)&d->d_mv4, n * 64) != hipSuccess || hipMalloc((void**)&d->d_refq, n * 4) != hipSuccess)
+            return dfail(d, MI355X_H264_E_NOMEM, "hipMalloc (per-macroblock decoder arrays)");
     }
     if (hipSetDevice(d->device) != hipSuccess) return dfail(d, MI355X_H264_E_HIP, "hipSetDevice");
     d->width = pic.width; d->height = pic.height; d->crop_x = 2 * sps.crop_l; d->crop_y = 2 * sps.crop_t;
@@ -1360,6 +1377,8 @@ int64_t mi355x_h264_parser_read(const mi355x_h264_parser* p, int what, void* dst
         case 2: src = c.aux.data(); n = c.aux.size(); break;
         case 3: src = c.levels.data(); n = c.levels.size() * sizeof(int16_t); break;
         case 4: src = c.mbqp.data(); n = c.mbqp.size(); break;
+        case 5: src = c.mv4.data(); n = c.mv4.size() * sizeof(int16_t); break;
+        case 6: src = c.refq.data(); n = c.refq.size(); break;
         default: return -1;
     }
     if (cap < n) return -1;

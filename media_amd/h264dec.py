@@ -129,6 +129,12 @@ class Parser:
         lib().mi355x_h264_parser_info(self.h, v, 17)
         return dict(zip(self.INFO, list(v)))
 
+    def vectors4(self):
+        """(vectors of the sixteen 4x4 blocks (n, 16, 2), raster order; ref_idx_l0 of the four quadrants (n, 4), 255 = intra)"""
+        i = self.info()
+        n = i["mbw"] * i["mbh"]
+        return self._read(5, np.empty((n, 16, 2), np.int16)), self._read(6, np.empty((n, 4), np.uint8))
+
     def mbqp(self):
         """QP_Y of every macroblock of the last picture (0 for I_PCM)"""
         i = self.info()

@@ -163,7 +163,17 @@ struct randsyn {
     int idc, oa, ob;     /* disable_deblocking_filter_idc, slice_alpha_c0_offset_div2, slice_beta_offset_div2 */
     int slice_qp[256];   /* SliceQP_Y per slice */
     int8_t *qpd;         /* mb_qp_delta per macroblock (written where the syntax carries one) */
+    int direct;          /* inter macroblocks are written from random draws at writing time: sub_mb_types down to 4x4, a
+                          * ref_idx_l0 per partition, mvd_l0 values as such (whatever they add up to IS the vector) */
+    uint32_t rng;
 };
+static uint32_t rs_next(uint32_t *s)
+{
+    uint32_t x = *s;
+    x ^= x << 13; x ^= x >> 17; x ^= x << 5;
+    return *s = x ? x : 0x9E3779B9u;
+}
+static int rs_below(uint32_t *s, int n) { return (int)(rs_next(s) % (uint32_t)n); }   /* 0 .. n - 1 */
 struct h264o_enc {
     h264o_config cfg;
     int mbw, mbh, cw, ch, level_idc;
@@ -185,7 +195,7 @@ struct h264o_enc {
     uint8_t *aux;          /* 16 bytes per macroblock: Intra4x4PredMode of the 16 blocks (blkIdx order) */
     int16_t *mvq;          /* 8 int16 per macroblock: vectors of the four 8x8 quadrants of an inter macroblock */
     uint8_t *pshape;       /* P pictures: partition shape the motion search chose (0 16x16, 1 16x8, 2 8x16, 3 8x8) */
-    const struct randsyn *rs;   /* h264o_enc_random_picture (decoder-peer tests): syntax the encoder itself never uses; NULL while encoding */
+    struct randsyn *rs;   /* h264o_enc_random_picture (decoder-peer tests): syntax the encoder itself never uses; NULL while encoding */
     uint8_t *want_intra;   /* P pictures: 1 = the motion search handed the macroblock to the intra pass; 2 = one of the "nothing
                             * left to code" tests hit: the prediction is the reconstruction, no transform is run (the tests use
                             * the 4x4 transform whatever transform the profile codes with) */
@@ -1151,6 +1161,33 @@ static void write_mb(h264o_enc *e, bitw *b, int mx, int my, int p_slice)
         const int shape = mb->type >= H264O_MB_P16X8 ? mb->type - H264O_MB_P16X8 + 1 : 0, nparts = shape == 0 ? 1 : shape == 3 ? 4 : 2;
         const int16_t *qv = e->mvq + (size_t)(my * e->mbw + mx) * 8;
         bw_ue(b, (uint32_t)shape);
+        if (e->rs && e->rs->direct) {   /* random-stream generator, every inter macroblock of the picture */
+            uint32_t *rng = &e->rs->rng;
+            int sub[4] = {0, 0, 0, 0}, all8x8 = 1;
+            if (shape == 3)
+                for (int k = 0; k < 4; k++) {
+                    sub[k] = rs_below(rng, 3) ? rs_below(rng, 4) : 0;   /* sub_mb_type: P_L0_8x8, 8x4, 4x8, 4x4 */
+                    if (sub[k]) all8x8 = 0;
+                    bw_ue(b, (uint32_t)sub[k]);
+                }
+            for (int k = 0; k < nparts; k++) {
+                int r = rs_below(rng, e->avail_refs);
+                if (e->avail_refs == 2) bw_put(b, 1, r ? 0 : 1);
+                else if (e->avail_refs > 2) bw_ue(b, (uint32_t)r);
+            }
+            for (int k = 0; k < nparts; k++) {
+                int nsub = shape == 3 ? (sub[k] == 0 ? 1 : sub[k] == 3 ? 4 : 2) : 1;
+                for (int j = 0; j < nsub; j++)
+                    for (int c = 0; c < 2; c++)
+                        bw_se(b, rs_below(rng, 8) ? rs_below(rng, 13) - 6 : rs_below(rng, 10) ? rs_below(rng, 161) - 80 : rs_below(rng, 1201) - 600);
+            }
+            int code = 0;
+            while (o_cbp_code2inter[code] != mb->cbp) code++;
+            bw_ue(b, (uint32_t)code);
+            if (e->cfg.profile_idc == 100 && (mb->cbp & 15) && all8x8) bw_put(b, 1, mb->i16_mode);
+            if (mb->cbp) bw_se(b, qpd);
+            goto residual;
+        }
         if (shape == 3) for (int k = 0; k < 4; k++) bw_ue(b, 0);
         for (int k = 0; k < nparts; k++) {
             if (e->avail_refs == 2) bw_put(b, 1, mb->chroma_mode ? 0 : 1);        /* ref_idx_l0, te(v) with cMax 1: the inverted bit */
@@ -1169,6 +1206,7 @@ static void write_mb(h264o_enc *e, bitw *b, int mx, int my, int p_slice)
         if (e->cfg.profile_idc == 100 && (mb->cbp & 15)) bw_put(b, 1, mb->i16_mode); /* transform_size_8x8_flag */
         if (mb->cbp) bw_se(b, qpd); /* mb_qp_delta */
     }
+residual:
     for (int b8 = 0; b8 < 4; b8++)
         if (cbpl & (1 << b8))
             for (int k = 0; k < 4; k++) {
@@ -1350,14 +1388,6 @@ int64_t h264o_enc_encode(h264o_enc *e, const uint8_t *y, int ys, const uint8_t *
  * slices in bands of whole rows, one reference index per macroblock, sub_mb_type P_L0_8x8, no Intra8x8.
  * Conformance: a prediction mode is only chosen where its neighbours are available (8.3.1.2, 8.3.3, 8.3.4), QP_Y stays in
  * 0..51, levels are small enough for every intermediate of 8.5 to fit 16 bits at the QPs drawn (bounded below). */
-static uint32_t rs_next(uint32_t *s)
-{
-    uint32_t x = *s;
-    x ^= x << 13; x ^= x >> 17; x ^= x << 5;
-    return *s = x ? x : 0x9E3779B9u;
-}
-static int rs_below(uint32_t *s, int n) { return (int)(rs_next(s) % (uint32_t)n); }   /* 0 .. n - 1 */
-
 /* n levels (zig-zag order) of one residual block: `density` in 1/16 of the positions non-zero, magnitudes 1 .. mag */
 static int rs_levels(uint32_t *s, int16_t *lv, int first, int n, int density, int mag)
 {
@@ -1393,6 +1423,7 @@ int64_t h264o_enc_random_picture(h264o_enc *e, uint32_t seed, int force_idr, int
     }
     rs.cqo[0] = cqo_sticky[0]; rs.cqo[1] = cqo_sticky[1];
     rs.idc = (features & 16) ? rs_below(&rng, 3) : (e->cfg.disable_deblock ? 1 : e->slice_rows < e->mbh ? 2 : 0);
+    rs.direct = (features & 32) != 0;
     rs.oa = (features & 4) ? rs_below(&rng, 13) - 6 : 0;
     rs.ob = (features & 4) ? rs_below(&rng, 13) - 6 : 0;
     const int qlo = 4, qhi = 48;   /* QP_Y range drawn from: wide enough for every row of Tables 8-15 / 8-16 that filters */
@@ -1429,6 +1460,10 @@ int64_t h264o_enc_random_picture(h264o_enc *e, uint32_t seed, int force_idr, int
                 mb->cbp = 0x2F;
                 memset(mb->tc, 16, 24);
                 if (mbqp_out) mbqp_out[mbi] = 0;   /* 8.7.2.2: qP of an I_PCM macroblock */
+                continue;
+            }
+            if (type == H264O_MB_PSKIP && rs.direct) {   /* (its vector is the decoder's business) */
+                if (mbqp_out) mbqp_out[mbi] = (uint8_t)qp;
                 continue;
             }
             if (type == H264O_MB_PSKIP) {
@@ -1474,7 +1509,7 @@ int64_t h264o_enc_random_picture(h264o_enc *e, uint32_t seed, int force_idr, int
             } else {
                 const int shape = type == H264O_MB_P16 ? 0 : type - H264O_MB_P16X8 + 1, nparts = shape == 0 ? 1 : shape == 3 ? 4 : 2;
                 mb->chroma_mode = (uint8_t)rs_below(&rng, e->avail_refs);   /* ref_idx_l0 of all its partitions */
-                for (int k = 0; k < nparts; k++) {
+                for (int k = 0; k < nparts && !rs.direct; k++) {
                     int x0 = 0, y0 = 0, w = 2, h = 2;
                     if (shape) part_rect(shape, k, &x0, &y0, &w, &h);
                     /* mostly near the predictor (short mvd codes), sometimes anywhere within +-40 samples, rarely far outside */
@@ -1516,6 +1551,7 @@ int64_t h264o_enc_random_picture(h264o_enc *e, uint32_t seed, int force_idr, int
     size_t pos = 0;
     bitw b;
     e->rs = &rs;
+    rs.rng = rng;
     if (idr) {
         memset(e->rbsp, 0, 256);
         b = (bitw){e->rbsp, e->rbsp_cap, 0};

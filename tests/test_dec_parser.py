@@ -153,15 +153,18 @@ def test_two_independent_parsers_agree_on_damaged_streams():
     assert both > 150, both
 
 
-def _compare_side_information(par, enc, label):
+def _compare_side_information(par, enc, label, vectors=True):
     mb, mvq, aux, lv = par.arrays()
     omb, omvq, oaux, olv = enc.mbinfo(), enc.mvq(), enc.mbaux(), enc.levels()
-    for fld in ("type", "cbp", "chroma_mode", "tc", "mvx", "mvy"):
-        assert np.array_equal(mb[fld], omb[fld]), "%s: %s" % (label, fld)
     i16 = omb["type"] == 0
     inter = np.isin(omb["type"], (1, 2, 5, 6, 7))
-    assert np.array_equal(mb["i16_mode"][i16 | inter], omb["i16_mode"][i16 | inter]), label
-    assert np.array_equal(mvq[inter], omvq[inter]), "%s: quadrant vectors" % label
+    for fld in ("type", "cbp", "tc") + (("chroma_mode", "mvx", "mvy") if vectors else ()):
+        assert np.array_equal(mb[fld], omb[fld]), "%s: %s" % (label, fld)
+    if vectors:
+        assert np.array_equal(mb["i16_mode"][i16 | inter], omb["i16_mode"][i16 | inter]), label
+        assert np.array_equal(mvq[inter], omvq[inter]), "%s: quadrant vectors" % label
+    else:   # the generator wrote mvd_l0 / ref_idx_l0 / sub_mb_type draws as such and holds no vectors
+        assert np.array_equal(mb["chroma_mode"][~inter], omb["chroma_mode"][~inter]) and np.array_equal(mb["i16_mode"][i16], omb["i16_mode"][i16]), label
     i4 = omb["type"] == 4
     assert np.array_equal(aux[i4], oaux[i4]), "%s: Intra4x4 modes" % label
     read = np.zeros(olv.shape, bool)
@@ -176,7 +179,8 @@ def _compare_side_information(par, enc, label):
 
 
 RANDOM_CASES = [(96, 80, 66, 0, 1, 31), (96, 80, 77, 3, 3, 31), (112, 64, 100, 2, 2, 31), (16, 16, 66, 0, 1, 31), (48, 160, 100, 4, 3, 31),
-                (96, 80, 100, 0, 3, 1), (96, 80, 66, 2, 1, 2 | 4), (64, 64, 77, 0, 2, 8 | 16)]
+                (96, 80, 100, 0, 3, 1), (96, 80, 66, 2, 1, 2 | 4), (64, 64, 77, 0, 2, 8 | 16),
+                (96, 80, 66, 0, 3, 63), (112, 64, 100, 2, 2, 63), (96, 80, 77, 3, 1, 32), (32, 32, 100, 0, 3, 63)]
 
 
 @pytest.mark.parametrize("w,h,prof,slices,refs,features", RANDOM_CASES)
@@ -184,7 +188,9 @@ def test_parser_reads_random_streams(w, h, prof, slices, refs, features):
     """Streams of RANDOM syntax (oracle/h264_enc.c h264o_enc_random_picture: every macroblock type, prediction mode and
     partition shape, random vectors, reference indices, levels, I_PCM, and what this repository's encoder never writes -
     mb_qp_delta, slice QPs, chroma_qp_index_offsets, filter offsets, every deblocking idc): the product parser must read back
-    exactly what was written, QP_Y of every macroblock included, and the oracle's independent decoder must agree on the QPs."""
+    exactly what was written, QP_Y of every macroblock included, and the oracle's independent decoder must agree on the QPs.
+    Feature 32: sub-macroblock partitions down to 4x4 and a reference index per partition, written as random mvd_l0 / ref_idx_l0
+    draws - the parser's vectors (its statement of 8.4.1.3 on the 4x4 grid) must be the oracle decoder's for every 4x4 block."""
     enc = OracleEncoder(w, h, qp=30, gop=4, profile_idc=prof, slices=slices, refs=refs)
     par, dec = h264dec.Parser(), OracleDecoder()
     seen = set()
@@ -192,7 +198,14 @@ def test_parser_reads_random_streams(w, h, prof, slices, refs, features):
         au, idr, mbqp = enc.random_picture(7919 * i + w + 3 * prof + features, features=features)
         assert dec.decode(au) == 1, "the oracle decoder accepts the stream"
         assert par.parse(au), "picture %d" % i
-        _compare_side_information(par, enc, "picture %d" % i)
+        _compare_side_information(par, enc, "picture %d" % i, vectors=not (features & 32))
+        if features & 32:
+            mv4, refq = par.vectors4()
+            for a in np.nonzero(np.isin(enc.mbinfo()["type"], (1, 2, 5, 6, 7)))[0]:
+                for b in range(16):
+                    want = dec.mb_mv(int(a), b)
+                    got = (int(mv4[a, b, 0]), int(mv4[a, b, 1]), int(refq[a, 2 * (b >> 3) + ((b >> 1) & 1)]))
+                    assert got == want, "picture %d macroblock %d block %d: %s, the oracle decoder has %s" % (i, a, b, got, want)
         assert np.array_equal(par.mbqp(), mbqp), "picture %d: QP_Y" % i
         assert np.array_equal(dec.mb_qps(), mbqp.astype(np.int32)), "picture %d: QP_Y (oracle decoder)" % i
         info = par.info()
