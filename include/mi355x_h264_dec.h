@@ -10,7 +10,8 @@
  * GPU with the encoder's own reconstruction kernels.  No device -> MI355X_H264_E_NODEVICE; there is no CPU reconstruction.
  *
  * Supported: baseline / main / high streams with CAVLC, frame macroblocks, I and P slices, Intra16x16 / Intra4x4 / I_PCM,
- * 16x16 .. 8x8 partitions, up to 3 reference pictures (sliding window), 4x4 and (inter) 8x8 transform, QP per macroblock
+ * 16x16 .. 4x4 partitions (every sub_mb_type), up to 3 reference pictures (sliding window, one index per partition), 4x4 and
+ * (inter) 8x8 transform, QP per macroblock
  * (slice_qp_delta, mb_qp_delta), chroma QP index offsets, deblocking filter offsets and idc 0 / 1 / 2 (one set per picture),
  * slices = equal bands of macroblock rows.  A stream outside that is refused with MI355X_H264_E_STREAM and a message naming the
  * syntax element; nothing is ever decoded approximately.

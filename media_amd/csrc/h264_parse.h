@@ -10,9 +10,9 @@
 //
 // Supported streams = a superset of what this repository's encoder produces (which is what the reference preset asks of
 // OpenH264 minus CABAC): baseline / main / high with CAVLC, frame macroblocks, I and P slices; Intra16x16, Intra4x4, I_PCM
-// (also in loop-filtered pictures); P_L0_16x16, 16x8, 8x16, P_8x8 / P_8x8ref0 with 8x8 sub-macroblocks, P_Skip; up to 3
-// reference pictures by sliding window, no reordering, one reference per macroblock; 4x4 transform, 8x8 transform on inter
-// macroblocks; QP per macroblock (slice_qp_delta per slice, mb_qp_delta), chroma_qp_index_offset and
+// (also in loop-filtered pictures); P_L0_16x16, 16x8, 8x16, P_8x8 / P_8x8ref0 with every sub_mb_type (8x8, 8x4, 4x8, 4x4),
+// P_Skip; up to 3 reference pictures by sliding window, no reordering, a reference index per partition; 4x4 transform, 8x8
+// transform on inter macroblocks; QP per macroblock (slice_qp_delta per slice, mb_qp_delta), chroma_qp_index_offset and
 // second_chroma_qp_index_offset, slice_alpha_c0_offset_div2 / slice_beta_offset_div2 (one pair per picture);
 // slices = bands of whole macroblock rows of equal height; disable_deblocking_filter_idc 0 / 1 / 2 (one value per picture).
 // Anything else is refused with a message naming the syntax element (never decoded wrongly).
