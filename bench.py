@@ -210,8 +210,10 @@ def openh264_differential(frames, count):
 def decode_bench(frames_n, device=0):
     """The decoder peer (row f4): a 1080p stream written by the HIP encoder (S1, QP 26, GOP 30) decoded access unit by access
     unit through include/mi355x_h264_dec.h - host CAVLC parse + upload of the parsed arrays + GPU reconstruction + loop
-    filter, synchronous per picture (the way VideoDecoderMI355X::SendStreamData uses it), with and without the D2H copy of the
-    picture.  Every decoded picture is compared with the encoder's reconstruction."""
+    filter, one access unit per call with the decoder's one picture of look-ahead (the call returns when the picture is
+    launched; the next access unit is parsed while the GPU reconstructs it), with and without the D2H copy of every picture
+    (which waits for the picture: no overlap then, the way VideoDecoderMI355X's Send / Retrieve pairs use it).  The last decoded
+    picture is compared with the encoder's reconstruction."""
     import numpy as np
     from media_amd import capi, synth, h264dec
     enc = capi.Encoder(WIDTH, HEIGHT, qp=QP, gop=GOP, device=device)
@@ -221,7 +223,8 @@ def decode_bench(frames_n, device=0):
         recs.append(enc.debug_read(capi.DBG_RECON_Y))
     enc.close()
     out = {"what": "VideoDecoder peer: 1080p S1 stream of the HIP encoder (QP %d, GOP %d, %d pictures, %.0f kB / picture), one access unit per call, "
-                   "synchronous; host parse + H2D of the parsed arrays + GPU reconstruction + loop filter" % (QP, GOP, frames_n, sum(map(len, aus)) / frames_n / 1e3)}
+                   "decode_only: the parse of unit n + 1 overlaps the reconstruction of picture n; decode_and_read_i420: every picture waited for and copied out; "
+                   "host parse + H2D of the parsed arrays + GPU reconstruction + loop filter" % (QP, GOP, frames_n, sum(map(len, aus)) / frames_n / 1e3)}
     for label, read in (("decode_only", False), ("decode_and_read_i420", True)):
         dec = h264dec.Decoder(device)
         dec.decode(aus[0])            # engine creation + first launches are not timed
@@ -232,12 +235,13 @@ def decode_bench(frames_n, device=0):
             dec.decode(au)
             if read:
                 dec.i420()
+        dec.sync()                    # the last picture is complete inside the timed region
         dt = time.perf_counter() - t0
         n, parse_ms, gpu_ms = dec.timing()
         ok = bool(np.array_equal(dec.plane(0), recs[-1]))
         dec.close()
         out[label] = {"fps": round(frames_n / dt, 1), "ms_per_picture": round(dt / frames_n * 1e3, 3), "host_parse_ms_per_picture": round(parse_ms / n, 3),
-                      "upload_and_gpu_ms_per_picture": round(gpu_ms / n, 3), "last_picture_equals_encoder_reconstruction": ok}
+                      "launch_and_wait_ms_per_picture": round(gpu_ms / n, 3), "last_picture_equals_encoder_reconstruction": ok}
     # several streams: S decoder objects on S host threads (each parses on its own core; the reconstructions share the GPU)
     out["streams"] = []
     for S in (4, 16):

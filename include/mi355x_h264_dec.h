@@ -37,8 +37,13 @@ void mi355x_h264_dec_destroy(mi355x_h264_decoder *dec);
 const char *mi355x_h264_dec_last_error(const mi355x_h264_decoder *dec);
 
 /* one access unit, Annex B with start codes (SendStreamData, VideoDecoderNetint.cpp:568).  *got_picture = 1 when a picture
- * was decoded (0: the unit held parameter sets / SEI only).  Synchronous: the picture is complete on return. */
+ * was decoded (0: the unit held parameter sets / SEI only).  The unit is parsed and the picture LAUNCHED on return, not
+ * necessarily finished: the next call parses its access unit while the GPU reconstructs this one (one picture of look-ahead).
+ * Every call that looks at the picture (read_i420, debug_plane, sync) waits for it first; a failure of the reconstruction
+ * itself (MI355X_H264_E_INTERNAL) is reported by that call or by the next decode. */
 int mi355x_h264_dec_decode(mi355x_h264_decoder *dec, const uint8_t *au, size_t len, int *got_picture);
+/* wait until the picture launched by the last decode call is complete */
+int mi355x_h264_dec_sync(mi355x_h264_decoder *dec);
 
 /* cropped and coded size of the last decoded picture (INDEX_PIC_INFO, VideoDecoder.h:57) */
 int mi355x_h264_dec_picture_info(const mi355x_h264_decoder *dec, int *width, int *height, int *coded_width, int *coded_height);

@@ -20,6 +20,8 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
+#include <new>
 #include <string>
 #include <vector>
 #include "h264_vlc_tables.h"
@@ -141,6 +143,43 @@ private:
 };
 inline const VlcLut& vlc() { static const VlcLut L; return L; }
 
+// The per-macroblock arrays are what the decoder uploads every picture: it switches the allocation to pinned host memory
+// (HostMem::use), so that the copies run asynchronously while the next access unit is parsed.  Every block remembers the
+// function that releases it, so blocks made before and after a switch can be freed in any order.
+struct HostMem {
+    typedef void* (*AllocFn)(size_t);
+    typedef void (*FreeFn)(void*);
+    static inline AllocFn alloc_fn = nullptr;   // nullptr: malloc / free
+    static inline FreeFn free_fn = nullptr;
+    static void use(AllocFn a, FreeFn f) { alloc_fn = a; free_fn = f; }
+    static void* get(size_t n)
+    {
+        const AllocFn a = alloc_fn;
+        const FreeFn f = a ? free_fn : nullptr;
+        char* raw = (char*)(a ? a(n + 64) : malloc(n + 64));
+        if (!raw) throw std::bad_alloc();
+        *(FreeFn*)raw = f;
+        return raw + 64;
+    }
+    static void put(void* p)
+    {
+        char* raw = (char*)p - 64;
+        const FreeFn f = *(FreeFn*)raw;
+        if (f) f(raw); else free(raw);
+    }
+};
+template <class T>
+struct HostAlloc {
+    typedef T value_type;
+    HostAlloc() = default;
+    template <class U> HostAlloc(const HostAlloc<U>&) {}
+    T* allocate(size_t n) { return (T*)HostMem::get(n * sizeof(T)); }
+    void deallocate(T* p, size_t) { HostMem::put(p); }
+    template <class U> bool operator==(const HostAlloc<U>&) const { return true; }
+    template <class U> bool operator!=(const HostAlloc<U>&) const { return false; }
+};
+template <class T> using HostVec = std::vector<T, HostAlloc<T>>;
+
 struct Picture {
     int mbw = 0, mbh = 0, width = 0, height = 0;   // macroblocks; cropped size
     bool idr = false, is_ref = true;
@@ -150,19 +189,22 @@ struct Picture {
     int filter_oa = 0, filter_ob = 0;   // FilterOffsetA / FilterOffsetB (2 * slice_alpha_c0_offset_div2, 2 * slice_beta_offset_div2)
     bool one_qp = true;              // every macroblock has QP_Y = qp, no chroma / filter offset, no I_PCM macroblock: the picture
                                      // reconstructs with the per-picture constants the encoder's kernels use
-    std::vector<uint8_t> mbqp;       // QP_Y of every macroblock (7.4.5); 0 for I_PCM, the value its edges filter with (8.7.2.2)
-    std::vector<MbRec> mb;
-    std::vector<int16_t> mvq;      // 8 per macroblock: the vectors of the four 8x8 quadrants' first blocks (the encoder's layout)
-    std::vector<int16_t> mv4;      // 32 per macroblock: the vector (x, y) of every 4x4 block, raster order (sub-macroblock partitions)
-    std::vector<uint8_t> refq;     // 4 per macroblock: ref_idx_l0 of the four quadrants (0xFF: intra)
-    std::vector<uint8_t> aux;      // 16 per macroblock
-    std::vector<int16_t> levels;   // L_STRIDE per macroblock (I_PCM: its 384 samples as bytes at the start)
+    HostVec<uint8_t> mbqp;       // QP_Y of every macroblock (7.4.5); 0 for I_PCM, the value its edges filter with (8.7.2.2)
+    HostVec<MbRec> mb;
+    HostVec<int16_t> mvq;      // 8 per macroblock: the vectors of the four 8x8 quadrants' first blocks (the encoder's layout)
+    HostVec<int16_t> mv4;      // 32 per macroblock: the vector (x, y) of every 4x4 block, raster order (sub-macroblock partitions)
+    HostVec<uint8_t> refq;     // 4 per macroblock: ref_idx_l0 of the four quadrants (0xFF: intra)
+    HostVec<uint8_t> aux;      // 16 per macroblock
+    HostVec<int16_t> levels;   // L_STRIDE per macroblock (I_PCM: its 384 samples as bytes at the start)
 };
 
 class Parser {
 public:
     const std::string& error() const { return err_; }
-    const Picture& picture() const { return pic_; }
+    const Picture& picture() const { return *picp_; }
+    // two picture buffers: the decoder parses access unit n + 1 into one while the arrays of picture n are still being uploaded
+    // from the other (select() before parse_access_unit)
+    void select(int k) { picp_ = &pics_[k & 1]; }
     const Sps& sps() const { return sps_[active_sps_]; }
 
     // one access unit (Annex B).  Returns 1: a picture is ready in picture(); 0: no slice in it (parameter sets only); -1: error()
@@ -183,7 +225,7 @@ public:
             i = e;
         }
         if (!have_pic) return 0;
-        if (next_mb != pic_.mbw * pic_.mbh) return fail("picture incomplete: slices cover %d of %d macroblocks", next_mb, pic_.mbw * pic_.mbh);
+        if (next_mb != picp_->mbw * picp_->mbh) return fail("picture incomplete: slices cover %d of %d macroblocks", next_mb, picp_->mbw * picp_->mbh);
         return 1;
     }
 
@@ -191,7 +233,8 @@ private:
     Sps sps_[32];
     Pps pps_[256];
     int active_sps_ = 0;
-    Picture pic_;
+    Picture pics_[2];
+    Picture* picp_ = &pics_[0];
     std::string err_;
     std::vector<uint8_t> rbsp_;
     // state of the slice being parsed
@@ -320,8 +363,8 @@ private:
     }
 
     // ---- neighbourhood helpers (6.4.9 .. 6.4.11): an address is available inside the picture and not before the slice's start
-    bool avail(int mx, int my) const { return mx >= 0 && mx < pic_.mbw && my >= 0 && my * pic_.mbw + mx >= slice_first_; }
-    MbRec& M(int mx, int my) { return pic_.mb[(size_t)my * pic_.mbw + mx]; }
+    bool avail(int mx, int my) const { return mx >= 0 && mx < picp_->mbw && my >= 0 && my * picp_->mbw + mx >= slice_first_; }
+    MbRec& M(int mx, int my) { return picp_->mb[(size_t)my * picp_->mbw + mx]; }
     static bool intra(int t) { return t == T_I16 || t == T_IPCM || t == T_I4; }
     static int blk_idx(int x, int y) { return (x & 1) | ((y & 1) << 1) | ((x & 2) << 1) | ((y & 2) << 2); }   // 4x4 raster -> blkIdx
 
@@ -424,11 +467,11 @@ private:
         Cand c{false, -1, 0, 0};
         if (!self && !avail(mx, my)) return c;
         c.av = true;
-        const size_t i = (size_t)my * pic_.mbw + mx;
-        if (!intra(pic_.mb[i].type)) {
-            c.ref = pic_.refq[i * 4 + 2 * (by >> 1) + (bx >> 1)];
-            c.x = pic_.mv4[i * 32 + 2 * (4 * by + bx)];
-            c.y = pic_.mv4[i * 32 + 2 * (4 * by + bx) + 1];
+        const size_t i = (size_t)my * picp_->mbw + mx;
+        if (!intra(picp_->mb[i].type)) {
+            c.ref = picp_->refq[i * 4 + 2 * (by >> 1) + (bx >> 1)];
+            c.x = picp_->mv4[i * 32 + 2 * (4 * by + bx)];
+            c.y = picp_->mv4[i * 32 + 2 * (4 * by + bx) + 1];
         }
         return c;
     }
@@ -510,55 +553,55 @@ private:
 
         if (!have_pic) {   // first slice of the picture
             if (first_mb != 0) { fail("first slice of the access unit starts at macroblock %d", first_mb); return false; }
-            pic_.mbw = sps.mbw; pic_.mbh = sps.mbh;
-            pic_.width = 16 * sps.mbw - 2 * (sps.crop_l + sps.crop_r); pic_.height = 16 * sps.mbh - 2 * (sps.crop_t + sps.crop_b);
-            pic_.idr = idr; pic_.is_ref = ref_idc != 0; pic_.qp = qp; pic_.deblock_idc = idc; pic_.slice_rows = 0;
-            pic_.num_ref_active = st == 0 ? num_ref : 0; pic_.t8x8_mode = pps.t8x8 ? 1 : 0; pic_.profile_idc = sps.profile_idc;
-            pic_.has_pcm = pic_.has_intra = pic_.has_inter = false;
-            pic_.cqo[0] = pps.cqo[0]; pic_.cqo[1] = pps.cqo[1]; pic_.filter_oa = oa; pic_.filter_ob = ob;
-            pic_.one_qp = pps.cqo[0] == 0 && pps.cqo[1] == 0 && oa == 0 && ob == 0;
+            picp_->mbw = sps.mbw; picp_->mbh = sps.mbh;
+            picp_->width = 16 * sps.mbw - 2 * (sps.crop_l + sps.crop_r); picp_->height = 16 * sps.mbh - 2 * (sps.crop_t + sps.crop_b);
+            picp_->idr = idr; picp_->is_ref = ref_idc != 0; picp_->qp = qp; picp_->deblock_idc = idc; picp_->slice_rows = 0;
+            picp_->num_ref_active = st == 0 ? num_ref : 0; picp_->t8x8_mode = pps.t8x8 ? 1 : 0; picp_->profile_idc = sps.profile_idc;
+            picp_->has_pcm = picp_->has_intra = picp_->has_inter = false;
+            picp_->cqo[0] = pps.cqo[0]; picp_->cqo[1] = pps.cqo[1]; picp_->filter_oa = oa; picp_->filter_ob = ob;
+            picp_->one_qp = pps.cqo[0] == 0 && pps.cqo[1] == 0 && oa == 0 && ob == 0;
             const size_t n = (size_t)sps.mbw * sps.mbh;
-            pic_.mbqp.assign(n, (uint8_t)qp);
-            pic_.mb.assign(n, MbRec{});
-            pic_.mvq.assign(n * 8, 0);
-            pic_.mv4.assign(n * 32, 0);
-            pic_.refq.assign(n * 4, 0xFF);
-            pic_.aux.assign(n * 16, 0);
-            pic_.levels.assign(n * L_STRIDE, 0);
+            picp_->mbqp.assign(n, (uint8_t)qp);
+            picp_->mb.assign(n, MbRec{});
+            picp_->mvq.assign(n * 8, 0);
+            picp_->mv4.assign(n * 32, 0);
+            picp_->refq.assign(n * 4, 0xFF);
+            picp_->aux.assign(n * 16, 0);
+            picp_->levels.assign(n * L_STRIDE, 0);
             have_pic = true;
         } else {
             if (first_mb != next_mb) { fail("slices out of order (first_mb_in_slice %d, expected %d)", first_mb, next_mb); return false; }
-            if (first_mb % pic_.mbw) { fail("slice starts inside a macroblock row (first_mb_in_slice %d)", first_mb); return false; }
-            if (pic_.slice_rows == 0) pic_.slice_rows = first_mb / pic_.mbw;
-            else if ((first_mb / pic_.mbw) % pic_.slice_rows) { fail("slices are not bands of equal height"); return false; }
-            if (qp != pic_.qp) pic_.one_qp = false;
-            if (idc != pic_.deblock_idc) { fail("disable_deblocking_filter_idc differs between slices"); return false; }
-            if (oa != pic_.filter_oa || ob != pic_.filter_ob) { fail("deblocking filter offsets differ between slices"); return false; }
-            if (pps.cqo[0] != pic_.cqo[0] || pps.cqo[1] != pic_.cqo[1]) { fail("chroma QP offsets differ between slices"); return false; }
-            if (st == 0 && pic_.num_ref_active && num_ref != pic_.num_ref_active) { fail("num_ref_idx_active differs between slices"); return false; }
-            if (st == 0 && !pic_.num_ref_active) pic_.num_ref_active = num_ref;
+            if (first_mb % picp_->mbw) { fail("slice starts inside a macroblock row (first_mb_in_slice %d)", first_mb); return false; }
+            if (picp_->slice_rows == 0) picp_->slice_rows = first_mb / picp_->mbw;
+            else if ((first_mb / picp_->mbw) % picp_->slice_rows) { fail("slices are not bands of equal height"); return false; }
+            if (qp != picp_->qp) picp_->one_qp = false;
+            if (idc != picp_->deblock_idc) { fail("disable_deblocking_filter_idc differs between slices"); return false; }
+            if (oa != picp_->filter_oa || ob != picp_->filter_ob) { fail("deblocking filter offsets differ between slices"); return false; }
+            if (pps.cqo[0] != picp_->cqo[0] || pps.cqo[1] != picp_->cqo[1]) { fail("chroma QP offsets differ between slices"); return false; }
+            if (st == 0 && picp_->num_ref_active && num_ref != picp_->num_ref_active) { fail("num_ref_idx_active differs between slices"); return false; }
+            if (st == 0 && !picp_->num_ref_active) picp_->num_ref_active = num_ref;
         }
         slice_first_ = first_mb; slice_type_ = st; slice_qp_ = qp; num_ref_ = num_ref;
         qp_ = qp;   // QP_Y,PRED of the slice's first macroblock (7.4.5)
 
         // ---- slice_data (7.3.4) ----
         int addr = first_mb;
-        const int nmb = pic_.mbw * pic_.mbh;
+        const int nmb = picp_->mbw * picp_->mbh;
         bool more = true;
         while (more) {
             if (st == 0) {
                 unsigned run = br.ue();
                 if (br.bad() || (int)run > nmb - addr) { fail("mb_skip_run past the picture"); return false; }
-                while (run--) { skip_mb(addr % pic_.mbw, addr / pic_.mbw); addr++; }
+                while (run--) { skip_mb(addr % picp_->mbw, addr / picp_->mbw); addr++; }
                 more = br.more_data();
                 if (!more) break;
             }
             if (addr >= nmb) { fail("slice data past the picture"); return false; }
-            if (!macroblock(br, addr % pic_.mbw, addr / pic_.mbw, pps)) return false;
+            if (!macroblock(br, addr % picp_->mbw, addr / picp_->mbw, pps)) return false;
             addr++;
             more = br.more_data();
         }
-        if (pic_.slice_rows && (addr % pic_.mbw)) { fail("slice ends inside a macroblock row"); return false; }
+        if (picp_->slice_rows && (addr % picp_->mbw)) { fail("slice ends inside a macroblock row"); return false; }
         next_mb = addr;
         return true;
     }
@@ -566,23 +609,23 @@ private:
     // the vector of the w4 x h4 blocks at (x4, y4); a quadrant's entry of mvq is its first block's
     void set_vectors(int mx, int my, int x4, int y4, int w4, int h4, int x, int y)
     {
-        const size_t i = (size_t)my * pic_.mbw + mx;
+        const size_t i = (size_t)my * picp_->mbw + mx;
         for (int by = y4; by < y4 + h4; by++)
             for (int bx = x4; bx < x4 + w4; bx++) {
-                int16_t* v = &pic_.mv4[i * 32 + 2 * (4 * by + bx)];
+                int16_t* v = &picp_->mv4[i * 32 + 2 * (4 * by + bx)];
                 v[0] = (int16_t)x; v[1] = (int16_t)y;
-                if (!(bx & 1) && !(by & 1)) { int16_t* q = &pic_.mvq[i * 8 + 2 * (2 * (by >> 1) + (bx >> 1))]; q[0] = (int16_t)x; q[1] = (int16_t)y; }
+                if (!(bx & 1) && !(by & 1)) { int16_t* q = &picp_->mvq[i * 8 + 2 * (2 * (by >> 1) + (bx >> 1))]; q[0] = (int16_t)x; q[1] = (int16_t)y; }
             }
     }
     void set_refs(int mx, int my, int r0, int r1, int r2, int r3)
     {
-        uint8_t* r = &pic_.refq[((size_t)my * pic_.mbw + mx) * 4];
+        uint8_t* r = &picp_->refq[((size_t)my * picp_->mbw + mx) * 4];
         r[0] = (uint8_t)r0; r[1] = (uint8_t)r1; r[2] = (uint8_t)r2; r[3] = (uint8_t)r3;
     }
     void set_qp(int mx, int my, int qp)
     {
-        pic_.mbqp[(size_t)my * pic_.mbw + mx] = (uint8_t)qp;
-        if (qp != pic_.qp) pic_.one_qp = false;
+        picp_->mbqp[(size_t)my * picp_->mbw + mx] = (uint8_t)qp;
+        if (qp != picp_->qp) picp_->one_qp = false;
     }
     void skip_mb(int mx, int my)
     {
@@ -596,15 +639,15 @@ private:
         predict(mx, my, 0, 0, 4, 4, 0, px, py, true, true);
         m.mvx = (int16_t)px; m.mvy = (int16_t)py;
         set_vectors(mx, my, 0, 0, 4, 4, px, py);
-        pic_.has_inter = true;
+        picp_->has_inter = true;
     }
 
     bool macroblock(BitReader& br, int mx, int my, const Pps& pps)
     {
         MbRec& m = M(mx, my);
         m = MbRec{};
-        int16_t* lv = &pic_.levels[((size_t)my * pic_.mbw + mx) * L_STRIDE];
-        uint8_t* am = &pic_.aux[((size_t)my * pic_.mbw + mx) * 16];
+        int16_t* lv = &picp_->levels[((size_t)my * picp_->mbw + mx) * L_STRIDE];
+        uint8_t* am = &picp_->aux[((size_t)my * picp_->mbw + mx) * 16];
         unsigned t = br.ue();
         bool is_intra = slice_type_ == 2;
         if (slice_type_ == 0 && t >= 5) { is_intra = true; t -= 5; }
@@ -620,13 +663,13 @@ private:
             if (br.bad()) { fail("I_PCM samples past the slice"); return false; }
             m.type = T_IPCM; m.cbp = 0x2F;
             memset(m.tc, 16, 24);
-            pic_.has_pcm = pic_.has_intra = true;
+            picp_->has_pcm = picp_->has_intra = true;
             set_qp(mx, my, 0);        // its edges filter with qP 0; QP_Y,PRED of the next macroblock stays
-            pic_.one_qp = false;
+            picp_->one_qp = false;
             return true;
         }
         if (is_intra) {
-            pic_.has_intra = true;
+            picp_->has_intra = true;
             if (t == 0) {   // I_NxN
                 m.type = T_I4;
                 if (pps.t8x8 && br.u(1)) { fail("Intra8x8 (transform_size_8x8_flag in an I_NxN macroblock)"); return false; }
@@ -639,7 +682,7 @@ private:
                     else mA = M(mx - 1, my).type == T_I4 ? (am - 16)[blk_idx(3, y)] : 2;
                     if (y > 0) mB = am[blk_idx(x, y - 1)];
                     else if (!avail(mx, my - 1)) { dc = true; mB = 2; }
-                    else mB = M(mx, my - 1).type == T_I4 ? (am - 16 * pic_.mbw)[blk_idx(x, 3)] : 2;
+                    else mB = M(mx, my - 1).type == T_I4 ? (am - 16 * picp_->mbw)[blk_idx(x, 3)] : 2;
                     const int pm = dc ? 2 : (mA < mB ? mA : mB);
                     int mode = pm;
                     if (!br.u(1)) { const int rem = (int)br.u(3); mode = rem < pm ? rem : rem + 1; }
@@ -655,7 +698,7 @@ private:
             if (cm > 3) { fail("intra_chroma_pred_mode %d", (int)cm); return false; }
             m.chroma_mode = (uint8_t)cm;
         } else {
-            pic_.has_inter = true;
+            picp_->has_inter = true;
             const int shape = t == 4 ? 3 : (int)t;
             m.type = (uint8_t)(shape == 0 ? T_P16 : T_P16X8 + shape - 1);
             const int nparts = shape == 0 ? 1 : (shape == 3 ? 4 : 2);
@@ -731,7 +774,7 @@ private:
                     const int b = 4 * b8 + k, bx = (b & 1) | ((b >> 1) & 2), by = ((b >> 1) & 1) | ((b >> 2) & 2);
                     if (!(cbp & (1 << b8))) continue;
                     const int n = residual_block(br, lv + L_LUMA + b * 16 + (i16 ? 1 : 0), i16 ? 15 : 16, nc_luma(mx, my, bx, by));
-                    if (n < 0) { fail("luma levels of macroblock %d", my * pic_.mbw + mx); return false; }
+                    if (n < 0) { fail("luma levels of macroblock %d", my * picp_->mbw + mx); return false; }
                     m.tc[b] = (uint8_t)n;
                 }
             if (cbp >> 4) {
@@ -746,7 +789,7 @@ private:
                         }
             }
         }
-        if (br.bad()) { fail("macroblock %d runs past the slice", my * pic_.mbw + mx); return false; }
+        if (br.bad()) { fail("macroblock %d runs past the slice", my * picp_->mbw + mx); return false; }
         set_qp(mx, my, qp_);
         return true;
     }

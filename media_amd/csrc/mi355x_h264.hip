@@ -1090,6 +1090,13 @@ struct mi355x_h264_decoder {
     uint8_t* d_mbqp = nullptr;   // QP_Y per macroblock of the picture being reconstructed
     int16_t* d_mv4 = nullptr;    // its vectors per 4x4 block (32 int16 per macroblock)
     uint8_t* d_refq = nullptr;   // and reference indices per quadrant (4 per macroblock)
+    // One picture of look-ahead: decode() returns once picture n is LAUNCHED; the parse of access unit n + 1 then runs on the
+    // host while the GPU reconstructs n.  The parser fills two picture buffers in turn (pinned memory: the uploads are
+    // asynchronous); up_done[k] = the uploads out of buffer k have finished, so it may be parsed into again.
+    int buf = 0;
+    hipEvent_t up_done[2] = {nullptr, nullptr};
+    bool up_pending[2] = {false, false};
+    bool busy = false;           // a picture is in flight on the engine's stream
     char err[256] = {0};
 };
 
@@ -1118,7 +1125,23 @@ double now_ms()
     return t.tv_sec * 1e3 + t.tv_nsec * 1e-6;
 }
 
-// launch the reconstruction of the parsed picture into ring slot e->cur
+// the picture in flight has finished (and its wavefront kernels did not time out)
+int dec_wait(mi355x_h264_decoder* d)
+{
+    if (!d->busy) return MI355X_H264_OK;
+    d->busy = false;
+    mi355x_h264_encoder* e = d->eng;
+    DHIP(d, hipStreamSynchronize(e->stream));
+    Slot& S = e->slots[0];
+    if (*S.h_err) {
+        const unsigned flag = *S.h_err;
+        *S.h_err = 0;
+        return dfail(d, MI355X_H264_E_INTERNAL, "wavefront kernel hand-off timed out (flag %u)", flag);
+    }
+    return MI355X_H264_OK;
+}
+
+// launch the reconstruction of the parsed picture (parser buffer d->buf) into ring slot e->cur; does not wait for it
 int dec_submit(mi355x_h264_decoder* d, const h264dec::Picture& pic)
 {
     mi355x_h264_encoder* e = d->eng;
@@ -1159,6 +1182,8 @@ int dec_submit(mi355x_h264_decoder* d, const h264dec::Picture& pic)
         DHIP(d, hipMemcpyAsync(e->d_anypcm, &flags[0], sizeof(unsigned), hipMemcpyHostToDevice, st));
         DHIP(d, hipMemcpyAsync(e->d_anyintra, &flags[1], sizeof(unsigned), hipMemcpyHostToDevice, st));
     }
+    DHIP(d, hipEventRecord(d->up_done[d->buf], st));   // every copy out of the parser's buffer has been queued
+    d->up_pending[d->buf] = true;
     Slot& S = e->slots[0];
     if (pic.has_inter) {
         hipLaunchKernelGGL(k_dec_inter, dim3(e->nmb, 1), dim3(64), 0, st, P);
@@ -1212,14 +1237,16 @@ int dec_submit(mi355x_h264_decoder* d, const h264dec::Picture& pic)
         }
     }
     DHIP(d, hipGetLastError());
-    DHIP(d, hipStreamSynchronize(st));
-    if (*S.h_err) {
-        const unsigned flag = *S.h_err;
-        *S.h_err = 0;
-        return dfail(d, MI355X_H264_E_INTERNAL, "wavefront kernel hand-off timed out (flag %u)", flag);
-    }
+    d->busy = true;
     return MI355X_H264_OK;
 }
+
+void* pinned_alloc(size_t n)
+{
+    void* p = nullptr;
+    return hipHostMalloc(&p, n, hipHostMallocPortable) == hipSuccess ? p : nullptr;
+}
+void pinned_free(void* p) { (void)hipHostFree(p); }
 
 }  // namespace
 
@@ -1234,6 +1261,13 @@ int mi355x_h264_dec_create(int device, mi355x_h264_decoder** out)
     mi355x_h264_decoder* d = new (std::nothrow) mi355x_h264_decoder();
     if (!d) return MI355X_H264_E_NOMEM;
     d->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipEventCreateWithFlags(&d->up_done[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&d->up_done[1], hipEventDisableTiming) != hipSuccess) {
+        delete d;
+        return MI355X_H264_E_HIP;
+    }
+    // the parsers' per-macroblock arrays from now on: pinned (asynchronous uploads); MI355X_H264_DEC_PAGEABLE=1 keeps malloc (measurements)
+    if (!getenv("MI355X_H264_DEC_PAGEABLE")) h264dec::HostMem::use(pinned_alloc, pinned_free);
     *out = d;
     return MI355X_H264_OK;
 }
@@ -1241,6 +1275,10 @@ int mi355x_h264_dec_create(int device, mi355x_h264_decoder** out)
 void mi355x_h264_dec_destroy(mi355x_h264_decoder* d)
 {
     if (!d) return;
+    (void)hipSetDevice(d->device);
+    if (d->eng) { (void)dec_wait(d); }
+    for (int k = 0; k < 2; k++)
+        if (d->up_done[k]) { if (d->up_pending[k]) (void)hipEventSynchronize(d->up_done[k]); (void)hipEventDestroy(d->up_done[k]); }
     if (d->eng) mi355x_h264_destroy(d->eng);
     if (d->d_mbqp) (void)hipFree(d->d_mbqp);
     if (d->d_mv4) (void)hipFree(d->d_mv4);
@@ -1255,12 +1293,24 @@ int mi355x_h264_dec_decode(mi355x_h264_decoder* d, const uint8_t* au, size_t len
     if (!d || !au) return MI355X_H264_E_ARG;
     if (got_picture) *got_picture = 0;
     d->err[0] = 0;
+    if (hipSetDevice(d->device) != hipSuccess) return dfail(d, MI355X_H264_E_HIP, "hipSetDevice");
+    // parse into the buffer the picture in flight does NOT come from (its uploads, two pictures back, have long finished)
+    const int k = d->buf ^ 1;
+    if (d->up_pending[k]) { DHIP(d, hipEventSynchronize(d->up_done[k])); d->up_pending[k] = false; }
+    d->parser.select(k);
     const double t0 = now_ms();
     const int rc = d->parser.parse_access_unit(au, len);
     const double t1 = now_ms();
     d->parse_ms += t1 - t0;
+    if (rc <= 0) d->parser.select(d->buf);   // nothing to launch: picture() stays the last good one
     if (rc < 0) return dfail(d, MI355X_H264_E_STREAM, "%s", d->parser.error().c_str());
     if (rc == 0) return MI355X_H264_OK;
+    {   // the picture in flight must be out of the way before this one is launched (one picture of look-ahead, and its
+        // time-out flag is checked here)
+        const int wrc = dec_wait(d);
+        if (wrc != MI355X_H264_OK) return wrc;
+    }
+    d->buf = k;
     const h264dec::Picture& pic = d->parser.picture();
     const h264dec::Sps& sps = d->parser.sps();
     if (!d->eng || d->mbw != pic.mbw || d->mbh != pic.mbh) {
@@ -1279,13 +1329,14 @@ int mi355x_h264_dec_decode(mi355x_h264_decoder* d, const uint8_t* au, size_t len
         if (hipMalloc((void**)&d->d_mbqp, n) != hipSuccess || hipMalloc((void**)&d->d_mv4, n * 64) != hipSuccess || hipMalloc((void**)&d->d_refq, n * 4) != hipSuccess)
             return dfail(d, MI355X_H264_E_NOMEM, "hipMalloc (per-macroblock decoder arrays)");
     }
-    if (hipSetDevice(d->device) != hipSuccess) return dfail(d, MI355X_H264_E_HIP, "hipSetDevice");
     d->width = pic.width; d->height = pic.height; d->crop_x = 2 * sps.crop_l; d->crop_y = 2 * sps.crop_t;
     d->max_refs = std::max(1, sps.max_refs);
     if (pic.idr) d->have_refs = 0;
     if (pic.has_inter && (d->have_refs < 1 || pic.num_ref_active > d->have_refs))
         return dfail(d, MI355X_H264_E_STREAM, "a P picture refers to %d reference pictures, %d are held", pic.num_ref_active, d->have_refs);
-    const int src = dec_submit(d, pic);
+    int src = dec_submit(d, pic);
+    static const bool no_lookahead = getenv("MI355X_H264_DEC_SYNC") != nullptr;   // (measurements: wait for every picture before returning)
+    if (src == MI355X_H264_OK && no_lookahead) src = dec_wait(d);
     d->gpu_ms += now_ms() - t1;
     if (src != MI355X_H264_OK) return src;
     d->last = d->eng->cur;
@@ -1296,6 +1347,14 @@ int mi355x_h264_dec_decode(mi355x_h264_decoder* d, const uint8_t* au, size_t len
     d->pictures++;
     if (got_picture) *got_picture = 1;
     return MI355X_H264_OK;
+}
+
+int mi355x_h264_dec_sync(mi355x_h264_decoder* d)
+{
+    if (!d) return MI355X_H264_E_ARG;
+    if (!d->eng) return MI355X_H264_OK;
+    if (hipSetDevice(d->device) != hipSuccess) return dfail(d, MI355X_H264_E_HIP, "hipSetDevice");
+    return dec_wait(d);
 }
 
 int mi355x_h264_dec_picture_info(const mi355x_h264_decoder* d, int* width, int* height, int* coded_width, int* coded_height)
@@ -1314,6 +1373,11 @@ static int64_t dec_read(mi355x_h264_decoder* d, void* dst, size_t cap, bool to_d
     if (!d || !dst || d->last < 0) return MI355X_H264_E_ARG;
     const size_t w = (size_t)d->width, h = (size_t)d->height, need = w * h * 3 / 2;
     if (cap < need) return MI355X_H264_E_ARG;
+    if (hipSetDevice(d->device) != hipSuccess) return dfail(d, MI355X_H264_E_HIP, "hipSetDevice");
+    {
+        const int wrc = dec_wait(d);   // the picture asked for may still be in flight
+        if (wrc != MI355X_H264_OK) return wrc;
+    }
     const mi355x_h264_encoder* e = d->eng;
     uint8_t* o = (uint8_t*)dst;
     const hipMemcpyKind kind = to_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
@@ -1335,6 +1399,11 @@ int64_t mi355x_h264_dec_debug_plane(mi355x_h264_decoder* d, int plane, void* dst
     const mi355x_h264_encoder* e = d->eng;
     const size_t n = (size_t)e->cw * e->ch / (plane ? 4 : 1);
     if (cap < n) return MI355X_H264_E_ARG;
+    if (hipSetDevice(d->device) != hipSuccess) return MI355X_H264_E_HIP;
+    {
+        const int wrc = dec_wait(d);
+        if (wrc != MI355X_H264_OK) return wrc;
+    }
     if (hipMemcpy(dst, e->d_planes[d->last][plane], n, hipMemcpyDeviceToHost) != hipSuccess) return MI355X_H264_E_HIP;
     return (int64_t)n;
 }

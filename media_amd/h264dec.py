@@ -23,6 +23,7 @@ def _bind():
     L.mi355x_h264_dec_read_i420.argtypes = [vp, vp, sz]; L.mi355x_h264_dec_read_i420.restype = C.c_int64
     L.mi355x_h264_dec_read_i420_device.argtypes = [vp, vp, sz]; L.mi355x_h264_dec_read_i420_device.restype = C.c_int64
     L.mi355x_h264_dec_debug_plane.argtypes = [vp, C.c_int, vp, sz]; L.mi355x_h264_dec_debug_plane.restype = C.c_int64
+    L.mi355x_h264_dec_sync.argtypes = [vp]
     L.mi355x_h264_dec_timing.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.mi355x_h264_parser_create.restype = vp
     L.mi355x_h264_parser_destroy.argtypes = [vp]; L.mi355x_h264_parser_destroy.restype = None
@@ -92,6 +93,12 @@ class Decoder:
         if n != a.nbytes:
             raise EncoderError("debug_plane -> %d" % n)
         return a
+
+    def sync(self):
+        """wait for the picture the last decode() launched"""
+        rc = lib().mi355x_h264_dec_sync(self.h)
+        if rc != 0:
+            raise EncoderError("dec_sync -> %d: %s" % (rc, lib().mi355x_h264_dec_last_error(self.h).decode()))
 
     def timing(self):
         n, a, b = C.c_uint64(0), C.c_double(0), C.c_double(0)

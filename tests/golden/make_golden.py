@@ -52,7 +52,37 @@ def run_case(name, w, h, kind, qp, gop, n, prof, slices=0, refs=0):
     return {"name": name, "width": w, "height": h, "kind": kind, "qp": qp, "gop": gop, "profile_idc": prof, "slices": slices, "refs": refs, "frames": frames}
 
 
+# Streams of random syntax for the decoder peer (oracle/h264_enc.c h264o_enc_random_picture): what is pinned is the stream
+# (sha256 of every access unit) and what the oracle's independent decoder makes of it (sha256 of its three planes).
+RANDOM_CASES = [
+    # name, width, height, profile_idc, slices, refs, features (oracle_lib.OracleEncoder.RAND_*), pictures
+    ("rand_qcif_all_baseline", 176, 144, 66, 0, 3, 63, 6),
+    ("rand_qvga_all_high_3slices", 320, 240, 100, 3, 2, 63, 6),
+    ("rand_qcif_qp_offsets_main", 176, 144, 77, 2, 1, 1 | 2 | 4 | 16, 5),
+    ("rand_tiny_pcm_subparts", 48, 32, 66, 0, 3, 8 | 32, 5),
+]
+
+
+def run_random_case(name, w, h, prof, slices, refs, features, n):
+    from oracle_lib import OracleDecoder
+    enc = OracleEncoder(w, h, qp=30, gop=4, profile_idc=prof, slices=slices, refs=refs)
+    dec = OracleDecoder()
+    frames = []
+    for i in range(n):
+        au, idr, _ = enc.random_picture(20261004 + 31 * i, features=features)
+        assert dec.decode(au) == 1
+        planes = hashlib.sha256(b"".join(dec.plane(p).tobytes() for p in range(3))).hexdigest()
+        frames.append({"idr": bool(idr), "bytes": len(au), "sha256": hashlib.sha256(au).hexdigest(), "decoded_sha256": planes})
+    enc.close()
+    return {"name": name, "width": w, "height": h, "profile_idc": prof, "slices": slices, "refs": refs, "features": features, "frames": frames}
+
+
 if __name__ == "__main__":
+    rnd = {"generator": "tests/golden/make_golden.py", "source": "CPU oracle (oracle/): random-syntax streams and its independent decoder's output, not the reference",
+           "cases": [run_random_case(*c) for c in RANDOM_CASES]}
+    with open(os.path.join(HERE, "random_streams.json"), "w") as f:
+        json.dump(rnd, f, indent=1)
+    print("wrote", len(rnd["cases"]), "random-syntax cases")
     out = {"generator": "tests/golden/make_golden.py", "source": "CPU oracle (oracle/), not the reference",
            "cases": [run_case(*c) for c in CASES]}
     with open(os.path.join(HERE, "oracle_vectors.json"), "w") as f:

@@ -215,3 +215,20 @@ def test_parser_reads_random_streams(w, h, prof, slices, refs, features):
             assert not info["one_qp"] or len(set(mbqp)) == 1
     assert seen >= ({0, 1, 2, 4, 5, 6, 7} | ({3} if features & 8 else set())) or w * h <= 256
     par.close()
+
+
+def test_random_stream_golden_vectors():
+    """tests/golden/random_streams.json (made by tests/golden/make_golden.py): the generator still writes the same access units
+    and the oracle's independent decoder still decodes them to the same pictures - the fixtures the GPU decoder is held to in
+    tests/test_gpu_decoder.py."""
+    import hashlib, json, os
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "random_streams.json")))
+    for c in gold["cases"]:
+        enc = OracleEncoder(c["width"], c["height"], qp=30, gop=4, profile_idc=c["profile_idc"], slices=c["slices"], refs=c["refs"])
+        dec, par = OracleDecoder(), h264dec.Parser()
+        for i, fr in enumerate(c["frames"]):
+            au, idr, _ = enc.random_picture(20261004 + 31 * i, features=c["features"])
+            assert (hashlib.sha256(au).hexdigest(), len(au), idr) == (fr["sha256"], fr["bytes"], fr["idr"]), "%s picture %d" % (c["name"], i)
+            assert dec.decode(au) == 1 and par.parse(au)
+            assert hashlib.sha256(b"".join(dec.plane(p).tobytes() for p in range(3))).hexdigest() == fr["decoded_sha256"], "%s picture %d" % (c["name"], i)
+        par.close()

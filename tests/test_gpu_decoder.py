@@ -102,3 +102,19 @@ def test_decoder_equals_the_independent_decoder_on_random_streams(w, h, prof, sl
                 raise AssertionError("picture %d (%s) plane %d: %d samples differ, first in macroblock %d (type %d, QP %d)"
                                      % (i, "IDR" if idr else "P", p, ys.size, k, int(enc.mbinfo()["type"][k]), int(mbqp[k])))
     dec.close()
+
+
+def test_decoder_against_the_committed_random_stream_vectors():
+    """tests/golden/random_streams.json: the decoded planes of every picture hash to the committed value (what the oracle's
+    independent decoder produced when the fixture was made; tests/test_dec_parser.py re-checks that on the CPU)."""
+    import hashlib, json, os
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "random_streams.json")))
+    for c in gold["cases"]:
+        enc = OracleEncoder(c["width"], c["height"], qp=30, gop=4, profile_idc=c["profile_idc"], slices=c["slices"], refs=c["refs"])
+        dec = h264dec.Decoder()
+        for i, fr in enumerate(c["frames"]):
+            au = enc.random_picture(20261004 + 31 * i, features=c["features"])[0]
+            assert hashlib.sha256(au).hexdigest() == fr["sha256"]
+            assert dec.decode(au)
+            assert hashlib.sha256(b"".join(dec.plane(p).tobytes() for p in range(3))).hexdigest() == fr["decoded_sha256"], "%s picture %d" % (c["name"], i)
+        dec.close()
