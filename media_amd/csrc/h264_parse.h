@@ -69,12 +69,16 @@ public:
     size_t pos() const { return pos_; }
     bool more_data() const { return pos_ < stop_; }
     bool aligned() const { return (pos_ & 7) == 0; }
-    uint32_t peek(int k)   // k <= 25; bits past the end read as 0
+    // The payload is followed by PAD zero bytes (the caller's buffer): eight bytes can be loaded at every position up to the
+    // end, and bits past the end read as 0.
+    enum { PAD = 8 };
+    uint32_t peek(int k)   // 1 <= k <= 32
     {
-        uint64_t v = 0;
-        const size_t byte = pos_ >> 3;
-        for (int i = 0; i < 5; i++) v = (v << 8) | (byte + (size_t)i < n_ ? p_[byte + (size_t)i] : 0);
-        return (uint32_t)((v >> (40 - (int)(pos_ & 7) - k)) & ((1ull << k) - 1));
+        const size_t byte = pos_ >> 3 < n_ ? pos_ >> 3 : n_;
+        uint64_t v;
+        memcpy(&v, p_ + byte, 8);
+        v = __builtin_bswap64(v) << (pos_ & 7);
+        return (uint32_t)(v >> (64 - k));
     }
     void skip(int k) { pos_ += (size_t)k; if (pos_ > n_ * 8) bad_ = true; }
     uint32_t u(int k)
@@ -86,11 +90,26 @@ public:
     }
     uint32_t ue()
     {
+        const uint32_t w = peek(32);
+        if (w >> 16) {   // up to 15 leading zeros: the whole code word (2 z + 1 bits) is inside w
+            const int z = __builtin_clz(w);
+            skip(2 * z + 1);
+            return (w >> (31 - 2 * z)) - 1u;
+        }
         int z = 0;
         while (z < 32 && peek(1) == 0 && !bad_) { skip(1); z++; }
         if (z >= 32) { bad_ = true; return 0; }
         skip(1);
         return z ? ((1u << z) - 1u + u(z)) : 0u;
+    }
+    // number of zero bits before the next 1 bit (level_prefix, 9.2.2.1), consumed with that bit; -1: none within 32 bits
+    int unary()
+    {
+        const uint32_t w = peek(32);
+        if (!w) return -1;
+        const int z = __builtin_clz(w);
+        skip(z + 1);
+        return z;
     }
     int32_t se() { const uint32_t k = ue(); return (k & 1) ? (int32_t)((k + 1) >> 1) : -(int32_t)(k >> 1); }
     const uint8_t* byte_ptr() const { return p_ + (pos_ >> 3); }
@@ -104,6 +123,7 @@ private:
 struct VlcLut {
     // entry: len << 8 | symbol; 0 = no code
     std::vector<uint16_t> ct[4], cdc, tz[15], ctz[3], run[7];
+    uint16_t ct8[4][256];   // coeff_token codes of up to 8 bits (nearly all that occur) by the next 8 bits: 2 kB instead of the 512 kB of ct[]
     uint8_t code2cbp_inter[48], code2cbp_intra[48];
     VlcLut()
     {
@@ -116,6 +136,7 @@ struct VlcLut {
         for (int c = 0; c < 4; c++) {
             ct[c].assign(1u << 16, 0);
             for (int s = 0; s < 68; s++) fill(ct[c], 16, ct_len[c][s], ct_bits[c][s], s, (s & 3) <= (s >> 2));
+            for (int i = 0; i < 256; i++) { const uint16_t e = ct[c][(size_t)i << 8]; ct8[c][i] = (e >> 8) <= 8 ? e : 0; }
         }
         cdc.assign(1u << 8, 0);
         for (int s = 0; s < 20; s++) fill(cdc, 8, cdc_len[s], cdc_bits[s], s, (s & 3) <= (s >> 2));
@@ -253,15 +274,16 @@ private:
         const int hdr = p[0], ref_idc = (hdr >> 5) & 3, type = hdr & 31;
         if (hdr & 0x80) { fail("forbidden_zero_bit set"); return false; }
         // emulation prevention (7.4.1.1): 00 00 03 -> 00 00
-        rbsp_.clear();
-        rbsp_.reserve(n);
+        rbsp_.resize(n + BitReader::PAD);
+        size_t m = 0;
         int zeros = 0;
         for (size_t i = 1; i < n; i++) {
             if (zeros >= 2 && p[i] == 3) { zeros = 0; continue; }
-            rbsp_.push_back(p[i]);
+            rbsp_[m++] = p[i];
             zeros = p[i] == 0 ? zeros + 1 : 0;
         }
-        BitReader br(rbsp_.data(), rbsp_.size());
+        memset(rbsp_.data() + m, 0, BitReader::PAD);
+        BitReader br(rbsp_.data(), m);
         if (type == 7) return parse_sps(br);
         if (type == 8) return parse_pps(br);
         if (type == 1 || type == 5) return parse_slice(br, type == 5, ref_idc, have_pic, next_mb);
@@ -401,7 +423,9 @@ private:
             br.skip(e >> 8); tc = (e & 255) >> 2; t1 = e & 3;
         } else {
             const int cls = nC < 2 ? 0 : (nC < 4 ? 1 : (nC < 8 ? 2 : 3));
-            const uint16_t e = L.ct[cls][br.peek(16)];
+            const uint32_t w = br.peek(16);
+            uint16_t e = L.ct8[cls][w >> 8];
+            if (!e) e = L.ct[cls][w];
             if (!e) return -1;
             br.skip(e >> 8); tc = (e & 255) >> 2; t1 = e & 3;
         }
@@ -411,10 +435,8 @@ private:
         int suffix_len = (tc > 10 && t1 < 3) ? 1 : 0;
         for (int i = 0; i < tc; i++) {
             if (i < t1) { level[i] = br.u(1) ? -1 : 1; continue; }
-            int prefix = 0;
-            while (prefix < 32 && br.peek(1) == 0 && !br.bad()) { br.skip(1); prefix++; }
-            if (prefix >= 32) return -1;
-            br.skip(1);
+            const int prefix = br.unary();
+            if (prefix < 0) return -1;
             int code = (prefix < 15 ? prefix : 15) << suffix_len;
             if (suffix_len > 0 || prefix >= 14) {
                 const int size = (prefix == 14 && suffix_len == 0) ? 4 : (prefix >= 15 ? prefix - 3 : suffix_len);
