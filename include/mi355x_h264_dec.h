@@ -13,7 +13,7 @@
  * 16x16 .. 4x4 partitions (every sub_mb_type), up to 3 reference pictures (sliding window, one index per partition), 4x4 and
  * (inter) 8x8 transform, QP per macroblock
  * (slice_qp_delta, mb_qp_delta), chroma QP index offsets, deblocking filter offsets and idc 0 / 1 / 2 (one set per picture),
- * slices = equal bands of macroblock rows.  A stream outside that is refused with MI355X_H264_E_STREAM and a message naming the
+ * slices of any shape in raster order (no FMO / ASO).  A stream outside that is refused with MI355X_H264_E_STREAM and a message naming the
  * syntax element; nothing is ever decoded approximately.
  */
 #ifndef MI355X_H264_DEC_H
@@ -63,13 +63,15 @@ mi355x_h264_parser *mi355x_h264_parser_create(void);
 void mi355x_h264_parser_destroy(mi355x_h264_parser *p);
 int mi355x_h264_parser_parse(mi355x_h264_parser *p, const uint8_t *au, size_t len);   /* 1 picture, 0 none, -1 error */
 const char *mi355x_h264_parser_error(const mi355x_h264_parser *p);
-/* out[12]: mbw, mbh, width, height, idr, qp (of the first slice), slice_rows (0 = one slice), deblocking idc, num_ref_idx_active,
+/* out[12]: mbw, mbh, width, height, idr, qp (of the first slice), slice_rows (0 = one slice, n > 0 = bands of n rows, -1 = slices
+ * of any other shape), deblocking idc, num_ref_idx_active,
  * transform_8x8_mode, has I_PCM, bit 0 has intra | bit 1 has inter; with n >= 17 also: chroma_qp_index_offset,
  * second_chroma_qp_index_offset, FilterOffsetA, FilterOffsetB, 1 = every macroblock has that one QP and no offset applies.
  * Returns the number of values written */
 int mi355x_h264_parser_info(const mi355x_h264_parser *p, int32_t *out, int n);
 /* what: 0 MbInfo (32 B / macroblock, layout of mi355x_h264.h), 1 quadrant vectors (8 int16), 2 Intra4x4 modes (16 B), 3 levels (416 int16),
- * 4 QP_Y (1 B / macroblock; 0 for I_PCM), 5 vectors per 4x4 block (32 int16, raster order), 6 ref_idx_l0 per 8x8 quadrant (4 B; 255 intra) */
+ * 4 QP_Y (1 B / macroblock; 0 for I_PCM), 5 vectors per 4x4 block (32 int16, raster order), 6 ref_idx_l0 per 8x8 quadrant (4 B; 255 intra),
+ * 7 neighbour availability (1 B: bit 0 left, 1 above, 2 above-right, 3 above-left macroblock usable for prediction) */
 int64_t mi355x_h264_parser_read(const mi355x_h264_parser *p, int what, void *dst, size_t cap);
 
 #ifdef __cplusplus

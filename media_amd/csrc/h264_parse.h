@@ -14,7 +14,8 @@
 // P_Skip; up to 3 reference pictures by sliding window, no reordering, a reference index per partition; 4x4 transform, 8x8
 // transform on inter macroblocks; QP per macroblock (slice_qp_delta per slice, mb_qp_delta), chroma_qp_index_offset and
 // second_chroma_qp_index_offset, slice_alpha_c0_offset_div2 / slice_beta_offset_div2 (one pair per picture);
-// slices = bands of whole macroblock rows of equal height; disable_deblocking_filter_idc 0 / 1 / 2 (one value per picture).
+// slices of any shape in raster order (bands of whole rows decode as independent wavefronts); disable_deblocking_filter_idc
+// 0 / 1 / 2 (one value per picture).
 // Anything else is refused with a message naming the syntax element (never decoded wrongly).
 #pragma once
 #include <stdint.h>
@@ -214,6 +215,9 @@ struct Picture {
     HostVec<MbRec> mb;
     HostVec<int16_t> mvq;      // 8 per macroblock: the vectors of the four 8x8 quadrants' first blocks (the encoder's layout)
     HostVec<int16_t> mv4;      // 32 per macroblock: the vector (x, y) of every 4x4 block, raster order (sub-macroblock partitions)
+    HostVec<uint8_t> mbavail;  // per macroblock: neighbours available for prediction (6.4.9: in the picture, in the same slice, decoded
+                               // before): bit 0 left, 1 above, 2 above-right, 3 above-left - slices may start and end at any macroblock
+    int slices = 0;            // slices of the picture; slice_rows > 0: they are bands of that many whole rows, -1: of any other shape
     HostVec<uint8_t> refq;     // 4 per macroblock: ref_idx_l0 of the four quadrants (0xFF: intra)
     HostVec<uint8_t> aux;      // 16 per macroblock
     HostVec<int16_t> levels;   // L_STRIDE per macroblock (I_PCM: its 384 samples as bytes at the start)
@@ -247,6 +251,8 @@ public:
         }
         if (!have_pic) return 0;
         if (next_mb != picp_->mbw * picp_->mbh) return fail("picture incomplete: slices cover %d of %d macroblocks", next_mb, picp_->mbw * picp_->mbh);
+        // bands of slice_rows rows only if every band start was seen (a last slice longer than the others is "any shape")
+        if (picp_->slice_rows > 0 && picp_->slices != (picp_->mbh + picp_->slice_rows - 1) / picp_->slice_rows) picp_->slice_rows = -1;
         return 1;
     }
 
@@ -588,14 +594,17 @@ private:
             picp_->mvq.assign(n * 8, 0);
             picp_->mv4.assign(n * 32, 0);
             picp_->refq.assign(n * 4, 0xFF);
+            picp_->mbavail.assign(n, 0);
+            picp_->slices = 1;
             picp_->aux.assign(n * 16, 0);
             picp_->levels.assign(n * L_STRIDE, 0);
             have_pic = true;
         } else {
             if (first_mb != next_mb) { fail("slices out of order (first_mb_in_slice %d, expected %d)", first_mb, next_mb); return false; }
-            if (first_mb % picp_->mbw) { fail("slice starts inside a macroblock row (first_mb_in_slice %d)", first_mb); return false; }
-            if (picp_->slice_rows == 0) picp_->slice_rows = first_mb / picp_->mbw;
-            else if ((first_mb / picp_->mbw) % picp_->slice_rows) { fail("slices are not bands of equal height"); return false; }
+            // bands of equal height (the last may be shorter): slice k starts at row k * slice_rows; anything else is "any shape"
+            if (picp_->slices == 1 && first_mb % picp_->mbw == 0) picp_->slice_rows = first_mb / picp_->mbw;
+            if (picp_->slice_rows <= 0 || first_mb != picp_->slices * picp_->slice_rows * picp_->mbw) picp_->slice_rows = -1;
+            picp_->slices++;
             if (qp != picp_->qp) picp_->one_qp = false;
             if (idc != picp_->deblock_idc) { fail("disable_deblocking_filter_idc differs between slices"); return false; }
             if (oa != picp_->filter_oa || ob != picp_->filter_ob) { fail("deblocking filter offsets differ between slices"); return false; }
@@ -623,7 +632,6 @@ private:
             addr++;
             more = br.more_data();
         }
-        if (picp_->slice_rows && (addr % picp_->mbw)) { fail("slice ends inside a macroblock row"); return false; }
         next_mb = addr;
         return true;
     }
@@ -644,6 +652,11 @@ private:
         uint8_t* r = &picp_->refq[((size_t)my * picp_->mbw + mx) * 4];
         r[0] = (uint8_t)r0; r[1] = (uint8_t)r1; r[2] = (uint8_t)r2; r[3] = (uint8_t)r3;
     }
+    void set_avail(int mx, int my)
+    {
+        picp_->mbavail[(size_t)my * picp_->mbw + mx] =
+            (uint8_t)((avail(mx - 1, my) ? 1 : 0) | (avail(mx, my - 1) ? 2 : 0) | (avail(mx + 1, my - 1) ? 4 : 0) | (avail(mx - 1, my - 1) ? 8 : 0));
+    }
     void set_qp(int mx, int my, int qp)
     {
         picp_->mbqp[(size_t)my * picp_->mbw + mx] = (uint8_t)qp;
@@ -655,6 +668,7 @@ private:
         m = MbRec{};
         m.type = T_PSKIP;
         m.chroma_mode = 0;   // ref_idx_l0 = 0
+        set_avail(mx, my);
         set_qp(mx, my, qp_);
         int px, py;
         set_refs(mx, my, 0, 0, 0, 0);
@@ -676,6 +690,7 @@ private:
         if (br.bad() || (is_intra && t > 25) || (!is_intra && t > 4)) { fail("mb_type %d", (int)t); return false; }
         int cbp = 0;
         bool i16 = false, t8flag = false;
+        set_avail(mx, my);
         if (is_intra) set_refs(mx, my, 0xFF, 0xFF, 0xFF, 0xFF);
         bool all8x8 = true;   // NoSubMbPartSizeLessThan8x8Flag
         if (is_intra && t == 25) {   // I_PCM

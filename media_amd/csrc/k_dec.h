@@ -125,7 +125,8 @@ struct DecBsParams {
     const uint8_t* refq;
     uint8_t* bs;
     int mbw, nmb;
-    SliceRows sl;      // the slices the FILTER sees (idc 0: one)
+    const uint8_t* mbavail;   // the parser's availability bits (bit 0 left, 1 above: the same slice)
+    int across;        // disable_deblocking_filter_idc 0: edges between slices are filtered too
     MbDiv mbdiv;
 };
 __global__ __launch_bounds__(64) void k_dec_bs(DecBsParams C, unsigned* anybs, unsigned serial)
@@ -135,7 +136,8 @@ __global__ __launch_bounds__(64) void k_dec_bs(DecBsParams C, unsigned* anybs, u
     if (mbi < C.nmb) {
         const int my = C.mbdiv.row(mbi), mx = mbi - my * C.mbw;
         const int dir = l >> 4, e = (l >> 2) & 3, k = l & 3;
-        const bool edge_ok = !(e == 0 && (dir == 0 ? mx == 0 : !C.sl.has_top(my)));
+        const int av = C.mbavail[mbi];
+        const bool edge_ok = e != 0 || (dir == 0 ? (C.across ? mx > 0 : (av & 1) != 0) : (C.across ? my > 0 : (av & 2) != 0));
         if (edge_ok) {
             const int pi = e == 0 ? (dir == 0 ? mbi - 1 : mbi - C.mbw) : mbi;
             const MbInfo *q = C.mb + mbi, *p = C.mb + pi;

@@ -140,8 +140,14 @@ template <bool DEC = false>
 __device__ __forceinline__ void intra_mb_core(const FrameParams& P, int mx, int my, IntraLds& S, int lane, bool use_i4, uint32_t auxw)
 {
     const int mbi = my * P.mbw + mx, bx = 16 * mx, by = 16 * my, cs = P.cw / 2;
-    const bool top = P.sl.has_top(my);   // the row above belongs to this slice
-    const int avail = (mx > 0 ? 1 : 0) | (top ? 2 : 0) | ((mx > 0 && top) ? 4 : 0);
+    // neighbouring macroblocks available for prediction (6.4.9: in the picture, in this slice, decoded before).  Encoder: slices are
+    // bands of whole rows.  DEC: the parser's bits per macroblock (1 left, 2 above, 4 above-right, 8 above-left) - slices of any shape
+    bool top = P.sl.has_top(my), left = mx > 0, topleft = mx > 0 && top, topright = top && mx + 1 < P.mbw;
+    if (DEC) {
+        const int a = __builtin_amdgcn_readfirstlane((int)P.mbavail[mbi]);
+        left = (a & 1) != 0; top = (a & 2) != 0; topright = (a & 4) != 0; topleft = (a & 8) != 0;
+    }
+    const int avail = (left ? 1 : 0) | (top ? 2 : 0) | (topleft ? 4 : 0);
     MbInfo* const mbp = P.mb + mbi;
     // DEC: the macroblock's own QP (mb_qp_delta) - of Quant only qp and dq[] are read on the decoding paths; chroma per component
     Quant dqy = {};
@@ -181,7 +187,7 @@ __device__ __forceinline__ void intra_mb_core(const FrameParams& P, int mx, int 
     if (use_i4) {
         const uint32_t m0 = (uint32_t)__builtin_amdgcn_readlane((int)auxw, 0), m1 = (uint32_t)__builtin_amdgcn_readlane((int)auxw, 1);
         const uint32_t m2 = (uint32_t)__builtin_amdgcn_readlane((int)auxw, 2), m3 = (uint32_t)__builtin_amdgcn_readlane((int)auxw, 3);
-        cbp_luma_i4 = i4_code_luma<DEC>(QY, S.i4, S.top, S.left, S.src, m0, m1, m2, m3, S.lv, S.dc, mx, top, top && mx + 1 < P.mbw, lane);   // (S.dc: TotalCoeff of the 16 blocks)
+        cbp_luma_i4 = i4_code_luma<DEC>(QY, S.i4, S.top, S.left, S.src, m0, m1, m2, m3, S.lv, S.dc, DEC ? (int)left : mx, top, topright, lane);   // (S.dc: TotalCoeff of the 16 blocks)
         const uint32_t o = *(const uint32_t*)(S.i4.rb + (1 + (lane >> 2)) * 32 + 4 + (lane & 3) * 4);
         *(uint32_t*)(S.rec_y + (lane >> 2) * 16 + (lane & 3) * 4) = o;
         *(uint32_t*)(P.rec[0] + (size_t)(by + (lane >> 2)) * P.cw + bx + (lane & 3) * 4) = o;

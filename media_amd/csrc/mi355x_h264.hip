@@ -1090,6 +1090,7 @@ struct mi355x_h264_decoder {
     uint8_t* d_mbqp = nullptr;   // QP_Y per macroblock of the picture being reconstructed
     int16_t* d_mv4 = nullptr;    // its vectors per 4x4 block (32 int16 per macroblock)
     uint8_t* d_refq = nullptr;   // and reference indices per quadrant (4 per macroblock)
+    uint8_t* d_mbavail = nullptr;   // neighbour availability bits per macroblock
     // One picture of look-ahead: decode() returns once picture n is LAUNCHED; the parse of access unit n + 1 then runs on the
     // host while the GPU reconstructs n.  The parser fills two picture buffers in turn (pinned memory: the uploads are
     // asynchronous); up_done[k] = the uploads out of buffer k have finished, so it may be parsed into again.
@@ -1152,6 +1153,7 @@ int dec_submit(mi355x_h264_decoder* d, const h264dec::Picture& pic)
     DHIP(d, hipMemcpyAsync(e->d_aux, pic.aux.data(), nmb * 16, hipMemcpyHostToDevice, st));
     DHIP(d, hipMemcpyAsync(e->d_levels, pic.levels.data(), nmb * LV_STRIDE * sizeof(int16_t), hipMemcpyHostToDevice, st));
     DHIP(d, hipMemcpyAsync(d->d_mbqp, pic.mbqp.data(), nmb, hipMemcpyHostToDevice, st));
+    DHIP(d, hipMemcpyAsync(d->d_mbavail, pic.mbavail.data(), nmb, hipMemcpyHostToDevice, st));
     if (pic.has_inter) {
         DHIP(d, hipMemcpyAsync(d->d_mv4, pic.mv4.data(), nmb * 64, hipMemcpyHostToDevice, st));
         DHIP(d, hipMemcpyAsync(d->d_refq, pic.refq.data(), nmb * 4, hipMemcpyHostToDevice, st));
@@ -1168,7 +1170,9 @@ int dec_submit(mi355x_h264_decoder* d, const h264dec::Picture& pic)
     }
     P.mb = e->d_mb; P.levels = e->d_levels; P.mvd = e->d_mvd; P.mvq = e->d_mvq; P.aux = e->d_aux; P.me_cost = e->d_me_cost; P.me_total = e->d_me_total; P.pmv = e->d_pmv;
     P.st_y = e->st_y; P.st_c = e->st_c; P.st_mb = e->nmb;
-    P.sl.rows = pic.slice_rows ? pic.slice_rows : e->mbh;
+    // slices that are bands of whole rows run as independent wavefronts; any other shape: one wavefront over the picture (what may
+    // be used for prediction is in mbavail either way)
+    P.sl.rows = pic.slice_rows > 0 ? pic.slice_rows : e->mbh;
     P.sl.inv = P.sl.rows > 1 ? (unsigned)(0x100000000ull / (unsigned)P.sl.rows) + 1u : 0u;
     P.band.row0 = 0; P.band.rows = e->mbh;
     P.mbdiv.inv = e->mbw > 1 ? (unsigned)(0x100000000ull / (unsigned)e->mbw) + 1u : 0u;
@@ -1176,7 +1180,7 @@ int dec_submit(mi355x_h264_decoder* d, const h264dec::Picture& pic)
     P.anypcm = e->d_anypcm; P.anyintra = e->d_anyintra; P.pic_serial = e->pic_serial;
     fill_quant(P.qy, pic.qp);                 // (the reconstruction kernels scale with the macroblock's own QP: mbqp)
     fill_quant(P.qc, h_chroma_qp[pic.qp]);
-    P.mbqp = d->d_mbqp; P.cqo_cb = pic.cqo[0]; P.cqo_cr = pic.cqo[1]; P.mv4 = d->d_mv4; P.refq = d->d_refq;
+    P.mbqp = d->d_mbqp; P.cqo_cb = pic.cqo[0]; P.cqo_cr = pic.cqo[1]; P.mv4 = d->d_mv4; P.refq = d->d_refq; P.mbavail = d->d_mbavail;
     {   // the flags the loop filter launches look at: intra macroblocks present (bS 3 / 4 form); I_PCM never switches the filter off here
         const unsigned flags[2] = {0u, pic.has_intra ? e->pic_serial : 0u};
         DHIP(d, hipMemcpyAsync(e->d_anypcm, &flags[0], sizeof(unsigned), hipMemcpyHostToDevice, st));
@@ -1197,21 +1201,18 @@ int dec_submit(mi355x_h264_decoder* d, const h264dec::Picture& pic)
         hipLaunchKernelGGL(k_pintra_rows<true>, dim3(e->mbh, 1), dim3(64), 0, st, R);
     }
     if (pic.deblock_idc != 1) {
-        CavlcParams C{};
         // disable_deblocking_filter_idc 0 filters the edges between slices too: the filter then sees one slice
         SliceRows dsl = P.sl;
-        if (pic.deblock_idc == 0) { dsl.rows = e->mbh; dsl.inv = e->mbh > 1 ? (unsigned)(0x100000000ull / (unsigned)e->mbh) + 1u : 0u; }
-        C.mb = e->d_mb; C.levels = e->d_levels; C.mvd = e->d_mvd; C.mvq = e->d_mvq; C.mbw = e->mbw; C.nmb = e->nmb; C.sl = dsl;
-        C.mb_first = 0; C.mb_end = e->nmb; C.mbdiv = P.mbdiv; C.bs = (uint8_t*)e->d_bs; C.st_mb = e->nmb; C.aux = e->d_aux;
-        C.slotbits = e->d_slotbits; C.slotcode = e->d_slotcode; C.mbbits = e->d_mbbits; C.prevcoded = e->d_prevcoded;
+        // (slices of any other shape than bands: k_dec_bs has zeroed the strengths of the edges between them where idc 2 says so)
+        if (pic.deblock_idc == 0 || pic.slice_rows < 0) { dsl.rows = e->mbh; dsl.inv = e->mbh > 1 ? (unsigned)(0x100000000ull / (unsigned)e->mbh) + 1u : 0u; }
         e->serial = e->serial == 0xFFFFFFFFu ? 1 : e->serial + 1;
         const unsigned db_serial = e->serial;
-        if (pic.has_inter) {   // vectors per 4x4 block, references per quadrant
+        {   // vectors per 4x4 block, references per quadrant, slice edges from the availability bits
             DecBsParams B{};
-            B.mb = e->d_mb; B.mv4 = d->d_mv4; B.refq = d->d_refq; B.bs = (uint8_t*)e->d_bs; B.mbw = e->mbw; B.nmb = e->nmb; B.sl = dsl; B.mbdiv = P.mbdiv;
+            B.mb = e->d_mb; B.mv4 = d->d_mv4; B.refq = d->d_refq; B.bs = (uint8_t*)e->d_bs; B.mbw = e->mbw; B.nmb = e->nmb; B.mbdiv = P.mbdiv;
+            B.mbavail = d->d_mbavail; B.across = pic.deblock_idc == 0;
             hipLaunchKernelGGL(k_dec_bs, dim3((e->nmb + 1) / 2, 1), dim3(64), 0, st, B, e->d_anybs, db_serial);
-        } else
-            hipLaunchKernelGGL(k_bs, dim3((e->nmb + 1) / 2, 1), dim3(64), 0, st, C, e->d_anybs, db_serial);
+        }
         DbParams D{};
         for (int p = 0; p < 3; p++) D.pl[p] = e->d_planes[cur][p];
         D.mb = e->d_mb; D.cw = e->cw; D.ch = e->ch; D.mbw = e->mbw; D.mbh = e->mbh; D.sl = dsl; D.bs = (const uint8_t*)e->d_bs;
@@ -1283,6 +1284,7 @@ void mi355x_h264_dec_destroy(mi355x_h264_decoder* d)
     if (d->d_mbqp) (void)hipFree(d->d_mbqp);
     if (d->d_mv4) (void)hipFree(d->d_mv4);
     if (d->d_refq) (void)hipFree(d->d_refq);
+    if (d->d_mbavail) (void)hipFree(d->d_mbavail);
     delete d;
 }
 
@@ -1325,8 +1327,10 @@ int mi355x_h264_dec_decode(mi355x_h264_decoder* d, const uint8_t* au, size_t len
         if (d->d_mbqp) { (void)hipFree(d->d_mbqp); d->d_mbqp = nullptr; }
         if (d->d_mv4) { (void)hipFree(d->d_mv4); d->d_mv4 = nullptr; }
         if (d->d_refq) { (void)hipFree(d->d_refq); d->d_refq = nullptr; }
+        if (d->d_mbavail) { (void)hipFree(d->d_mbavail); d->d_mbavail = nullptr; }
         const size_t n = (size_t)pic.mbw * pic.mbh;
-        if (hipMalloc((void**)&d->d_mbqp, n) != hipSuccess || hipMalloc((void**)&d->d_mv4, n * 64) != hipSuccess || hipMalloc((void**)&d->d_refq, n * 4) != hipSuccess)
+        if (hipMalloc((void**)&d->d_mbqp, n) != hipSuccess || hipMalloc((void**)&d->d_mv4, n * 64) != hipSuccess || hipMalloc((void**)&d->d_refq, n * 4) != hipSuccess ||
+            hipMalloc((void**)&d->d_mbavail, n) != hipSuccess)
             return dfail(d, MI355X_H264_E_NOMEM, "hipMalloc (per-macroblock decoder arrays)");
     }
     d->width = pic.width; d->height = pic.height; d->crop_x = 2 * sps.crop_l; d->crop_y = 2 * sps.crop_t;
@@ -1448,6 +1452,7 @@ int64_t mi355x_h264_parser_read(const mi355x_h264_parser* p, int what, void* dst
         case 4: src = c.mbqp.data(); n = c.mbqp.size(); break;
         case 5: src = c.mv4.data(); n = c.mv4.size() * sizeof(int16_t); break;
         case 6: src = c.refq.data(); n = c.refq.size(); break;
+        case 7: src = c.mbavail.data(); n = c.mbavail.size(); break;
         default: return -1;
     }
     if (cap < n) return -1;

@@ -163,6 +163,8 @@ struct randsyn {
     int idc, oa, ob;     /* disable_deblocking_filter_idc, slice_alpha_c0_offset_div2, slice_beta_offset_div2 */
     int slice_qp[256];   /* SliceQP_Y per slice */
     int8_t *qpd;         /* mb_qp_delta per macroblock (written where the syntax carries one) */
+    int32_t *slice_first;/* non-NULL: slices of any shape - per macroblock, the address of the first macroblock of its slice */
+    int cur_slice_qp;    /* SliceQP_Y of the slice whose header is being written (slice_first mode) */
     int direct;          /* inter macroblocks are written from random draws at writing time: sub_mb_types down to 4x4, a
                           * ref_idx_l0 per partition, mvd_l0 values as such (whatever they add up to IS the vector) */
     uint32_t rng;
@@ -410,7 +412,7 @@ static void write_slice_header(h264o_enc *e, bitw *b, int idr, int first_mb)
         bw_put(b, 1, 0); /* adaptive_ref_pic_marking_mode_flag */
     }
     if (e->rs) {   /* random-stream generator: its own QP and filter parameters */
-        bw_se(b, e->rs->slice_qp[(first_mb / e->mbw / e->slice_rows) & 255] - 26);
+        bw_se(b, (e->rs->slice_first ? e->rs->cur_slice_qp : e->rs->slice_qp[(first_mb / e->mbw / e->slice_rows) & 255]) - 26);
         bw_ue(b, (uint32_t)e->rs->idc);
         if (e->rs->idc != 1) { bw_se(b, e->rs->oa); bw_se(b, e->rs->ob); }
         return;
@@ -1087,14 +1089,23 @@ static void finish_inter_mb(h264o_enc *e, int mx, int my)
 }
 
 /* ------------------------------------------------------------ slice data 7.3.4/7.3.5 */
+/* 6.4.9: macroblock (nx, ny), a neighbour of (mx, my) to the left or in the row above, is available - inside the picture, in
+ * the same slice, earlier in decoding order.  The encoder's slices are bands of whole rows; the random-stream generator may
+ * cut slices anywhere (slice_first) */
+static int mb_avail(const h264o_enc *e, int mx, int my, int nx, int ny)
+{
+    if (nx < 0 || nx >= e->mbw || ny < 0) return 0;
+    if (e->rs && e->rs->slice_first) return ny * e->mbw + nx >= e->rs->slice_first[my * e->mbw + mx];
+    return ny == my ? 1 : top_in_slice(e, my);
+}
 static int nc_luma(const h264o_enc *e, int mx, int my, int b)
 {
     int x = o_blk_x[b], y = o_blk_y[b], nA = -1, nB = -1;
     const h264o_mbinfo *m = &e->mb[my * e->mbw + mx];
     if (x > 0) nA = m->tc[xy2blk[4 * y + x - 1]];
-    else if (mx > 0) nA = (m - 1)->tc[xy2blk[4 * y + 3]];
+    else if (mb_avail(e, mx, my, mx - 1, my)) nA = (m - 1)->tc[xy2blk[4 * y + 3]];
     if (y > 0) nB = m->tc[xy2blk[4 * (y - 1) + x]];
-    else if (top_in_slice(e, my)) nB = (m - e->mbw)->tc[xy2blk[12 + x]];
+    else if (mb_avail(e, mx, my, mx, my - 1)) nB = (m - e->mbw)->tc[xy2blk[12 + x]];
     if (nA >= 0 && nB >= 0) return (nA + nB + 1) >> 1;
     return nA >= 0 ? nA : nB >= 0 ? nB : 0;
 }
@@ -1103,9 +1114,9 @@ static int nc_chroma(const h264o_enc *e, int mx, int my, int pl, int b)
     int x = b & 1, y = b >> 1, nA = -1, nB = -1, base = 16 + pl * 4;
     const h264o_mbinfo *m = &e->mb[my * e->mbw + mx];
     if (x > 0) nA = m->tc[base + 2 * y];
-    else if (mx > 0) nA = (m - 1)->tc[base + 2 * y + 1];
+    else if (mb_avail(e, mx, my, mx - 1, my)) nA = (m - 1)->tc[base + 2 * y + 1];
     if (y > 0) nB = m->tc[base + x];
-    else if (top_in_slice(e, my)) nB = (m - e->mbw)->tc[base + 2 + x];
+    else if (mb_avail(e, mx, my, mx, my - 1)) nB = (m - e->mbw)->tc[base + 2 + x];
     if (nA >= 0 && nB >= 0) return (nA + nB + 1) >> 1;
     return nA >= 0 ? nA : nB >= 0 ? nB : 0;
 }
@@ -1134,10 +1145,10 @@ static void write_mb(h264o_enc *e, bitw *b, int mx, int my, int p_slice)
         for (int k = 0; k < 16; k++) {   /* 8.3.1.1: predicted mode = the smaller of the left and upper blocks' modes */
             int x = o_blk_x[k], y = o_blk_y[k], mA, mB, dc_only = 0;
             if (x > 0) mA = am[xy2blk[4 * y + x - 1]];
-            else if (mx == 0) { dc_only = 1; mA = 2; }
+            else if (!mb_avail(e, mx, my, mx - 1, my)) { dc_only = 1; mA = 2; }
             else mA = (mb - 1)->type == H264O_MB_I4 ? (am - 16)[xy2blk[4 * y + 3]] : 2;
             if (y > 0) mB = am[xy2blk[4 * (y - 1) + x]];
-            else if (!top_in_slice(e, my)) { dc_only = 1; mB = 2; }
+            else if (!mb_avail(e, mx, my, mx, my - 1)) { dc_only = 1; mB = 2; }
             else mB = (mb - e->mbw)->type == H264O_MB_I4 ? (am - 16 * e->mbw)[xy2blk[12 + x]] : 2;
             int pm = dc_only ? 2 : (mA < mB ? mA : mB), m = am[k];
             if (m == pm) bw_put(b, 1, 1);
@@ -1424,6 +1435,16 @@ int64_t h264o_enc_random_picture(h264o_enc *e, uint32_t seed, int force_idr, int
     rs.cqo[0] = cqo_sticky[0]; rs.cqo[1] = cqo_sticky[1];
     rs.idc = (features & 16) ? rs_below(&rng, 3) : (e->cfg.disable_deblock ? 1 : e->slice_rows < e->mbh ? 2 : 0);
     rs.direct = (features & 32) != 0;
+    /* feature 64 (with 32: vectors are then not predicted here): slices cut at random macroblocks, up to 6 per picture */
+    rs.slice_first = NULL;
+    if ((features & 64) && rs.direct) {
+        rs.slice_first = (int32_t *)calloc((size_t)nmb, sizeof(int32_t));
+        int ncut = rs_below(&rng, 6), first = 0;
+        for (int i = 0; i < nmb; i++) {
+            if (i > 0 && ncut > 0 && rs_below(&rng, nmb) < ncut) first = i;
+            rs.slice_first[i] = first;
+        }
+    }
     rs.oa = (features & 4) ? rs_below(&rng, 13) - 6 : 0;
     rs.ob = (features & 4) ? rs_below(&rng, 13) - 6 : 0;
     const int qlo = 4, qhi = 48;   /* QP_Y range drawn from: wide enough for every row of Tables 8-15 / 8-16 that filters */
@@ -1436,7 +1457,8 @@ int64_t h264o_enc_random_picture(h264o_enc *e, uint32_t seed, int force_idr, int
     memset(e->levels, 0, (size_t)nmb * H264O_LV_STRIDE * sizeof(int16_t));
     memset(e->aux, 0, (size_t)nmb * 16);
     memset(e->mvq, 0, (size_t)nmb * 8 * sizeof(int16_t));
-    int qp = 26;
+    int qp = 26, nslice = 0;
+    e->rs = &rs;   /* (mb_avail reads the slice layout) */
     for (int my = 0; my < e->mbh; my++)
         for (int mx = 0; mx < e->mbw; mx++) {
             const int mbi = my * e->mbw + mx;
@@ -1444,8 +1466,11 @@ int64_t h264o_enc_random_picture(h264o_enc *e, uint32_t seed, int force_idr, int
             int16_t *lv = e->levels + (size_t)mbi * H264O_LV_STRIDE, *qv = e->mvq + (size_t)mbi * 8;
             uint8_t *am = e->aux + (size_t)mbi * 16;
             memset(mb, 0, sizeof(*mb));
-            if (mx == 0 && my % e->slice_rows == 0) qp = rs.slice_qp[(my / e->slice_rows) & 255];   /* QP_Y,PRED at a slice start */
-            const int left = mx > 0, top = top_in_slice(e, my);
+            if (rs.slice_first ? rs.slice_first[mbi] == mbi : (mx == 0 && my % e->slice_rows == 0)) {   /* QP_Y,PRED at a slice start */
+                nslice++;
+                qp = rs.slice_qp[(rs.slice_first ? nslice - 1 : my / e->slice_rows) & 255];
+            }
+            const int left = mb_avail(e, mx, my, mx - 1, my), top = mb_avail(e, mx, my, mx, my - 1), topleft = mb_avail(e, mx, my, mx - 1, my - 1);
             int kind = rs_below(&rng, 100);
             /* I picture: I4 45 %, I16 45 %, I_PCM 10 %; P picture: skip 22, 16x16 22, 16x8 10, 8x16 10, 8x8 12, I16 9, I4 9, PCM 6 */
             int type;
@@ -1478,12 +1503,12 @@ int64_t h264o_enc_random_picture(h264o_enc *e, uint32_t seed, int force_idr, int
             if (type == H264O_MB_I16 || type == H264O_MB_I4) {
                 /* chroma: 0 DC, 1 horizontal (left), 2 vertical (top), 3 plane (left, top, top-left) */
                 int cm;
-                do cm = rs_below(&rng, 4); while ((cm == 1 && !left) || (cm == 2 && !top) || (cm == 3 && !(left && top)));
+                do cm = rs_below(&rng, 4); while ((cm == 1 && !left) || (cm == 2 && !top) || (cm == 3 && !(left && top && topleft)));
                 mb->chroma_mode = (uint8_t)cm;
             }
             if (type == H264O_MB_I16) {
                 int m;
-                do m = rs_below(&rng, 4); while ((m == 0 && !top) || (m == 1 && !left) || (m == 3 && !(left && top)));
+                do m = rs_below(&rng, 4); while ((m == 0 && !top) || (m == 1 && !left) || (m == 3 && !(left && top && topleft)));
                 mb->i16_mode = (uint8_t)m;
                 const int cbpl = rs_below(&rng, 2) ? 15 : 0, cbpc = rs_below(&rng, 3);
                 mb->cbp = (uint8_t)(cbpl | (cbpc << 4));
@@ -1495,7 +1520,7 @@ int64_t h264o_enc_random_picture(h264o_enc *e, uint32_t seed, int force_idr, int
                 for (int k = 0; k < 16; k++) {
                     const int x = o_blk_x[k], y = o_blk_y[k];
                     const int aL = x > 0 || left, aT = y > 0 || top;
-                    const int aTL = (x > 0 && y > 0) || (x > 0 && y == 0 && top) || (x == 0 && y > 0 && left) || (x == 0 && y == 0 && left && top);
+                    const int aTL = (x > 0 && y > 0) || (x > 0 && y == 0 && top) || (x == 0 && y > 0 && left) || (x == 0 && y == 0 && topleft);
                     int m;
                     for (;;) {
                         m = rs_below(&rng, 9);
@@ -1563,14 +1588,18 @@ int64_t h264o_enc_random_picture(h264o_enc *e, uint32_t seed, int force_idr, int
         if (pos != (size_t)-1) pos = emit_nal(out, out_cap, pos, 3, 8, e->rbsp, (size_t)(b.bits >> 3));
     }
     memset(e->rbsp, 0, e->rbsp_cap);
-    for (int row0 = 0; row0 < e->mbh && pos != (size_t)-1; row0 += e->slice_rows) {
-        int row1 = row0 + e->slice_rows < e->mbh ? row0 + e->slice_rows : e->mbh;
+    int slice_no = 0;
+    for (int a0 = 0; a0 < nmb && pos != (size_t)-1; slice_no++) {
+        int a1;   /* the slice is macroblocks a0 .. a1 - 1 */
+        if (rs.slice_first) { a1 = a0 + 1; while (a1 < nmb && rs.slice_first[a1] == a0) a1++; }
+        else { a1 = a0 + e->slice_rows * e->mbw; if (a1 > nmb) a1 = nmb; }
         b = (bitw){e->rbsp, e->rbsp_cap, 0};
-        write_slice_header(e, &b, idr, row0 * e->mbw);
+        rs.cur_slice_qp = rs.slice_qp[slice_no & 255];
+        write_slice_header(e, &b, idr, a0);
         int skip_run = 0;
-        for (int my = row0; my < row1; my++)
-            for (int mx = 0; mx < e->mbw; mx++) {
-                const h264o_mbinfo *mb = &e->mb[my * e->mbw + mx];
+        for (int a = a0; a < a1; a++) {
+                const int mx = a % e->mbw, my = a / e->mbw;
+                const h264o_mbinfo *mb = &e->mb[a];
                 if (!idr) {
                     if (mb->type == H264O_MB_PSKIP) { skip_run++; continue; }
                     bw_ue(&b, (uint32_t)skip_run);
@@ -1578,6 +1607,7 @@ int64_t h264o_enc_random_picture(h264o_enc *e, uint32_t seed, int force_idr, int
                 }
                 write_mb(e, &b, mx, my, !idr);
             }
+        a0 = a1;
         if (skip_run) bw_ue(&b, (uint32_t)skip_run);
         bw_trailing(&b);
         if ((b.bits >> 3) > e->rbsp_cap) { pos = (size_t)-1; break; }
@@ -1587,6 +1617,8 @@ int64_t h264o_enc_random_picture(h264o_enc *e, uint32_t seed, int force_idr, int
     e->rs = NULL;
     free(rs.qpd);
     rs.qpd = NULL;
+    free(rs.slice_first);
+    rs.slice_first = NULL;
     if (pos == (size_t)-1) return -2;
     if (idr) e->idr_id = (e->idr_id + e->idr_step) & 0xFF;
     e->frame_num = (e->frame_num + 1) & 255;

@@ -180,7 +180,8 @@ def _compare_side_information(par, enc, label, vectors=True):
 
 RANDOM_CASES = [(96, 80, 66, 0, 1, 31), (96, 80, 77, 3, 3, 31), (112, 64, 100, 2, 2, 31), (16, 16, 66, 0, 1, 31), (48, 160, 100, 4, 3, 31),
                 (96, 80, 100, 0, 3, 1), (96, 80, 66, 2, 1, 2 | 4), (64, 64, 77, 0, 2, 8 | 16),
-                (96, 80, 66, 0, 3, 63), (112, 64, 100, 2, 2, 63), (96, 80, 77, 3, 1, 32), (32, 32, 100, 0, 3, 63)]
+                (96, 80, 66, 0, 3, 63), (112, 64, 100, 2, 2, 63), (96, 80, 77, 3, 1, 32), (32, 32, 100, 0, 3, 63),
+                (96, 80, 66, 0, 3, 127), (112, 64, 100, 0, 2, 127), (16, 64, 77, 0, 1, 32 | 64)]
 
 
 @pytest.mark.parametrize("w,h,prof,slices,refs,features", RANDOM_CASES)
@@ -190,7 +191,8 @@ def test_parser_reads_random_streams(w, h, prof, slices, refs, features):
     mb_qp_delta, slice QPs, chroma_qp_index_offsets, filter offsets, every deblocking idc): the product parser must read back
     exactly what was written, QP_Y of every macroblock included, and the oracle's independent decoder must agree on the QPs.
     Feature 32: sub-macroblock partitions down to 4x4 and a reference index per partition, written as random mvd_l0 / ref_idx_l0
-    draws - the parser's vectors (its statement of 8.4.1.3 on the 4x4 grid) must be the oracle decoder's for every 4x4 block."""
+    draws - the parser's vectors (its statement of 8.4.1.3 on the 4x4 grid) must be the oracle decoder's for every 4x4 block.
+    Feature 64: slices cut at random macroblocks (neighbour availability per macroblock instead of per row)."""
     enc = OracleEncoder(w, h, qp=30, gop=4, profile_idc=prof, slices=slices, refs=refs)
     par, dec = h264dec.Parser(), OracleDecoder()
     seen = set()

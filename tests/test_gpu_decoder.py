@@ -76,7 +76,8 @@ def test_intra4x4_block_3_0_reads_the_macroblock_above_right():
 RANDOM_CASES = [(96, 80, 66, 0, 1, 31), (96, 80, 77, 3, 3, 31), (112, 64, 100, 2, 2, 31), (16, 16, 66, 0, 1, 31), (48, 160, 100, 4, 3, 31),
                 (96, 80, 100, 0, 3, 1), (96, 80, 66, 2, 1, 2 | 4), (64, 64, 77, 0, 2, 8 | 16), (96, 80, 66, 0, 1, 0), (352, 288, 100, 3, 3, 31),
                 (640, 368, 100, 0, 2, 31), (96, 80, 66, 0, 3, 63), (112, 64, 100, 2, 2, 63), (96, 80, 77, 3, 1, 32), (32, 32, 100, 0, 3, 63),
-                (352, 288, 66, 0, 3, 63), (640, 368, 100, 4, 3, 63)]
+                (352, 288, 66, 0, 3, 63), (640, 368, 100, 4, 3, 63), (96, 80, 66, 0, 3, 127), (112, 64, 100, 0, 2, 127), (16, 64, 77, 0, 1, 32 | 64),
+                (352, 288, 100, 0, 3, 127), (640, 368, 66, 0, 2, 127)]
 
 
 @pytest.mark.parametrize("w,h,prof,slices,refs,features", RANDOM_CASES)
@@ -84,7 +85,8 @@ def test_decoder_equals_the_independent_decoder_on_random_streams(w, h, prof, sl
     """Streams of RANDOM syntax (oracle/h264_enc.c h264o_enc_random_picture; tests/test_dec_parser.py lists what they hold):
     every macroblock type / mode / partition shape next to every other, QP changing per slice and per macroblock, chroma QP
     offsets (Cb and Cr apart under High), filter offsets, I_PCM inside filtered pictures, filtering across slice edges, and
-    (feature 32) sub-macroblock partitions down to 4x4 with a reference index per partition.  No
+    (feature 32) sub-macroblock partitions down to 4x4 with a reference index per partition, (feature 64) slices cut at random
+    macroblocks.  No
     encoder reconstruction exists for these; the oracle's spec-literal decoder says what they decode to, and the GPU decoder
     must produce the same samples in every picture (errors would also propagate through the P pictures' references)."""
     enc = OracleEncoder(w, h, qp=30, gop=5, profile_idc=prof, slices=slices, refs=refs)
