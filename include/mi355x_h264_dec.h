@@ -10,7 +10,8 @@
  * GPU with the encoder's own reconstruction kernels.  No device -> MI355X_H264_E_NODEVICE; there is no CPU reconstruction.
  *
  * Supported: baseline / main / high streams with CAVLC, frame macroblocks, I and P slices, Intra16x16 / Intra4x4 / I_PCM,
- * 16x16 .. 4x4 partitions (every sub_mb_type), up to 3 reference pictures (sliding window, one index per partition), 4x4 and
+ * 16x16 .. 4x4 partitions (every sub_mb_type), up to 3 reference pictures (sliding window, list modification by short-term
+ * picture numbers, one index per partition), 4x4 and
  * (inter) 8x8 transform, QP per macroblock
  * (slice_qp_delta, mb_qp_delta), chroma QP index offsets, deblocking filter offsets and idc 0 / 1 / 2 (one set per picture),
  * slices of any shape in raster order (no FMO / ASO).  A stream outside that is refused with MI355X_H264_E_STREAM and a message naming the
@@ -66,7 +67,8 @@ const char *mi355x_h264_parser_error(const mi355x_h264_parser *p);
 /* out[12]: mbw, mbh, width, height, idr, qp (of the first slice), slice_rows (0 = one slice, n > 0 = bands of n rows, -1 = slices
  * of any other shape), deblocking idc, num_ref_idx_active,
  * transform_8x8_mode, has I_PCM, bit 0 has intra | bit 1 has inter; with n >= 17 also: chroma_qp_index_offset,
- * second_chroma_qp_index_offset, FilterOffsetA, FilterOffsetB, 1 = every macroblock has that one QP and no offset applies.
+ * second_chroma_qp_index_offset, FilterOffsetA, FilterOffsetB, 1 = every macroblock has that one QP and no offset applies;
+ * with n >= 20 also RefPicList0 entries 0..2 as "reference pictures ago" (0 = the one decoded last; default 0, 1, 2).
  * Returns the number of values written */
 int mi355x_h264_parser_info(const mi355x_h264_parser *p, int32_t *out, int n);
 /* what: 0 MbInfo (32 B / macroblock, layout of mi355x_h264.h), 1 quadrant vectors (8 int16), 2 Intra4x4 modes (16 B), 3 levels (416 int16),

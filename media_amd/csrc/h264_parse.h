@@ -11,8 +11,8 @@
 // Supported streams = a superset of what this repository's encoder produces (which is what the reference preset asks of
 // OpenH264 minus CABAC): baseline / main / high with CAVLC, frame macroblocks, I and P slices; Intra16x16, Intra4x4, I_PCM
 // (also in loop-filtered pictures); P_L0_16x16, 16x8, 8x16, P_8x8 / P_8x8ref0 with every sub_mb_type (8x8, 8x4, 4x8, 4x4),
-// P_Skip; up to 3 reference pictures by sliding window, no reordering, a reference index per partition; 4x4 transform, 8x8
-// transform on inter macroblocks; QP per macroblock (slice_qp_delta per slice, mb_qp_delta), chroma_qp_index_offset and
+// P_Skip; up to 3 reference pictures by sliding window, ref_pic_list_modification by short-term picture numbers, a reference
+// index per partition; 4x4 transform, 8x8 transform on inter macroblocks; QP per macroblock (slice_qp_delta per slice, mb_qp_delta), chroma_qp_index_offset and
 // second_chroma_qp_index_offset, slice_alpha_c0_offset_div2 / slice_beta_offset_div2 (one pair per picture);
 // slices of any shape in raster order (bands of whole rows decode as independent wavefronts); disable_deblocking_filter_idc
 // 0 / 1 / 2 (one value per picture).
@@ -217,6 +217,8 @@ struct Picture {
     HostVec<int16_t> mv4;      // 32 per macroblock: the vector (x, y) of every 4x4 block, raster order (sub-macroblock partitions)
     HostVec<uint8_t> mbavail;  // per macroblock: neighbours available for prediction (6.4.9: in the picture, in the same slice, decoded
                                // before): bit 0 left, 1 above, 2 above-right, 3 above-left - slices may start and end at any macroblock
+    int ref_age[3] = {0, 1, 2};   // RefPicList0: entry r is the reference picture decoded ref_age[r] + 1 reference pictures ago (the default
+                               // order is 0, 1, 2; ref_pic_list_modification permutes it)
     int slices = 0;            // slices of the picture; slice_rows > 0: they are bands of that many whole rows, -1: of any other shape
     HostVec<uint8_t> refq;     // 4 per macroblock: ref_idx_l0 of the four quadrants (0xFF: intra)
     HostVec<uint8_t> aux;      // 16 per macroblock
@@ -253,6 +255,13 @@ public:
         if (next_mb != picp_->mbw * picp_->mbh) return fail("picture incomplete: slices cover %d of %d macroblocks", next_mb, picp_->mbw * picp_->mbh);
         // bands of slice_rows rows only if every band start was seen (a last slice longer than the others is "any shape")
         if (picp_->slice_rows > 0 && picp_->slices != (picp_->mbh + picp_->slice_rows - 1) / picp_->slice_rows) picp_->slice_rows = -1;
+        // the picture enters the reference buffer (what the decoder's ring does with its samples)
+        if (picp_->idr) dpb_fn_.clear();
+        if (picp_->is_ref) {
+            dpb_fn_.insert(dpb_fn_.begin(), cur_frame_num_);
+            const size_t cap = (size_t)(sps().max_refs > 0 ? sps().max_refs : 1);
+            if (dpb_fn_.size() > cap) dpb_fn_.resize(cap);
+        }
         return 1;
     }
 
@@ -267,6 +276,9 @@ private:
     // state of the slice being parsed
     int slice_first_ = 0, slice_type_ = 0, slice_qp_ = 26, num_ref_ = 1;
     int qp_ = 26;   // QP_Y of the previous macroblock of the slice in decoding order
+    // frame_num of the short-term reference pictures, the one decoded last first (sliding window, 8.2.5.3)
+    std::vector<int> dpb_fn_;
+    int cur_frame_num_ = 0;
 
     int fail(const char* fmt, int a = 0, int b = 0)
     {
@@ -533,6 +545,51 @@ private:
         else { px = med3(a.x, b.x, c.x); py = med3(a.y, b.y, c.y); }
     }
 
+    // RefPicList0 of a P slice (frames, short-term pictures only): 8.2.4.1 PicNum = FrameNumWrap, 8.2.4.2.1 the initial order
+    // (descending PicNum), 8.2.4.3.1 the slice header's modification commands.  list[r] = age of entry r: position in dpb_fn_
+    // (0 = the reference picture decoded last), which is how the decoder's reconstruction ring is indexed.
+    bool ref_list(BitReader& br, const Sps& sps, int frame_num, int num_ref, bool modify, int list[4])
+    {
+        const int max_fn = 1 << sps.log2_max_frame_num, n = (int)dpb_fn_.size();
+        int picnum[4], order[5] = {-1, -1, -1, -1, -1}, cnt = 0;
+        for (int i = 0; i < n && i < 4; i++) picnum[i] = dpb_fn_[i] > frame_num ? dpb_fn_[i] - max_fn : dpb_fn_[i];
+        for (int i = 0; i < n && i < 4; i++) {
+            int k = cnt++;
+            while (k > 0 && picnum[order[k - 1]] < picnum[i]) { order[k] = order[k - 1]; k--; }
+            order[k] = i;
+        }
+        for (int i = num_ref < 4 ? num_ref : 4; i < 5; i++) order[i] = -1;   // the initial list is cut to num_ref_idx_l0_active entries
+        if (modify) {
+            if (num_ref > 4) { fail("ref_pic_list_modification with more than 4 active references"); return false; }
+            int pred = frame_num, idx = 0;
+            for (int guard = 0;; guard++) {
+                const unsigned idc = br.ue();
+                if (br.bad() || guard > 32) { fail("ref_pic_list_modification damaged"); return false; }
+                if (idc == 3) break;
+                if (idc == 2) { fail("long-term reference pictures (modification_of_pic_nums_idc 2)"); return false; }
+                if (idc > 3) { fail("modification_of_pic_nums_idc %d", (int)idc); return false; }
+                const unsigned du = br.ue();
+                if (du >= (unsigned)max_fn || idx >= num_ref) { fail("ref_pic_list_modification damaged"); return false; }
+                const int diff = (int)du + 1;
+                int nowrap;
+                if (idc == 0) { nowrap = pred - diff; if (nowrap < 0) nowrap += max_fn; }
+                else { nowrap = pred + diff; if (nowrap >= max_fn) nowrap -= max_fn; }
+                pred = nowrap;
+                const int pn = nowrap > frame_num ? nowrap - max_fn : nowrap;
+                int k = -1;
+                for (int i = 0; i < n && i < 4; i++) if (picnum[i] == pn) k = i;
+                if (k < 0) { fail("ref_pic_list_modification names picture number %d, which is not a reference picture", pn); return false; }
+                for (int c = num_ref; c > idx; c--) order[c] = order[c - 1];
+                order[idx++] = k;
+                int w = idx;
+                for (int c = idx; c <= num_ref; c++) if (order[c] != k) order[w++] = order[c];
+                for (; w <= num_ref; w++) order[w] = -1;
+            }
+        }
+        for (int r = 0; r < 4; r++) list[r] = order[r] >= 0 ? order[r] : r;   // (entries without a picture are refused by the decoder)
+        return true;
+    }
+
     bool parse_slice(BitReader& br, bool idr, int ref_idc, bool& have_pic, int& next_mb)
     {
         const unsigned fm = br.ue(), stu = br.ue();
@@ -546,7 +603,7 @@ private:
         const Pps& pps = pps_[pps_id];
         active_sps_ = pps.sps_id;
         const Sps& sps = sps_[active_sps_];
-        br.u(sps.log2_max_frame_num);   // frame_num (sliding window only: not needed)
+        const int frame_num = (int)br.u(sps.log2_max_frame_num);
         if (idr) br.ue();               // idr_pic_id
         if (sps.poc_type == 0) {
             br.u(sps.log2_max_poc_lsb);
@@ -557,9 +614,11 @@ private:
         }
         if (pps.redundant_pic_cnt) br.ue();
         int num_ref = pps.num_ref_default;
+        int list[4] = {0, 1, 2, 3};
         if (st == 0) {
             if (br.u(1)) { const unsigned nr = br.ue(); num_ref = nr > 31 ? 99 : (int)nr + 1; }
-            if (br.u(1)) { fail("ref_pic_list_modification"); return false; }
+            if (idr) { fail("P slice in an IDR picture"); return false; }
+            if (!ref_list(br, sps, frame_num, num_ref, br.u(1) != 0, list)) return false;
         }
         if (ref_idc != 0) {
             if (idr) { br.u(1); if (br.u(1)) { fail("long_term_reference_flag"); return false; } }
@@ -584,6 +643,8 @@ private:
             picp_->mbw = sps.mbw; picp_->mbh = sps.mbh;
             picp_->width = 16 * sps.mbw - 2 * (sps.crop_l + sps.crop_r); picp_->height = 16 * sps.mbh - 2 * (sps.crop_t + sps.crop_b);
             picp_->idr = idr; picp_->is_ref = ref_idc != 0; picp_->qp = qp; picp_->deblock_idc = idc; picp_->slice_rows = 0;
+            for (int r = 0; r < 3; r++) picp_->ref_age[r] = list[r];
+            cur_frame_num_ = frame_num;
             picp_->num_ref_active = st == 0 ? num_ref : 0; picp_->t8x8_mode = pps.t8x8 ? 1 : 0; picp_->profile_idc = sps.profile_idc;
             picp_->has_pcm = picp_->has_intra = picp_->has_inter = false;
             picp_->cqo[0] = pps.cqo[0]; picp_->cqo[1] = pps.cqo[1]; picp_->filter_oa = oa; picp_->filter_ob = ob;
@@ -610,7 +671,8 @@ private:
             if (oa != picp_->filter_oa || ob != picp_->filter_ob) { fail("deblocking filter offsets differ between slices"); return false; }
             if (pps.cqo[0] != picp_->cqo[0] || pps.cqo[1] != picp_->cqo[1]) { fail("chroma QP offsets differ between slices"); return false; }
             if (st == 0 && picp_->num_ref_active && num_ref != picp_->num_ref_active) { fail("num_ref_idx_active differs between slices"); return false; }
-            if (st == 0 && !picp_->num_ref_active) picp_->num_ref_active = num_ref;
+            if (st == 0 && !picp_->num_ref_active) { picp_->num_ref_active = num_ref; for (int r = 0; r < 3; r++) picp_->ref_age[r] = list[r]; }
+            else if (st == 0 && (list[0] != picp_->ref_age[0] || list[1] != picp_->ref_age[1] || list[2] != picp_->ref_age[2])) { fail("reference picture lists differ between slices"); return false; }
         }
         slice_first_ = first_mb; slice_type_ = st; slice_qp_ = qp; num_ref_ = num_ref;
         qp_ = qp;   // QP_Y,PRED of the slice's first macroblock (7.4.5)

@@ -1164,8 +1164,11 @@ int dec_submit(mi355x_h264_decoder* d, const h264dec::Picture& pic)
     P.nref = std::max(1, d->have_refs);
     for (int p = 0; p < 3; p++) {
         P.rec[p] = e->d_planes[cur][p];
-        for (int r = 0; r < mi355x_h264_encoder::MAX_REFS; r++)
-            P.refs[r][p] = e->d_planes[(cur + e->nbuf - 1 - std::min(r, std::max(0, d->have_refs - 1))) % e->nbuf][p];
+        for (int r = 0; r < mi355x_h264_encoder::MAX_REFS; r++) {
+            // RefPicList0 entry r = the reference picture decoded ref_age[r] + 1 reference pictures ago (ring slot cur - 1 - age)
+            const int age = std::min(r < pic.num_ref_active ? pic.ref_age[r] : r, std::max(0, d->have_refs - 1));
+            P.refs[r][p] = e->d_planes[(cur + e->nbuf - 1 - age) % e->nbuf][p];
+        }
         P.ref[p] = P.refs[0][p];
     }
     P.mb = e->d_mb; P.levels = e->d_levels; P.mvd = e->d_mvd; P.mvq = e->d_mvq; P.aux = e->d_aux; P.me_cost = e->d_me_cost; P.me_total = e->d_me_total; P.pmv = e->d_pmv;
@@ -1338,6 +1341,8 @@ int mi355x_h264_dec_decode(mi355x_h264_decoder* d, const uint8_t* au, size_t len
     if (pic.idr) d->have_refs = 0;
     if (pic.has_inter && (d->have_refs < 1 || pic.num_ref_active > d->have_refs))
         return dfail(d, MI355X_H264_E_STREAM, "a P picture refers to %d reference pictures, %d are held", pic.num_ref_active, d->have_refs);
+    for (int r = 0; pic.has_inter && r < pic.num_ref_active && r < 3; r++)
+        if (pic.ref_age[r] < 0 || pic.ref_age[r] >= d->have_refs) return dfail(d, MI355X_H264_E_STREAM, "reference list entry %d is not a held picture", r);
     int src = dec_submit(d, pic);
     static const bool no_lookahead = getenv("MI355X_H264_DEC_SYNC") != nullptr;   // (measurements: wait for every picture before returning)
     if (src == MI355X_H264_OK && no_lookahead) src = dec_wait(d);
@@ -1431,9 +1436,9 @@ int mi355x_h264_parser_info(const mi355x_h264_parser* p, int32_t* out, int n)
 {
     if (!p || !out || n < 12) return -1;
     const h264dec::Picture& c = p->p.picture();
-    const int32_t v[17] = {c.mbw, c.mbh, c.width, c.height, c.idr, c.qp, c.slice_rows, c.deblock_idc, c.num_ref_active, c.t8x8_mode, c.has_pcm, c.has_intra | (c.has_inter << 1),
-                           c.cqo[0], c.cqo[1], c.filter_oa, c.filter_ob, c.one_qp};
-    const int m = n < 17 ? 12 : 17;   // (a caller with the first layout's 12 slots gets those)
+    const int32_t v[20] = {c.mbw, c.mbh, c.width, c.height, c.idr, c.qp, c.slice_rows, c.deblock_idc, c.num_ref_active, c.t8x8_mode, c.has_pcm, c.has_intra | (c.has_inter << 1),
+                           c.cqo[0], c.cqo[1], c.filter_oa, c.filter_ob, c.one_qp, c.ref_age[0], c.ref_age[1], c.ref_age[2]};
+    const int m = n < 17 ? 12 : (n < 20 ? 17 : 20);   // (a caller with an earlier layout's slots gets those)
     memcpy(out, v, (size_t)m * sizeof(int32_t));
     return m;
 }

@@ -108,7 +108,7 @@ class Decoder:
 
 class Parser:
     INFO = ("mbw", "mbh", "width", "height", "idr", "qp", "slice_rows", "deblock_idc", "num_ref_active", "t8x8_mode", "has_pcm", "kinds",
-            "cqo_cb", "cqo_cr", "filter_oa", "filter_ob", "one_qp")
+            "cqo_cb", "cqo_cr", "filter_oa", "filter_ob", "one_qp", "ref_age0", "ref_age1", "ref_age2")
 
     def __init__(self):
         self.h = C.c_void_p(_bind().mi355x_h264_parser_create())
@@ -132,8 +132,8 @@ class Parser:
         return rc == 1
 
     def info(self):
-        v = (C.c_int32 * 17)()
-        lib().mi355x_h264_parser_info(self.h, v, 17)
+        v = (C.c_int32 * 20)()
+        lib().mi355x_h264_parser_info(self.h, v, 20)
         return dict(zip(self.INFO, list(v)))
 
     def vectors4(self):

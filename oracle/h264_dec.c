@@ -13,12 +13,12 @@
  *
  * Covered (frame macroblocks, 4:2:0, 8 bit, CAVLC): I and P slices; I_NxN (Intra4x4), Intra16x16, I_PCM;
  * P_L0_16x16 / 16x8 / 8x16 / P_8x8 (all sub-macroblock types) / P_8x8ref0 / P_Skip; intra macroblocks in P slices;
- * several reference frames (sliding window marking, default list order); mb_qp_delta;
+ * several reference frames (sliding window marking; reference list modification by short-term picture numbers); mb_qp_delta;
  * chroma_qp_index_offset; transform_size_8x8_flag for inter macroblocks (8x8 residual blocks,
  * 8.5.13) -- Intra8x8 is refused; deblocking 8.7 with slice alpha/beta offsets and
  * disable_deblocking_filter_idc 0/1/2; several slices per picture.
  * Not covered (refused with an error): CABAC, B slices, interlace, weighted prediction, FMO/ASO,
- * reference list modification, memory management control operations, scaling matrices.
+ * long-term reference pictures, memory management control operations, scaling matrices.
  *
  * Clause map: 7.3 syntax -> parse_*; 7.4.1.1 NAL -> h264o_dec_decode; 9.1 -> rd_ue/rd_se/rd_te; 9.2 -> residual_block;
  * 8.3.1 -> intra4x4_*; 8.3.3 -> intra16x16_pred; 8.3.4 -> intra_chroma_pred; 8.3.5 -> I_PCM; 8.4.1 -> mv prediction;
@@ -255,8 +255,9 @@ struct h264o_dec {
     /* picture */
     int cw, ch;
     dpic cur, out;             /* `out`: last finished picture (returned by h264o_dec_plane) */
-    dpic refs[D_MAXREF];       /* short-term reference frames, most recent first (8.2.4.2.1: descending PicNum) */
+    dpic refs[D_MAXREF];       /* short-term reference frames, most recent first */
     int nrefs;
+    int list0[D_MAXREF + 1];   /* RefPicList0 of the current slice: indices into refs[], -1 = "no reference picture" */
     int32_t next_id;
     dmb *mb;
     int slice_type, nal_type, slice_count;
@@ -848,8 +849,8 @@ static void predict_mv(const h264o_dec *d, const dmb *cur, const uint8_t done[16
 /* ------------------------------------------------------------------ macroblock layer 7.3.5 */
 static const dpic *ref_of(h264o_dec *d, int idx, int nactive)
 {
-    if (idx < 0 || idx >= nactive || idx >= d->nrefs) return NULL;
-    return &d->refs[idx];
+    if (idx < 0 || idx >= nactive || d->list0[idx] < 0) return NULL;
+    return &d->refs[d->list0[idx]];
 }
 
 /* residual_luma + reconstruction for non-Intra16x16 macroblocks: blocks in blkIdx order; for intra4x4 the prediction of a
@@ -1304,6 +1305,48 @@ static int finish_picture(h264o_dec *d)
     return 1;
 }
 
+/* RefPicList0 of a P slice of a frame: 8.2.4.1 picture numbers (FrameNumWrap, 8-27; PicNum = FrameNumWrap, 8-28), 8.2.4.2.1
+ * initial order (descending PicNum), 8.2.4.3 / 8.2.4.3.1 modification by the slice header's commands (short-term only) */
+static int build_list0(h264o_dec *d, bitr *b, int frame_num, int nactive, int modify)
+{
+    const int max_fn = 1 << d->log2_max_frame_num;
+    int picnum[D_MAXREF];
+    for (int i = 0; i < d->nrefs; i++) picnum[i] = d->refs[i].frame_num > frame_num ? d->refs[i].frame_num - max_fn : d->refs[i].frame_num;
+    int n = 0;
+    for (int i = 0; i < d->nrefs; i++) {   /* insertion sort, descending PicNum */
+        int k = n++;
+        while (k > 0 && picnum[d->list0[k - 1]] < picnum[i]) { d->list0[k] = d->list0[k - 1]; k--; }
+        d->list0[k] = i;
+    }
+    for (int i = (n < nactive ? n : nactive); i <= D_MAXREF; i++) d->list0[i] = -1;   /* longer than num_ref_idx_l0_active: truncated (8.2.4.2) */
+    if (!modify) return 0;
+    int pred = frame_num, idx = 0;   /* picNumL0Pred = CurrPicNum */
+    for (int guard = 0; guard < 64; guard++) {
+        const uint32_t idc = rd_ue(b);
+        if (b->err) return fail(d, "ref_pic_list_modification truncated");
+        if (idc == 3) return 0;
+        if (idc == 2) return fail(d, "long-term reference pictures unsupported");
+        if (idc > 3) return fail(d, "modification_of_pic_nums_idc out of range");
+        const int diff = (int)rd_ue(b) + 1;
+        if (idx >= nactive || nactive > D_MAXREF) return fail(d, "more list modifications than list entries");
+        int nowrap;
+        if (idc == 0) { nowrap = pred - diff; if (nowrap < 0) nowrap += max_fn; }              /* (8-34) */
+        else { nowrap = pred + diff; if (nowrap >= max_fn) nowrap -= max_fn; }                 /* (8-35) */
+        pred = nowrap;
+        const int pn = nowrap > frame_num ? nowrap - max_fn : nowrap;                          /* (8-36) */
+        int k = -1;
+        for (int i = 0; i < d->nrefs; i++) if (picnum[i] == pn) k = i;
+        if (k < 0) return fail(d, "list modification names a picture that is not a reference");
+        /* (8-37): the entries from idx on move up by one, the picture is put at idx, its other occurrence is dropped */
+        for (int c = nactive; c > idx; c--) d->list0[c] = d->list0[c - 1];
+        d->list0[idx++] = k;
+        int w = idx;
+        for (int c = idx; c <= nactive; c++) if (d->list0[c] != k) d->list0[w++] = d->list0[c];
+        for (; w <= nactive; w++) d->list0[w] = -1;
+    }
+    return fail(d, "too many list modifications");
+}
+
 static int decode_slice(h264o_dec *d, bitr *b, int nal_type, int nal_ref_idc)
 {
     if (!d->have_sps || !d->have_pps) return fail(d, "slice before parameter sets");
@@ -1318,7 +1361,8 @@ static int decode_slice(h264o_dec *d, bitr *b, int nal_type, int nal_ref_idc)
     if (st == 0) {
         if (rd_bit(b)) nactive = (int)rd_ue(b) + 1;       /* num_ref_idx_active_override_flag */
         if (nactive > D_MAXREF) return fail(d, "num_ref_idx_l0_active > 16");
-        if (rd_bit(b)) return fail(d, "ref_pic_list_modification unsupported");
+        if (nal_type == 5) return fail(d, "P slice in an IDR picture");
+        if (build_list0(d, b, frame_num, nactive, rd_bit(b))) return -1;   /* ref_pic_list_modification_flag_l0 */
     }
     if (nal_ref_idc) {
         if (nal_type == 5) { rd_bit(b); if (rd_bit(b)) return fail(d, "long_term_reference_flag unsupported"); }

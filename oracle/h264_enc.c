@@ -165,6 +165,9 @@ struct randsyn {
     int8_t *qpd;         /* mb_qp_delta per macroblock (written where the syntax carries one) */
     int32_t *slice_first;/* non-NULL: slices of any shape - per macroblock, the address of the first macroblock of its slice */
     int cur_slice_qp;    /* SliceQP_Y of the slice whose header is being written (slice_first mode) */
+    int reorder;         /* P slices carry ref_pic_list_modification commands: nreorder of them, target pictures reorder_age[]
+                          * (1 = the previous picture ...), the same in every slice of the picture */
+    int nreorder, reorder_age[4];
     int direct;          /* inter macroblocks are written from random draws at writing time: sub_mb_types down to 4x4, a
                           * ref_idx_l0 per partition, mvd_l0 values as such (whatever they add up to IS the vector) */
     uint32_t rng;
@@ -403,6 +406,17 @@ static void write_slice_header(h264o_enc *e, bitw *b, int idr, int first_mb)
         /* the first pictures after an IDR have fewer reference pictures than the PPS default announces */
         if (e->avail_refs != e->nrefs) { bw_put(b, 1, 1); bw_ue(b, (uint32_t)e->avail_refs - 1); }
         else bw_put(b, 1, 0); /* num_ref_idx_active_override_flag */
+        if (e->rs && e->rs->reorder) {   /* 7.3.3.1: short-term commands by differences of picture numbers (frame_num never wraps here) */
+            int pred = e->frame_num;
+            bw_put(b, 1, 1);
+            for (int k = 0; k < e->rs->nreorder; k++) {
+                int target = e->frame_num - e->rs->reorder_age[k];
+                if (target < pred) { bw_ue(b, 0); bw_ue(b, (uint32_t)(pred - target - 1)); }
+                else { bw_ue(b, 1); bw_ue(b, (uint32_t)(target - pred - 1)); }
+                pred = target;
+            }
+            bw_ue(b, 3);
+        } else
         bw_put(b, 1, 0); /* ref_pic_list_modification_flag_l0 */
     }
     if (idr) {
@@ -1435,6 +1449,20 @@ int64_t h264o_enc_random_picture(h264o_enc *e, uint32_t seed, int force_idr, int
     rs.cqo[0] = cqo_sticky[0]; rs.cqo[1] = cqo_sticky[1];
     rs.idc = (features & 16) ? rs_below(&rng, 3) : (e->cfg.disable_deblock ? 1 : e->slice_rows < e->mbh ? 2 : 0);
     rs.direct = (features & 32) != 0;
+    /* feature 128: reference list modification - up to avail_refs commands naming distinct reference pictures, never the same
+     * picture as the command before (a difference of 0 cannot be written) */
+    rs.reorder = 0; rs.nreorder = 0;
+    if ((features & 128) && !idr && e->frame_num >= e->avail_refs) {
+        rs.reorder = 1;
+        rs.nreorder = rs_below(&rng, e->avail_refs + 1);
+        int used = 0;
+        for (int k = 0; k < rs.nreorder; k++) {
+            int age;
+            do age = 1 + rs_below(&rng, e->avail_refs); while (used & (1 << age));
+            used |= 1 << age;
+            rs.reorder_age[k] = age;
+        }
+    }
     /* feature 64 (with 32: vectors are then not predicted here): slices cut at random macroblocks, up to 6 per picture */
     rs.slice_first = NULL;
     if ((features & 64) && rs.direct) {

@@ -2,7 +2,7 @@
 independent decoder on streams of RANDOM syntax (oracle/h264_enc.c h264o_enc_random_picture: every macroblock type, mode and
 partition shape, random vectors / reference indices / levels, QP per slice and per macroblock, chroma QP offsets, filter
 offsets, I_PCM in filtered pictures, every deblocking idc, sub-macroblock partitions down to 4x4 with a reference index per
-partition, slices cut at random macroblocks): random geometry, profile, slices, references, GOP and feature
+partition, slices cut at random macroblocks, reference list modification): random geometry, profile, slices, references, GOP and feature
 set per case, 8 pictures each, every plane of every picture compared."""
 import sys, time; sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import numpy as np, random, os, pickle
@@ -15,7 +15,7 @@ dec = h264dec.Decoder()
 for case in range(ncase):
     w, h = 2 * rng.randint(8, 200), 2 * rng.randint(8, 150)
     prof = rng.choice([66, 77, 100]); sl = rng.choice([0, 0, 2, 3, 5]); refs = rng.choice([1, 1, 2, 3]); gop = rng.choice([1, 3, 8, 30])
-    feat = rng.choice([127, 127, 127, 63, 63, 31, 31, 32, 32 | 64, 1, 2, 4, 8, 16, 0, 1 | 8, 2 | 4 | 16, 32 | 8])
+    feat = rng.choice([255, 255, 255, 127, 127, 63, 31 | 128, 31, 32, 32 | 64, 128, 128 | 32, 1, 2, 4, 8, 16, 0, 1 | 8, 2 | 4 | 16, 32 | 8])
     tag = (case, w, h, prof, sl, refs, gop, feat)
     try:
         enc = OracleEncoder(w, h, qp=rng.randint(10, 51), gop=gop, profile_idc=prof, slices=sl, refs=refs, disable_deblock=int(rng.random() < 0.15))
