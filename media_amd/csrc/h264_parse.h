@@ -344,8 +344,11 @@ private:
             for (unsigned k = 0; k < n && !br.bad(); k++) br.se();
         }
         const unsigned mr = br.ue();
-        if (mr > 3) { fail("max_num_ref_frames %d (up to 3)", (int)mr); return false; }
-        s.max_refs = (int)mr;
+        if (mr > 16) { fail("max_num_ref_frames %d", (int)mr); return false; }
+        // The decoder holds the three most recent reference pictures.  A stream that announces more is decoded as long as it only
+        // USES those three (the default list order is the same); a slice with more active references, or a list modification that
+        // names an older picture, is refused where it occurs.
+        s.max_refs = mr > 3 ? 3 : (int)mr;
         br.u(1);   // gaps_in_frame_num_value_allowed_flag
         const unsigned wmb = br.ue(), hmb = br.ue();
         if (wmb > 255 || hmb > 255) { fail("picture of %d x %d macroblocks (up to 256 x 256)", (int)wmb + 1, (int)hmb + 1); return false; }
@@ -618,6 +621,7 @@ private:
         if (st == 0) {
             if (br.u(1)) { const unsigned nr = br.ue(); num_ref = nr > 31 ? 99 : (int)nr + 1; }
             if (idr) { fail("P slice in an IDR picture"); return false; }
+            if (br.bad() || num_ref < 1 || num_ref > 3) { fail("num_ref_idx_l0_active %d (the decoder holds three reference pictures)", num_ref); return false; }
             if (!ref_list(br, sps, frame_num, num_ref, br.u(1) != 0, list)) return false;
         }
         if (ref_idc != 0) {

@@ -165,6 +165,9 @@ struct randsyn {
     int8_t *qpd;         /* mb_qp_delta per macroblock (written where the syntax carries one) */
     int32_t *slice_first;/* non-NULL: slices of any shape - per macroblock, the address of the first macroblock of its slice */
     int cur_slice_qp;    /* SliceQP_Y of the slice whose header is being written (slice_first mode) */
+    int ohstyle;         /* headers laid out the way OpenH264 writes them (feature 256): 15-bit frame_num, pic_order_cnt_type 0 with
+                          * pic_order_cnt_lsb in every slice header, VUI with bitstream restrictions, and every P slice carries
+                          * ref_pic_list_modification (its one command names the previous picture) */
     int reorder;         /* P slices carry ref_pic_list_modification commands: nreorder of them, target pictures reorder_age[]
                           * (1 = the previous picture ...), the same in every slice of the picture */
     int nreorder, reorder_age[4];
@@ -348,8 +351,14 @@ static void write_sps(h264o_enc *e, bitw *b)
         bw_put(b, 1, 0); /* qpprime_y_zero_transform_bypass_flag */
         bw_put(b, 1, 0); /* seq_scaling_matrix_present_flag */
     }
+    if (e->rs && e->rs->ohstyle) {
+        bw_ue(b, 11);    /* log2_max_frame_num_minus4 -> 15 bits */
+        bw_ue(b, 0);     /* pic_order_cnt_type 0 */
+        bw_ue(b, 12);    /* log2_max_pic_order_cnt_lsb_minus4 -> 16 bits */
+    } else {
     bw_ue(b, 4);     /* log2_max_frame_num_minus4 -> MaxFrameNum 256 */
     bw_ue(b, 2);     /* pic_order_cnt_type 2: output order == decode order */
+    }
     bw_ue(b, (uint32_t)e->nrefs); /* max_num_ref_frames (ref :290 iNumRefFrame = 1; configs[4]: 3) */
     bw_put(b, 1, 0); /* gaps_in_frame_num_value_allowed_flag */
     bw_ue(b, (uint32_t)e->mbw - 1);
@@ -366,6 +375,25 @@ static void write_sps(h264o_enc *e, bitw *b)
     } else {
         bw_put(b, 1, 0);
     }
+    if (e->rs && e->rs->ohstyle) {   /* E.1.1 vui_parameters(): nothing but the bitstream restrictions */
+        bw_put(b, 1, 1); /* vui_parameters_present_flag */
+        bw_put(b, 1, 0); /* aspect_ratio_info_present_flag */
+        bw_put(b, 1, 0); /* overscan_info_present_flag */
+        bw_put(b, 1, 0); /* video_signal_type_present_flag */
+        bw_put(b, 1, 0); /* chroma_loc_info_present_flag */
+        bw_put(b, 1, 0); /* timing_info_present_flag */
+        bw_put(b, 1, 0); /* nal_hrd_parameters_present_flag */
+        bw_put(b, 1, 0); /* vcl_hrd_parameters_present_flag */
+        bw_put(b, 1, 0); /* pic_struct_present_flag */
+        bw_put(b, 1, 1); /* bitstream_restriction_flag */
+        bw_put(b, 1, 1); /* motion_vectors_over_pic_boundaries_flag */
+        bw_ue(b, 0);     /* max_bytes_per_pic_denom */
+        bw_ue(b, 0);     /* max_bits_per_mb_denom */
+        bw_ue(b, 16);    /* log2_max_mv_length_horizontal */
+        bw_ue(b, 16);    /* log2_max_mv_length_vertical */
+        bw_ue(b, 0);     /* max_num_reorder_frames */
+        bw_ue(b, (uint32_t)e->nrefs); /* max_dec_frame_buffering */
+    } else
     bw_put(b, 1, 0); /* vui_parameters_present_flag */
     bw_trailing(b);
 }
@@ -400,8 +428,11 @@ static void write_slice_header(h264o_enc *e, bitw *b, int idr, int first_mb)
     bw_ue(b, (uint32_t)first_mb); /* first_mb_in_slice */
     bw_ue(b, idr ? 7 : 5);    /* slice_type: all slices of the picture I / P */
     bw_ue(b, 0);              /* pic_parameter_set_id */
+    if (e->rs && e->rs->ohstyle) bw_put(b, 15, (uint32_t)e->frame_num);
+    else
     bw_put(b, 8, (uint32_t)e->frame_num);
     if (idr) bw_ue(b, (uint32_t)e->idr_id);
+    if (e->rs && e->rs->ohstyle) bw_put(b, 16, (uint32_t)(2 * e->frame_in_gop) & 0xFFFFu);   /* pic_order_cnt_lsb */
     if (!idr) {
         /* the first pictures after an IDR have fewer reference pictures than the PPS default announces */
         if (e->avail_refs != e->nrefs) { bw_put(b, 1, 1); bw_ue(b, (uint32_t)e->avail_refs - 1); }
@@ -1451,7 +1482,9 @@ int64_t h264o_enc_random_picture(h264o_enc *e, uint32_t seed, int force_idr, int
     rs.direct = (features & 32) != 0;
     /* feature 128: reference list modification - up to avail_refs commands naming distinct reference pictures, never the same
      * picture as the command before (a difference of 0 cannot be written) */
+    rs.ohstyle = (features & 256) != 0;
     rs.reorder = 0; rs.nreorder = 0;
+    if (rs.ohstyle && !idr) { rs.reorder = 1; rs.nreorder = 1; rs.reorder_age[0] = 1; }
     if ((features & 128) && !idr && e->frame_num >= e->avail_refs) {
         rs.reorder = 1;
         rs.nreorder = rs_below(&rng, e->avail_refs + 1);

@@ -60,6 +60,8 @@ RANDOM_CASES = [
     ("rand_qvga_all_high_3slices", 320, 240, 100, 3, 2, 63, 6),
     ("rand_qcif_qp_offsets_main", 176, 144, 77, 2, 1, 1 | 2 | 4 | 16, 5),
     ("rand_tiny_pcm_subparts", 48, 32, 66, 0, 3, 8 | 32, 5),
+    ("rand_qcif_everything", 176, 144, 100, 0, 3, 511, 6),                       # + slices of any shape, list modification, OpenH264-style headers
+    ("rand_qcif_openh264_shape", 176, 144, 66, 0, 1, 256 | 1 | 2 | 4 | 32, 6),  # one reference, QP per macroblock, offsets, sub-partitions
 ]
 
 

@@ -182,7 +182,8 @@ RANDOM_CASES = [(96, 80, 66, 0, 1, 31), (96, 80, 77, 3, 3, 31), (112, 64, 100, 2
                 (96, 80, 100, 0, 3, 1), (96, 80, 66, 2, 1, 2 | 4), (64, 64, 77, 0, 2, 8 | 16),
                 (96, 80, 66, 0, 3, 63), (112, 64, 100, 2, 2, 63), (96, 80, 77, 3, 1, 32), (32, 32, 100, 0, 3, 63),
                 (96, 80, 66, 0, 3, 127), (112, 64, 100, 0, 2, 127), (16, 64, 77, 0, 1, 32 | 64),
-                (96, 80, 66, 0, 3, 255), (112, 64, 100, 2, 2, 128), (96, 80, 77, 0, 3, 128 | 32)]
+                (96, 80, 66, 0, 3, 255), (112, 64, 100, 2, 2, 128), (96, 80, 77, 0, 3, 128 | 32),
+                (96, 80, 66, 0, 1, 256 | 1 | 2 | 32), (112, 64, 66, 0, 3, 511)]
 
 
 @pytest.mark.parametrize("w,h,prof,slices,refs,features", RANDOM_CASES)
@@ -194,7 +195,10 @@ def test_parser_reads_random_streams(w, h, prof, slices, refs, features):
     Feature 32: sub-macroblock partitions down to 4x4 and a reference index per partition, written as random mvd_l0 / ref_idx_l0
     draws - the parser's vectors (its statement of 8.4.1.3 on the 4x4 grid) must be the oracle decoder's for every 4x4 block.
     Feature 64: slices cut at random macroblocks (neighbour availability per macroblock instead of per row).  Feature 128:
-    ref_pic_list_modification commands in the P slices (at least one picture of such a case must come out with a permuted list)."""
+    ref_pic_list_modification commands in the P slices (at least one picture of such a case must come out with a permuted list).
+    Feature 256: parameter sets and slice headers laid out the way OpenH264 writes them (15-bit frame_num, POC type 0, VUI, a
+    list modification naming the previous picture in every P slice) - with one reference picture, QP per macroblock, chroma
+    offset and sub-partitions that is the shape of a stream of the reference's own encoder."""
     enc = OracleEncoder(w, h, qp=30, gop=4, profile_idc=prof, slices=slices, refs=refs)
     par, dec = h264dec.Parser(), OracleDecoder()
     seen = set()
@@ -219,7 +223,7 @@ def test_parser_reads_random_streams(w, h, prof, slices, refs, features):
         if features & 1:
             assert not info["one_qp"] or len(set(mbqp)) == 1
     assert seen >= ({0, 1, 2, 4, 5, 6, 7} | ({3} if features & 8 else set())) or w * h <= 256
-    assert permuted == bool(features & 128 and refs > 1), "reference list modification seen where, and only where, it was written"
+    assert permuted == bool(features & 128 and refs > 1), "a permuted reference list where, and only where, one was written"
     par.close()
 
 
