@@ -51,3 +51,26 @@ def test_plugin_decoder_protocol():
     assert d.send(p) == vd.DECODE_FAIL
     assert d.stop() == vd.SUCCESS and d.stop() == vd.SUCCESS and d.send(au) == vd.DECODE_FAIL
     assert d.delete() == vd.SUCCESS
+
+
+def test_plugin_decoder_on_streams_of_other_encoders():
+    """A stream shaped like what the reference's encoder side sends (OpenH264-style headers, a list modification in every P
+    slice, QP per macroblock, chroma QP offset, sub-macroblock partitions, intra and I_PCM macroblocks in P pictures; random
+    syntax from oracle/h264_enc.c) through the plugin surface: every retrieved picture equals the oracle's independent decoder's,
+    cropped to the display size (130 x 98 in 144 x 112 coded samples)."""
+    from oracle_lib import OracleDecoder
+    w, h = 130, 98
+    enc = OracleEncoder(w, h, qp=30, gop=6, profile_idc=66, refs=1)
+    ref = OracleDecoder()
+    d = vd.PluginDecoder()
+    assert d.create_decoder(vd.STREAM_AVC) == vd.SUCCESS and d.init() == vd.SUCCESS and d.install_hooks() == vd.SUCCESS
+    assert d.set_pic_info(w, h) == vd.SUCCESS and d.start() == vd.SUCCESS
+    cap = w * h * 3 // 2
+    for i in range(13):
+        au = enc.random_picture(977 * i + 5, features=256 | 1 | 2 | 4 | 8 | 32)[0]
+        assert ref.decode(au) == 1
+        assert d.send(au) == vd.SUCCESS, "picture %d" % i
+        rc, out = d.retrieve(cap)
+        want = np.concatenate([ref.plane(0)[:h, :w].ravel(), ref.plane(1)[: h // 2, : w // 2].ravel(), ref.plane(2)[: h // 2, : w // 2].ravel()])
+        assert rc == vd.SUCCESS and np.array_equal(out, want), "picture %d" % i
+    assert d.stop() == vd.SUCCESS and d.delete() == vd.SUCCESS
