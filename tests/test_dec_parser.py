@@ -242,3 +242,50 @@ def test_random_stream_golden_vectors():
             assert dec.decode(au) == 1 and par.parse(au)
             assert hashlib.sha256(b"".join(dec.plane(p).tobytes() for p in range(3))).hexdigest() == fr["decoded_sha256"], "%s picture %d" % (c["name"], i)
         par.close()
+
+
+def test_parser_under_address_sanitizer(tmp_path):
+    """tools/fuzz_parser.cpp: the parser built with AddressSanitizer + UBSan walks 1 500 access units of random-syntax streams
+    (every feature of the generator), two thirds of them damaged (bit flips, truncations, splices, duplicated and injected NAL
+    units): no read or write outside an array, no undefined arithmetic - the run must end with its summary line."""
+    import os, random, shutil, struct, subprocess
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "fuzz_parser")
+    r = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                        "-I", os.path.join(root, "media_amd", "csrc"), os.path.join(root, "tools", "fuzz_parser.cpp"), "-o", exe], capture_output=True, text=True)
+    if r.returncode != 0:
+        pytest.skip("sanitizer build not available: " + r.stderr[-200:])
+    rng = random.Random(5)
+    units = []
+    for (w, h, prof, sl, refs, feat) in ((96, 80, 66, 0, 3, 511), (112, 64, 100, 2, 2, 255), (48, 32, 77, 0, 1, 256 | 1 | 2 | 32)):
+        enc = OracleEncoder(w, h, qp=30, gop=4, profile_idc=prof, slices=sl, refs=refs)
+        aus = [enc.random_picture(rng.getrandbits(30), features=feat)[0] for _ in range(10)]
+        for rep in range(50):
+            for au in aus:
+                b = bytearray(au)
+                how = rng.randrange(8)
+                if how == 0:
+                    for _ in range(rng.randint(1, 6)):
+                        b[rng.randrange(len(b))] ^= 1 << rng.randrange(8)
+                elif how == 1:
+                    b = b[: rng.randrange(1, len(b))]
+                elif how == 2:
+                    a, c = sorted(rng.randrange(len(b)) for _ in range(2))
+                    b[a:c] = bytes(rng.randrange(256) for _ in range(rng.randint(0, 12)))
+                elif how == 3:
+                    b = b + bytearray(rng.choice(aus))
+                elif how == 4:
+                    k = rng.randrange(4, len(b))
+                    b[k:k] = b"\x00\x00\x01" + bytes([rng.randrange(256)])
+                units.append(bytes(b))
+    path = str(tmp_path / "units.bin")
+    with open(path, "wb") as f:
+        for u in units:
+            f.write(struct.pack("<I", len(u)))
+            f.write(u)
+    r = subprocess.run([exe, path], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.startswith("parsed "), (r.stdout[-300:], r.stderr[-1500:])
+    parsed, refused = int(r.stdout.split()[1]), int(r.stdout.split()[3])
+    assert parsed > 400 and refused > 400, r.stdout
