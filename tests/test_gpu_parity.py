@@ -596,11 +596,16 @@ def test_configs4_4k_three_references_eight_slices_on_band_instances():
     parts = [capi.Encoder(w, h, qp=28, gop=30, slices=slices, refs=3, band_index=r, band_count=W) for r in range(W)]
     orc = OracleEncoder(w, h, qp=28, gop=30, slices=slices, refs=3)
     dec = OracleDecoder()
+    from media_amd import h264dec
+    gdec = h264dec.Decoder()   # the decoder peer on the same 4K / 8-slice / 3-reference stream
     buf = torch.empty(parts[0].band_info()[4], dtype=torch.uint8, device="cuda")
     for i, f in enumerate(synth.sequence("s1", w, h, 4)):
         got = b"".join(p.encode(f)[0] for p in parts)
         assert got == orc.encode(f)[0], "picture %d" % i
         assert dec.decode(got) == 1
+        assert gdec.decode(got)
+        for pl in range(3):
+            assert np.array_equal(gdec.plane(pl), dec.plane(pl)), "picture %d plane %d: GPU decoder vs the independent decoder" % (i, pl)
         for r in range(W):
             if r > 0:
                 parts[r].halo_export(0, buf.data_ptr())
@@ -608,6 +613,7 @@ def test_configs4_4k_three_references_eight_slices_on_band_instances():
             if r < W - 1:
                 parts[r].halo_export(1, buf.data_ptr())
                 parts[r + 1].halo_import(0, buf.data_ptr())
+    gdec.close()
     for p in parts:
         p.close()
 
