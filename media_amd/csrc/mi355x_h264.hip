@@ -1137,6 +1137,7 @@ int dec_wait(mi355x_h264_decoder* d)
     if (*S.h_err) {
         const unsigned flag = *S.h_err;
         *S.h_err = 0;
+        d->have_refs = 0;   // that picture is not a usable reference: P pictures are refused until the next IDR
         return dfail(d, MI355X_H264_E_INTERNAL, "wavefront kernel hand-off timed out (flag %u)", flag);
     }
     return MI355X_H264_OK;
