@@ -222,7 +222,12 @@ struct Picture {
     int slices = 0;            // slices of the picture; slice_rows > 0: they are bands of that many whole rows, -1: of any other shape
     HostVec<uint8_t> refq;     // 4 per macroblock: ref_idx_l0 of the four quadrants (0xFF: intra)
     HostVec<uint8_t> aux;      // 16 per macroblock
-    HostVec<int16_t> levels;   // L_STRIDE per macroblock (I_PCM: its 384 samples as bytes at the start)
+    // The levels travel to the GPU as ONE BYTE each (L_STRIDE per macroblock, the layout of dev_common.h LV_*; an I_PCM macroblock's
+    // 384 samples as bytes at the start of its area): half the upload of an int16 array.  The few that do not fit a signed byte
+    // are 0 there and listed in `big` (index into levels8, value); the decoder widens the array on the GPU and patches those in.
+    HostVec<int8_t> levels8;
+    struct Big { uint32_t idx; int32_t val; };
+    HostVec<Big> big;
 };
 
 class Parser {
@@ -434,7 +439,12 @@ private:
     }
 
     // 9.2: one residual block; out[0 .. maxc - 1] in scan order (out is zeroed by the caller); returns TotalCoeff or -1
-    int residual_block(BitReader& br, int16_t* out, int maxc, int nC)
+    void put_level(int8_t* p, int v)
+    {
+        if (v >= -128 && v <= 127) *p = (int8_t)v;
+        else { *p = 0; picp_->big.push_back(Picture::Big{(uint32_t)(p - picp_->levels8.data()), (int32_t)(int16_t)v}); }
+    }
+    int residual_block(BitReader& br, int8_t* out, int maxc, int nC)
     {
         const VlcLut& L = vlc();
         int tc, t1;
@@ -487,7 +497,7 @@ private:
         int pos = tc + zeros_left - 1;   // scan position of the first (highest-frequency) coefficient
         for (int i = 0; i < tc; i++) {
             if (pos < 0) return -1;
-            out[pos] = (int16_t)level[i];
+            put_level(out + pos, level[i]);
             int run = 0;
             if (i < tc - 1 && zeros_left > 0) {
                 const uint16_t e = L.run[(zeros_left < 7 ? zeros_left : 7) - 1][br.peek(11)];
@@ -662,7 +672,8 @@ private:
             picp_->mbavail.assign(n, 0);
             picp_->slices = 1;
             picp_->aux.assign(n * 16, 0);
-            picp_->levels.assign(n * L_STRIDE, 0);
+            picp_->levels8.assign(n * L_STRIDE, 0);
+            picp_->big.clear();
             have_pic = true;
         } else {
             if (first_mb != next_mb) { fail("slices out of order (first_mb_in_slice %d, expected %d)", first_mb, next_mb); return false; }
@@ -748,7 +759,7 @@ private:
     {
         MbRec& m = M(mx, my);
         m = MbRec{};
-        int16_t* lv = &picp_->levels[((size_t)my * picp_->mbw + mx) * L_STRIDE];
+        int8_t* lv = &picp_->levels8[((size_t)my * picp_->mbw + mx) * L_STRIDE];
         uint8_t* am = &picp_->aux[((size_t)my * picp_->mbw + mx) * 16];
         unsigned t = br.ue();
         bool is_intra = slice_type_ == 2;
@@ -868,9 +879,7 @@ private:
             qp_ = (qp_ + dq + 52) % 52;
             // residual (7.3.5.3)
             if (i16) {
-                int16_t dc[16] = {0};
-                if (residual_block(br, dc, 16, nc_luma(mx, my, 0, 0)) < 0) { fail("Intra16x16 DC levels"); return false; }
-                memcpy(lv + L_LUMA_DC, dc, sizeof(dc));
+                if (residual_block(br, lv + L_LUMA_DC, 16, nc_luma(mx, my, 0, 0)) < 0) { fail("Intra16x16 DC levels"); return false; }
             }
             for (int b8 = 0; b8 < 4; b8++)
                 for (int k = 0; k < 4; k++) {

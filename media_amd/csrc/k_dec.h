@@ -6,6 +6,8 @@
 //                 sample rules straight from the reference plane, chroma by the 1/8-sample bilinear rule), written into the
 //                 picture; lane = (row, four samples), one wave per macroblock; a vector per 4x4 block and a reference
 //                 picture per 8x8 quadrant (the parser's mv4 / refq: partitions down to 4x4, 7.3.5.2)
+//   k_dec_widen   the levels arrive as one byte each (half the upload): widened into the int16 level lists the kernels read;
+//                 k_dec_patch puts the few values that did not fit a byte in place
 //   k_dec_bs      boundary strengths (8.7.2.1) from those arrays - the encoder's k_bs knows vectors per quadrant only
 //   k_dec_resid   scaling + inverse transform (4x4: 8.5.12, 8x8: 8.5.13, chroma DC: 8.5.11) of the inter macroblocks' levels,
 //                 added to the prediction in place; lane = one 4x4 block, four macroblocks per wave
@@ -115,6 +117,31 @@ __global__ __launch_bounds__(64) void k_dec_inter(FrameParams P0)
         if (vb != va) o = (o & 0xFFFFu) | (pred(vb) & 0xFFFF0000u);
         *(uint32_t*)(rec_chroma(P, pl) + (size_t)(8 * my + cyy) * (P.cw / 2) + 8 * mx + cxx) = o;
     }
+}
+
+// lane = four consecutive levels of one macroblock (LV_STRIDE = 416 = 104 words per macroblock); an I_PCM macroblock's area holds
+// its 384 samples as bytes, which keep their place at the start of the int16 area (intra_mb_core<DEC> reads them there)
+__global__ __launch_bounds__(256) void k_dec_widen(const uint32_t* lv8, const MbInfo* mb, int16_t* lv16, int nmb)
+{
+    const int i = (int)(blockIdx.x * 256 + threadIdx.x);   // word index
+    if (i >= nmb * (LV_STRIDE / 4)) return;
+    const int mbi = i / (LV_STRIDE / 4), k = i - mbi * (LV_STRIDE / 4);
+    const uint32_t w = lv8[i];
+    if (mb[mbi].type == MB_IPCM) {
+        if (k < 96) ((uint32_t*)(lv16 + (size_t)mbi * LV_STRIDE))[k] = w;
+        return;
+    }
+    const int a = (int)(int8_t)(w & 255u), b = (int)(int8_t)((w >> 8) & 255u), c = (int)(int8_t)((w >> 16) & 255u), d = (int)(int8_t)(w >> 24);
+    uint2 o;
+    o.x = ((uint32_t)a & 0xFFFFu) | ((uint32_t)b << 16);
+    o.y = ((uint32_t)c & 0xFFFFu) | ((uint32_t)d << 16);
+    ((uint2*)(lv16 + (size_t)mbi * LV_STRIDE))[k] = o;
+}
+struct DecBigLevel { uint32_t idx; int32_t val; };
+__global__ __launch_bounds__(256) void k_dec_patch(const DecBigLevel* big, int n, int16_t* lv16)
+{
+    const int i = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (i < n) lv16[big[i].idx] = (int16_t)big[i].val;
 }
 
 // 8.7.2.1 for the decoder: lane = (macroblock of the pair, direction, edge, segment); vectors per 4x4 block, references per

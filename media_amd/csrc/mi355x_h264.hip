@@ -1091,6 +1091,9 @@ struct mi355x_h264_decoder {
     int16_t* d_mv4 = nullptr;    // its vectors per 4x4 block (32 int16 per macroblock)
     uint8_t* d_refq = nullptr;   // and reference indices per quadrant (4 per macroblock)
     uint8_t* d_mbavail = nullptr;   // neighbour availability bits per macroblock
+    uint32_t* d_lv8 = nullptr;      // the levels as they arrive: one byte each (k_dec_widen fills the engine's int16 lists)
+    DecBigLevel* d_big = nullptr;   // levels that did not fit a byte
+    size_t big_cap = 0;
     // One picture of look-ahead: decode() returns once picture n is LAUNCHED; the parse of access unit n + 1 then runs on the
     // host while the GPU reconstructs n.  The parser fills two picture buffers in turn (pinned memory: the uploads are
     // asynchronous); up_done[k] = the uploads out of buffer k have finished, so it may be parsed into again.
@@ -1152,7 +1155,23 @@ int dec_submit(mi355x_h264_decoder* d, const h264dec::Picture& pic)
     DHIP(d, hipMemcpyAsync(e->d_mb, pic.mb.data(), nmb * sizeof(MbInfo), hipMemcpyHostToDevice, st));
     DHIP(d, hipMemcpyAsync(e->d_mvq, pic.mvq.data(), nmb * 16, hipMemcpyHostToDevice, st));
     DHIP(d, hipMemcpyAsync(e->d_aux, pic.aux.data(), nmb * 16, hipMemcpyHostToDevice, st));
-    DHIP(d, hipMemcpyAsync(e->d_levels, pic.levels.data(), nmb * LV_STRIDE * sizeof(int16_t), hipMemcpyHostToDevice, st));
+    DHIP(d, hipMemcpyAsync(d->d_lv8, pic.levels8.data(), nmb * LV_STRIDE, hipMemcpyHostToDevice, st));
+    {
+        const int words = (int)(nmb * (LV_STRIDE / 4));
+        hipLaunchKernelGGL(k_dec_widen, dim3((words + 255) / 256), dim3(256), 0, st, (const uint32_t*)d->d_lv8, (const MbInfo*)e->d_mb, e->d_levels, (int)nmb);
+        if (!pic.big.empty()) {
+            static_assert(sizeof(h264dec::Picture::Big) == sizeof(DecBigLevel), "layout of the list of large levels");
+            if (pic.big.size() > d->big_cap) {
+                DHIP(d, hipStreamSynchronize(st));
+                if (d->d_big) (void)hipFree(d->d_big);
+                d->d_big = nullptr;
+                d->big_cap = pic.big.size() * 2 + 1024;
+                DHIP(d, hipMalloc((void**)&d->d_big, d->big_cap * sizeof(DecBigLevel)));
+            }
+            DHIP(d, hipMemcpyAsync(d->d_big, pic.big.data(), pic.big.size() * sizeof(DecBigLevel), hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(k_dec_patch, dim3(((int)pic.big.size() + 255) / 256), dim3(256), 0, st, (const DecBigLevel*)d->d_big, (int)pic.big.size(), e->d_levels);
+        }
+    }
     DHIP(d, hipMemcpyAsync(d->d_mbqp, pic.mbqp.data(), nmb, hipMemcpyHostToDevice, st));
     DHIP(d, hipMemcpyAsync(d->d_mbavail, pic.mbavail.data(), nmb, hipMemcpyHostToDevice, st));
     if (pic.has_inter) {
@@ -1289,6 +1308,8 @@ void mi355x_h264_dec_destroy(mi355x_h264_decoder* d)
     if (d->d_mv4) (void)hipFree(d->d_mv4);
     if (d->d_refq) (void)hipFree(d->d_refq);
     if (d->d_mbavail) (void)hipFree(d->d_mbavail);
+    if (d->d_lv8) (void)hipFree(d->d_lv8);
+    if (d->d_big) (void)hipFree(d->d_big);
     delete d;
 }
 
@@ -1332,9 +1353,10 @@ int mi355x_h264_dec_decode(mi355x_h264_decoder* d, const uint8_t* au, size_t len
         if (d->d_mv4) { (void)hipFree(d->d_mv4); d->d_mv4 = nullptr; }
         if (d->d_refq) { (void)hipFree(d->d_refq); d->d_refq = nullptr; }
         if (d->d_mbavail) { (void)hipFree(d->d_mbavail); d->d_mbavail = nullptr; }
+        if (d->d_lv8) { (void)hipFree(d->d_lv8); d->d_lv8 = nullptr; }
         const size_t n = (size_t)pic.mbw * pic.mbh;
         if (hipMalloc((void**)&d->d_mbqp, n) != hipSuccess || hipMalloc((void**)&d->d_mv4, n * 64) != hipSuccess || hipMalloc((void**)&d->d_refq, n * 4) != hipSuccess ||
-            hipMalloc((void**)&d->d_mbavail, n) != hipSuccess)
+            hipMalloc((void**)&d->d_mbavail, n) != hipSuccess || hipMalloc((void**)&d->d_lv8, n * LV_STRIDE) != hipSuccess)
             return dfail(d, MI355X_H264_E_NOMEM, "hipMalloc (per-macroblock decoder arrays)");
     }
     d->width = pic.width; d->height = pic.height; d->crop_x = 2 * sps.crop_l; d->crop_y = 2 * sps.crop_t;
@@ -1454,7 +1476,19 @@ int64_t mi355x_h264_parser_read(const mi355x_h264_parser* p, int what, void* dst
         case 0: src = c.mb.data(); n = c.mb.size() * sizeof(h264dec::MbRec); break;
         case 1: src = c.mvq.data(); n = c.mvq.size() * sizeof(int16_t); break;
         case 2: src = c.aux.data(); n = c.aux.size(); break;
-        case 3: src = c.levels.data(); n = c.levels.size() * sizeof(int16_t); break;
+        case 3: {   // the level lists as int16 (what k_dec_widen + k_dec_patch make of levels8 + big on the GPU)
+            n = c.levels8.size() * sizeof(int16_t);
+            if (cap < n) return -1;
+            int16_t* o = (int16_t*)dst;
+            for (size_t m = 0; m < c.mb.size(); m++) {
+                const int8_t* s8 = c.levels8.data() + m * h264dec::L_STRIDE;
+                int16_t* d16 = o + m * h264dec::L_STRIDE;
+                if (c.mb[m].type == h264dec::T_IPCM) { memset(d16, 0, h264dec::L_STRIDE * sizeof(int16_t)); memcpy(d16, s8, 384); }
+                else for (int k = 0; k < h264dec::L_STRIDE; k++) d16[k] = s8[k];
+            }
+            for (const auto& b : c.big) o[b.idx] = (int16_t)b.val;
+            return (int64_t)n;
+        }
         case 4: src = c.mbqp.data(); n = c.mbqp.size(); break;
         case 5: src = c.mv4.data(); n = c.mv4.size() * sizeof(int16_t); break;
         case 6: src = c.refq.data(); n = c.refq.size(); break;

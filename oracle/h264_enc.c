@@ -1451,7 +1451,8 @@ static int rs_levels(uint32_t *s, int16_t *lv, int first, int n, int density, in
     for (int i = first; i < n; i++) {
         lv[i] = 0;
         if (rs_below(s, 16) < density) {
-            int a = 1 + (rs_below(s, 4) == 0 ? rs_below(s, mag) : 0);
+            int a = 1 + (rs_below(s, 4) == 0 ? rs_below(s, mag > 1000 ? 9 : mag) : 0);
+            if (mag > 1000 && rs_below(s, 8) == 0) a = 128 + rs_below(s, mag - 1000);   /* a level that needs more than a signed byte */
             lv[i] = (int16_t)(rs_below(s, 2) ? -a : a);
             tc++;
         }
@@ -1541,7 +1542,8 @@ int64_t h264o_enc_random_picture(h264o_enc *e, uint32_t seed, int force_idr, int
             if (type == H264O_MB_IPCM && !(features & 8)) type = H264O_MB_I16;
             mb->type = (uint8_t)type;
             /* residual density / magnitude of this macroblock (kept small at high QP: 16-bit intermediates of 8.5) */
-            const int dens = 1 + rs_below(&rng, 6), mag = qp > 40 ? 2 : qp > 30 ? 4 : 9;
+            /* feature 512: at QP_Y <= 14 an eighth of the levels is 128 .. 427 (scaled coefficients stay below 2^15) */
+            const int dens = 1 + rs_below(&rng, 6), mag = ((features & 512) && qp <= 14) ? 1300 : qp > 40 ? 2 : qp > 30 ? 4 : 9;
             if (type == H264O_MB_IPCM) {
                 mb->cbp = 0x2F;
                 memset(mb->tc, 16, 24);

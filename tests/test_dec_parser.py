@@ -183,7 +183,7 @@ RANDOM_CASES = [(96, 80, 66, 0, 1, 31), (96, 80, 77, 3, 3, 31), (112, 64, 100, 2
                 (96, 80, 66, 0, 3, 63), (112, 64, 100, 2, 2, 63), (96, 80, 77, 3, 1, 32), (32, 32, 100, 0, 3, 63),
                 (96, 80, 66, 0, 3, 127), (112, 64, 100, 0, 2, 127), (16, 64, 77, 0, 1, 32 | 64),
                 (96, 80, 66, 0, 3, 255), (112, 64, 100, 2, 2, 128), (96, 80, 77, 0, 3, 128 | 32),
-                (96, 80, 66, 0, 1, 256 | 1 | 2 | 32), (112, 64, 66, 0, 3, 511)]
+                (96, 80, 66, 0, 1, 256 | 1 | 2 | 32), (112, 64, 66, 0, 3, 511), (96, 80, 66, 0, 2, 1 | 512), (112, 64, 100, 2, 3, 1023)]
 
 
 @pytest.mark.parametrize("w,h,prof,slices,refs,features", RANDOM_CASES)
@@ -198,7 +198,8 @@ def test_parser_reads_random_streams(w, h, prof, slices, refs, features):
     ref_pic_list_modification commands in the P slices (at least one picture of such a case must come out with a permuted list).
     Feature 256: parameter sets and slice headers laid out the way OpenH264 writes them (15-bit frame_num, POC type 0, VUI, a
     list modification naming the previous picture in every P slice) - with one reference picture, QP per macroblock, chroma
-    offset and sub-partitions that is the shape of a stream of the reference's own encoder."""
+    offset and sub-partitions that is the shape of a stream of the reference's own encoder.  Feature 512: levels beyond a signed
+    byte (the parser keeps one byte per level and a list of the exceptions; what it hands out as int16 must be what was written)."""
     enc = OracleEncoder(w, h, qp=30, gop=4, profile_idc=prof, slices=slices, refs=refs)
     par, dec = h264dec.Parser(), OracleDecoder()
     seen = set()
@@ -222,8 +223,11 @@ def test_parser_reads_random_streams(w, h, prof, slices, refs, features):
         permuted = locals().get("permuted", False) or (info["ref_age0"], info["ref_age1"], info["ref_age2"]) != (0, 1, 2)
         if features & 1:
             assert not info["one_qp"] or len(set(mbqp)) == 1
+        if features & 512:
+            big_levels = locals().get("big_levels", 0) + int((np.abs(par.arrays()[3][~np.isin(enc.mbinfo()["type"], (2, 3))].astype(np.int32)) > 127).sum())
     assert seen >= ({0, 1, 2, 4, 5, 6, 7} | ({3} if features & 8 else set())) or w * h <= 256
     assert permuted == bool(features & 128 and refs > 1), "a permuted reference list where, and only where, one was written"
+    assert not (features & 512) or big_levels > 100, "levels beyond a byte were in play"
     par.close()
 
 
