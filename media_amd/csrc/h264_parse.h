@@ -6,7 +6,7 @@
 // sets, slice headers and slice data on the host and fills, per macroblock, exactly the side arrays the encoder's kernels
 // exchange (MbInfo, quadrant vectors, Intra4x4 modes, level lists); the reconstruction - motion compensation, inverse
 // transforms, intra prediction in row-wavefront order, the loop filter - then runs on the GPU (k_dec.h and the encoder's own
-// k_bs / k_deblock_rows).  Nothing here touches samples except I_PCM's raw bytes.
+// k_deblock_rows).  Nothing here touches samples except I_PCM's raw bytes.
 //
 // Supported streams = a superset of what this repository's encoder produces (which is what the reference preset asks of
 // OpenH264 minus CABAC): baseline / main / high with CAVLC, frame macroblocks, I and P slices; Intra16x16, Intra4x4, I_PCM

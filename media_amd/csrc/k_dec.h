@@ -12,7 +12,7 @@
 //   k_dec_resid   scaling + inverse transform (4x4: 8.5.12, 8x8: 8.5.13, chroma DC: 8.5.11) of the inter macroblocks' levels,
 //                 added to the prediction in place; lane = one 4x4 block, four macroblocks per wave
 //   k_pintra_rows<true> (k_intra.h)  the intra macroblocks in row-wavefront order, intra_mb_core<true>
-//   k_bs / k_deblock_rows (encoder)  boundary strengths and the loop filter, unchanged
+//   k_deblock_rows (encoder)  the loop filter (PERMB = true when QPs or offsets differ inside the picture)
 #pragma once
 #include "dev_common.h"
 #include "mc_filters.h"
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void k_dec_patch(const DecBigLevel* big, int n
 }
 
 // 8.7.2.1 for the decoder: lane = (macroblock of the pair, direction, edge, segment); vectors per 4x4 block, references per
-// quadrant (one list, never reordered: equal indices = the same picture).  Writes the layout k_bs writes.
+// quadrant (every slice of the picture has the same list of distinct pictures: equal indices = the same picture).  Writes the layout k_bs writes.
 struct DecBsParams {
     const MbInfo* mb;
     const int16_t* mv4;

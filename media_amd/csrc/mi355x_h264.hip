@@ -1073,7 +1073,7 @@ int mi355x_h264_stats_read(mi355x_h264_encoder* e, mi355x_h264_stats* out, int r
 
 // ===========================================================================
 // Decoder peer (include/mi355x_h264_dec.h): host parser (h264_parse.h) + the reconstruction kernels (k_dec.h, k_intra.h,
-// k_cavlc.h k_bs, k_deblock.h).  The decoder owns an engine instance for its device buffers (reconstruction ring, per-macroblock
+// k_deblock.h).  The decoder owns an engine instance for its device buffers (reconstruction ring, per-macroblock
 // arrays, hand-off granules, streams): decoding is the encoder's reconstruction path run from parsed decisions.
 // ===========================================================================
 struct mi355x_h264_decoder {
