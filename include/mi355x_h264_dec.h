@@ -73,7 +73,8 @@ const char *mi355x_h264_parser_error(const mi355x_h264_parser *p);
 int mi355x_h264_parser_info(const mi355x_h264_parser *p, int32_t *out, int n);
 /* what: 0 MbInfo (32 B / macroblock, layout of mi355x_h264.h), 1 quadrant vectors (8 int16), 2 Intra4x4 modes (16 B), 3 levels (416 int16),
  * 4 QP_Y (1 B / macroblock; 0 for I_PCM), 5 vectors per 4x4 block (32 int16, raster order), 6 ref_idx_l0 per 8x8 quadrant (4 B; 255 intra),
- * 7 neighbour availability (1 B: bit 0 left, 1 above, 2 above-right, 3 above-left macroblock usable for prediction) */
+ * 7 neighbour availability (1 B: bits 0..3 the left, above, above-right, above-left macroblock lies in this slice and was decoded
+ *   before; bits 4..7 it may also be used for intra prediction: constrained_intra_pred_flag) */
 int64_t mi355x_h264_parser_read(const mi355x_h264_parser *p, int what, void *dst, size_t cap);
 
 #ifdef __cplusplus

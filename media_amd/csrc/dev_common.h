@@ -100,7 +100,7 @@ struct FrameParams {
     int cqo_cb, cqo_cr;  // chroma_qp_index_offset, second_chroma_qp_index_offset
     const int16_t* mv4;  // 32 int16 per macroblock: the vector (x, y) of every 4x4 block, raster order (sub-macroblock partitions)
     const uint8_t* refq; // 4 per macroblock: ref_idx_l0 of the four 8x8 quadrants
-    const uint8_t* mbavail;   // per macroblock: neighbours available for prediction, bit 0 left, 1 above, 2 above-right, 3 above-left
+    const uint8_t* mbavail;   // per macroblock: neighbours (left, above, above-right, above-left) in this slice: bits 0..3; usable for intra prediction: bits 4..7
 };
 
 // the parameter block of batch item g (pointers advanced by g strides)

@@ -50,6 +50,7 @@ struct Pps {
     int sps_id = 0, num_ref_default = 1, pic_init_qp = 26;
     int cqo[2] = {0, 0};   // chroma_qp_index_offset, second_chroma_qp_index_offset (Cb, Cr)
     bool deblock_control = false, t8x8 = false, bottom_field_pic_order = false, redundant_pic_cnt = false;
+    bool constrained_intra = false;   // constrained_intra_pred_flag: inter macroblocks are not available for intra prediction
 };
 
 class BitReader {
@@ -281,6 +282,7 @@ private:
     // state of the slice being parsed
     int slice_first_ = 0, slice_type_ = 0, slice_qp_ = 26, num_ref_ = 1;
     int qp_ = 26;   // QP_Y of the previous macroblock of the slice in decoding order
+    bool constrained_ = false;   // constrained_intra_pred_flag of the slice's picture parameter set
     // frame_num of the short-term reference pictures, the one decoded last first (sliding window, 8.2.5.3)
     std::vector<int> dpb_fn_;
     int cur_frame_num_ = 0;
@@ -395,7 +397,7 @@ private:
         if (cq < -12 || cq > 12) { fail("chroma_qp_index_offset %d", cq); return false; }
         p.cqo[0] = p.cqo[1] = cq;
         p.deblock_control = br.u(1) != 0;
-        if (br.u(1)) { fail("constrained_intra_pred_flag = 1"); return false; }
+        p.constrained_intra = br.u(1) != 0;
         p.redundant_pic_cnt = br.u(1) != 0;
         if (br.more_data()) {
             p.t8x8 = br.u(1) != 0;
@@ -691,6 +693,7 @@ private:
         }
         slice_first_ = first_mb; slice_type_ = st; slice_qp_ = qp; num_ref_ = num_ref;
         qp_ = qp;   // QP_Y,PRED of the slice's first macroblock (7.4.5)
+        constrained_ = pps.constrained_intra;
 
         // ---- slice_data (7.3.4) ----
         int addr = first_mb;
@@ -729,10 +732,15 @@ private:
         uint8_t* r = &picp_->refq[((size_t)my * picp_->mbw + mx) * 4];
         r[0] = (uint8_t)r0; r[1] = (uint8_t)r1; r[2] = (uint8_t)r2; r[3] = (uint8_t)r3;
     }
+    // bits 0..3: the neighbour (left, above, above-right, above-left) is in the picture, in this slice, decoded before (6.4.9);
+    // bits 4..7: and may be used for intra prediction - with constrained_intra_pred_flag a macroblock coded in Inter
+    // prediction mode may not (8.3.1.2, 8.3.3, 8.3.4)
+    bool intra_avail(int mx, int my) { return avail(mx, my) && (!constrained_ || intra(M(mx, my).type)); }
     void set_avail(int mx, int my)
     {
         picp_->mbavail[(size_t)my * picp_->mbw + mx] =
-            (uint8_t)((avail(mx - 1, my) ? 1 : 0) | (avail(mx, my - 1) ? 2 : 0) | (avail(mx + 1, my - 1) ? 4 : 0) | (avail(mx - 1, my - 1) ? 8 : 0));
+            (uint8_t)((avail(mx - 1, my) ? 1 : 0) | (avail(mx, my - 1) ? 2 : 0) | (avail(mx + 1, my - 1) ? 4 : 0) | (avail(mx - 1, my - 1) ? 8 : 0) |
+                      (intra_avail(mx - 1, my) ? 16 : 0) | (intra_avail(mx, my - 1) ? 32 : 0) | (intra_avail(mx + 1, my - 1) ? 64 : 0) | (intra_avail(mx - 1, my - 1) ? 128 : 0));
     }
     void set_qp(int mx, int my, int qp)
     {
@@ -792,10 +800,10 @@ private:
                     int mA, mB;
                     bool dc = false;
                     if (x > 0) mA = am[blk_idx(x - 1, y)];
-                    else if (!avail(mx - 1, my)) { dc = true; mA = 2; }
+                    else if (!intra_avail(mx - 1, my)) { dc = true; mA = 2; }
                     else mA = M(mx - 1, my).type == T_I4 ? (am - 16)[blk_idx(3, y)] : 2;
                     if (y > 0) mB = am[blk_idx(x, y - 1)];
-                    else if (!avail(mx, my - 1)) { dc = true; mB = 2; }
+                    else if (!intra_avail(mx, my - 1)) { dc = true; mB = 2; }
                     else mB = M(mx, my - 1).type == T_I4 ? (am - 16 * picp_->mbw)[blk_idx(x, 3)] : 2;
                     const int pm = dc ? 2 : (mA < mB ? mA : mB);
                     int mode = pm;

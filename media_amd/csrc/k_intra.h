@@ -141,11 +141,11 @@ __device__ __forceinline__ void intra_mb_core(const FrameParams& P, int mx, int 
 {
     const int mbi = my * P.mbw + mx, bx = 16 * mx, by = 16 * my, cs = P.cw / 2;
     // neighbouring macroblocks available for prediction (6.4.9: in the picture, in this slice, decoded before).  Encoder: slices are
-    // bands of whole rows.  DEC: the parser's bits per macroblock (1 left, 2 above, 4 above-right, 8 above-left) - slices of any shape
+    // bands of whole rows.  DEC: the parser's bits per macroblock (16 left, 32 above, 64 above-right, 128 above-left) - slices of any shape, constrained_intra_pred_flag
     bool top = P.sl.has_top(my), left = mx > 0, topleft = mx > 0 && top, topright = top && mx + 1 < P.mbw;
     if (DEC) {
         const int a = __builtin_amdgcn_readfirstlane((int)P.mbavail[mbi]);
-        left = (a & 1) != 0; top = (a & 2) != 0; topright = (a & 4) != 0; topleft = (a & 8) != 0;
+        left = (a & 16) != 0; top = (a & 32) != 0; topright = (a & 64) != 0; topleft = (a & 128) != 0;   // (bits 4..7: usable for intra prediction)
     }
     const int avail = (left ? 1 : 0) | (top ? 2 : 0) | (topleft ? 4 : 0);
     MbInfo* const mbp = P.mb + mbi;

@@ -14,7 +14,7 @@
  * Covered (frame macroblocks, 4:2:0, 8 bit, CAVLC): I and P slices; I_NxN (Intra4x4), Intra16x16, I_PCM;
  * P_L0_16x16 / 16x8 / 8x16 / P_8x8 (all sub-macroblock types) / P_8x8ref0 / P_Skip; intra macroblocks in P slices;
  * several reference frames (sliding window marking; reference list modification by short-term picture numbers); mb_qp_delta;
- * chroma_qp_index_offset; transform_size_8x8_flag for inter macroblocks (8x8 residual blocks,
+ * chroma_qp_index_offset; constrained_intra_pred_flag; transform_size_8x8_flag for inter macroblocks (8x8 residual blocks,
  * 8.5.13) -- Intra8x8 is refused; deblocking 8.7 with slice alpha/beta offsets and
  * disable_deblocking_filter_idc 0/1/2; several slices per picture.
  * Not covered (refused with an error): CABAC, B slices, interlace, weighted prediction, FMO/ASO,
@@ -251,7 +251,7 @@ struct h264o_dec {
     int have_sps, profile, level, log2_max_frame_num, poc_type, log2_max_poc_lsb, max_refs;
     int mbw, mbh, crop_r, crop_b;
     /* PPS */
-    int have_pps, init_qp, cqp_off[2], dbf_ctrl, num_ref_default, t8x8_mode;
+    int have_pps, init_qp, cqp_off[2], dbf_ctrl, num_ref_default, t8x8_mode, constrained_intra;
     /* picture */
     int cw, ch;
     dpic cur, out;             /* `out`: last finished picture (returned by h264o_dec_plane) */
@@ -380,7 +380,7 @@ static int parse_pps(h264o_dec *d, bitr *b)
     rd_se(b); /* pic_init_qs */
     d->cqp_off[0] = d->cqp_off[1] = rd_se(b);
     d->dbf_ctrl = (int)rd_bit(b);
-    if (rd_bit(b)) return fail(d, "constrained_intra_pred_flag unsupported");
+    d->constrained_intra = (int)rd_bit(b);   /* constrained_intra_pred_flag */
     if (rd_bit(b)) return fail(d, "redundant_pic_cnt_present_flag unsupported");
     d->t8x8_mode = 0;
     if (b->err) return fail(d, "pps truncated");
@@ -903,6 +903,14 @@ static int decode_intra_mb(mbctx *c, int mbt /* I-slice mb_type */, int *qp)
     uint8_t *Y = d->cur.pl[0] + (size_t)16 * my * cw + 16 * mx;
     const dmb *mA = mb_at(d, mx - 1, my, c->sl, c->addr), *mB = mb_at(d, mx, my - 1, c->sl, c->addr);
     const dmb *mC = mb_at(d, mx + 1, my - 1, c->sl, c->addr), *mD = mb_at(d, mx - 1, my - 1, c->sl, c->addr);
+    if (d->constrained_intra) {
+        /* 8.3.1.1 / 8.3.1.2 / 8.3.3 / 8.3.4: with constrained_intra_pred_flag a macroblock coded in Inter prediction mode is "not
+         * available" for intra prediction (nor for the derivation of Intra4x4PredMode) */
+        if (mA && (mA->kind == DMB_INTER || mA->kind == DMB_SKIP)) mA = NULL;
+        if (mB && (mB->kind == DMB_INTER || mB->kind == DMB_SKIP)) mB = NULL;
+        if (mC && (mC->kind == DMB_INTER || mC->kind == DMB_SKIP)) mC = NULL;
+        if (mD && (mD->kind == DMB_INTER || mD->kind == DMB_SKIP)) mD = NULL;
+    }
     for (int i = 0; i < 4; i++) { m->refidx[i] = -1; m->refpic[i] = -1; }
     if (mbt == 25) { /* I_PCM, 7.3.5 + 8.3.5 */
         m->kind = DMB_IPCM;

@@ -165,6 +165,7 @@ struct randsyn {
     int8_t *qpd;         /* mb_qp_delta per macroblock (written where the syntax carries one) */
     int32_t *slice_first;/* non-NULL: slices of any shape - per macroblock, the address of the first macroblock of its slice */
     int cur_slice_qp;    /* SliceQP_Y of the slice whose header is being written (slice_first mode) */
+    int constrained;     /* constrained_intra_pred_flag = 1 (feature 1024): inter macroblocks are not available for intra prediction */
     int ohstyle;         /* headers laid out the way OpenH264 writes them (feature 256): 15-bit frame_num, pic_order_cnt_type 0 with
                           * pic_order_cnt_lsb in every slice header, VUI with bitstream restrictions, and every P slice carries
                           * ref_pic_list_modification (its one command names the previous picture) */
@@ -413,7 +414,7 @@ static void write_pps(h264o_enc *e, bitw *b)
     bw_se(b, 0);     /* pic_init_qs_minus26 */
     bw_se(b, e->rs ? e->rs->cqo[0] : 0);     /* chroma_qp_index_offset */
     bw_put(b, 1, 1); /* deblocking_filter_control_present_flag */
-    bw_put(b, 1, 0); /* constrained_intra_pred_flag */
+    bw_put(b, 1, e->rs && e->rs->constrained ? 1 : 0); /* constrained_intra_pred_flag */
     bw_put(b, 1, 0); /* redundant_pic_cnt_present_flag */
     if (e->cfg.profile_idc == 100) {
         bw_put(b, 1, 1); /* transform_8x8_mode_flag: inter macroblocks use the 8x8 transform */
@@ -1143,6 +1144,13 @@ static int mb_avail(const h264o_enc *e, int mx, int my, int nx, int ny)
     if (e->rs && e->rs->slice_first) return ny * e->mbw + nx >= e->rs->slice_first[my * e->mbw + mx];
     return ny == my ? 1 : top_in_slice(e, my);
 }
+/* ... and usable for intra prediction and for the derivation of Intra4x4PredMode (8.3.1.1): with constrained_intra_pred_flag
+ * (the generator only) a macroblock coded in Inter prediction mode is not */
+static int intra_avail(const h264o_enc *e, int mx, int my, int nx, int ny)
+{
+    if (!mb_avail(e, mx, my, nx, ny)) return 0;
+    return !(e->rs && e->rs->constrained) || H264O_MB_IS_INTRA(e->mb[ny * e->mbw + nx].type);
+}
 static int nc_luma(const h264o_enc *e, int mx, int my, int b)
 {
     int x = o_blk_x[b], y = o_blk_y[b], nA = -1, nB = -1;
@@ -1190,10 +1198,10 @@ static void write_mb(h264o_enc *e, bitw *b, int mx, int my, int p_slice)
         for (int k = 0; k < 16; k++) {   /* 8.3.1.1: predicted mode = the smaller of the left and upper blocks' modes */
             int x = o_blk_x[k], y = o_blk_y[k], mA, mB, dc_only = 0;
             if (x > 0) mA = am[xy2blk[4 * y + x - 1]];
-            else if (!mb_avail(e, mx, my, mx - 1, my)) { dc_only = 1; mA = 2; }
+            else if (!intra_avail(e, mx, my, mx - 1, my)) { dc_only = 1; mA = 2; }
             else mA = (mb - 1)->type == H264O_MB_I4 ? (am - 16)[xy2blk[4 * y + 3]] : 2;
             if (y > 0) mB = am[xy2blk[4 * (y - 1) + x]];
-            else if (!mb_avail(e, mx, my, mx, my - 1)) { dc_only = 1; mB = 2; }
+            else if (!intra_avail(e, mx, my, mx, my - 1)) { dc_only = 1; mB = 2; }
             else mB = (mb - e->mbw)->type == H264O_MB_I4 ? (am - 16 * e->mbw)[xy2blk[12 + x]] : 2;
             int pm = dc_only ? 2 : (mA < mB ? mA : mB), m = am[k];
             if (m == pm) bw_put(b, 1, 1);
@@ -1484,6 +1492,11 @@ int64_t h264o_enc_random_picture(h264o_enc *e, uint32_t seed, int force_idr, int
     /* feature 128: reference list modification - up to avail_refs commands naming distinct reference pictures, never the same
      * picture as the command before (a difference of 0 cannot be written) */
     rs.ohstyle = (features & 256) != 0;
+    {   /* the PPS travels with IDR pictures only: the flag holds until the next one */
+        static int constrained_sticky;
+        if (idr) constrained_sticky = (features & 1024) != 0;
+        rs.constrained = constrained_sticky;
+    }
     rs.reorder = 0; rs.nreorder = 0;
     if (rs.ohstyle && !idr) { rs.reorder = 1; rs.nreorder = 1; rs.reorder_age[0] = 1; }
     if ((features & 128) && !idr && e->frame_num >= e->avail_refs) {
@@ -1532,7 +1545,7 @@ int64_t h264o_enc_random_picture(h264o_enc *e, uint32_t seed, int force_idr, int
                 nslice++;
                 qp = rs.slice_qp[(rs.slice_first ? nslice - 1 : my / e->slice_rows) & 255];
             }
-            const int left = mb_avail(e, mx, my, mx - 1, my), top = mb_avail(e, mx, my, mx, my - 1), topleft = mb_avail(e, mx, my, mx - 1, my - 1);
+            const int left = intra_avail(e, mx, my, mx - 1, my), top = intra_avail(e, mx, my, mx, my - 1), topleft = intra_avail(e, mx, my, mx - 1, my - 1);
             int kind = rs_below(&rng, 100);
             /* I picture: I4 45 %, I16 45 %, I_PCM 10 %; P picture: skip 22, 16x16 22, 16x8 10, 8x16 10, 8x8 12, I16 9, I4 9, PCM 6 */
             int type;

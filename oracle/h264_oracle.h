@@ -109,7 +109,8 @@ uint32_t h264o_enc_last_me_cost(const h264o_enc *e);
  * ref_idx_l0 per partition, random mvd_l0 (the vectors are then whatever the decoder adds up: mvq / mbinfo vectors are not filled),
  * 64 (with 32) slices cut at random macroblocks instead of bands of rows, 128 ref_pic_list_modification commands in P slices,
  * 256 parameter sets and slice headers laid out the way OpenH264 writes them (15-bit frame_num, POC type 0, VUI, a list modification
- * in every P slice; the same for every picture of a stream), 512 levels of 128 .. 427 at QP_Y <= 14 (use with 1: QPs are then drawn from 4 .. 48).  mbqp_out (one byte per macroblock, may be NULL) receives QP_Y of every
+ * in every P slice; the same for every picture of a stream), 512 levels of 128 .. 427 at QP_Y <= 14 (use with 1: QPs are then drawn from 4 .. 48),
+ * 1024 constrained_intra_pred_flag = 1.  mbqp_out (one byte per macroblock, may be NULL) receives QP_Y of every
  * macroblock (0 for I_PCM, the value the loop filter uses).  Side information: h264o_enc_mbinfo / _mvq / _mbaux / _levels. */
 int64_t h264o_enc_random_picture(h264o_enc *e, uint32_t seed, int force_idr, int features, uint8_t *out, size_t out_cap,
                                  int *is_idr, uint8_t *mbqp_out);

@@ -137,7 +137,7 @@ class OracleEncoder:
             raise RuntimeError("oracle encode failed %d" % n)
         return bytes(self.out[:n]), bool(idr.value)
 
-    RAND_QP, RAND_CHROMA_OFF, RAND_FILTER_OFF, RAND_PCM, RAND_IDC, RAND_SUBPARTS, RAND_SLICES, RAND_REORDER, RAND_OPENH264_HEADERS, RAND_BIG_LEVELS, RAND_ALL = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1023
+    RAND_QP, RAND_CHROMA_OFF, RAND_FILTER_OFF, RAND_PCM, RAND_IDC, RAND_SUBPARTS, RAND_SLICES, RAND_REORDER, RAND_OPENH264_HEADERS, RAND_BIG_LEVELS, RAND_CONSTRAINED_INTRA, RAND_ALL = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2047
 
     def random_picture(self, seed, force_idr=False, features=31):
         """one picture of random conforming syntax (h264o_enc_random_picture): (access unit, is_idr, QP_Y per macroblock);

@@ -183,7 +183,8 @@ RANDOM_CASES = [(96, 80, 66, 0, 1, 31), (96, 80, 77, 3, 3, 31), (112, 64, 100, 2
                 (96, 80, 66, 0, 3, 63), (112, 64, 100, 2, 2, 63), (96, 80, 77, 3, 1, 32), (32, 32, 100, 0, 3, 63),
                 (96, 80, 66, 0, 3, 127), (112, 64, 100, 0, 2, 127), (16, 64, 77, 0, 1, 32 | 64),
                 (96, 80, 66, 0, 3, 255), (112, 64, 100, 2, 2, 128), (96, 80, 77, 0, 3, 128 | 32),
-                (96, 80, 66, 0, 1, 256 | 1 | 2 | 32), (112, 64, 66, 0, 3, 511), (96, 80, 66, 0, 2, 1 | 512), (112, 64, 100, 2, 3, 1023)]
+                (96, 80, 66, 0, 1, 256 | 1 | 2 | 32), (112, 64, 66, 0, 3, 511), (96, 80, 66, 0, 2, 1 | 512), (112, 64, 100, 2, 3, 1023),
+                (96, 80, 66, 0, 2, 1024 | 8), (112, 64, 100, 0, 3, 2047)]
 
 
 @pytest.mark.parametrize("w,h,prof,slices,refs,features", RANDOM_CASES)
@@ -199,7 +200,8 @@ def test_parser_reads_random_streams(w, h, prof, slices, refs, features):
     Feature 256: parameter sets and slice headers laid out the way OpenH264 writes them (15-bit frame_num, POC type 0, VUI, a
     list modification naming the previous picture in every P slice) - with one reference picture, QP per macroblock, chroma
     offset and sub-partitions that is the shape of a stream of the reference's own encoder.  Feature 512: levels beyond a signed
-    byte (the parser keeps one byte per level and a list of the exceptions; what it hands out as int16 must be what was written)."""
+    byte (the parser keeps one byte per level and a list of the exceptions; what it hands out as int16 must be what was written).
+    Feature 1024: constrained_intra_pred_flag (an inter neighbour counts as missing when Intra4x4PredMode is predicted)."""
     enc = OracleEncoder(w, h, qp=30, gop=4, profile_idc=prof, slices=slices, refs=refs)
     par, dec = h264dec.Parser(), OracleDecoder()
     seen = set()

@@ -79,7 +79,8 @@ RANDOM_CASES = [(96, 80, 66, 0, 1, 31), (96, 80, 77, 3, 3, 31), (112, 64, 100, 2
                 (352, 288, 66, 0, 3, 63), (640, 368, 100, 4, 3, 63), (96, 80, 66, 0, 3, 127), (112, 64, 100, 0, 2, 127), (16, 64, 77, 0, 1, 32 | 64),
                 (352, 288, 100, 0, 3, 127), (640, 368, 66, 0, 2, 127), (96, 80, 66, 0, 3, 255), (112, 64, 100, 2, 2, 128), (96, 80, 77, 0, 3, 128 | 32),
                 (352, 288, 100, 0, 3, 255), (640, 368, 66, 3, 2, 128 | 31), (96, 80, 66, 0, 1, 256 | 1 | 2 | 32), (112, 64, 66, 0, 3, 511),
-                (640, 368, 66, 0, 1, 256 | 1 | 2 | 4 | 32), (96, 80, 66, 0, 2, 1 | 512), (112, 64, 100, 2, 3, 1023), (352, 288, 100, 0, 3, 1023)]
+                (640, 368, 66, 0, 1, 256 | 1 | 2 | 4 | 32), (96, 80, 66, 0, 2, 1 | 512), (112, 64, 100, 2, 3, 1023), (352, 288, 100, 0, 3, 1023),
+                (96, 80, 66, 0, 2, 1024 | 8), (112, 64, 100, 0, 3, 2047), (352, 288, 66, 0, 1, 1024 | 256 | 1 | 2 | 32)]
 
 
 @pytest.mark.parametrize("w,h,prof,slices,refs,features", RANDOM_CASES)
@@ -89,7 +90,7 @@ def test_decoder_equals_the_independent_decoder_on_random_streams(w, h, prof, sl
     offsets (Cb and Cr apart under High), filter offsets, I_PCM inside filtered pictures, filtering across slice edges, and
     (feature 32) sub-macroblock partitions down to 4x4 with a reference index per partition, (feature 64) slices cut at random
     macroblocks, (feature 128) ref_pic_list_modification commands that permute the reference pictures, (feature 256) headers
-    laid out the way OpenH264 writes them, (feature 512) levels that do not fit the byte the upload gives each.  No
+    laid out the way OpenH264 writes them, (feature 512) levels that do not fit the byte the upload gives each, (feature 1024) constrained_intra_pred_flag.  No
     encoder reconstruction exists for these; the oracle's spec-literal decoder says what they decode to, and the GPU decoder
     must produce the same samples in every picture (errors would also propagate through the P pictures' references)."""
     enc = OracleEncoder(w, h, qp=30, gop=5, profile_idc=prof, slices=slices, refs=refs)

@@ -15,7 +15,7 @@ dec = h264dec.Decoder()
 for case in range(ncase):
     w, h = 2 * rng.randint(8, 200), 2 * rng.randint(8, 150)
     prof = rng.choice([66, 77, 100]); sl = rng.choice([0, 0, 2, 3, 5]); refs = rng.choice([1, 1, 2, 3]); gop = rng.choice([1, 3, 8, 30])
-    feat = rng.choice([1023, 1023, 1 | 512, 511, 511, 255, 255, 255, 127, 127, 63, 31 | 128, 31, 32, 32 | 64, 128, 128 | 32, 256, 256 | 1 | 2 | 32, 1, 2, 4, 8, 16, 0, 1 | 8, 2 | 4 | 16, 32 | 8])
+    feat = rng.choice([2047, 2047, 1024, 1024 | 63, 1023, 1023, 1 | 512, 511, 511, 255, 255, 255, 127, 127, 63, 31 | 128, 31, 32, 32 | 64, 128, 128 | 32, 256, 256 | 1 | 2 | 32, 1, 2, 4, 8, 16, 0, 1 | 8, 2 | 4 | 16, 32 | 8])
     tag = (case, w, h, prof, sl, refs, gop, feat)
     try:
         enc = OracleEncoder(w, h, qp=rng.randint(10, 51), gop=gop, profile_idc=prof, slices=sl, refs=refs, disable_deblock=int(rng.random() < 0.15))
