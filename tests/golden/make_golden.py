@@ -62,6 +62,7 @@ RANDOM_CASES = [
     ("rand_tiny_pcm_subparts", 48, 32, 66, 0, 3, 8 | 32, 5),
     ("rand_qcif_everything", 176, 144, 100, 0, 3, 511, 6),                       # + slices of any shape, list modification, OpenH264-style headers
     ("rand_qcif_openh264_shape", 176, 144, 66, 0, 1, 256 | 1 | 2 | 4 | 32, 6),  # one reference, QP per macroblock, offsets, sub-partitions
+    ("rand_qcif_all_features", 176, 144, 100, 0, 3, 2047, 6),                    # + levels beyond a byte, constrained_intra_pred_flag
 ]
 
 
