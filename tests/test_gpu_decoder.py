@@ -124,3 +124,18 @@ def test_decoder_against_the_committed_random_stream_vectors():
             assert dec.decode(au)
             assert hashlib.sha256(b"".join(dec.plane(p).tobytes() for p in range(3))).hexdigest() == fr["decoded_sha256"], "%s picture %d" % (c["name"], i)
         dec.close()
+
+
+def test_decoder_long_stream_across_frame_num_wraps():
+    """600 pictures of one GOP (8-bit frame_num: it wraps twice), three reference pictures, list modification in most P slices,
+    QP per macroblock, sub-partitions: PicNum / FrameNumWrap arithmetic (8.2.4.1) and the reconstruction ring over a long run -
+    every picture equals the independent decoder's."""
+    w = h = 48
+    enc = OracleEncoder(w, h, qp=30, gop=1000, profile_idc=66, refs=3)
+    ref_dec, dec = OracleDecoder(), h264dec.Decoder()
+    for i in range(600):
+        au = enc.random_picture(7 * i + 1, features=1 | 32 | 128)[0]
+        assert ref_dec.decode(au) == 1 and dec.decode(au), "picture %d" % i
+        for p in range(3):
+            assert np.array_equal(dec.plane(p), ref_dec.plane(p)), "picture %d plane %d" % (i, p)
+    dec.close()
