@@ -204,6 +204,7 @@ struct h264o_enc {
     uint8_t *aux;          /* 16 bytes per macroblock: Intra4x4PredMode of the 16 blocks (blkIdx order) */
     int16_t *mvq;          /* 8 int16 per macroblock: vectors of the four 8x8 quadrants of an inter macroblock */
     uint8_t *pshape;       /* P pictures: partition shape the motion search chose (0 16x16, 1 16x8, 2 8x16, 3 8x8) */
+    int rs_cqo[2], rs_constrained;   /* what the last parameter sets of h264o_enc_random_picture said (they travel with IDR pictures only) */
     struct randsyn *rs;   /* h264o_enc_random_picture (decoder-peer tests): syntax the encoder itself never uses; NULL while encoding */
     uint8_t *want_intra;   /* P pictures: 1 = the motion search handed the macroblock to the intra pass; 2 = one of the "nothing
                             * left to code" tests hit: the prediction is the reconstruction, no transform is run (the tests use
@@ -1476,7 +1477,7 @@ int64_t h264o_enc_random_picture(h264o_enc *e, uint32_t seed, int force_idr, int
     rs_next(&rng);
     const int nmb = e->mbw * e->mbh, high = e->cfg.profile_idc == 100;
     static struct randsyn rs;   /* (one generator at a time: test infrastructure) */
-    static int cqo_sticky[2];   /* the PPS travels with IDR pictures only: its offsets hold until the next one */
+    int *cqo_sticky = e->rs_cqo;   /* the PPS travels with IDR pictures only: its offsets hold until the next one */
     int idr = force_idr || e->frames == 0 || e->frame_in_gop >= e->cfg.gop;
     if (idr) { e->frame_in_gop = 0; e->frame_num = 0; }
     if (is_idr) *is_idr = idr;
@@ -1492,11 +1493,8 @@ int64_t h264o_enc_random_picture(h264o_enc *e, uint32_t seed, int force_idr, int
     /* feature 128: reference list modification - up to avail_refs commands naming distinct reference pictures, never the same
      * picture as the command before (a difference of 0 cannot be written) */
     rs.ohstyle = (features & 256) != 0;
-    {   /* the PPS travels with IDR pictures only: the flag holds until the next one */
-        static int constrained_sticky;
-        if (idr) constrained_sticky = (features & 1024) != 0;
-        rs.constrained = constrained_sticky;
-    }
+    if (idr) e->rs_constrained = (features & 1024) != 0;   /* (the PPS travels with IDR pictures only) */
+    rs.constrained = e->rs_constrained;
     rs.reorder = 0; rs.nreorder = 0;
     if (rs.ohstyle && !idr) { rs.reorder = 1; rs.nreorder = 1; rs.reorder_age[0] = 1; }
     if ((features & 128) && !idr && e->frame_num >= e->avail_refs) {
