@@ -1476,7 +1476,8 @@ int64_t h264o_enc_random_picture(h264o_enc *e, uint32_t seed, int force_idr, int
     uint32_t rng = seed * 2654435761u + 12345u;
     rs_next(&rng);
     const int nmb = e->mbw * e->mbh, high = e->cfg.profile_idc == 100;
-    static struct randsyn rs;   /* (one generator at a time: test infrastructure) */
+    struct randsyn rs;
+    memset(&rs, 0, sizeof(rs));
     int *cqo_sticky = e->rs_cqo;   /* the PPS travels with IDR pictures only: its offsets hold until the next one */
     int idr = force_idr || e->frames == 0 || e->frame_in_gop >= e->cfg.gop;
     if (idr) { e->frame_in_gop = 0; e->frame_num = 0; }
