@@ -295,8 +295,9 @@ def valu_issue_bound(nmb):
                 per[k] = v["SQ_INSTS_VALU"]
         entropy = sum(per.get(k, 0) for k in ("k_bs", "k_cavlc<false>", "k_cavlc<true>", "k_bit_scan", "k_pack"))
         # (the loop filter's name carries its template arguments: <BS4> until r02c, <BS4, PERMB> since)
-        db_p = per.get("k_deblock_rows<false, false>", per.get("k_deblock_rows<false>", 0))
-        db_i = per.get("k_deblock_rows<true, false>", per.get("k_deblock_rows<true>", 0))
+        # (lockstep batches of 8 pictures or more run the pair form of the filter since r02f)
+        db_p = per.get("k_deblock_pairs<false>") or per.get("k_deblock_rows<false, false>", per.get("k_deblock_rows<false>", 0))
+        db_i = per.get("k_deblock_pairs<true>") or per.get("k_deblock_rows<true, false>", per.get("k_deblock_rows<true>", 0))
         p_pic = entropy + db_p + sum(per.get(k, 0) for k in ("k_me", "k_tq", "k_mvpred", "k_skip_scan", "k_pintra_rows", "k_pintra_rows<false>"))
         idr = entropy + db_i + sum(per.get(k, 0) for k in ("k_i4_decide", "k_intra_rows"))
         if not per.get("k_me") or not per.get("k_tq"):

@@ -614,10 +614,10 @@ __global__ __launch_bounds__(64) void k_deblock_pairs(DbRowParams R)
             }
             const int e0 = (int)((b0.x >> seg8) & 255), e1 = (int)(((isC ? b0.z : b0.y) >> seg8) & 255);
             const int e2 = isC ? 0 : (int)((b0.z >> seg8) & 255), e3 = isC ? 0 : (int)((b0.w >> seg8) & 255);
-            filt_uni<BS4>(px[0], px[1], px[2], px[3], px[4], px[5], px[6], px[7], e0, isC, al, be, t1, t2, t3);
-            filt_uni<BS4>(px[4], px[5], px[6], px[7], px[8], px[9], px[10], px[11], e1, isC, al, be, t1, t2, t3);
-            filt_uni<BS4>(px[8], px[9], px[10], px[11], px[12], px[13], px[14], px[15], e2, isC, al, be, t1, t2, t3);
-            filt_uni<BS4>(px[12], px[13], px[14], px[15], px[16], px[17], px[18], px[19], e3, isC, al, be, t1, t2, t3);
+            if (__ballot(e0 != 0) != 0ull) filt_uni<BS4>(px[0], px[1], px[2], px[3], px[4], px[5], px[6], px[7], e0, isC, al, be, t1, t2, t3);
+            if (__ballot(e1 != 0) != 0ull) filt_uni<BS4>(px[4], px[5], px[6], px[7], px[8], px[9], px[10], px[11], e1, isC, al, be, t1, t2, t3);
+            if (__ballot(e2 != 0) != 0ull) filt_uni<BS4>(px[8], px[9], px[10], px[11], px[12], px[13], px[14], px[15], e2, isC, al, be, t1, t2, t3);
+            if (__ballot(e3 != 0) != 0ull) filt_uni<BS4>(px[12], px[13], px[14], px[15], px[16], px[17], px[18], px[19], e3, isC, al, be, t1, t2, t3);
 #pragma unroll
             for (int w = 0; w < 5; w++)
                 if (w < 3 || !isC)
@@ -631,10 +631,10 @@ __global__ __launch_bounds__(64) void k_deblock_pairs(DbRowParams R)
             for (int r = 0; r < 20; r++) px[r] = hcol[r * hstride];
             const int e0 = (int)((b1.x >> seg8) & 255), e1 = (int)(((isC ? b1.z : b1.y) >> seg8) & 255);
             const int e2 = isC ? 0 : (int)((b1.z >> seg8) & 255), e3 = isC ? 0 : (int)((b1.w >> seg8) & 255);
-            filt_uni<BS4>(px[0], px[1], px[2], px[3], px[4], px[5], px[6], px[7], e0, isC, al, be, t1, t2, t3);
-            filt_uni<BS4>(px[4], px[5], px[6], px[7], px[8], px[9], px[10], px[11], e1, isC, al, be, t1, t2, t3);
-            filt_uni<BS4>(px[8], px[9], px[10], px[11], px[12], px[13], px[14], px[15], e2, isC, al, be, t1, t2, t3);
-            filt_uni<BS4>(px[12], px[13], px[14], px[15], px[16], px[17], px[18], px[19], e3, isC, al, be, t1, t2, t3);
+            if (__ballot(e0 != 0) != 0ull) filt_uni<BS4>(px[0], px[1], px[2], px[3], px[4], px[5], px[6], px[7], e0, isC, al, be, t1, t2, t3);
+            if (__ballot(e1 != 0) != 0ull) filt_uni<BS4>(px[4], px[5], px[6], px[7], px[8], px[9], px[10], px[11], e1, isC, al, be, t1, t2, t3);
+            if (__ballot(e2 != 0) != 0ull) filt_uni<BS4>(px[8], px[9], px[10], px[11], px[12], px[13], px[14], px[15], e2, isC, al, be, t1, t2, t3);
+            if (__ballot(e3 != 0) != 0ull) filt_uni<BS4>(px[12], px[13], px[14], px[15], px[16], px[17], px[18], px[19], e3, isC, al, be, t1, t2, t3);
 #pragma unroll
             for (int r = 1; r < 19; r++) {
                 const bool both = r == 3 || r == 4 || r == 7 || r == 8;

@@ -170,8 +170,8 @@ struct mi355x_h264_encoder {
     uint8_t* d_planes[MAX_REFS + 1][3] = {{nullptr}};  // ring: [index][plane]; `cur` is written, cur - 1 - r (mod nbuf) is ref_idx_l0 r
     uint8_t* d_pre[3] = {nullptr};           // copy of the reconstruction before the loop filter (debug)
     int cur = 0;                             // index written by the picture being encoded
-    bool pair_filter = false;                // MI355X_H264_PAIR_FILTER=N: two macroblock rows per wave in the loop filter for batches of N pictures or more
-    int pair_min_batch = 16;
+    bool pair_filter = true;                 // two macroblock rows per wave in the loop filter for lockstep batches of pair_min_batch pictures or more
+    int pair_min_batch = 8;                  // (MI355X_H264_PAIR_FILTER=N sets it, 0 turns the pair form off)
     MbInfo* d_mb = nullptr;
     int16_t* d_levels = nullptr;
     int16_t* d_mvd = nullptr;
@@ -463,7 +463,7 @@ int submit(mi355x_h264_encoder* e, const uint8_t* d_src, size_t src_item_stride,
             R.serial = db_serial; R.row0 = e->b_row0;
             R.bs = e->d_bs; R.anybs = e->d_anybs;
             R.anypcm = e->d_anypcm; R.anyintra = e->d_anyintra; R.pic_serial = e->pic_serial;
-            // optional (MI355X_H264_PAIR_FILTER): two macroblock rows per wave (k_deblock_pairs) for pictures of one slice; else one row per wave
+            // two macroblock rows per wave (k_deblock_pairs) for lockstep batches of pictures of one slice; else one row per wave
             const bool pairs = e->pair_filter && e->G >= e->pair_min_batch && e->nsl == 1 && e->b_rows == e->mbh;
             const dim3 grid(pairs ? (unsigned)((e->b_rows + 1) / 2) : (unsigned)e->b_rows, G);
             if (idr) {
@@ -715,12 +715,14 @@ int mi355x_h264_create(const mi355x_h264_config* cfg, mi355x_h264_encoder** out)
     e->last_me_cost.assign(Gn, 0);
     e->diag_mode = getenv("MI355X_H264_DIAG") != nullptr && e->G == 1 && e->b_nsl == e->nsl;
     {
-        // MI355X_H264_PAIR_FILTER=N (1..64): the loop filter takes two macroblock rows per wave (k_deblock_pairs) from a lockstep batch
-        // of N pictures on.  Off by default: measured on the bench workload it shortens the filter launch by 7 % (0.787 -> 0.728 ms
-        // per 32 pictures) and costs the pipeline 1 %.
+        // The loop filter takes two macroblock rows per wave (k_deblock_pairs) from a lockstep batch of 8 pictures on (pictures of one
+        // slice): measured on the bench workload with the filter's edge skip in place, same box, row form / pair form: batch 4
+        // 8 837 / 8 851 fps, batch 8 15.0 / 15.3 k, batch 16 21.2 / 22.1 k, batch 32 24.0 / 25.0 k; one GOP in flight 1 230 / 1 209 fps -
+        // so small batches and the latency mode keep one row per wave.  MI355X_H264_PAIR_FILTER=N moves the threshold, 0 turns the
+        // pair form off.
         const char* pf = getenv("MI355X_H264_PAIR_FILTER");
-        e->pair_filter = pf && pf[0] >= '1' && pf[0] <= '9';
-        e->pair_min_batch = e->pair_filter ? atoi(pf) : 1 << 30;
+        e->pair_filter = !(pf && pf[0] == '0');
+        e->pair_min_batch = (pf && pf[0] >= '1' && pf[0] <= '9') ? atoi(pf) : 8;
     }
     e->frame_bytes = (size_t)cfg->width * cfg->height * 3 / 2;
     CK(hipMalloc((void**)&e->d_stage, e->frame_bytes + 256));

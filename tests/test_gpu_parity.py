@@ -220,6 +220,29 @@ def test_loop_filter_with_two_rows_per_wave(monkeypatch, kind, w, h, qp, prof, r
     enc.close()
 
 
+@pytest.mark.parametrize("setting", [None, "0"])
+def test_loop_filter_forms_in_a_batch_of_eight(monkeypatch, setting):
+    """from a lockstep batch of 8 pictures on the loop filter takes two macroblock rows per wave by default
+    (MI355X_H264_PAIR_FILTER=0: one row per wave); both forms must give the oracle's streams - here with an odd number of
+    macroblock rows and intra macroblocks in the P pictures"""
+    import torch
+    if setting is not None:
+        monkeypatch.setenv("MI355X_H264_PAIR_FILTER", setting)
+    w, h, G, gop = 176, 112, 8, 3
+    frames = synth.sequence("cut", w, h, G * gop)
+    orc = OracleEncoder(w, h, qp=27, gop=gop)
+    want = [orc.encode(f)[0] for f in frames]
+    fbytes = w * h * 3 // 2
+    dev = torch.from_numpy(np.stack(frames)).cuda()
+    enc = capi.Encoder(w, h, qp=27, gop=gop, batch=G)
+    cap = 2 * gop * fbytes
+    out, szs, gb = np.zeros(G * cap, np.uint8), np.zeros(G * gop, np.uint32), np.zeros(G, np.uint64)
+    enc.encode_gops_device(dev.data_ptr(), fbytes, gop * fbytes, gop, out, cap, szs, gb)
+    for g in range(G):
+        assert out[g * cap: g * cap + int(gb[g])].tobytes() == b"".join(want[g * gop:(g + 1) * gop]), "GOP %d" % g
+    enc.close()
+
+
 def test_reference_forms_of_the_kernels(monkeypatch):
     """the simpler first forms of the two row-wavefront kernels (one launch per wavefront step) stay selectable for
     debugging and must give the same stream"""
