@@ -469,11 +469,13 @@ __global__ __launch_bounds__(64) void k_deblock_rows(DbRowParams R)
 // iteration t - 1, read in iteration t) instead of 24 global granules and their latency.  Between pairs the hand-off is
 // the row form's ({tag, 4 samples} granules in global memory), and so is everything else: tile layout, the branch-free
 // filter, prefetch one macroblock ahead, one writer per picture sample, bounded spins.
-// MEASURED (bench workload, 32 pictures per launch): the launch gets 7 % shorter (0.787 -> 0.728 ms alone, 0.893 -> 0.845 ms beside
-// the other instance), the pipeline 1 % slower (23.5 -> 23.3 k fps): each step of the 254-step critical path now carries the data
-// movement of two macroblocks (32 lanes per row instead of 64), and the waves the row form had too many of were asleep in their
-// hand-off spins, not contending for issue.  So this form is an option (MI355X_H264_PAIR_FILTER=N: batches of N pictures or
-// more, pictures of one slice), kept correct by tests/test_gpu_parity.py, and the row form stays the default.
+// MEASURED (bench workload, 32 pictures per launch): at first the launch got 7 % shorter and the pipeline 1 % slower (each step of
+// the critical path carries the data movement of two macroblocks with 32 lanes per row instead of 64, and the waves the row form
+// had too many of were asleep in their hand-off spins, not contending for issue).  With the edge skip below (an edge no line of
+// which is filtered costs one scalar branch) the instruction count decides: 152 VALU per macroblock here, 181 in the row form,
+// half the waves - 25.0 k fps against 24.0 k on one box.  So this form is the default from a lockstep batch of 8 pictures on
+// (pictures of one slice; MI355X_H264_PAIR_FILTER=N moves the threshold, 0 turns it off); smaller batches, the latency mode and
+// the decoder use the row form.  tests/test_gpu_parity.py runs both forms at batch 8 and this one forced on single pictures.
 // ===========================================================================
 template <bool BS4>
 __global__ __launch_bounds__(64) void k_deblock_pairs(DbRowParams R)
