@@ -220,15 +220,15 @@ def test_loop_filter_with_two_rows_per_wave(monkeypatch, kind, w, h, qp, prof, r
     enc.close()
 
 
-@pytest.mark.parametrize("setting", [None, "0"])
-def test_loop_filter_forms_in_a_batch_of_eight(monkeypatch, setting):
+@pytest.mark.parametrize("setting,w,h", [(None, 176, 112), ("0", 176, 112), (None, 64, 16), (None, 16, 64), (None, 18, 18)])
+def test_loop_filter_forms_in_a_batch_of_eight(monkeypatch, setting, w, h):
     """from a lockstep batch of 8 pictures on the loop filter takes two macroblock rows per wave by default
     (MI355X_H264_PAIR_FILTER=0: one row per wave); both forms must give the oracle's streams - here with an odd number of
-    macroblock rows and intra macroblocks in the P pictures"""
+    macroblock rows and intra macroblocks in the P pictures, and on pictures of one macroblock row / column"""
     import torch
     if setting is not None:
         monkeypatch.setenv("MI355X_H264_PAIR_FILTER", setting)
-    w, h, G, gop = 176, 112, 8, 3
+    G, gop = 8, 3
     frames = synth.sequence("cut", w, h, G * gop)
     orc = OracleEncoder(w, h, qp=27, gop=gop)
     want = [orc.encode(f)[0] for f in frames]
