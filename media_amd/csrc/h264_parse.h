@@ -234,14 +234,39 @@ struct Picture {
 class Parser {
 public:
     const std::string& error() const { return err_; }
+    void set_error(const std::string& e) { err_ = e; }
     const Picture& picture() const { return *picp_; }
     // two picture buffers: the decoder parses access unit n + 1 into one while the arrays of picture n are still being uploaded
     // from the other (select() before parse_access_unit)
     void select(int k) { picp_ = &pics_[k & 1]; }
     const Sps& sps() const { return sps_[active_sps_]; }
 
-    // one access unit (Annex B).  Returns 1: a picture is ready in picture(); 0: no slice in it (parameter sets only); -1: error()
-    int parse_access_unit(const uint8_t* au, size_t len)
+    // one access unit (Annex B).  Returns 1: a picture is ready in picture(); 0: no slice in it (parameter sets only); -1: error().
+    // The picture enters the parser's list of reference pictures (dpb_fn_, the mirror of the decoder's reconstruction ring) through
+    // commit(): at once with auto_commit (the parser used alone), else when the decoder has accepted and launched it - a picture
+    // the decoder still refuses must not shift the list.  An access unit that is refused - here or by the decoder - may have been
+    // a reference picture: lose_refs() empties the list, and P pictures are refused until the next IDR picture.
+    int parse_access_unit(const uint8_t* au, size_t len, bool auto_commit = true)
+    {
+        const int rc = parse_access_unit_(au, len);
+        if (rc < 0) lose_refs();
+        else if (rc > 0 && auto_commit) commit();
+        return rc;
+    }
+    void commit()
+    {
+        if (picp_->idr) dpb_fn_.clear();
+        if (picp_->is_ref) {
+            dpb_fn_.insert(dpb_fn_.begin(), cur_frame_num_);
+            const size_t cap = (size_t)(sps().max_refs > 0 ? sps().max_refs : 1);
+            if (dpb_fn_.size() > cap) dpb_fn_.resize(cap);
+            prev_ref_fn_ = cur_frame_num_;
+        }
+    }
+    void lose_refs() { dpb_fn_.clear(); prev_ref_fn_ = -1; }
+
+private:
+    int parse_access_unit_(const uint8_t* au, size_t len)
     {
         err_.clear();
         bool have_pic = false;
@@ -261,17 +286,9 @@ public:
         if (next_mb != picp_->mbw * picp_->mbh) return fail("picture incomplete: slices cover %d of %d macroblocks", next_mb, picp_->mbw * picp_->mbh);
         // bands of slice_rows rows only if every band start was seen (a last slice longer than the others is "any shape")
         if (picp_->slice_rows > 0 && picp_->slices != (picp_->mbh + picp_->slice_rows - 1) / picp_->slice_rows) picp_->slice_rows = -1;
-        // the picture enters the reference buffer (what the decoder's ring does with its samples)
-        if (picp_->idr) dpb_fn_.clear();
-        if (picp_->is_ref) {
-            dpb_fn_.insert(dpb_fn_.begin(), cur_frame_num_);
-            const size_t cap = (size_t)(sps().max_refs > 0 ? sps().max_refs : 1);
-            if (dpb_fn_.size() > cap) dpb_fn_.resize(cap);
-        }
         return 1;
     }
 
-private:
     Sps sps_[32];
     Pps pps_[256];
     int active_sps_ = 0;
@@ -286,6 +303,7 @@ private:
     // frame_num of the short-term reference pictures, the one decoded last first (sliding window, 8.2.5.3)
     std::vector<int> dpb_fn_;
     int cur_frame_num_ = 0;
+    int prev_ref_fn_ = -1;   // frame_num of the previous reference picture (PrevRefFrameNum, 7.4.3); -1: none held
 
     int fail(const char* fmt, int a = 0, int b = 0)
     {
@@ -441,10 +459,10 @@ private:
     }
 
     // 9.2: one residual block; out[0 .. maxc - 1] in scan order (out is zeroed by the caller); returns TotalCoeff or -1
-    void put_level(int8_t* p, int v)
+    void put_level(int8_t* p, int v)   // (|v| <= 32767: residual_block refuses anything larger)
     {
         if (v >= -128 && v <= 127) *p = (int8_t)v;
-        else { *p = 0; picp_->big.push_back(Picture::Big{(uint32_t)(p - picp_->levels8.data()), (int32_t)(int16_t)v}); }
+        else { *p = 0; picp_->big.push_back(Picture::Big{(uint32_t)(p - picp_->levels8.data()), (int32_t)v}); }
     }
     int residual_block(BitReader& br, int8_t* out, int maxc, int nC)
     {
@@ -469,7 +487,9 @@ private:
         for (int i = 0; i < tc; i++) {
             if (i < t1) { level[i] = br.u(1) ? -1 : 1; continue; }
             const int prefix = br.unary();
-            if (prefix < 0) return -1;
+            // level_prefix is at most 15 in the Baseline / Main / Extended profiles and 16 for the 8-bit High profile (9.2.2.1 with
+            // bit depth 8): a longer one would make a level outside the int16 lists the reconstruction kernels read - refused
+            if (prefix < 0 || prefix > 16) return -1;
             int code = (prefix < 15 ? prefix : 15) << suffix_len;
             if (suffix_len > 0 || prefix >= 14) {
                 const int size = (prefix == 14 && suffix_len == 0) ? 4 : (prefix >= 15 ? prefix - 3 : suffix_len);
@@ -479,6 +499,7 @@ private:
             if (prefix >= 16) code += (1 << (prefix - 3)) - 4096;
             if (i == t1 && t1 < 3) code += 2;
             level[i] = (code & 1) ? (-code - 1) >> 1 : (code + 2) >> 1;
+            if (level[i] < -32767 || level[i] > 32767) return -1;
             if (suffix_len == 0) suffix_len = 1;
             const int a = level[i] < 0 ? -level[i] : level[i];
             if (a > (3 << (suffix_len - 1)) && suffix_len < 6) suffix_len++;
@@ -633,6 +654,7 @@ private:
         if (st == 0) {
             if (br.u(1)) { const unsigned nr = br.ue(); num_ref = nr > 31 ? 99 : (int)nr + 1; }
             if (idr) { fail("P slice in an IDR picture"); return false; }
+            if (dpb_fn_.empty()) { fail("P slice without a reference picture (none decoded yet, or lost with a refused access unit)"); return false; }
             if (br.bad() || num_ref < 1 || num_ref > 3) { fail("num_ref_idx_l0_active %d (the decoder holds three reference pictures)", num_ref); return false; }
             if (!ref_list(br, sps, frame_num, num_ref, br.u(1) != 0, list)) return false;
         }
@@ -656,6 +678,13 @@ private:
 
         if (!have_pic) {   // first slice of the picture
             if (first_mb != 0) { fail("first slice of the access unit starts at macroblock %d", first_mb); return false; }
+            // 7.4.3 without gaps_in_frame_num: an IDR picture has frame_num 0, every other picture PrevRefFrameNum + 1.  Anything
+            // else means a reference picture went missing between the two: predicting from the ring would use the wrong pictures
+            if (idr && frame_num != 0) { fail("frame_num %d in an IDR picture", frame_num); return false; }
+            if (!idr && prev_ref_fn_ >= 0 && frame_num != ((prev_ref_fn_ + 1) & ((1 << sps.log2_max_frame_num) - 1))) {
+                fail("frame_num %d does not follow the previous reference picture's %d: a picture is missing", frame_num, prev_ref_fn_);
+                return false;
+            }
             picp_->mbw = sps.mbw; picp_->mbh = sps.mbh;
             picp_->width = 16 * sps.mbw - 2 * (sps.crop_l + sps.crop_r); picp_->height = 16 * sps.mbh - 2 * (sps.crop_t + sps.crop_b);
             picp_->idr = idr; picp_->is_ref = ref_idc != 0; picp_->qp = qp; picp_->deblock_idc = idc; picp_->slice_rows = 0;
@@ -702,7 +731,9 @@ private:
         while (more) {
             if (st == 0) {
                 unsigned run = br.ue();
-                if (br.bad() || (int)run > nmb - addr) { fail("mb_skip_run past the picture"); return false; }
+                // (compared as unsigned: a code word with 31 leading zeros carries a value of 2^31 or more, which a cast to int
+                // would turn negative and let through)
+                if (br.bad() || addr > nmb || run > (unsigned)(nmb - addr)) { fail("mb_skip_run past the picture"); return false; }
                 while (run--) { skip_mb(addr % picp_->mbw, addr / picp_->mbw); addr++; }
                 more = br.more_data();
                 if (!more) break;

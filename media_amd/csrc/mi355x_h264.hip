@@ -1317,7 +1317,7 @@ void mi355x_h264_dec_destroy(mi355x_h264_decoder* d)
 
 const char* mi355x_h264_dec_last_error(const mi355x_h264_decoder* d) { return d ? d->err : "no decoder"; }
 
-int mi355x_h264_dec_decode(mi355x_h264_decoder* d, const uint8_t* au, size_t len, int* got_picture)
+static int dec_decode_unit(mi355x_h264_decoder* d, const uint8_t* au, size_t len, int* got_picture)
 {
     if (!d || !au) return MI355X_H264_E_ARG;
     if (got_picture) *got_picture = 0;
@@ -1328,7 +1328,7 @@ int mi355x_h264_dec_decode(mi355x_h264_decoder* d, const uint8_t* au, size_t len
     if (d->up_pending[k]) { DHIP(d, hipEventSynchronize(d->up_done[k])); d->up_pending[k] = false; }
     d->parser.select(k);
     const double t0 = now_ms();
-    const int rc = d->parser.parse_access_unit(au, len);
+    const int rc = d->parser.parse_access_unit(au, len, false);   // (the picture enters the parser's reference list below, once launched)
     const double t1 = now_ms();
     d->parse_ms += t1 - t0;
     if (rc <= 0) d->parser.select(d->buf);   // nothing to launch: picture() stays the last good one
@@ -1374,6 +1374,7 @@ int mi355x_h264_dec_decode(mi355x_h264_decoder* d, const uint8_t* au, size_t len
     d->gpu_ms += now_ms() - t1;
     if (src != MI355X_H264_OK) return src;
     d->last = d->eng->cur;
+    d->parser.commit();   // parser and ring take the picture in together
     if (pic.is_ref) {   // sliding window (8.2.5.3)
         d->eng->cur = (d->eng->cur + 1) % d->eng->nbuf;
         d->have_refs = std::min(d->have_refs + 1, std::min(d->max_refs, d->eng->nrefs));
@@ -1381,6 +1382,30 @@ int mi355x_h264_dec_decode(mi355x_h264_decoder* d, const uint8_t* au, size_t len
     d->pictures++;
     if (got_picture) *got_picture = 1;
     return MI355X_H264_OK;
+}
+
+
+// The C entry point: no exception leaves it (the parser's arrays are std::vectors over pinned memory: an allocation failure
+// arrives as std::bad_alloc), and an access unit that is refused at ANY stage - parser, stream checks, allocation, launch, the
+// time-out of the picture in flight - may have been a reference picture: parser and ring then drop their reference pictures
+// together, so that every P picture is refused until the next IDR picture instead of being predicted from the wrong slot.
+int mi355x_h264_dec_decode(mi355x_h264_decoder* d, const uint8_t* au, size_t len, int* got_picture)
+{
+    if (!d || !au) return MI355X_H264_E_ARG;
+    int rc;
+    try {
+        rc = dec_decode_unit(d, au, len, got_picture);
+    } catch (const std::bad_alloc&) {
+        rc = dfail(d, MI355X_H264_E_NOMEM, "out of host memory while parsing the access unit");
+    } catch (const std::exception& ex) {
+        rc = dfail(d, MI355X_H264_E_NOMEM, "access unit refused: %s", ex.what());
+    }
+    if (rc != MI355X_H264_OK) {
+        d->have_refs = 0;
+        d->parser.lose_refs();
+        if (got_picture) *got_picture = 0;
+    }
+    return rc;
 }
 
 int mi355x_h264_dec_sync(mi355x_h264_decoder* d)
@@ -1455,7 +1480,17 @@ int mi355x_h264_dec_timing(const mi355x_h264_decoder* d, uint64_t* pictures, dou
 struct mi355x_h264_parser { h264dec::Parser p; };
 mi355x_h264_parser* mi355x_h264_parser_create(void) { return new (std::nothrow) mi355x_h264_parser(); }
 void mi355x_h264_parser_destroy(mi355x_h264_parser* p) { delete p; }
-int mi355x_h264_parser_parse(mi355x_h264_parser* p, const uint8_t* au, size_t len) { return p && au ? p->p.parse_access_unit(au, len) : -1; }
+int mi355x_h264_parser_parse(mi355x_h264_parser* p, const uint8_t* au, size_t len)
+{
+    if (!p || !au) return -1;
+    try {
+        return p->p.parse_access_unit(au, len);
+    } catch (const std::exception& ex) {   // (allocation failure of a per-macroblock array: reported, never thrown through the C ABI)
+        p->p.lose_refs();
+        p->p.set_error(std::string("out of memory: ") + ex.what());
+        return -1;
+    }
+}
 const char* mi355x_h264_parser_error(const mi355x_h264_parser* p) { return p ? p->p.error().c_str() : "no parser"; }
 int mi355x_h264_parser_info(const mi355x_h264_parser* p, int32_t* out, int n)
 {

@@ -8,13 +8,20 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-    # GPU runs: bring torch's HIP runtime up before the encoder library's (tests that hand device-resident pictures to
-    # the C ABI need both in one process, and torch refuses to initialise after another HIP user has)
+
+
+def pytest_collection_modifyitems(config, items):
+    """GPU runs: bring torch's HIP runtime up before the encoder library's (tests that hand device-resident pictures to the C
+    ABI need both in one process, and torch refuses to initialise after another HIP user has).  Decided by what was COLLECTED,
+    not by what was typed: `pytest -k one_test` or a single node id on the GPU box selects gpu-marked tests without `-m gpu`
+    (VERDICT r02 "harness fragility").  Items deselected by -m "not gpu" are still listed here on some pytest versions, so the
+    mark expression is honoured too; on a box without a GPU this does nothing."""
     expr = getattr(config.option, "markexpr", "") or ""
-    if "gpu" in expr and "not gpu" not in expr:
-        try:
-            import torch
-            if torch.cuda.is_available():
-                torch.cuda.init()
-        except Exception:
-            pass
+    if "not gpu" in expr or not any(it.get_closest_marker("gpu") is not None for it in items):
+        return
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:
+        pass

@@ -269,7 +269,7 @@ def test_parser_under_address_sanitizer(tmp_path):
         enc = OracleEncoder(w, h, qp=30, gop=4, profile_idc=prof, slices=sl, refs=refs)
         aus = [enc.random_picture(rng.getrandbits(30), features=feat)[0] for _ in range(10)]
         for rep in range(50):
-            for au in aus:
+            for i, au in enumerate(aus):
                 b = bytearray(au)
                 how = rng.randrange(8)
                 if how == 0:
@@ -285,7 +285,11 @@ def test_parser_under_address_sanitizer(tmp_path):
                 elif how == 4:
                     k = rng.randrange(4, len(b))
                     b[k:k] = b"\x00\x00\x01" + bytes([rng.randrange(256)])
+                # a refused unit costs the parser its reference pictures (P pictures are then refused until the next IDR picture), so
+                # every unit comes behind the intact pictures of its GOP: the damage is met with the references in place
+                units.extend(aus[i - i % 4:i])
                 units.append(bytes(b))
+    units.extend(_crafted_units_with_huge_exp_golomb_values())
     path = str(tmp_path / "units.bin")
     with open(path, "wb") as f:
         for u in units:
@@ -294,4 +298,140 @@ def test_parser_under_address_sanitizer(tmp_path):
     r = subprocess.run([exe, path], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.startswith("parsed "), (r.stdout[-300:], r.stderr[-1500:])
     parsed, refused = int(r.stdout.split()[1]), int(r.stdout.split()[3])
-    assert parsed > 400 and refused > 400, r.stdout
+    assert parsed > 1500 and refused > 400, r.stdout
+
+
+class _Bits:
+    """MSB-first bit writer for the crafted slices below"""
+    def __init__(self):
+        self.bits = []
+
+    def u(self, n, v):
+        self.bits += [(v >> (n - 1 - i)) & 1 for i in range(n)]
+        return self
+
+    def ue(self, v):
+        x = v + 1
+        n = x.bit_length() - 1
+        return self.u(n, 0).u(n + 1, x)
+
+    def se(self, v):
+        return self.ue(2 * v - 1 if v > 0 else -2 * v)
+
+    def nal(self, hdr):
+        bits = self.bits + [1]
+        bits += [0] * (-len(bits) % 8)
+        raw = bytes(sum(b << (7 - k) for k, b in enumerate(bits[i:i + 8])) for i in range(0, len(bits), 8))
+        out, zeros = bytearray(), 0
+        for c in raw:
+            if zeros >= 2 and c <= 3:
+                out.append(3)
+                zeros = 0
+            out.append(c)
+            zeros = zeros + 1 if c == 0 else 0
+        return b"\x00\x00\x00\x01" + bytes([hdr]) + bytes(out)
+
+
+_HUGE = [(1 << 31) - 1, 1 << 31, (1 << 31) + 12345, (1 << 32) - 2]   # code words with 30 / 31 leading zeros
+
+
+def _crafted_p_slices(field):
+    """P slices for the oracle encoder's parameter sets (8-bit frame_num, POC type 2, deblocking control present, one reference)
+    in which ONE Exp-Golomb element carries a value of about 2^31: as ue() the cast to int is negative, as se() it is +-2^30."""
+    out = []
+    for huge in _HUGE:
+        def v(name, normal):
+            return huge if name == field else normal
+        b = _Bits()
+        b.ue(v("first_mb_in_slice", 0)).ue(v("slice_type", 5)).ue(v("pic_parameter_set_id", 0)).u(8, 1)
+        if field == "num_ref_idx_active":
+            b.u(1, 1).ue(huge)
+        else:
+            b.u(1, 0)
+        if field == "modification":
+            b.u(1, 1).ue(0).ue(huge).ue(3)
+        else:
+            b.u(1, 0)
+        b.u(1, 0)                                        # adaptive_ref_pic_marking_mode_flag
+        b.ue(v("slice_qp_delta", 0))                     # (se: the same code words)
+        b.ue(v("disable_deblocking_filter_idc", 1))
+        b.ue(v("mb_skip_run", 2))
+        b.ue(v("mb_type", 0))                            # P_L0_16x16
+        b.ue(v("mvd_x", 0)).ue(v("mvd_y", 0))
+        b.ue(v("coded_block_pattern", 0))
+        b.ue(v("mb_skip_run_2", 1))
+        b.ue(v("mb_type_2", 3))                          # P_8x8
+        for k in range(4):
+            b.ue(v("sub_mb_type", 0) if k == 2 else 0)
+        for k in range(8):
+            b.ue(0)
+        b.ue(v("coded_block_pattern_2", 0))
+        b.ue(v("mb_skip_run_3", 0))
+        b.ue(v("mb_type_3", 5 + 1))                      # I_16x16_0_0_0 inside a P slice
+        b.ue(v("intra_chroma_pred_mode", 0))
+        b.ue(v("mb_qp_delta", 0))
+        b.u(1, 1)                                        # coeff_token of the DC block: no coefficients
+        out.append(b.nal(0x41))
+    return out
+
+
+_CRAFTED_FIELDS = ("first_mb_in_slice", "slice_type", "pic_parameter_set_id", "num_ref_idx_active", "modification", "slice_qp_delta",
+                   "disable_deblocking_filter_idc", "mb_skip_run", "mb_type", "mvd_x", "mvd_y", "coded_block_pattern", "mb_skip_run_2", "mb_type_2",
+                   "sub_mb_type", "coded_block_pattern_2", "mb_skip_run_3", "mb_type_3", "intra_chroma_pred_mode", "mb_qp_delta")
+
+
+def _crafted_units_with_huge_exp_golomb_values():
+    """every crafted slice behind an intact IDR picture of the stream whose parameter sets it uses; plus the unmodified form"""
+    enc = OracleEncoder(48, 32, qp=30, gop=30)
+    idr = enc.encode(synth.sequence("s1", 48, 32, 1)[0])[0]
+    units = []
+    for field in _CRAFTED_FIELDS + ("none",):
+        for au in _crafted_p_slices(field)[:1 if field == "none" else None]:
+            units += [idr, au]
+    # 32 zero bits where a code word should start (no terminating 1 within reach)
+    units += [idr, _Bits().ue(0).ue(5).ue(0).u(8, 1).u(3, 0).se(0).ue(1).u(32, 0).u(8, 0xFF).nal(0x41)]
+    return units
+
+
+def test_exp_golomb_values_of_two_to_the_31_are_refused():
+    """mb_skip_run was read as unsigned and checked as int - a code word with 31 leading zeros passed the check
+    and skip_mb() wrote far past the picture's arrays.  Every ue() / se() element of a P slice is given such a value in turn: the
+    product parser must refuse the unit (or, where the element is legitimately that wide, keep every array in range), and the
+    unmodified crafted slice must parse - the crafting itself is sound.  The same units run under AddressSanitizer in
+    test_parser_under_address_sanitizer."""
+    enc = OracleEncoder(48, 32, qp=30, gop=30)
+    idr = enc.encode(synth.sequence("s1", 48, 32, 1)[0])[0]
+    par = h264dec.Parser()
+    assert par.parse(idr)
+    assert par.parse(_crafted_p_slices("none")[0]), "the crafted slice is well-formed"
+    mb = par.arrays()[0]
+    assert list(mb["type"]) == [2, 2, 1, 2, 7, 0], "two skipped, one 16x16, one skipped, one 8x8, one Intra16x16 macroblock"
+    for field in _CRAFTED_FIELDS:
+        for au in _crafted_p_slices(field):
+            assert par.parse(idr)
+            with pytest.raises(h264dec.StreamError):
+                par.parse(au)
+    par.close()
+
+
+def test_a_dropped_reference_picture_is_noticed():
+    """parser and reconstruction ring must not drift apart.  With one P access unit dropped from a stream, the next P
+    picture's frame_num no longer follows the previous reference picture's (7.4.3): it is refused, and so is every further P
+    picture until an IDR picture arrives - never predicted from the wrong picture.  A refused unit has the same effect."""
+    enc = OracleEncoder(64, 48, qp=28, gop=5, refs=2)
+    aus = [enc.encode(f)[0] for f in synth.sequence("s1", 64, 48, 12)]
+    par = h264dec.Parser()
+    for au in aus[:3]:
+        assert par.parse(au)
+    with pytest.raises(h264dec.StreamError, match="missing"):
+        par.parse(aus[4])                                  # aus[3] was lost on the way
+    with pytest.raises(h264dec.StreamError, match="without a reference"):
+        par.parse(aus[4])                                  # and nothing is predicted from the ring until ...
+    for au in aus[5:8]:                                    # ... the next IDR picture (picture 5)
+        assert par.parse(au)
+    with pytest.raises(h264dec.StreamError):
+        par.parse(aus[8][: len(aus[8]) // 2])              # a damaged reference picture: refused ...
+    with pytest.raises(h264dec.StreamError, match="without a reference"):
+        par.parse(aus[9])                                  # ... and the picture after it is not decoded against a stale list
+    assert par.parse(aus[10]) and par.parse(aus[11])       # picture 10 is an IDR picture
+    par.close()

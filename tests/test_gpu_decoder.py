@@ -58,6 +58,40 @@ def test_decoder_on_the_hip_encoders_streams_and_size_change():
     dec.close()
 
 
+def test_decoder_never_predicts_from_the_wrong_picture_after_a_loss():
+    """a dropped or refused reference picture must not leave parser and reconstruction ring out of step.  With two
+    reference pictures in use, one P access unit is dropped: the next P picture is refused (frame_num gap) and so is every one
+    after it until the IDR picture, from which on every picture again equals the encoder's reconstruction; a damaged unit that
+    the parser refuses has the same effect."""
+    w, h = 176, 144
+    enc = OracleEncoder(w, h, qp=28, gop=5, refs=2)
+    aus, recs = [], []
+    for f in synth.sequence("s1", w, h, 12):
+        aus.append(enc.encode(f)[0])
+        recs.append([enc.recon(p).copy() for p in range(3)])
+    dec = h264dec.Decoder()
+
+    def good(i):
+        assert dec.decode(aus[i]), "picture %d" % i
+        for p in range(3):
+            assert np.array_equal(dec.plane(p), recs[i][p]), "picture %d plane %d" % (i, p)
+
+    for i in range(3):
+        good(i)
+    for i in (4, 4):                                   # picture 3 is lost
+        with pytest.raises(h264dec.StreamError):
+            dec.decode(aus[i])
+    for i in (5, 6, 7):                                # IDR picture 5 and on
+        good(i)
+    with pytest.raises(h264dec.StreamError):
+        dec.decode(aus[8][: len(aus[8]) // 2])
+    with pytest.raises(h264dec.StreamError):
+        dec.decode(aus[9])
+    good(10)
+    good(11)
+    dec.close()
+
+
 def test_intra4x4_block_3_0_reads_the_macroblock_above_right():
     """tests/golden/dec_damaged_i4_topright.h264: an IDR picture of the oracle encoder with a few flipped bits, found by
     tools/soak_decoder.py's differential run.  It is still a conforming picture, and one of its Intra4x4 macroblocks predicts
