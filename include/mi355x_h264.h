@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define MI355X_H264_ABI_VERSION 2
+#define MI355X_H264_ABI_VERSION 3
 
 enum {
     MI355X_H264_OK = 0,
@@ -201,6 +201,14 @@ typedef struct mi355x_h264_stats {
     uint64_t launches[MI355X_H264_K_COUNT];
     uint64_t mbs[MI355X_H264_K_COUNT];    /* macroblocks processed by that kernel */
     uint64_t frames;
+    /* what the P pictures' macroblocks became (counted on the device by the entropy stage, always on; ABI 3):
+     * p_mbs      macroblocks of P pictures;
+     * me_searched_mbs  of those, the ones k_me's "nothing left to code" tests did NOT settle - the search, the
+     *            sub-sample refinement and the prediction write ran for them;
+     * tq_coded_mbs     of those, the ones k_tq / k_tq8 coded (searched, and not handed to the intra pass): the
+     *            macroblocks the transform kernel loads and stores samples and levels for.  bench.py prices the
+     *            roofline of the two kernels on these counts, not on the launch geometry. */
+    uint64_t p_mbs, me_searched_mbs, tq_coded_mbs;
 } mi355x_h264_stats;
 int mi355x_h264_stats_enable(mi355x_h264_encoder *enc, int on);
 int mi355x_h264_stats_read(mi355x_h264_encoder *enc, mi355x_h264_stats *out, int reset);

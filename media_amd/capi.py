@@ -37,7 +37,7 @@ class Config(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("ms", C.c_double * 5), ("launches", C.c_uint64 * 5), ("mbs", C.c_uint64 * 5),
-                ("frames", C.c_uint64)]
+                ("frames", C.c_uint64), ("p_mbs", C.c_uint64), ("me_searched_mbs", C.c_uint64), ("tq_coded_mbs", C.c_uint64)]
 
 
 _lib = None
@@ -211,7 +211,7 @@ class Encoder:
     def stats(self, reset=True):
         s = Stats()
         self._check(lib().mi355x_h264_stats_read(self.h, C.byref(s), int(reset)))
-        return {"frames": s.frames,
+        return {"frames": s.frames, "p_mbs": s.p_mbs, "me_searched_mbs": s.me_searched_mbs, "tq_coded_mbs": s.tq_coded_mbs,
                 "kernels": {K_NAMES[i]: {"ms": s.ms[i], "launches": s.launches[i], "mbs": s.mbs[i]} for i in range(5)}}
 
     def close(self):

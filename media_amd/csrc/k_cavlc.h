@@ -504,7 +504,9 @@ struct SliceInfo {       // lives in pinned host memory, written by the device
     uint32_t epb_count;  // positions needing an emulation prevention byte
     uint32_t error;
     uint32_t me_cost;    // scene-change statistic gathered by k_me (0 for IDR pictures)
-    uint32_t pad[3];
+    uint32_t searched;   // P slices: macroblocks k_me searched (its "nothing left to code" tests settled the others: me_cost 0)
+    uint32_t tq_coded;   // of those, the ones k_tq / k_tq8 coded (not handed to the intra pass: me_cost bit 15)
+    uint32_t pad[1];
 };
 
 // one workgroup of SCAN_NT threads per slice (item = picture * nsl + slice): exclusive scan of mbbits over the
@@ -532,9 +534,9 @@ __global__ __launch_bounds__(SCAN_NT) void k_bit_scan(CavlcParams C0, HdrBatch H
     const unsigned base = (unsigned)sl * slice_cap * 8u, hdr_len = fl.n + (unsigned)hdr_rest;
     SliceInfo* info = info0 + item;
     __shared__ unsigned s_part[SCAN_NT];
-    __shared__ unsigned s_cost;
+    __shared__ unsigned s_cost, s_searched, s_intra;
     const int t = threadIdx.x;
-    if (t == 0) s_cost = 0;
+    if (t == 0) { s_cost = 0; s_searched = 0; s_intra = 0; }
     const int per = (cnt + SCAN_NT - 1) / SCAN_NT;
     const int b0 = min(mb1, mb0 + t * per), b1 = min(mb1, b0 + per);
     unsigned sum = 0, flag = 0;
@@ -546,9 +548,13 @@ __global__ __launch_bounds__(SCAN_NT) void k_bit_scan(CavlcParams C0, HdrBatch H
     __shared__ unsigned s_total;
     if (C.p_slice) {   // scene-change statistic: sum of the per-macroblock motion costs k_me left
         const uint16_t* mc = me_cost0 + (size_t)pic * C.st_mb;
-        unsigned cs = 0;
-        for (int i = b0; i < b1; i++) cs += mc[i] & 0x7FFFu;   // (bit 15 marks macroblocks of the intra pass)
+        // (bit 15 marks macroblocks of the intra pass; a macroblock settled by k_me's tests has cost 0, a searched one at least
+        // 2 lambda: the two counts say what k_me and k_tq really worked on - the bench's roofline blocks are priced on them)
+        unsigned cs = 0, ns = 0, ni = 0;
+        for (int i = b0; i < b1; i++) { const unsigned v = mc[i]; cs += v & 0x7FFFu; ns += v != 0u; ni += v >> 15; }
         if (cs) atomicAdd(&s_cost, cs);
+        if (ns) atomicAdd(&s_searched, ns);
+        if (ni) atomicAdd(&s_intra, ni);
     }
     for (int o = 1; o < SCAN_NT; o <<= 1) {
         const unsigned v = t >= o ? s_part[t - o] : 0;
@@ -600,6 +606,8 @@ __global__ __launch_bounds__(SCAN_NT) void k_bit_scan(CavlcParams C0, HdrBatch H
         info->epb_count = 0;
         info->error = fits ? 0u : 1u;   // 1: the slice outgrew its share of the payload buffer (k_cavlc<true> writes nothing past it)
         info->me_cost = s_cost;   // complete: every thread passed the scan's barriers after its atomicAdd
+        info->searched = s_searched;
+        info->tq_coded = s_searched - s_intra;
     }
 }
 

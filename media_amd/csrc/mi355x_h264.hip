@@ -537,8 +537,10 @@ int finish_item(mi355x_h264_encoder* e, int slot_idx, int g, uint8_t** out, uint
             }
             need += 5 + (size_t)si.total_bytes * 3 / 2 + 16;
             cost += si.me_cost;
+            if (!S.idr) { e->stats.me_searched_mbs += si.searched; e->stats.tq_coded_mbs += si.tq_coded; }
         }
         e->last_me_cost[g] = cost;
+        if (!S.idr) e->stats.p_mbs += (uint64_t)e->b_nmb;
         eb.resize(need);
         size_t pos = 0;
         if (S.idr && e->b_sl0 == 0) { memcpy(eb.data(), e->sps_pps.data(), e->sps_pps.size()); pos = e->sps_pps.size(); }   // parameter sets go with the first band
@@ -558,6 +560,7 @@ int finish_item(mi355x_h264_encoder* e, int slot_idx, int g, uint8_t** out, uint
     }
     const SliceInfo info = S.h_info[g];
     e->last_me_cost[g] = info.me_cost;
+    if (!S.idr) { e->stats.p_mbs += (uint64_t)e->b_nmb; e->stats.me_searched_mbs += info.searched; e->stats.tq_coded_mbs += info.tq_coded; }
     if (info.error) {
         e->force_idr = 1;   // the refused picture is missing from the stream: the next one must not refer to it
         return fail(e, info.error == 1 ? MI355X_H264_E_OVERFLOW : MI355X_H264_E_INTERNAL, "device reported error %u", info.error);

@@ -28,7 +28,7 @@ def test_every_declared_symbol_is_exported():
     assert declared <= exported, "missing: %s" % sorted(declared - exported)
     assert set(capi.EXPORTS) <= exported
     L = capi.lib()
-    assert L.mi355x_h264_abi_version() == 2   # 2: config.refs (round 2)
+    assert L.mi355x_h264_abi_version() == 3   # 2: config.refs (round 2); 3: stats carry the coded-macroblock counts (round 3)
     cfg = capi.Config()
     L.mi355x_h264_default_config(C.byref(cfg))
     assert cfg.struct_size == C.sizeof(capi.Config) and (cfg.width, cfg.height, cfg.gop) == (720, 1280, 30)
