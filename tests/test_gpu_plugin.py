@@ -151,3 +151,46 @@ def test_content_no_encoder_setting_can_code_never_fails_the_call():
         assert rc == vc.SUCCESS and dec.decode(bs) == 1
     e.destroy()
     assert e.delete() == vc.SUCCESS
+
+
+def test_configs3_four_1080p_streams_on_four_threads():
+    """BASELINE.json configs[3], "4 x 1080p30 independent streams", as far as one GPU goes: four encoder
+    objects through the plugin surface (CreateVideoEncoder, format 3, fixed-QP key) on four host threads at once, each with its
+    OWN 1920x1080 content, three pictures each; every access unit must be the CPU oracle's for that stream (the scene-change
+    rule of the class replayed on the oracle).  On four GPUs the same objects sit one per device (media_amd/shard.py maps
+    stream k to rank k, tests/test_shard_gloo.py); the kernels they run are these."""
+    import threading
+    w, h = 1920, 1080
+    nmb = (w // 16) * ((h + 15) // 16)
+    contents = [synth.sequence("s1", w, h, 3), synth.sequence("scroll", w, h, 3), synth.sequence("split", w, h, 3), synth.sequence("s1", w, h, 3, start=500)]
+    vc.set_video_mode(w, h, qp=26, gop=30)
+    encs = []
+    for _ in range(4):
+        e = vc.VideoEncoder()
+        assert e.rc_create == vc.SUCCESS and e.init() == vc.SUCCESS and e.start() == vc.SUCCESS
+        encs.append(e)
+    got = [[] for _ in range(4)]
+
+    def work(k):
+        for f in contents[k]:
+            got[k].append(encs[k].encode(f))
+
+    ths = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    for k in range(4):
+        orc = OracleEncoder(w, h, qp=26, gop=30)
+        for i, f in enumerate(contents[k]):
+            obs, idr = orc.encode(f)
+            if not idr and orc.me_cost() > 3000 * nmb:
+                obs, idr = orc.encode(f, force_idr=True)
+            rc, bs = got[k][i]
+            assert rc == vc.SUCCESS and bs == obs, "stream %d picture %d" % (k, i)
+        orc.close()
+    assert len({got[k][2][1] for k in range(4)}) == 4, "four different streams"
+    for e in encs:
+        assert e.stop() == vc.SUCCESS
+        e.destroy()
+        assert e.delete() == vc.SUCCESS
