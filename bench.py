@@ -134,7 +134,10 @@ def plugin_bench(streams, frames_per_stream, bitrate, device=0):
     import numpy as np
     from media_amd import synth
     from media_amd import videocodec as vc
-    nsrc = 30
+    # one pool of consecutive pictures of the S1 sequence, never wrapped: stream k codes pictures k + 1, k + 2, ... (picture k is
+    # its warm-up), so every stream has its own phase of the content and nobody meets a cut (the 30-picture source
+    # used to wrap, the scene detector fired at every wrap and those pictures were coded twice inside the clock)
+    nsrc = frames_per_stream + max(streams) + 1
     frames = [np.ascontiguousarray(f) for f in synth.sequence("s1", WIDTH, HEIGHT, nsrc)]
     out = []
     for S in streams:
@@ -148,22 +151,26 @@ def plugin_bench(streams, frames_per_stream, bitrate, device=0):
             encs.append(e)
         lat = [[] for _ in range(S)]
         nbytes = [0] * S
+        first2s = [0] * S            # bytes of the first 60 pictures (2 s at 30 Hz), warm-up IDR included: how fast the controller settles
         fail = [0] * S
+        cuts0 = sum(e.scene_cuts() for e in encs)
         psnr = []
 
         def work(k):
             e = encs[k]
             for i in range(frames_per_stream):
-                f = frames[(i + 3 * k) % nsrc]
+                f = frames[k + 1 + i]
                 t0 = time.perf_counter()
                 rc, bs = e.encode(f)
                 lat[k].append(time.perf_counter() - t0)
                 if rc != vc.SUCCESS:
                     fail[k] += 1
                 nbytes[k] += len(bs)
+                if i < 59:
+                    first2s[k] += len(bs)
 
         for k in range(S):   # warm-up outside the clock: first IDR, allocations
-            encs[k].encode(frames[0])
+            first2s[k] += len(encs[k].encode(frames[k])[1])
         ths = [threading.Thread(target=work, args=(k,)) for k in range(S)]
         t0 = time.perf_counter()
         for t in ths:
@@ -171,10 +178,10 @@ def plugin_bench(streams, frames_per_stream, bitrate, device=0):
         for t in ths:
             t.join()
         dt = time.perf_counter() - t0
-        for j in range(3):   # quality, outside the clock: a few more pictures of stream 0 against its reconstruction
-            f = frames[(frames_per_stream + j + 1) % nsrc]
-            encs[0].encode(f)
-            psnr.append(synth.psnr(f[:WIDTH * HEIGHT].reshape(HEIGHT, WIDTH), encs[0].recon_y()[:HEIGHT, :WIDTH]))
+        cuts = sum(e.scene_cuts() for e in encs) - cuts0
+        # quality, outside the clock: the last picture of stream 0 against its reconstruction
+        f = frames[frames_per_stream]
+        psnr.append(synth.psnr(f[:WIDTH * HEIGHT].reshape(HEIGHT, WIDTH), encs[0].recon_y()[:HEIGHT, :WIDTH]))
         for e in encs:
             e.stop(); e.destroy(); e.delete()
         allat = np.sort(np.concatenate([np.asarray(x) for x in lat])) * 1e3
@@ -182,9 +189,13 @@ def plugin_bench(streams, frames_per_stream, bitrate, device=0):
         out.append({"streams": S, "fps_aggregate": round(n / dt, 1), "fps_per_stream": round(n / dt / S, 1),
                     "latency_ms_p50": round(float(allat[len(allat) // 2]), 3), "latency_ms_p99": round(float(allat[min(len(allat) - 1, int(len(allat) * 0.99))]), 3),
                     "bytes_per_picture": round(sum(nbytes) / n, 1), "bitrate_target": bitrate, "bitrate_achieved": round(sum(nbytes) * 8 * 30 / n),
+                    "bitrate_first_2s": round(sum(first2s) * 8 * 30 / (S * min(60, frames_per_stream + 1))), "scene_cut_recodes": cuts,
+                    "h2d_GBps": round(n / dt * WIDTH * HEIGHT * 1.5 / 1e9, 2),
                     "psnr_y_db": round(float(np.mean(psnr)), 2) if psnr else None, "pictures": n, "encode_failures": sum(fail)})
     res = {"what": "VideoCodecApi plugin surface (CreateVideoEncoder / EncodeOneFrame), host I420 pictures over PCIe, bitrate mode, scene detection on, "
-                   "1080p30 S1, GOP 30, baseline; S encoder objects on S host threads of one process (Python threads over ctypes)",
+                   "1080p30 S1, GOP 30, baseline; S encoder objects on S host threads of one process (Python threads over ctypes), %d pictures per stream "
+                   "from a non-wrapping source; the objects are streams of one shared engine (pictures of different streams coded in one lockstep step) "
+                   "unless MI355X_H264_HUB=0" % frames_per_stream,
            "results": out}
     try:
         native = plugin_bench_native(streams, frames_per_stream, bitrate, device)
@@ -205,7 +216,7 @@ def plugin_bench_native(streams, frames_per_stream, bitrate, device=0):
     exe = os.path.join(ROOT, "media_amd", "lib", "plugin_bench")
     if not os.path.exists(exe):
         return None
-    nsrc = 30
+    nsrc = frames_per_stream + max(streams) + 1
     env = dict(os.environ)
     env.update({"RO_VMI_DEMO_VIDEO_ENCODE_FORMAT": "3", "RO_SYS_VMI_CLOUDPHONE": "video", "RO_HARDWARE_WIDTH": str(WIDTH),
                 "RO_HARDWARE_HEIGHT": str(HEIGHT), "RO_HARDWARE_FPS": "30", "PERSIST_VMI_VIDEO_ENCODE_BITRATE": str(bitrate),
@@ -380,8 +391,8 @@ def main():
                     help="slices per picture (bands of macroblock rows, SURVEY.md 8e-3); 0/1 = one slice, the reference preset and the headline")
     ap.add_argument("--mode", default="gops", choices=["gops", "plugin", "decode"],
                     help="gops: the headline (closed GOPs resident in HBM); plugin: only the measurement through the VideoEncoder plugin surface")
-    ap.add_argument("--streams", default="1,4,16", help="plugin measurement: numbers of concurrent streams (encoder objects), comma separated")
-    ap.add_argument("--plugin-frames", type=int, default=60, help="plugin measurement: pictures per stream")
+    ap.add_argument("--streams", default="1,4,16,64", help="plugin measurement: numbers of concurrent streams (encoder objects), comma separated")
+    ap.add_argument("--plugin-frames", type=int, default=300, help="plugin measurement: pictures per stream (10 s at 30 Hz)")
     ap.add_argument("--bitrate", type=int, default=5000000, help="plugin measurement: target bitrate (the reference accepts 1..10 Mbps)")
     ap.add_argument("--no-plugin", action="store_true", help="leave the plugin measurement out of the default line")
     args = ap.parse_args()

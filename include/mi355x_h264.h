@@ -186,6 +186,34 @@ int mi355x_h264_debug_keep_pre(mi355x_h264_encoder *enc, int on);
 /* copies the named device buffer of the last encoded picture (batch item 0) to dst; returns bytes or <0 */
 int64_t mi355x_h264_debug_read(mi355x_h264_encoder *enc, int what, void *dst, size_t cap);
 
+/* ---- streams (ABI 3): many encoders of one geometry, one picture per call each, sharing one engine ----
+ * The reference's operating mode is one VideoEncoder object per cloud-phone stream, each driven by its own thread with one
+ * EncodeOneFrame per tick (/root/reference/video_codec/VideoEncoderOpenH264.cpp:304-352).  A stream is such an encoder whose
+ * pictures are coded together with the pictures other streams of the same geometry (size, fps, profile, slices, filter switch,
+ * device) deliver at about the same time: ONE lockstep launch sequence per step instead of one per stream, every picture with
+ * its own QP, picture type, frame_num and reference pictures.  mi355x_h264_stream_encode is synchronous and may be called from
+ * one thread per stream concurrently; the output is bit-for-bit what mi355x_h264_create / mi355x_h264_encode with the same
+ * config and the same QP sequence produce (tests/test_gpu_streams.py).  One reference picture (refs <= 1), host I420 input.
+ * *out stays valid until the stream's next encode / close.  MI355X_H264_HUB_ITEMS (default 32) streams share an engine;
+ * MI355X_H264_HUB_WINDOW_US (default 200): how long a step waits for pictures that are already being uploaded. */
+typedef struct mi355x_h264_stream mi355x_h264_stream;
+int mi355x_h264_stream_open(const mi355x_h264_config *cfg, mi355x_h264_stream **out);
+void mi355x_h264_stream_close(mi355x_h264_stream *s);
+int mi355x_h264_stream_encode(mi355x_h264_stream *s, const uint8_t *y, int y_stride, const uint8_t *u, int u_stride,
+                              const uint8_t *v, int v_stride, uint8_t **out, uint32_t *out_len, int *frame_type);
+int mi355x_h264_stream_set_qp(mi355x_h264_stream *s, int qp);            /* as mi355x_h264_set_qp            */
+int mi355x_h264_stream_force_idr(mi355x_h264_stream *s);                 /* as mi355x_h264_force_idr         */
+int mi355x_h264_stream_set_idr_pic_id(mi355x_h264_stream *s, int next);  /* idr_pic_id of the next IDR       */
+int mi355x_h264_stream_last_me_cost(const mi355x_h264_stream *s, uint32_t *cost);   /* as mi355x_h264_last_me_cost */
+const char *mi355x_h264_stream_last_error(const mi355x_h264_stream *s);
+int mi355x_h264_stream_coded_width(const mi355x_h264_stream *s);
+int mi355x_h264_stream_coded_height(const mi355x_h264_stream *s);
+/* reconstruction plane (MI355X_H264_DBG_RECON_Y / _U / _V) of the stream's last picture; returns bytes or < 0 */
+int64_t mi355x_h264_stream_debug_read(mi355x_h264_stream *s, int what, void *dst, size_t cap);
+/* how the stream's engine has been batching: steps launched, pictures coded, largest step, streams open on it */
+int mi355x_h264_stream_hub_stats(const mi355x_h264_stream *s, uint64_t *steps, uint64_t *pictures, uint64_t *max_batch,
+                                 int *open_streams);
+
 /* per-kernel device time accumulated since the last reset, measured with HIP
  * events on the encoder's own stream */
 enum {

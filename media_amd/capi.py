@@ -25,6 +25,9 @@ EXPORTS = [
     "mi355x_h264_debug_keep_pre", "mi355x_h264_debug_read", "mi355x_h264_stats_enable", "mi355x_h264_stats_read",
     "mi355x_h264_set_qp", "mi355x_h264_set_idr_pic_id", "mi355x_h264_encode_nv12", "mi355x_h264_encode_nv12_device",
     "mi355x_h264_encode_gops_device", "mi355x_h264_last_me_cost",
+    "mi355x_h264_stream_open", "mi355x_h264_stream_close", "mi355x_h264_stream_encode", "mi355x_h264_stream_set_qp",
+    "mi355x_h264_stream_force_idr", "mi355x_h264_stream_set_idr_pic_id", "mi355x_h264_stream_last_me_cost",
+    "mi355x_h264_stream_last_error", "mi355x_h264_stream_debug_read", "mi355x_h264_stream_hub_stats",
 ]
 
 
@@ -77,6 +80,21 @@ def lib():
         L.mi355x_h264_debug_keep_pre.argtypes = [vp, C.c_int]
         L.mi355x_h264_debug_read.argtypes = [vp, C.c_int, vp, C.c_size_t]
         L.mi355x_h264_debug_read.restype = C.c_int64
+        L.mi355x_h264_stream_open.argtypes = [C.POINTER(Config), C.POINTER(vp)]
+        L.mi355x_h264_stream_close.argtypes = [vp]
+        L.mi355x_h264_stream_close.restype = None
+        L.mi355x_h264_stream_encode.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_uint32), C.POINTER(C.c_int)]
+        L.mi355x_h264_stream_set_qp.argtypes = [vp, C.c_int]
+        L.mi355x_h264_stream_force_idr.argtypes = [vp]
+        L.mi355x_h264_stream_set_idr_pic_id.argtypes = [vp, C.c_int]
+        L.mi355x_h264_stream_last_me_cost.argtypes = [vp, C.POINTER(C.c_uint32)]
+        L.mi355x_h264_stream_last_error.argtypes = [vp]
+        L.mi355x_h264_stream_last_error.restype = C.c_char_p
+        L.mi355x_h264_stream_coded_width.argtypes = [vp]
+        L.mi355x_h264_stream_coded_height.argtypes = [vp]
+        L.mi355x_h264_stream_debug_read.argtypes = [vp, C.c_int, vp, C.c_size_t]
+        L.mi355x_h264_stream_debug_read.restype = C.c_int64
+        L.mi355x_h264_stream_hub_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
         L.mi355x_h264_stats_enable.argtypes = [vp, C.c_int]
         L.mi355x_h264_stats_read.argtypes = [vp, C.POINTER(Stats), C.c_int]
         _lib = L
@@ -217,6 +235,73 @@ class Encoder:
     def close(self):
         if getattr(self, "h", None):
             lib().mi355x_h264_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Stream:
+    """a stream of the shared engine (include/mi355x_h264.h, "streams"): one picture per call, coded together with the pictures
+    other streams of the same geometry deliver at about the same time; thread-safe across streams (one thread per stream)"""
+
+    def __init__(self, width, height, qp=26, gop=30, fps=30, profile_idc=66, device=0, disable_deblock=0, slices=0):
+        L = lib()
+        cfg = Config()
+        L.mi355x_h264_default_config(C.byref(cfg))
+        cfg.width, cfg.height, cfg.qp, cfg.gop, cfg.fps = width, height, qp, gop, fps
+        cfg.profile_idc, cfg.device, cfg.disable_deblock, cfg.slices = profile_idc, device, disable_deblock, slices
+        self.h = C.c_void_p()
+        rc = L.mi355x_h264_stream_open(C.byref(cfg), C.byref(self.h))
+        if rc != 0:
+            self.h = None
+            raise EncoderError("mi355x_h264_stream_open failed: %d" % rc)
+        self.width, self.height = width, height
+        self.cw, self.ch = L.mi355x_h264_stream_coded_width(self.h), L.mi355x_h264_stream_coded_height(self.h)
+
+    def _check(self, rc):
+        if rc != 0:
+            raise EncoderError("rc=%d: %s" % (rc, lib().mi355x_h264_stream_last_error(self.h).decode()))
+
+    def encode(self, i420):
+        w, h = self.width, self.height
+        f = np.ascontiguousarray(i420, dtype=np.uint8)
+        base = f.ctypes.data
+        out, n, ft = C.c_void_p(), C.c_uint32(), C.c_int()
+        self._check(lib().mi355x_h264_stream_encode(self.h, base, w, base + w * h, w // 2, base + w * h * 5 // 4, w // 2,
+                                                    C.byref(out), C.byref(n), C.byref(ft)))
+        return C.string_at(out.value, n.value), ft.value
+
+    def set_qp(self, qp):
+        self._check(lib().mi355x_h264_stream_set_qp(self.h, qp))
+
+    def force_idr(self):
+        self._check(lib().mi355x_h264_stream_force_idr(self.h))
+
+    def me_cost(self):
+        c = C.c_uint32()
+        self._check(lib().mi355x_h264_stream_last_me_cost(self.h, C.byref(c)))
+        return c.value
+
+    def recon(self, p):
+        n = self.cw * self.ch // (4 if p else 1)
+        a = np.zeros(n, np.uint8)
+        got = lib().mi355x_h264_stream_debug_read(self.h, DBG_RECON_Y + p, a.ctypes.data, a.size)
+        if got != n:
+            raise EncoderError("stream_debug_read -> %d" % got)
+        return a.reshape(self.ch // (2 if p else 1), self.cw // (2 if p else 1))
+
+    def hub_stats(self):
+        st, pc, mx, op = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_int()
+        self._check(lib().mi355x_h264_stream_hub_stats(self.h, C.byref(st), C.byref(pc), C.byref(mx), C.byref(op)))
+        return {"steps": st.value, "pictures": pc.value, "max_batch": mx.value, "open_streams": op.value}
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().mi355x_h264_stream_close(self.h)
             self.h = None
 
     def __del__(self):

@@ -39,6 +39,9 @@ struct Quant {
     int mf8[6], ls8[6]; // 8x8 transform (High profile): forward multipliers and 16 * normAdjust8x8 by position class (8.5.9)
 };
 
+// everything a picture's QP fixes, prepared once per encoder for every QP (the host's fill_quant): indirect launches read it
+struct QpEntry { Quant qy, qc; int lambda, sad_nz; };
+
 // Slices are bands of `rows` whole macroblock rows (the last band may be shorter); with one slice rows = mbh.
 // row_in_slice() is my % rows through a 32-bit reciprocal (inv = floor(2^32 / rows) + 1, exact for my < 65536):
 // two scalar multiplies where a runtime modulo would be a float division sequence.
@@ -101,8 +104,24 @@ struct FrameParams {
     const int16_t* mv4;  // 32 int16 per macroblock: the vector (x, y) of every 4x4 block, raster order (sub-macroblock partitions)
     const uint8_t* refq; // 4 per macroblock: ref_idx_l0 of the four 8x8 quadrants
     const uint8_t* mbavail;   // per macroblock: neighbours (left, above, above-right, above-left) in this slice: bits 0..3; usable for intra prediction: bits 4..7
+    // INDIRECT launches (kernels instantiated with IND = true; the stream hub of mi355x_h264.hip: pictures of DIFFERENT streams in
+    // one lockstep step).  gridDim.y counts POSITIONS; itemtab[position] names the batch item, the ring slot its picture is
+    // reconstructed into and its QP.  rec[] then holds the BASE of the reconstruction planes, which lie [item][ring slot]
+    // (st_y / st_c bytes between items, st_ring_y / st_ring_c between the nbuf slots of one item); qtab is the table of
+    // quantiser constants by QP.  Direct launches leave itemtab null and never read these.
+    const uint32_t* itemtab;
+    const QpEntry* qtab;
+    size_t st_ring_y, st_ring_c;
+    int nbuf;
 };
 
+// itemtab word: bits 0..7 batch item, 8..9 ring slot of the picture being coded, 16..21 QP
+struct ItemRef { int item, cur, qp; };
+__device__ __forceinline__ ItemRef item_ref(const uint32_t* itemtab, int pos)
+{
+    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)itemtab[pos]);   // uniform: a scalar load
+    return ItemRef{(int)(w & 0xFFu), (int)((w >> 8) & 3u), (int)((w >> 16) & 63u)};
+}
 // the parameter block of batch item g (pointers advanced by g strides)
 __device__ __forceinline__ FrameParams batch_view(FrameParams P, int g)
 {
@@ -120,6 +139,46 @@ __device__ __forceinline__ FrameParams batch_view(FrameParams P, int g)
     P.anypcm += g; P.anyintra += g;
     P.me_total += (size_t)g * P.st_mb; P.pmv += (size_t)g * P.st_mb;
     return P;
+}
+// IND = true: the view of POSITION pos of an indirect launch - the item's arrays, its own ring slots and its own QP's constants
+template <bool IND>
+__device__ __forceinline__ FrameParams batch_view(FrameParams P, int pos)
+{
+    if constexpr (!IND) return batch_view(P, pos);
+    else {
+        const ItemRef it = item_ref(P.itemtab, pos);
+        uint8_t* const by = P.rec[0] + (size_t)it.item * P.st_y;
+        uint8_t* const bu = P.rec[1] + (size_t)it.item * P.st_c;
+        uint8_t* const bv = P.rec[2] + (size_t)it.item * P.st_c;
+        P.rec[0] = by + (size_t)it.cur * P.st_ring_y; P.rec[1] = bu + (size_t)it.cur * P.st_ring_c; P.rec[2] = bv + (size_t)it.cur * P.st_ring_c;
+        int rs = it.cur;
+#pragma unroll
+        for (int r = 0; r < 3; r++) {   // ref_idx_l0 r: the slot written r + 1 pictures ago
+            rs = rs == 0 ? P.nbuf - 1 : rs - 1;
+            P.refs[r][0] = by + (size_t)rs * P.st_ring_y; P.refs[r][1] = bu + (size_t)rs * P.st_ring_c; P.refs[r][2] = bv + (size_t)rs * P.st_ring_c;
+        }
+        P.ref[0] = P.refs[0][0]; P.ref[1] = P.refs[0][1]; P.ref[2] = P.refs[0][2];
+        const int g = it.item;
+        P.src += (size_t)g * P.st_src;
+        P.mb += (size_t)g * P.st_mb;
+        P.levels += (size_t)g * P.st_mb * LV_STRIDE;
+        P.mvd += (size_t)g * P.st_mb * 8;
+        P.mvq += (size_t)g * P.st_mb * 8;
+        P.aux += (size_t)g * P.st_mb * 16;
+        P.me_cost += (size_t)g * P.st_mb;
+        P.anypcm += g; P.anyintra += g;
+        P.me_total += (size_t)g * P.st_mb; P.pmv += (size_t)g * P.st_mb;
+        const QpEntry* q = P.qtab + it.qp;
+        P.qy = q->qy; P.qc = q->qc; P.lambda = q->lambda; P.sad_nz = q->sad_nz;
+        return P;
+    }
+}
+// the batch item a position of the grid stands for (per-item scratch outside FrameParams: hand-off granules, flags)
+template <bool IND>
+__device__ __forceinline__ int batch_item(const uint32_t* itemtab, int pos)
+{
+    if constexpr (!IND) return pos;
+    else return item_ref(itemtab, pos).item;
 }
 
 // Synchronisation inside a ONE-WAVE workgroup.  LDS instructions of one wave execute in program order,

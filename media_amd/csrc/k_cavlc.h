@@ -238,6 +238,7 @@ struct CavlcParams {
     int w, h, src_nv12;
     size_t st_src;
     const uint8_t* aux;   // 16 bytes per macroblock: Intra4x4PredMode of the blocks of MB_I4 macroblocks (blkIdx order)
+    const uint32_t* itemtab;   // indirect launches (IND = true): position -> batch item (dev_common.h item_ref); null otherwise
 };
 __device__ __forceinline__ CavlcParams batch_view(CavlcParams C, int g)
 {
@@ -249,6 +250,8 @@ __device__ __forceinline__ CavlcParams batch_view(CavlcParams C, int g)
     C.aux += (size_t)g * C.st_mb * 16;
     return C;
 }
+template <bool IND>
+__device__ __forceinline__ CavlcParams batch_view(CavlcParams C, int pos) { return batch_view(C, batch_item<IND>(C.itemtab, pos)); }
 enum { MAX_BATCH = 64 };
 // One limit for both halves of the overflow guard: a slice is accepted by k_bit_scan only when header + data +
 // tail end at least SLICE_GUARD_BITS before the end of its share of the payload buffer, and k_cavlc<true> drops a slot
@@ -401,10 +404,11 @@ __device__ __forceinline__ void code_slot(S& s, const CavlcParams& C, int mbi, i
 // launch on the reconstruction stream: the filter then never waits for the entropy-coding stream.
 // anybs[item] is set to the picture's serial as soon as any strength of the picture is non-zero: a picture without
 // any (a static screen) needs no loop filter pass at all, and k_deblock_rows returns at once.
+template <bool IND = false>
 __global__ __launch_bounds__(64) void k_bs(CavlcParams C0, unsigned* anybs, unsigned serial)
 {
     __builtin_amdgcn_s_setprio(2);
-    const CavlcParams C = batch_view(C0, blockIdx.y);
+    const CavlcParams C = batch_view<IND>(C0, blockIdx.y);
     const int lane = threadIdx.x, slot = lane & 31;
     const int mbi = C.mb_first + blockIdx.x * 2 + (lane >> 5);
     int bs = 0;
@@ -413,15 +417,16 @@ __global__ __launch_bounds__(64) void k_bs(CavlcParams C0, unsigned* anybs, unsi
         bs = mb_edge_strength(C.mb + mbi, C.mvq + (size_t)mbi * 8, mbi - my * C.mbw, C.sl.has_top(my), C.mbw, slot);
         C.bs[(size_t)mbi * 32 + slot] = (uint8_t)bs;
     }
-    if (__ballot(bs != 0) != 0ull && lane == 0) anybs[blockIdx.y] = serial;   // same value from every writer: a plain store
+    if (__ballot(bs != 0) != 0ull && lane == 0) anybs[batch_item<IND>(C0.itemtab, blockIdx.y)] = serial;   // same value from every writer: a plain store
 }
 
 // P slices: prevcoded[i] = index of the last macroblock before i that is not P_Skip (a prefix maximum over the
 // picture, one 256-thread workgroup per picture), so that mb_skip_run costs no walk over the skipped macroblocks
 // (a static screen is one long run).
+template <bool IND = false>
 __global__ __launch_bounds__(256) void k_skip_scan(CavlcParams C0)
 {
-    const CavlcParams C = batch_view(C0, blockIdx.x);
+    const CavlcParams C = batch_view<IND>(C0, blockIdx.x);
     __shared__ int s_last[256];
     const int t = threadIdx.x;
     const int per = (C.mb_end - C.mb_first + 255) / 256;
@@ -445,11 +450,11 @@ __global__ __launch_bounds__(256) void k_skip_scan(CavlcParams C0)
     if (t == 255) C.prevcoded[C.mb_end] = s_last[255];
 }
 
-template <bool WRITE>
+template <bool WRITE, bool IND = false>
 __global__ __launch_bounds__(64) void k_cavlc(CavlcParams C0)
 {
     __builtin_amdgcn_s_setprio(1);
-    const CavlcParams C = batch_view(C0, blockIdx.y);
+    const CavlcParams C = batch_view<IND>(C0, blockIdx.y);
     const int lane = threadIdx.x, slot = lane & 31;
     const int mbi = C.mb_first + blockIdx.x * 2 + (lane >> 5);
     const bool live = mbi < C.mb_end;
@@ -517,17 +522,20 @@ struct SliceInfo {       // lives in pinned host memory, written by the device
 enum { SCAN_NT = 256 };
 // H: the picture's slice header; Hpcm: the same with disable_deblocking_filter_idc 1, taken when the picture holds an I_PCM
 // macroblock (anypcm[picture] == pic_serial): such a picture is not loop-filtered.
+// IND: blockIdx.x / nsl is a POSITION of the step; H / Hpcm are laid out by position, everything else by batch item
+template <bool IND = false>
 __global__ __launch_bounds__(SCAN_NT) void k_bit_scan(CavlcParams C0, HdrBatch H, HdrBatch Hpcm, const unsigned* anypcm, unsigned pic_serial, SliceInfo* info0,
                                                    const uint16_t* me_cost0, int nsl, int sl0, unsigned slice_cap)
 {   // nsl slices of this instance's band per picture, the first of them is slice sl0 of the picture
     __builtin_amdgcn_s_setprio(1);
-    const int item = blockIdx.x, pic = item / nsl, sl = sl0 + item - pic * nsl;
+    const int pos = blockIdx.x / nsl, sl = sl0 + blockIdx.x - pos * nsl;
+    const int pic = batch_item<IND>(C0.itemtab, pos), item = pic * nsl + (sl - sl0);
     const CavlcParams C = batch_view(C0, pic);
     const int mb0 = sl * C.sl.rows * C.mbw, mb1 = min(C.nmb, mb0 + C.sl.rows * C.mbw), cnt = mb1 - mb0;
     // slice_header(): first_mb_in_slice is written here, the rest (the same for every slice of the picture) comes from the host
     const bool pcm_pic = anypcm[pic] == pic_serial;
-    const unsigned long long hdr_bits = pcm_pic ? Hpcm.bits[pic] : H.bits[pic];
-    const int hdr_rest = pcm_pic ? Hpcm.len[pic] : H.len[pic];
+    const unsigned long long hdr_bits = pcm_pic ? Hpcm.bits[pos] : H.bits[pos];
+    const int hdr_rest = pcm_pic ? Hpcm.len[pos] : H.len[pos];
     BitCount fl;
     fl.init(0);
     put_ue(fl, (unsigned)mb0);
@@ -613,10 +621,12 @@ __global__ __launch_bounds__(SCAN_NT) void k_bit_scan(CavlcParams C0, HdrBatch H
 
 // Copy the payload of one slice to the pinned access unit buffer, count emulation-prevention sites, publish
 // SliceInfo to pinned host memory and leave the device bit buffer zeroed for its next use (one workgroup per slice).
+template <bool IND = false>
 __global__ __launch_bounds__(SCAN_NT) void k_pack(uint8_t* bitbuf0, size_t st_bitbuf_bytes, uint8_t* dst0, size_t st_dst, const SliceInfo* info0,
-                                               SliceInfo* host_info0, int nsl, int sl0, unsigned slice_cap)
+                                               SliceInfo* host_info0, int nsl, int sl0, unsigned slice_cap, const uint32_t* itemtab)
 {
-    const int item = blockIdx.x, pic = item / nsl, sl = sl0 + item - pic * nsl;
+    const int pos = blockIdx.x / nsl, sl = sl0 + blockIdx.x - pos * nsl;
+    const int pic = batch_item<IND>(itemtab, pos), item = pic * nsl + (sl - sl0);
     uint8_t* bitbuf = bitbuf0 + (size_t)pic * st_bitbuf_bytes + (size_t)sl * slice_cap;
     uint8_t* dst = dst0 + (size_t)pic * st_dst + (size_t)sl * slice_cap;
     const SliceInfo* info = info0 + item;

@@ -203,6 +203,9 @@ struct DbRowParams {
     size_t st_y, st_c, st_handoff;   // bytes, bytes, u64 words
     int st_mb;
     int row0;            // first macroblock row of this instance's band (blockIdx.x counts from it)
+    // indirect launches (IND = true, dev_common.h item_ref): position -> item, its ring slot and its QP; d.pl[] = plane bases
+    const uint32_t* itemtab;
+    size_t st_ring_y, st_ring_c;
 };
 
 // One edge, one line of samples held in registers, branch-free so that luma and
@@ -249,22 +252,31 @@ enum { DR_LP = 40, DR_CP = 24 };  // LDS pitches; luma tile cols -16..15 (+4 pad
 // the chroma QPs go through chroma_qp_index_offset, indexA / indexB through the slice's filter offsets - three threshold
 // sets per macroblock (left edge, top edge, inner edges), looked up in LDS copies of Tables 8-15 / 8-16.  PERMB = false is
 // the encoder's form: one set per picture, prepared on the host.
-template <bool BS4, bool PERMB = false>
+template <bool BS4, bool PERMB = false, bool IND = false>
 __global__ __launch_bounds__(64) void k_deblock_rows(DbRowParams R)
 {
     // dependency-bound: when a throughput kernel of another stream shares the SIMD, this wave issues first
     __builtin_amdgcn_s_setprio(3);
-    if (R.anybs[blockIdx.y] != R.serial) return;   // no edge of this picture is filtered: nothing to do, nobody waits
-    if (R.anypcm[blockIdx.y] == R.pic_serial) return;
-    if (R.need_intra != 0 && (R.anyintra[blockIdx.y] == R.pic_serial) != (R.need_intra > 0)) return;
+    const int bitem = batch_item<IND>(R.itemtab, blockIdx.y);
+    if (R.anybs[bitem] != R.serial) return;   // no edge of this picture is filtered: nothing to do, nobody waits
+    if (R.anypcm[bitem] == R.pic_serial) return;
+    if (R.need_intra != 0 && (R.anyintra[bitem] == R.pic_serial) != (R.need_intra > 0)) return;
     DbParams D = R.d;
     {
-        const size_t g = blockIdx.y;
+        const size_t g = (size_t)bitem;
         D.pl[0] += g * R.st_y; D.pl[1] += g * R.st_c; D.pl[2] += g * R.st_c; D.mb += g * R.st_mb;
+        if constexpr (IND) {   // the item's own ring slot and its own QP's thresholds (Tables 8-16 / 8-17, chroma through Table 8-15)
+            const ItemRef it = item_ref(R.itemtab, blockIdx.y);
+            D.pl[0] += (size_t)it.cur * R.st_ring_y; D.pl[1] += (size_t)it.cur * R.st_ring_c; D.pl[2] += (size_t)it.cur * R.st_ring_c;
+            const int qpc = c_chroma_qp[it.qp];
+            D.alpha_y = c_alpha[it.qp]; D.beta_y = c_beta[it.qp]; D.alpha_c = c_alpha[qpc]; D.beta_c = c_beta[qpc];
+#pragma unroll
+            for (int i = 0; i < 3; i++) { D.tc0_y[i] = c_tc0[it.qp][i]; D.tc0_c[i] = c_tc0[qpc][i]; }
+        }
         if (PERMB) D.mbqp += g * R.st_mb;
     }
-    u64* const handoff = R.handoff + (size_t)blockIdx.y * R.st_handoff;
-    const uint32_t* const bsw = R.bs + (size_t)blockIdx.y * R.st_mb * 8;
+    u64* const handoff = R.handoff + (size_t)bitem * R.st_handoff;
+    const uint32_t* const bsw = R.bs + (size_t)bitem * R.st_mb * 8;
     const int lane = threadIdx.x, my = R.row0 + blockIdx.x, cs = D.cw / 2;   // (row0: first row of this instance's band)
     // a slice's rows form a wavefront of their own: its first row waits for nobody (no edge to the slice above is
     // filtered), its last row stores all sixteen sample rows itself
@@ -477,20 +489,29 @@ __global__ __launch_bounds__(64) void k_deblock_rows(DbRowParams R)
 // (pictures of one slice; MI355X_H264_PAIR_FILTER=N moves the threshold, 0 turns it off); smaller batches, the latency mode and
 // the decoder use the row form.  tests/test_gpu_parity.py runs both forms at batch 8 and this one forced on single pictures.
 // ===========================================================================
-template <bool BS4>
+template <bool BS4, bool IND = false>
 __global__ __launch_bounds__(64) void k_deblock_pairs(DbRowParams R)
 {
     __builtin_amdgcn_s_setprio(3);
-    if (R.anybs[blockIdx.y] != R.serial) return;
-    if (R.anypcm[blockIdx.y] == R.pic_serial) return;
-    if (R.need_intra != 0 && (R.anyintra[blockIdx.y] == R.pic_serial) != (R.need_intra > 0)) return;
+    const int bitem = batch_item<IND>(R.itemtab, blockIdx.y);
+    if (R.anybs[bitem] != R.serial) return;
+    if (R.anypcm[bitem] == R.pic_serial) return;
+    if (R.need_intra != 0 && (R.anyintra[bitem] == R.pic_serial) != (R.need_intra > 0)) return;
     DbParams D = R.d;
     {
-        const size_t g = blockIdx.y;
+        const size_t g = (size_t)bitem;
         D.pl[0] += g * R.st_y; D.pl[1] += g * R.st_c; D.pl[2] += g * R.st_c; D.mb += g * R.st_mb;
+        if constexpr (IND) {   // the item's own ring slot and its own QP's thresholds (Tables 8-16 / 8-17, chroma through Table 8-15)
+            const ItemRef it = item_ref(R.itemtab, blockIdx.y);
+            D.pl[0] += (size_t)it.cur * R.st_ring_y; D.pl[1] += (size_t)it.cur * R.st_ring_c; D.pl[2] += (size_t)it.cur * R.st_ring_c;
+            const int qpc = c_chroma_qp[it.qp];
+            D.alpha_y = c_alpha[it.qp]; D.beta_y = c_beta[it.qp]; D.alpha_c = c_alpha[qpc]; D.beta_c = c_beta[qpc];
+#pragma unroll
+            for (int i = 0; i < 3; i++) { D.tc0_y[i] = c_tc0[it.qp][i]; D.tc0_c[i] = c_tc0[qpc][i]; }
+        }
     }
-    u64* const handoff = R.handoff + (size_t)blockIdx.y * R.st_handoff;
-    const uint32_t* const bsw = R.bs + (size_t)blockIdx.y * R.st_mb * 8;
+    u64* const handoff = R.handoff + (size_t)bitem * R.st_handoff;
+    const uint32_t* const bsw = R.bs + (size_t)bitem * R.st_mb * 8;
     const int lane = threadIdx.x, half = lane >> 5, hl = lane & 31, cs = D.cw / 2;
     const int rowA = R.row0 + 2 * (int)blockIdx.x, rowB = rowA + 1;
     const bool hasB = rowB < D.mbh;                 // (an odd number of rows: the last wave has an upper row only)

@@ -513,11 +513,12 @@ struct IntraRowParams {
     unsigned serial;
 };
 
+template <bool IND = false>
 __global__ __launch_bounds__(64) void k_intra_rows(IntraRowParams R)
 {
     __builtin_amdgcn_s_setprio(3);   // dependency-bound row wavefront: issue ahead of co-resident throughput kernels
-    const FrameParams P = batch_view(R.p, blockIdx.y);
-    unsigned long long* const handoff = R.handoff + (size_t)blockIdx.y * R.st_handoff;
+    const FrameParams P = batch_view<IND>(R.p, blockIdx.y);
+    unsigned long long* const handoff = R.handoff + (size_t)batch_item<IND>(R.p.itemtab, blockIdx.y) * R.st_handoff;
     const int lane = threadIdx.x, my = P.band.row0 + blockIdx.x;
     const bool top = P.sl.has_top(my);   // first row of a slice: nothing above to wait for, the slices' wavefronts run side by side
     __shared__ IntraLds S;
@@ -611,13 +612,13 @@ __global__ __launch_bounds__(64) void k_intra_rows(IntraRowParams R)
 // ===========================================================================
 // DEC (the decoder peer): the intra macroblocks are those of intra type in the MbInfo the host parser filled (every macroblock
 // of an I picture); they are reconstructed from the given modes and levels.
-template <bool DEC>
+template <bool DEC, bool IND = false>
 __global__ __launch_bounds__(64) void k_pintra_rows(IntraRowParams R)
 {
     __builtin_amdgcn_s_setprio(3);
-    const FrameParams P = batch_view(R.p, blockIdx.y);
+    const FrameParams P = batch_view<IND>(R.p, blockIdx.y);
     if (!DEC && *P.anyintra != P.pic_serial) return;
-    unsigned long long* const handoff = R.handoff + (size_t)blockIdx.y * R.st_handoff;
+    unsigned long long* const handoff = R.handoff + (size_t)batch_item<IND>(R.p.itemtab, blockIdx.y) * R.st_handoff;
     const int lane = threadIdx.x, my = P.band.row0 + blockIdx.x, cs = P.cw / 2;
     const bool top = P.sl.has_top(my);
     __shared__ IntraLds S;

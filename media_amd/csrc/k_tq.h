@@ -179,10 +179,11 @@ __device__ __forceinline__ void tq_chroma8(const FrameParams& P, const int first
         }
 }
 
+template <bool IND = false>
 __global__ __launch_bounds__(64) void k_tq(FrameParams P0)
 {
     __builtin_amdgcn_s_setprio(2);   // short and on the way to the loop filter: ahead of another stream's motion search
-    const FrameParams P = batch_view(P0, blockIdx.y);
+    const FrameParams P = batch_view<IND>(P0, blockIdx.y);
     const int lane = threadIdx.x;
     const int nmb = P.mbw * P.band.rows, mb0 = P.band.row0 * P.mbw, end = mb0 + nmb;
     const int first = mb0 + 8 * xcd_mb_index(blockIdx.x, (nmb + 7) >> 3);
@@ -292,10 +293,11 @@ __device__ constexpr int pos_class8(int pos)
          : ((i % 4 == 0 && (j & 1)) || ((i & 1) && j % 4 == 0)) ? 3 : ((i % 4 == 0 && j % 4 == 2) || (i % 4 == 2 && j % 4 == 0)) ? 4 : 5;
 }
 
+template <bool IND = false>
 __global__ __launch_bounds__(64) void k_tq8(FrameParams P0)
 {
     __builtin_amdgcn_s_setprio(2);
-    const FrameParams P = batch_view(P0, blockIdx.y);
+    const FrameParams P = batch_view<IND>(P0, blockIdx.y);
     const int lane = threadIdx.x;
     const int nmb = P.mbw * P.band.rows, mb0 = P.band.row0 * P.mbw, end = mb0 + nmb;
     const int first = mb0 + 16 * xcd_mb_index(blockIdx.x, (nmb + 15) >> 4);
@@ -414,10 +416,11 @@ __global__ __launch_bounds__(64) void k_tq8(FrameParams P0)
 // 8.4.1.3 with vectors kept per 8x8 quadrant (mvq), the granularity of the smallest partition: a neighbouring partition
 // is the quadrant (qx, qy) of its macroblock; A left of the partition's top-left sample, B above it, C above-right of its
 // top-right sample or, when that is outside or later in decoding order, D above-left (6.4.11.7).
+template <bool IND = false>
 __global__ __launch_bounds__(64) void k_mvpred(FrameParams P0)
 {
     __builtin_amdgcn_s_setprio(1);
-    const FrameParams P = batch_view(P0, blockIdx.y);
+    const FrameParams P = batch_view<IND>(P0, blockIdx.y);
     const int nmb = P.mbw * P.band.rows, mb0 = P.band.row0 * P.mbw;
     const int i = blockIdx.x * 64 + threadIdx.x;
     if (i >= nmb) return;

@@ -129,6 +129,17 @@ void fill_quant(Quant& q, int qp)
     for (int c = 0; c < 6; c++) { q.mf8[c] = m8[qp % 6][c]; q.ls8[c] = 16 * v8[qp % 6][c]; }
 }
 
+// everything one picture QP fixes for the kernels (FrameParams qy / qc / lambda / sad_nz; QpEntry of the indirect launches)
+void fill_qp(Quant& qy, Quant& qc, int& lambda, int& sad_nz, int qp)
+{
+    fill_quant(qy, qp);
+    fill_quant(qc, h_chroma_qp[qp]);
+    lambda = h_lambda[qp];
+    // k_me's shortcut for the "quantises to nothing" test: 64 sqrt(sum over the 16 positions of t^2 / (n_i n_j)), rounded up
+    const double t0 = qy.thr_inter[0], t1 = qy.thr_inter[1], t2 = qy.thr_inter[2];
+    sad_nz = (int)std::ceil(64.0 * std::sqrt(4 * t0 * t0 / 16.0 + 4 * t1 * t1 / 100.0 + 8 * t2 * t2 / 40.0)) + 1;
+}
+
 constexpr int NSLOT = 3;          // access-unit slots in flight
 
 struct Slot {
@@ -168,6 +179,12 @@ struct mi355x_h264_encoder {
     enum { MAX_REFS = 3 };
     int nrefs = 1, nbuf = 2;                 // reference frames searched (config.refs) and reconstruction buffers (nrefs + 1)
     uint8_t* d_planes[MAX_REFS + 1][3] = {{nullptr}};  // ring: [index][plane]; `cur` is written, cur - 1 - r (mod nbuf) is ref_idx_l0 r
+    // the planes lie [batch item][ring slot]: d_planes[b][p] = d_plane_base[p] + b * st_ring, st_y / st_c (the item strides) = nbuf
+    // ring strides - so that an indirect launch (stream hub) can address every item's OWN ring slot from one base pointer
+    uint8_t* d_plane_base[3] = {nullptr, nullptr, nullptr};
+    size_t st_ring_y = 0, st_ring_c = 0;
+    QpEntry* d_qtab = nullptr;               // [52] quantiser constants by QP (indirect launches)
+    int nslots = NSLOT;                      // access-unit slots allocated (the hub's engine needs one)
     uint8_t* d_pre[3] = {nullptr};           // copy of the reconstruction before the loop filter (debug)
     int cur = 0;                             // index written by the picture being encoded
     bool pair_filter = true;                 // two macroblock rows per wave in the loop filter for lockstep batches of pair_min_batch pictures or more
@@ -270,19 +287,20 @@ void build_parameter_sets(mi355x_h264_encoder* e)
 // is written by k_bit_scan); returns bit count (< 64)
 int avail_refs(const mi355x_h264_encoder* e, bool idr) { return idr ? 0 : std::min(e->nrefs, e->frame_in_gop); }
 
-int build_slice_header(const mi355x_h264_encoder* e, bool idr, int idr_id, bool no_filter, uint64_t* bits)
+// frame_num, qp, nact (num_ref_idx_l0_active of a P slice): the picture's own - one per batch item in the stream hub's steps
+int build_slice_header(const mi355x_h264_encoder* e, bool idr, int idr_id, bool no_filter, int frame_num, int qp, int nact, uint64_t* bits)
 {
     HostBits h;
     h.ue(idr ? 7 : 5);
     h.ue(0);
-    h.put(8, (uint32_t)e->frame_num);
+    h.put(8, (uint32_t)frame_num);
     if (idr) h.ue((uint32_t)idr_id);
     if (!idr) {   // num_ref_idx_active_override_flag: the first pictures after an IDR have fewer reference pictures than the PPS announces
-        if (avail_refs(e, false) != e->nrefs) { h.put(1, 1); h.ue((uint32_t)avail_refs(e, false) - 1); } else h.put(1, 0);
+        if (nact != e->nrefs) { h.put(1, 1); h.ue((uint32_t)nact - 1); } else h.put(1, 0);
         h.put(1, 0);   // ref_pic_list_modification_flag_l0
     }
     if (idr) { h.put(1, 0); h.put(1, 0); } else h.put(1, 0);
-    h.se(e->qp - 26);
+    h.se(qp - 26);
     no_filter = no_filter || e->cfg.disable_deblock;            // (a picture with an I_PCM macroblock is not filtered)
     h.ue(no_filter ? 1 : e->nsl > 1 ? 2 : 0);   // several slices: no filtering across slice edges, the bands stay independent
     if (!no_filter) { h.se(0); h.se(0); }
@@ -313,91 +331,113 @@ struct StatScope {
     }
 };
 
-// enqueue everything for one picture whose I420 samples are at d_src
-int submit(mi355x_h264_encoder* e, const uint8_t* d_src, size_t src_item_stride, int slot_idx, bool nv12)
+// ---- one lockstep step: which pictures, where from, on which streams ----
+// Direct (items == nullptr): the n = e->G batch items of the encoder, one QP, one ring position, consecutive idr_pic_ids - the
+// closed-GOP batch of mi355x_h264_encode_gops_device and the single-picture calls.  Indirect (the stream hub below): position k
+// of the grid is picture items[k] - its own batch item, ring slot, QP, frame_num and idr_pic_id; the kernels are the IND = true
+// instantiations and read d_itemtab.  A step holds pictures of ONE type (IDR or P): the two run different kernels.
+struct ItemPic { int item, cur, qp, frame_num, idr_id; };
+struct Step {
+    const uint8_t* d_src = nullptr; size_t src_item_stride = 0; bool nv12 = false; bool idr = false;
+    int n = 1;
+    const ItemPic* items = nullptr;
+    const uint32_t* d_itemtab = nullptr;
+    hipStream_t st = nullptr, ec = nullptr;
+    hipEvent_t recon_ready = nullptr, entropy_done = nullptr, done = nullptr;
+    unsigned* h_err = nullptr;
+    Slot* slot = nullptr;   // payload / access-unit buffers (laid out by batch item) and, with stats on, the event list
+    // out: where the access units lie in slot->h_au
+    size_t au_start = 0, payload_off = 0;
+    int nal_hdr = 0;
+};
+
+#define LAUNCH2(ind, KT, KF, grid, block, stream, ...)                                   \
+    do {                                                                                 \
+        if (ind) hipLaunchKernelGGL(KT, grid, block, 0, stream, __VA_ARGS__);            \
+        else hipLaunchKernelGGL(KF, grid, block, 0, stream, __VA_ARGS__);                \
+    } while (0)
+
+int submit_step(mi355x_h264_encoder* e, Step& T)
 {
-    Slot& S = e->slots[slot_idx];
-    const bool idr = e->force_idr || e->frames == 0 || e->frame_in_gop >= e->cfg.gop;
-    if (idr) { e->frame_in_gop = 0; e->frame_num = 0; }
-    e->force_idr = 0;
+    Slot& S = *T.slot;
+    const bool idr = T.idr, ind = T.items != nullptr;
     const int cur = e->cur;
     FrameParams P{};
-    P.src = d_src; P.src_nv12 = nv12 ? 1 : 0; P.w = e->cfg.width; P.h = e->cfg.height;
+    P.src = T.d_src; P.src_nv12 = T.nv12 ? 1 : 0; P.w = e->cfg.width; P.h = e->cfg.height;
     P.cw = e->cw; P.ch = e->ch; P.mbw = e->mbw; P.mbh = e->mbh;
-    P.nref = std::max(1, avail_refs(e, idr));
+    P.nref = ind ? 1 : std::max(1, avail_refs(e, idr));
     for (int p = 0; p < 3; p++) {
-        P.rec[p] = e->d_planes[cur][p];
+        P.rec[p] = ind ? e->d_plane_base[p] : e->d_planes[cur][p];
         for (int r = 0; r < mi355x_h264_encoder::MAX_REFS; r++) P.refs[r][p] = e->d_planes[(cur + e->nbuf - 1 - std::min(r, e->nrefs - 1)) % e->nbuf][p];
         P.ref[p] = P.refs[0][p];
     }
+    P.itemtab = T.d_itemtab; P.qtab = e->d_qtab; P.st_ring_y = e->st_ring_y; P.st_ring_c = e->st_ring_c; P.nbuf = e->nbuf;
     P.mb = e->d_mb; P.levels = e->d_levels; P.mvd = e->d_mvd; P.mvq = e->d_mvq; P.aux = e->d_aux; P.me_cost = e->d_me_cost; P.me_total = e->d_me_total; P.pmv = e->d_pmv;
-    P.st_src = src_item_stride; P.st_y = e->st_y; P.st_c = e->st_c; P.st_mb = e->nmb; P.sl = e->sl;
+    P.st_src = T.src_item_stride; P.st_y = e->st_y; P.st_c = e->st_c; P.st_mb = e->nmb; P.sl = e->sl;
     P.band.row0 = e->b_row0; P.band.rows = e->b_rows;
     P.mbdiv.inv = e->mbw > 1 ? (unsigned)(0x100000000ull / (unsigned)e->mbw) + 1u : 0u;
     e->pic_serial = e->pic_serial == 0xFFFFFFFFu ? 1u : e->pic_serial + 1u;
     P.anypcm = e->d_anypcm; P.anyintra = e->d_anyintra; P.pic_serial = e->pic_serial;
-    const unsigned G = (unsigned)e->G;
-    fill_quant(P.qy, e->qp);
-    fill_quant(P.qc, h_chroma_qp[e->qp]);
-    P.lambda = h_lambda[e->qp];
-    {   // k_me's shortcut for the "quantises to nothing" test: 64 sqrt(sum over the 16 positions of t^2 / (n_i n_j)), rounded up
-        const double t0 = P.qy.thr_inter[0], t1 = P.qy.thr_inter[1], t2 = P.qy.thr_inter[2];
-        P.sad_nz = (int)std::ceil(64.0 * std::sqrt(4 * t0 * t0 / 16.0 + 4 * t1 * t1 / 100.0 + 8 * t2 * t2 / 40.0)) + 1;
-    }
-    hipStream_t st = e->stream;
+    const unsigned pic_serial = e->pic_serial;
+    const unsigned G = (unsigned)T.n;
+    fill_qp(P.qy, P.qc, P.lambda, P.sad_nz, e->qp);   // (indirect launches take these from qtab by the item's own QP)
+    hipStream_t st = T.st;
+    auto next_serial = [&]() { e->serial = e->serial == 0xFFFFFFFFu ? 1 : e->serial + 1; return e->serial; };
 
-    // (the payload buffer of this slot was left zeroed by the k_pack of its previous use)
+    // (the payload buffers of the items were left zeroed by the k_pack of their previous use)
 
     if (idr) {
-        StatScope sc(e, &S, MI355X_H264_K_INTRA, (uint32_t)(e->diag_mode ? e->mbw + e->mbh - 1 : 1), (uint32_t)(e->b_nmb * e->G));
-        hipLaunchKernelGGL(k_i4_decide, dim3((e->b_nmb + 3) / 4, G), dim3(64), 0, st, P, 0);   // Intra4x4 or Intra16x16, and the block modes: from the source alone
-        if (e->diag_mode) {
+        StatScope sc(e, &S, MI355X_H264_K_INTRA, (uint32_t)(e->diag_mode ? e->mbw + e->mbh - 1 : 1), (uint32_t)(e->b_nmb * T.n), st);
+        LAUNCH2(ind, k_i4_decide<true>, k_i4_decide<false>, dim3((e->b_nmb + 3) / 4, G), dim3(64), st, P, 0);   // Intra4x4 or Intra16x16, and the block modes: from the source alone
+        if (e->diag_mode && !ind) {
             for (int s = 0; s < e->mbw + e->mbh - 1; s++) {
                 const int ymin = std::max(0, s - e->mbw + 1), ymax = std::min(e->mbh - 1, s);
                 hipLaunchKernelGGL(k_intra_diag, dim3(ymax - ymin + 1, G), dim3(64), 0, st, P, s);
             }
         } else {
             IntraRowParams R{};
-            R.p = P; R.handoff = e->d_handoff; R.st_handoff = e->st_handoff; R.err = S.h_err;
-            e->serial = e->serial == 0xFFFFFFFFu ? 1 : e->serial + 1;
-            R.serial = e->serial;
-            hipLaunchKernelGGL(k_intra_rows, dim3(e->b_rows, G), dim3(64), 0, st, R);
+            R.p = P; R.handoff = e->d_handoff; R.st_handoff = e->st_handoff; R.err = T.h_err;
+            R.serial = next_serial();
+            LAUNCH2(ind, k_intra_rows<true>, k_intra_rows<false>, dim3(e->b_rows, G), dim3(64), st, R);
         }
     } else {
-        { StatScope sc(e, &S, MI355X_H264_K_ME, (uint32_t)P.nref, (uint32_t)(e->b_nmb * e->G));
+        { StatScope sc(e, &S, MI355X_H264_K_ME, (uint32_t)P.nref, (uint32_t)(e->b_nmb * T.n), st);
           FrameParams Q = P;   // one launch per reference picture (config.refs): Q.ref = the planes of ref_idx_l0 = Q.rf
           Q.rf_last = P.nref - 1;
           for (int r = 0; r < P.nref; r++) {
               Q.rf = r;
               for (int p = 0; p < 3; p++) Q.ref[p] = P.refs[r][p];
-              hipLaunchKernelGGL(k_me, dim3(e->b_nmb, G), dim3(64), 0, st, Q);
+              LAUNCH2(ind, k_me<true>, k_me<false>, dim3(e->b_nmb, G), dim3(64), st, Q);
           } }
-        { StatScope sc(e, &S, MI355X_H264_K_PMB, 1, (uint32_t)(e->b_nmb * e->G));
-          if (e->cfg.profile_idc == 100) hipLaunchKernelGGL(k_tq8, dim3((e->b_nmb + 15) / 16, G), dim3(64), 0, st, P);   // High: 8x8 transform, sixteen macroblocks per wave
-          else hipLaunchKernelGGL(k_tq, dim3((e->b_nmb + 7) / 8, G), dim3(64), 0, st, P); }   // one wave per eight macroblocks
+        { StatScope sc(e, &S, MI355X_H264_K_PMB, 1, (uint32_t)(e->b_nmb * T.n), st);
+          if (e->cfg.profile_idc == 100) LAUNCH2(ind, k_tq8<true>, k_tq8<false>, dim3((e->b_nmb + 15) / 16, G), dim3(64), st, P);   // High: 8x8 transform, sixteen macroblocks per wave
+          else LAUNCH2(ind, k_tq<true>, k_tq<false>, dim3((e->b_nmb + 7) / 8, G), dim3(64), st, P); }   // one wave per eight macroblocks
         {   // macroblocks the motion search handed to the intra pass (returns at once when there are none)
             IntraRowParams R{};
-            R.p = P; R.handoff = e->d_handoff; R.st_handoff = e->st_handoff; R.err = S.h_err;
-            e->serial = e->serial == 0xFFFFFFFFu ? 1 : e->serial + 1;
-            R.serial = e->serial;
-            hipLaunchKernelGGL(k_i4_decide, dim3((e->b_nmb + 3) / 4, G), dim3(64), 0, st, P, 1);
-            hipLaunchKernelGGL(k_pintra_rows<false>, dim3(e->b_rows, G), dim3(64), 0, st, R);
+            R.p = P; R.handoff = e->d_handoff; R.st_handoff = e->st_handoff; R.err = T.h_err;
+            R.serial = next_serial();
+            LAUNCH2(ind, k_i4_decide<true>, k_i4_decide<false>, dim3((e->b_nmb + 3) / 4, G), dim3(64), st, P, 1);
+            LAUNCH2(ind, (k_pintra_rows<false, true>), (k_pintra_rows<false, false>), dim3(e->b_rows, G), dim3(64), st, R);
         }
     }
-    // entropy coding
+    // entropy coding: slice headers per position
     HdrBatch H{}, Hpcm{};
-    for (int g = 0; g < e->G; g++) {
+    for (int g = 0; g < T.n; g++) {
         uint64_t hdr = 0;
-        H.len[g] = (unsigned char)build_slice_header(e, idr, (e->idr_id + g * e->idr_step) & 0xFF, false, &hdr);
+        const int fn = ind ? T.items[g].frame_num : e->frame_num, qp = ind ? T.items[g].qp : e->qp;
+        const int id = ind ? T.items[g].idr_id : ((e->idr_id + g * e->idr_step) & 0xFF);
+        const int nact = ind ? (idr ? 0 : 1) : avail_refs(e, idr);
+        H.len[g] = (unsigned char)build_slice_header(e, idr, id, false, fn, qp, nact, &hdr);
         H.bits[g] = hdr;
-        Hpcm.len[g] = (unsigned char)build_slice_header(e, idr, (e->idr_id + g * e->idr_step) & 0xFF, true, &hdr);
+        Hpcm.len[g] = (unsigned char)build_slice_header(e, idr, id, true, fn, qp, nact, &hdr);
         Hpcm.bits[g] = hdr;
     }
     // entropy coding needs only levels / MbInfo, the loop filter the reconstruction and the boundary strengths
     // (a small launch of its own on this stream): the two run side by side and the filter never waits for the coder
-    hipStream_t ec = e->stream_ec;
+    hipStream_t ec = T.ec;
     CavlcParams C{};
-    C.mb = e->d_mb; C.levels = e->d_levels; C.mvd = e->d_mvd; C.mbw = e->mbw; C.nmb = e->nmb; C.p_slice = idr ? 0 : 1; C.t8x8 = e->cfg.profile_idc == 100 ? 1 : 0; C.nref = avail_refs(e, idr); C.sl = e->sl;
+    C.mb = e->d_mb; C.levels = e->d_levels; C.mvd = e->d_mvd; C.mbw = e->mbw; C.nmb = e->nmb; C.p_slice = idr ? 0 : 1; C.t8x8 = e->cfg.profile_idc == 100 ? 1 : 0;
+    C.nref = ind ? (idr ? 0 : 1) : avail_refs(e, idr); C.sl = e->sl;
     C.mb_first = e->b_row0 * e->mbw; C.mb_end = C.mb_first + e->b_nmb;
     C.slice_cap = (unsigned)e->slice_cap;
     C.mbdiv = P.mbdiv;
@@ -405,52 +445,56 @@ int submit(mi355x_h264_encoder* e, const uint8_t* d_src, size_t src_item_stride,
     C.bs = (uint8_t*)e->d_bs; C.prevcoded = e->d_prevcoded;
     C.st_mb = e->nmb; C.st_bitbuf = e->st_bitbuf_bytes / 4;
     C.aux = e->d_aux; C.mvq = e->d_mvq;
-    C.src = d_src; C.w = e->cfg.width; C.h = e->cfg.height; C.src_nv12 = nv12 ? 1 : 0; C.st_src = src_item_stride;
+    C.src = T.d_src; C.w = e->cfg.width; C.h = e->cfg.height; C.src_nv12 = T.nv12 ? 1 : 0; C.st_src = T.src_item_stride;
+    C.itemtab = T.d_itemtab;
     const int cavlc_grid = (e->b_nmb + 1) / 2;
     unsigned db_serial = 0;
     if (!e->cfg.disable_deblock) {   // (the diagonal debug form of the filter reads the strengths too)
-        e->serial = e->serial == 0xFFFFFFFFu ? 1 : e->serial + 1;   // the serial the loop filter of this picture will run under
-        db_serial = e->serial;
-        hipLaunchKernelGGL(k_bs, dim3(cavlc_grid, G), dim3(64), 0, st, C, e->d_anybs, db_serial);
+        db_serial = next_serial();   // the serial the loop filter of this picture will run under
+        LAUNCH2(ind, k_bs<true>, k_bs<false>, dim3(cavlc_grid, G), dim3(64), st, C, e->d_anybs, db_serial);
     }
-    HIPCHK(e, hipEventRecord(S.recon_ready, st));
-    HIPCHK(e, hipStreamWaitEvent(ec, S.recon_ready, 0));
+    const bool fork = ec != st;
+    if (fork) {
+        HIPCHK(e, hipEventRecord(T.recon_ready, st));
+        HIPCHK(e, hipStreamWaitEvent(ec, T.recon_ready, 0));
+    }
     {
-        StatScope sc(e, &S, MI355X_H264_K_CAVLC, 4, (uint32_t)(e->b_nmb * e->G), ec);
+        StatScope sc(e, &S, MI355X_H264_K_CAVLC, 4, (uint32_t)(e->b_nmb * T.n), ec);
         const int grid = cavlc_grid;
         if (!idr) {
-            hipLaunchKernelGGL(k_mvpred, dim3((e->b_nmb + 63) / 64, G), dim3(64), 0, ec, P);   // vectors + coded_block_pattern are final: mvd, P_Skip
-            hipLaunchKernelGGL(k_skip_scan, dim3(G), dim3(256), 0, ec, C);
+            LAUNCH2(ind, k_mvpred<true>, k_mvpred<false>, dim3((e->b_nmb + 63) / 64, G), dim3(64), ec, P);   // vectors + coded_block_pattern are final: mvd, P_Skip
+            LAUNCH2(ind, k_skip_scan<true>, k_skip_scan<false>, dim3(G), dim3(256), ec, C);
         }
-        hipLaunchKernelGGL(k_cavlc<false>, dim3(grid, G), dim3(64), 0, ec, C);
-        hipLaunchKernelGGL(k_bit_scan, dim3(G * (unsigned)e->b_nsl), dim3(SCAN_NT), 0, ec, C, H, Hpcm, (const unsigned*)e->d_anypcm, e->pic_serial, S.d_info, e->d_me_cost,
-                           e->b_nsl, e->b_sl0, (unsigned)e->slice_cap);
-        hipLaunchKernelGGL(k_cavlc<true>, dim3(grid, G), dim3(64), 0, ec, C);
+        LAUNCH2(ind, (k_cavlc<false, true>), (k_cavlc<false, false>), dim3(grid, G), dim3(64), ec, C);
+        LAUNCH2(ind, k_bit_scan<true>, k_bit_scan<false>, dim3(G * (unsigned)e->b_nsl), dim3(SCAN_NT), ec, C, H, Hpcm, (const unsigned*)e->d_anypcm, pic_serial, S.d_info, e->d_me_cost,
+                e->b_nsl, e->b_sl0, (unsigned)e->slice_cap);
+        LAUNCH2(ind, (k_cavlc<true, true>), (k_cavlc<true, false>), dim3(grid, G), dim3(64), ec, C);
         // access unit layout in the pinned buffer: [pad][SPS PPS (IDR only)][00 00 00 01 hdr][payload...];
         // with several slices: the payload of slice s at s * slice_cap, the access unit is put together by finish_item
         const size_t pre = (idr ? e->sps_pps.size() : 0) + 5;
         const size_t pad = (16 - (pre & 15)) & 15;
-        S.au_start = pad;
-        S.payload_off = e->nsl > 1 ? 0 : pad + pre;
-        S.idr = idr;
-        S.nal_hdr = idr ? ((3 << 5) | 5) : ((2 << 5) | 1);
-        hipLaunchKernelGGL(k_pack, dim3(G * (unsigned)e->b_nsl), dim3(SCAN_NT), 0, ec, (uint8_t*)S.d_bitbuf, e->st_bitbuf_bytes, S.h_au + S.payload_off, e->st_au,
-                           (const SliceInfo*)S.d_info, S.h_info, e->b_nsl, e->b_sl0, (unsigned)e->slice_cap);
+        T.au_start = pad;
+        T.payload_off = e->nsl > 1 ? 0 : pad + pre;
+        T.nal_hdr = idr ? ((3 << 5) | 5) : ((2 << 5) | 1);
+        LAUNCH2(ind, k_pack<true>, k_pack<false>, dim3(G * (unsigned)e->b_nsl), dim3(SCAN_NT), ec, (uint8_t*)S.d_bitbuf, e->st_bitbuf_bytes, S.h_au + T.payload_off, e->st_au,
+                (const SliceInfo*)S.d_info, S.h_info, e->b_nsl, e->b_sl0, (unsigned)e->slice_cap, T.d_itemtab);
     }
-    HIPCHK(e, hipEventRecord(S.entropy_done, ec));
-    if (e->keep_pre)
-        for (int p = 0; p < 3; p++)
-            HIPCHK(e, hipMemcpyAsync(e->d_pre[p], e->d_planes[cur][p], (p ? e->st_c : e->st_y) * e->G, hipMemcpyDeviceToDevice, st));
+    if (fork) HIPCHK(e, hipEventRecord(T.entropy_done, ec));
+    if (e->keep_pre && !ind)
+        for (int p = 0; p < 3; p++) {   // (the items' planes lie nbuf ring slots apart: one row of the 2-D copy per item)
+            const size_t ring = p ? e->st_ring_c : e->st_ring_y;
+            HIPCHK(e, hipMemcpy2DAsync(e->d_pre[p], ring, e->d_planes[cur][p], p ? e->st_c : e->st_y, ring, (size_t)e->G, hipMemcpyDeviceToDevice, st));
+        }
     if (!e->cfg.disable_deblock) {
         const int steps = e->mbw + 2 * (e->mbh - 1);
-        StatScope sc(e, &S, MI355X_H264_K_DEBLOCK, (uint32_t)(e->diag_mode ? steps : 1), (uint32_t)(e->b_nmb * e->G));
+        StatScope sc(e, &S, MI355X_H264_K_DEBLOCK, (uint32_t)(e->diag_mode ? steps : 1), (uint32_t)(e->b_nmb * T.n), st);
         DbParams D{};
-        for (int p = 0; p < 3; p++) D.pl[p] = e->d_planes[cur][p];
+        for (int p = 0; p < 3; p++) D.pl[p] = ind ? e->d_plane_base[p] : e->d_planes[cur][p];
         D.mb = e->d_mb; D.cw = e->cw; D.ch = e->ch; D.mbw = e->mbw; D.mbh = e->mbh; D.sl = e->sl; D.bs = (const uint8_t*)e->d_bs;
-        const int qp = e->qp, qpc = h_chroma_qp[qp];
+        const int qp = e->qp, qpc = h_chroma_qp[qp];   // (indirect launches look the item's own QP up on the device)
         D.alpha_y = h_alpha[qp]; D.beta_y = h_beta[qp]; D.alpha_c = h_alpha[qpc]; D.beta_c = h_beta[qpc];
         for (int i = 0; i < 3; i++) { D.tc0_y[i] = h_tc0[qp][i]; D.tc0_c[i] = h_tc0[qpc][i]; }
-        if (e->diag_mode) {
+        if (e->diag_mode && !ind) {
             for (int s = 0; s < steps; s++) {
                 const int ymin = std::max(0, (s - (e->mbw - 1) + 1) >> 1), ymax = std::min(e->mbh - 1, s >> 1);
                 if (ymax < ymin) continue;
@@ -458,31 +502,48 @@ int submit(mi355x_h264_encoder* e, const uint8_t* d_src, size_t src_item_stride,
             }
         } else {
             DbRowParams R{};
-            R.d = D; R.handoff = e->d_handoff; R.err = S.h_err;
+            R.d = D; R.handoff = e->d_handoff; R.err = T.h_err;
             R.st_y = e->st_y; R.st_c = e->st_c; R.st_handoff = e->st_handoff; R.st_mb = e->nmb;
             R.serial = db_serial; R.row0 = e->b_row0;
             R.bs = e->d_bs; R.anybs = e->d_anybs;
-            R.anypcm = e->d_anypcm; R.anyintra = e->d_anyintra; R.pic_serial = e->pic_serial;
+            R.anypcm = e->d_anypcm; R.anyintra = e->d_anyintra; R.pic_serial = pic_serial;
+            R.itemtab = T.d_itemtab; R.st_ring_y = e->st_ring_y; R.st_ring_c = e->st_ring_c;
             // two macroblock rows per wave (k_deblock_pairs) for lockstep batches of pictures of one slice; else one row per wave
-            const bool pairs = e->pair_filter && e->G >= e->pair_min_batch && e->nsl == 1 && e->b_rows == e->mbh;
+            const bool pairs = e->pair_filter && T.n >= e->pair_min_batch && e->nsl == 1 && e->b_rows == e->mbh;
             const dim3 grid(pairs ? (unsigned)((e->b_rows + 1) / 2) : (unsigned)e->b_rows, G);
-            if (idr) {
-                R.need_intra = 0;
-                if (pairs) hipLaunchKernelGGL(k_deblock_pairs<true>, grid, dim3(64), 0, st, R);
-                else hipLaunchKernelGGL(k_deblock_rows<true>, grid, dim3(64), 0, st, R);
-            } else {   // P pictures: the form without the bS 4 filter, or - when the picture has intra macroblocks - the one with it
-                R.need_intra = -1;
-                if (pairs) hipLaunchKernelGGL(k_deblock_pairs<false>, grid, dim3(64), 0, st, R);
-                else hipLaunchKernelGGL(k_deblock_rows<false>, grid, dim3(64), 0, st, R);
-                R.need_intra = 1;
-                if (pairs) hipLaunchKernelGGL(k_deblock_pairs<true>, grid, dim3(64), 0, st, R);
-                else hipLaunchKernelGGL(k_deblock_rows<true>, grid, dim3(64), 0, st, R);
+            auto filter = [&](bool bs4) {
+                if (pairs) { if (bs4) LAUNCH2(ind, (k_deblock_pairs<true, true>), (k_deblock_pairs<true, false>), grid, dim3(64), st, R);
+                             else LAUNCH2(ind, (k_deblock_pairs<false, true>), (k_deblock_pairs<false, false>), grid, dim3(64), st, R); }
+                else { if (bs4) LAUNCH2(ind, (k_deblock_rows<true, false, true>), (k_deblock_rows<true, false, false>), grid, dim3(64), st, R);
+                       else LAUNCH2(ind, (k_deblock_rows<false, false, true>), (k_deblock_rows<false, false, false>), grid, dim3(64), st, R); }
+            };
+            if (idr) { R.need_intra = 0; filter(true); }
+            else {   // P pictures: the form without the bS 4 filter, or - when the picture has intra macroblocks - the one with it
+                R.need_intra = -1; filter(false);
+                R.need_intra = 1; filter(true);
             }
         }
     }
-    HIPCHK(e, hipStreamWaitEvent(st, S.entropy_done, 0));   // join: the next picture rewrites MbInfo / levels
-    HIPCHK(e, hipEventRecord(S.done, st));
+    if (fork) HIPCHK(e, hipStreamWaitEvent(st, T.entropy_done, 0));   // join: the next picture rewrites MbInfo / levels
+    HIPCHK(e, hipEventRecord(T.done, st));
     HIPCHK(e, hipGetLastError());
+    return MI355X_H264_OK;
+}
+
+// enqueue everything for one picture (every batch item's) whose I420 samples are at d_src: the direct form
+int submit(mi355x_h264_encoder* e, const uint8_t* d_src, size_t src_item_stride, int slot_idx, bool nv12)
+{
+    Slot& S = e->slots[slot_idx];
+    const bool idr = e->force_idr || e->frames == 0 || e->frame_in_gop >= e->cfg.gop;
+    if (idr) { e->frame_in_gop = 0; e->frame_num = 0; }
+    e->force_idr = 0;
+    Step T;
+    T.d_src = d_src; T.src_item_stride = src_item_stride; T.nv12 = nv12; T.idr = idr; T.n = e->G;
+    T.st = e->stream; T.ec = e->stream_ec; T.recon_ready = S.recon_ready; T.entropy_done = S.entropy_done; T.done = S.done; T.h_err = S.h_err;
+    T.slot = &S;
+    const int rc = submit_step(e, T);
+    if (rc) return rc;
+    S.au_start = T.au_start; S.payload_off = T.payload_off; S.idr = idr; S.nal_hdr = T.nal_hdr;
     S.busy = true;
     // bookkeeping for the next picture
     e->cur = (e->cur + 1) % e->nbuf;
@@ -519,10 +580,16 @@ int wait_slot(mi355x_h264_encoder* e, int slot_idx)
     return MI355X_H264_OK;
 }
 
-// finish the access unit of batch item g of a waited slot on the host
+// finish the access unit of batch item g on the host: S = the buffers it was written to, L = where and of which type
+struct AuLayout { size_t au_start, payload_off; bool idr; int nal_hdr; };
+int finish_item(mi355x_h264_encoder* e, Slot& S, const AuLayout& L, int g, uint8_t** out, uint32_t* out_len, int* frame_type);
 int finish_item(mi355x_h264_encoder* e, int slot_idx, int g, uint8_t** out, uint32_t* out_len, int* frame_type)
 {
     Slot& S = e->slots[slot_idx];
+    return finish_item(e, S, AuLayout{S.au_start, S.payload_off, S.idr, S.nal_hdr}, g, out, out_len, frame_type);
+}
+int finish_item(mi355x_h264_encoder* e, Slot& S, const AuLayout& L, int g, uint8_t** out, uint32_t* out_len, int* frame_type)
+{
     uint8_t* base = S.h_au + (size_t)g * e->st_au;
     if (e->nsl > 1) {
         // several slices: one NAL unit each, put together here (the payloads lie slice_cap apart in the pinned buffer)
@@ -537,38 +604,38 @@ int finish_item(mi355x_h264_encoder* e, int slot_idx, int g, uint8_t** out, uint
             }
             need += 5 + (size_t)si.total_bytes * 3 / 2 + 16;
             cost += si.me_cost;
-            if (!S.idr) { e->stats.me_searched_mbs += si.searched; e->stats.tq_coded_mbs += si.tq_coded; }
+            if (!L.idr) { e->stats.me_searched_mbs += si.searched; e->stats.tq_coded_mbs += si.tq_coded; }
         }
         e->last_me_cost[g] = cost;
-        if (!S.idr) e->stats.p_mbs += (uint64_t)e->b_nmb;
+        if (!L.idr) e->stats.p_mbs += (uint64_t)e->b_nmb;
         eb.resize(need);
         size_t pos = 0;
-        if (S.idr && e->b_sl0 == 0) { memcpy(eb.data(), e->sps_pps.data(), e->sps_pps.size()); pos = e->sps_pps.size(); }   // parameter sets go with the first band
+        if (L.idr && e->b_sl0 == 0) { memcpy(eb.data(), e->sps_pps.data(), e->sps_pps.size()); pos = e->sps_pps.size(); }   // parameter sets go with the first band
         for (int sl = 0; sl < e->b_nsl; sl++) {
             const SliceInfo& si = S.h_info[(size_t)g * e->b_nsl + sl];
             const uint8_t* pay = base + (size_t)(e->b_sl0 + sl) * e->slice_cap;
             uint8_t* o = eb.data() + pos;
-            o[0] = 0; o[1] = 0; o[2] = 0; o[3] = 1; o[4] = (uint8_t)S.nal_hdr;
+            o[0] = 0; o[1] = 0; o[2] = 0; o[3] = 1; o[4] = (uint8_t)L.nal_hdr;
             pos += 5;
             if (si.epb_count == 0) { memcpy(eb.data() + pos, pay, si.total_bytes); pos += si.total_bytes; }
             else pos += nal_escape(pay, si.total_bytes, eb.data() + pos);
         }
         *out = eb.data();
         *out_len = (uint32_t)pos;
-        if (frame_type) *frame_type = S.idr ? MI355X_H264_FRAME_IDR : MI355X_H264_FRAME_P;
+        if (frame_type) *frame_type = L.idr ? MI355X_H264_FRAME_IDR : MI355X_H264_FRAME_P;
         return MI355X_H264_OK;
     }
     const SliceInfo info = S.h_info[g];
     e->last_me_cost[g] = info.me_cost;
-    if (!S.idr) { e->stats.p_mbs += (uint64_t)e->b_nmb; e->stats.me_searched_mbs += info.searched; e->stats.tq_coded_mbs += info.tq_coded; }
+    if (!L.idr) { e->stats.p_mbs += (uint64_t)e->b_nmb; e->stats.me_searched_mbs += info.searched; e->stats.tq_coded_mbs += info.tq_coded; }
     if (info.error) {
         e->force_idr = 1;   // the refused picture is missing from the stream: the next one must not refer to it
         return fail(e, info.error == 1 ? MI355X_H264_E_OVERFLOW : MI355X_H264_E_INTERNAL, "device reported error %u", info.error);
     }
-    uint8_t* au = base + S.au_start;
+    uint8_t* au = base + L.au_start;
     size_t pos = 0;
-    if (S.idr) { memcpy(au, e->sps_pps.data(), e->sps_pps.size()); pos = e->sps_pps.size(); }
-    au[pos++] = 0; au[pos++] = 0; au[pos++] = 0; au[pos++] = 1; au[pos++] = (uint8_t)S.nal_hdr;
+    if (L.idr) { memcpy(au, e->sps_pps.data(), e->sps_pps.size()); pos = e->sps_pps.size(); }
+    au[pos++] = 0; au[pos++] = 0; au[pos++] = 0; au[pos++] = 1; au[pos++] = (uint8_t)L.nal_hdr;
     if (info.epb_count == 0) {
         *out = au;
         *out_len = (uint32_t)(pos + info.total_bytes);
@@ -576,11 +643,11 @@ int finish_item(mi355x_h264_encoder* e, int slot_idx, int g, uint8_t** out, uint
         std::vector<uint8_t>& eb = e->esc_buf[g];
         eb.resize(pos + (size_t)info.total_bytes * 3 / 2 + 16);
         memcpy(eb.data(), au, pos);
-        const size_t n = nal_escape(base + S.payload_off, info.total_bytes, eb.data() + pos);
+        const size_t n = nal_escape(base + L.payload_off, info.total_bytes, eb.data() + pos);
         *out = eb.data();
         *out_len = (uint32_t)(pos + n);
     }
-    if (frame_type) *frame_type = S.idr ? MI355X_H264_FRAME_IDR : MI355X_H264_FRAME_P;
+    if (frame_type) *frame_type = L.idr ? MI355X_H264_FRAME_IDR : MI355X_H264_FRAME_P;
     return MI355X_H264_OK;
 }
 
@@ -614,7 +681,11 @@ void mi355x_h264_default_config(mi355x_h264_config* c)
     c->rc_mode = MI355X_H264_RC_FIXED_QP; c->qp = 26; c->device = 0; c->disable_deblock = 0;
 }
 
-int mi355x_h264_create(const mi355x_h264_config* cfg, mi355x_h264_encoder** out)
+// hub_engine: the engine of a stream hub (below) - one set of output buffers instead of NSLOT, never more than one HIP stream
+// pair of its own (the hub's step contexts bring theirs)
+static int create_engine(const mi355x_h264_config* cfg, mi355x_h264_encoder** out, bool hub_engine);
+int mi355x_h264_create(const mi355x_h264_config* cfg, mi355x_h264_encoder** out) { return create_engine(cfg, out, false); }
+static int create_engine(const mi355x_h264_config* cfg, mi355x_h264_encoder** out, bool hub_engine)
 {
     if (!cfg || !out || cfg->struct_size != sizeof(mi355x_h264_config)) return MI355X_H264_E_ARG;
     *out = nullptr;
@@ -682,13 +753,20 @@ int mi355x_h264_create(const mi355x_h264_config* cfg, mi355x_h264_encoder** out)
     }
     const size_t ysz = (size_t)e->cw * e->ch;
     const size_t Gn = (size_t)e->G;
-    e->st_y = ysz + 256; e->st_c = ysz / 4 + 256;
-    for (int b = 0; b < e->nbuf; b++)
-        for (int p = 0; p < 3; p++) {
-            CK(hipMalloc((void**)&e->d_planes[b][p], (p ? e->st_c : e->st_y) * Gn));
-            CK(hipMemset(e->d_planes[b][p], 0, (p ? e->st_c : e->st_y) * Gn));
-        }
-    for (int p = 0; p < 3; p++) CK(hipMalloc((void**)&e->d_pre[p], (p ? e->st_c : e->st_y) * Gn));
+    e->st_ring_y = ysz + 256; e->st_ring_c = ysz / 4 + 256;
+    e->st_y = e->st_ring_y * e->nbuf; e->st_c = e->st_ring_c * e->nbuf;
+    for (int p = 0; p < 3; p++) {
+        CK(hipMalloc((void**)&e->d_plane_base[p], (p ? e->st_c : e->st_y) * Gn));
+        CK(hipMemset(e->d_plane_base[p], 0, (p ? e->st_c : e->st_y) * Gn));
+        for (int b = 0; b < e->nbuf; b++) e->d_planes[b][p] = e->d_plane_base[p] + (size_t)b * (p ? e->st_ring_c : e->st_ring_y);
+    }
+    for (int p = 0; p < 3; p++) CK(hipMalloc((void**)&e->d_pre[p], (p ? e->st_ring_c : e->st_ring_y) * Gn));
+    {
+        std::vector<QpEntry> qt(52);
+        for (int q = 0; q < 52; q++) fill_qp(qt[q].qy, qt[q].qc, qt[q].lambda, qt[q].sad_nz, q);
+        CK(hipMalloc((void**)&e->d_qtab, 52 * sizeof(QpEntry)));
+        CK(hipMemcpy(e->d_qtab, qt.data(), 52 * sizeof(QpEntry), hipMemcpyHostToDevice));
+    }
     CK(hipMalloc((void**)&e->d_mb, Gn * e->nmb * sizeof(MbInfo)));
     CK(hipMemset(e->d_mb, 0, Gn * e->nmb * sizeof(MbInfo)));
     CK(hipMalloc((void**)&e->d_levels, Gn * e->nmb * LV_STRIDE * sizeof(int16_t)));
@@ -739,7 +817,9 @@ int mi355x_h264_create(const mi355x_h264_config* cfg, mi355x_h264_encoder** out)
     e->st_bitbuf_bytes = (e->bitbuf_cap + 256 + 255) & ~(size_t)255;
     e->au_cap = e->bitbuf_cap + e->sps_pps.size() + 64;
     e->st_au = (e->au_cap + 256 + 255) & ~(size_t)255;
-    for (auto& S : e->slots) {
+    e->nslots = hub_engine ? 1 : NSLOT;
+    for (int si = 0; si < e->nslots; si++) {
+        Slot& S = e->slots[si];
         CK(hipMalloc((void**)&S.d_bitbuf, e->st_bitbuf_bytes * Gn));
         CK(hipMemset(S.d_bitbuf, 0, e->st_bitbuf_bytes * Gn));
         CK(hipMalloc((void**)&S.d_info, sizeof(SliceInfo) * Gn * e->nsl));
@@ -762,9 +842,8 @@ void mi355x_h264_destroy(mi355x_h264_encoder* e)
     if (!e) return;
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
-    for (int b = 0; b <= mi355x_h264_encoder::MAX_REFS; b++)
-        for (int p = 0; p < 3; p++) (void)hipFree(e->d_planes[b][p]);
-    for (int p = 0; p < 3; p++) (void)hipFree(e->d_pre[p]);
+    for (int p = 0; p < 3; p++) { (void)hipFree(e->d_plane_base[p]); (void)hipFree(e->d_pre[p]); }
+    (void)hipFree(e->d_qtab);
     (void)hipFree(e->d_mb); (void)hipFree(e->d_levels); (void)hipFree(e->d_mvd); (void)hipFree(e->d_mvq); (void)hipFree(e->d_aux); (void)hipFree(e->d_me_total); (void)hipFree(e->d_pmv);
     (void)hipFree(e->d_slotbits); (void)hipFree(e->d_slotcode); (void)hipFree(e->d_mbbits); (void)hipFree(e->d_prevcoded); (void)hipFree(e->d_anybs); (void)hipFree(e->d_anypcm); (void)hipFree(e->d_anyintra); (void)hipFree(e->d_stage);
     (void)hipFree(e->d_handoff); (void)hipFree(e->d_bs); (void)hipFree(e->d_me_cost);
@@ -1071,6 +1150,399 @@ int mi355x_h264_stats_read(mi355x_h264_encoder* e, mi355x_h264_stats* out, int r
     if (!e || !out) return MI355X_H264_E_ARG;
     *out = e->stats;
     if (reset) memset(&e->stats, 0, sizeof(e->stats));
+    return MI355X_H264_OK;
+}
+
+}  // extern "C"
+
+// ===========================================================================
+// Stream hub (include/mi355x_h264.h, "streams"): the reference's operating mode - many encoder objects in one process, each
+// handed ONE picture per call by its own thread (VideoEncoderOpenH264.cpp:304-352) - without one engine and ~15 single-picture
+// launches per object.  Streams of one geometry share an engine whose batch items are the streams; the pictures that calls
+// deliver while the engine is busy leave together as ONE lockstep step (the IND = true kernels: every position of the grid has
+// its own item, ring slot, QP, frame_num, idr_pic_id), split only by picture type.  No thread is created: the caller that finds
+// a free step context becomes the step's leader (gathers what is queued, launches, waits, finishes every picture of the step),
+// the others sleep until their picture is done.  Two step contexts per hub: one step's loop filter overlaps the next one's
+// motion search, as two instances do in the closed-GOP mode.
+// ===========================================================================
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
+
+namespace {
+
+struct HubItem {
+    bool open = false;
+    // coding state of the stream (what mi355x_h264_encoder keeps for its one stream)
+    int cur = 0, frame_in_gop = 0, frame_num = 0, idr_id = 0, force_idr = 0, qp = 26, gop = 30;
+    long frames = 0;
+    int last_cur = 0;                // ring slot of the last finished picture
+    hipEvent_t copied = nullptr;     // the picture's upload has finished
+    // the request in flight
+    bool pending = false, done = false;
+    int rc = 0, frame_type = 0;
+    uint8_t* out = nullptr;
+    uint32_t out_len = 0;
+    char err[256] = {0};
+};
+
+struct HubCtx {
+    hipStream_t st = nullptr, ec = nullptr;
+    hipEvent_t recon_ready[2] = {nullptr, nullptr}, entropy_done[2] = {nullptr, nullptr}, done[2] = {nullptr, nullptr};   // per picture type
+    unsigned* h_err = nullptr;       // pinned: hand-off time-out flag of the wavefront kernels
+    uint32_t* h_itemtab = nullptr;   // pinned, 2 * MAX_BATCH words (P positions, then IDR positions)
+    uint32_t* d_itemtab = nullptr;
+    bool busy = false;
+};
+
+struct Hub {
+    std::mutex mu;                   // queue + item states
+    std::condition_variable cv;
+    std::mutex launch_mu;            // one leader at a time touches the engine's host state (serials, statistics)
+    mi355x_h264_encoder* e = nullptr;
+    mi355x_h264_config cfg{};
+    int cap = 0, nopen = 0, uploading = 0;
+    HubItem items[MAX_BATCH];
+    std::vector<int> queue;
+    bool collecting = false;
+    HubCtx ctx[2];
+    uint8_t* d_stage = nullptr;      // [cap] pictures as the callers hand them over (tight I420)
+    uint8_t* h_stage = nullptr;      // pinned
+    size_t st_stage = 0;
+    hipStream_t copy_st[2] = {nullptr, nullptr};
+    int window_us = 200;
+    uint64_t steps = 0, pictures = 0, max_batch = 0;
+};
+
+std::mutex g_hubs_mu;
+std::vector<Hub*> g_hubs;
+
+bool same_geometry(const mi355x_h264_config& a, const mi355x_h264_config& b)
+{
+    return a.width == b.width && a.height == b.height && a.fps == b.fps && a.profile_idc == b.profile_idc && a.device == b.device &&
+           a.disable_deblock == b.disable_deblock && a.slices == b.slices;
+}
+
+void hub_free(Hub* h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->cfg.device);
+    for (auto& c : h->ctx) {
+        if (c.st) (void)hipStreamSynchronize(c.st);
+        if (c.ec && c.ec != c.st) { (void)hipStreamSynchronize(c.ec); (void)hipStreamDestroy(c.ec); }
+        if (c.st) (void)hipStreamDestroy(c.st);
+        for (int k = 0; k < 2; k++) {
+            if (c.recon_ready[k]) (void)hipEventDestroy(c.recon_ready[k]);
+            if (c.entropy_done[k]) (void)hipEventDestroy(c.entropy_done[k]);
+            if (c.done[k]) (void)hipEventDestroy(c.done[k]);
+        }
+        if (c.h_err) (void)hipHostFree(c.h_err);
+        if (c.h_itemtab) (void)hipHostFree(c.h_itemtab);
+        (void)hipFree(c.d_itemtab);
+    }
+    for (auto& cs : h->copy_st) if (cs) { (void)hipStreamSynchronize(cs); (void)hipStreamDestroy(cs); }
+    for (auto& it : h->items) if (it.copied) (void)hipEventDestroy(it.copied);
+    (void)hipFree(h->d_stage);
+    if (h->h_stage) (void)hipHostFree(h->h_stage);
+    if (h->e) mi355x_h264_destroy(h->e);
+    delete h;
+}
+
+int hub_create(const mi355x_h264_config& cfg, Hub** out)
+{
+    Hub* h = new (std::nothrow) Hub();
+    if (!h) return MI355X_H264_E_NOMEM;
+    h->cfg = cfg;
+    const char* ci = getenv("MI355X_H264_HUB_ITEMS");
+    h->cap = std::min((int)MAX_BATCH, std::max(1, ci ? atoi(ci) : 32));
+    const char* wu = getenv("MI355X_H264_HUB_WINDOW_US");
+    if (wu) h->window_us = std::max(0, atoi(wu));
+    mi355x_h264_config ec = cfg;
+    ec.batch = h->cap; ec.refs = 1; ec.band_index = 0; ec.band_count = 0; ec.input_format = MI355X_H264_INPUT_I420;
+    int rc = create_engine(&ec, &h->e, true);
+    if (rc != MI355X_H264_OK) { h->e = nullptr; hub_free(h); return rc; }
+    const size_t fb = (size_t)cfg.width * cfg.height * 3 / 2;
+    h->st_stage = (fb + 255) & ~(size_t)255;
+#define HK(call) do { if ((call) != hipSuccess) { hub_free(h); return MI355X_H264_E_HIP; } } while (0)
+    HK(hipSetDevice(cfg.device));
+    HK(hipMalloc((void**)&h->d_stage, h->st_stage * h->cap));
+    HK(hipHostMalloc((void**)&h->h_stage, h->st_stage * h->cap, hipHostMallocDefault));
+    for (auto& cs : h->copy_st) HK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+    for (auto& c : h->ctx) {
+        HK(hipStreamCreateWithFlags(&c.st, hipStreamNonBlocking));
+        const char* one = getenv("MI355X_H264_ONE_STREAM");
+        if (one && one[0] == '1') c.ec = c.st; else HK(hipStreamCreateWithFlags(&c.ec, hipStreamNonBlocking));
+        for (int k = 0; k < 2; k++) {
+            HK(hipEventCreateWithFlags(&c.recon_ready[k], hipEventDisableTiming));
+            HK(hipEventCreateWithFlags(&c.entropy_done[k], hipEventDisableTiming));
+            HK(hipEventCreateWithFlags(&c.done[k], hipEventDisableTiming));
+        }
+        HK(hipHostMalloc((void**)&c.h_err, sizeof(unsigned), hipHostMallocDefault));
+        *c.h_err = 0;
+        HK(hipHostMalloc((void**)&c.h_itemtab, 2 * MAX_BATCH * sizeof(uint32_t), hipHostMallocDefault));
+        HK(hipMalloc((void**)&c.d_itemtab, 2 * MAX_BATCH * sizeof(uint32_t)));
+    }
+    for (int i = 0; i < h->cap; i++) HK(hipEventCreateWithFlags(&h->items[i].copied, hipEventDisableTiming));
+#undef HK
+    *out = h;
+    return MI355X_H264_OK;
+}
+
+// one lockstep step for the queued pictures `batch` on context c: launch (P pictures, then IDR pictures), wait, finish
+void hub_run_step(Hub* h, HubCtx& c, const std::vector<int>& batch)
+{
+    mi355x_h264_encoder* e = h->e;
+    (void)hipSetDevice(h->cfg.device);
+    ItemPic pics[2][MAX_BATCH];
+    int n[2] = {0, 0};   // [0] P pictures, [1] IDR pictures
+    for (int idx : batch) {
+        HubItem& it = h->items[idx];
+        const bool idr = it.force_idr || it.frames == 0 || it.frame_in_gop >= it.gop;
+        if (idr) { it.frame_in_gop = 0; it.frame_num = 0; }
+        it.force_idr = 0;
+        pics[idr][n[idr]++] = ItemPic{idx, it.cur, it.qp, it.frame_num, it.idr_id};
+    }
+    Step T[2];
+    int rc = MI355X_H264_OK;
+    char errtxt[256] = {0};
+    {
+        std::lock_guard<std::mutex> lk(h->launch_mu);
+        for (int ty = 0; ty < 2 && rc == MI355X_H264_OK; ty++) {
+            if (!n[ty]) continue;
+            uint32_t* tab = c.h_itemtab + ty * MAX_BATCH;
+            for (int k = 0; k < n[ty]; k++) {
+                tab[k] = (uint32_t)pics[ty][k].item | ((uint32_t)pics[ty][k].cur << 8) | ((uint32_t)pics[ty][k].qp << 16);
+                if (hipStreamWaitEvent(c.st, h->items[pics[ty][k].item].copied, 0) != hipSuccess) rc = MI355X_H264_E_HIP;
+            }
+            if (hipMemcpyAsync(c.d_itemtab + ty * MAX_BATCH, tab, (size_t)n[ty] * sizeof(uint32_t), hipMemcpyHostToDevice, c.st) != hipSuccess) rc = MI355X_H264_E_HIP;
+            if (rc != MI355X_H264_OK) break;
+            Step& S = T[ty];
+            S.d_src = h->d_stage; S.src_item_stride = h->st_stage; S.nv12 = false; S.idr = ty == 1; S.n = n[ty];
+            S.items = pics[ty]; S.d_itemtab = c.d_itemtab + ty * MAX_BATCH;
+            S.st = c.st; S.ec = c.ec; S.recon_ready = c.recon_ready[ty]; S.entropy_done = c.entropy_done[ty]; S.done = c.done[ty]; S.h_err = c.h_err;
+            S.slot = &e->slots[0];
+            rc = submit_step(e, S);
+        }
+        if (rc != MI355X_H264_OK) snprintf(errtxt, sizeof(errtxt), "%s", e->err);
+    }
+    if (rc == MI355X_H264_OK) {
+        const int last = n[1] ? 1 : 0;
+        if (hipEventSynchronize(c.done[last]) != hipSuccess) { rc = MI355X_H264_E_HIP; snprintf(errtxt, sizeof(errtxt), "hipEventSynchronize failed"); }
+    } else (void)hipStreamSynchronize(c.st);
+    if (rc == MI355X_H264_OK && *c.h_err) {
+        snprintf(errtxt, sizeof(errtxt), "wavefront kernel hand-off timed out (flag %u)", *c.h_err);
+        *c.h_err = 0;
+        rc = MI355X_H264_E_INTERNAL;
+    }
+    std::lock_guard<std::mutex> lk(h->launch_mu);   // (finish_item touches the engine's statistics and error text)
+    for (int ty = 0; ty < 2; ty++)
+        for (int k = 0; k < n[ty]; k++) {
+            HubItem& it = h->items[pics[ty][k].item];
+            it.rc = rc;
+            if (rc == MI355X_H264_OK) {
+                const AuLayout L{T[ty].au_start, T[ty].payload_off, ty == 1, T[ty].nal_hdr};
+                it.rc = finish_item(e, e->slots[0], L, pics[ty][k].item, &it.out, &it.out_len, &it.frame_type);
+                if (it.rc != MI355X_H264_OK) snprintf(it.err, sizeof(it.err), "%s", e->err);
+            } else snprintf(it.err, sizeof(it.err), "%s", errtxt);
+            if (it.rc == MI355X_H264_OK) {
+                it.last_cur = it.cur;
+                it.cur = (it.cur + 1) % e->nbuf;
+                if (ty == 1) it.idr_id = (it.idr_id + 1) & 0xFF;
+                it.frame_num = (it.frame_num + 1) & 255;
+                it.frame_in_gop++;
+                it.frames++;
+            } else it.force_idr = 1;   // the picture is missing from the stream (or not to be trusted): the next one must not refer to it
+        }
+}
+
+}  // namespace
+
+struct mi355x_h264_stream { Hub* hub; int item; };
+
+extern "C" {
+
+int mi355x_h264_stream_open(const mi355x_h264_config* cfg, mi355x_h264_stream** out)
+{
+    if (!cfg || !out || cfg->struct_size != sizeof(mi355x_h264_config)) return MI355X_H264_E_ARG;
+    *out = nullptr;
+    if (cfg->refs > 1 || cfg->band_count > 1 || cfg->batch > 1 || cfg->input_format != MI355X_H264_INPUT_I420) return MI355X_H264_E_ARG;
+    if (cfg->qp < 10 || cfg->qp > 51 || cfg->gop < 1) return MI355X_H264_E_ARG;
+    mi355x_h264_stream* s = new (std::nothrow) mi355x_h264_stream();
+    if (!s) return MI355X_H264_E_NOMEM;
+    std::lock_guard<std::mutex> gl(g_hubs_mu);
+    Hub* h = nullptr;
+    for (Hub* c : g_hubs) {
+        std::lock_guard<std::mutex> lk(c->mu);
+        if (same_geometry(c->cfg, *cfg) && c->nopen < c->cap) { h = c; break; }
+    }
+    if (!h) {
+        const int rc = hub_create(*cfg, &h);
+        if (rc != MI355X_H264_OK) { delete s; return rc; }
+        g_hubs.push_back(h);
+    }
+    std::lock_guard<std::mutex> lk(h->mu);
+    int idx = 0;
+    while (h->items[idx].open) idx++;
+    HubItem& it = h->items[idx];
+    hipEvent_t ev = it.copied;
+    it = HubItem();
+    it.copied = ev;
+    it.open = true; it.qp = cfg->qp; it.gop = cfg->gop;
+    h->nopen++;
+    s->hub = h; s->item = idx;
+    *out = s;
+    return MI355X_H264_OK;
+}
+
+void mi355x_h264_stream_close(mi355x_h264_stream* s)
+{
+    if (!s) return;
+    std::lock_guard<std::mutex> gl(g_hubs_mu);
+    Hub* h = s->hub;
+    bool last;
+    {
+        std::unique_lock<std::mutex> lk(h->mu);
+        h->items[s->item].open = false;
+        last = --h->nopen == 0;
+        if (last) h->cv.wait(lk, [&] { return !h->ctx[0].busy && !h->ctx[1].busy; });
+    }
+    if (last) {
+        g_hubs.erase(std::find(g_hubs.begin(), g_hubs.end(), h));
+        hub_free(h);
+    }
+    delete s;
+}
+
+int mi355x_h264_stream_encode(mi355x_h264_stream* s, const uint8_t* y, int ys, const uint8_t* u, int us, const uint8_t* v, int vs,
+                              uint8_t** out, uint32_t* out_len, int* frame_type)
+{
+    if (!s || !y || !u || !v || !out || !out_len) return MI355X_H264_E_ARG;
+    Hub* h = s->hub;
+    HubItem& it = h->items[s->item];
+    const int w = h->cfg.width, hh = h->cfg.height;
+    if (ys < w || us < w / 2 || vs < w / 2) { snprintf(it.err, sizeof(it.err), "stride smaller than width"); return MI355X_H264_E_ARG; }
+    if (hipSetDevice(h->cfg.device) != hipSuccess) { snprintf(it.err, sizeof(it.err), "hipSetDevice"); return MI355X_H264_E_HIP; }
+    {
+        std::lock_guard<std::mutex> lk(h->mu);
+        h->uploading++;   // a step that is being gathered waits (briefly) for this picture
+    }
+    // 1. the picture into the stream's staging slot: pinned copy, then the transfer - in pieces, so that the copy of piece k + 1
+    // runs while piece k is on the bus (the reference's tight layout, InitSrcPic ref :354-365; other layouts row by row)
+    uint8_t* hs = h->h_stage + (size_t)s->item * h->st_stage;
+    uint8_t* ds = h->d_stage + (size_t)s->item * h->st_stage;
+    hipStream_t cs = h->copy_st[s->item & 1];
+    const size_t ysz = (size_t)w * hh, fb = ysz * 3 / 2;
+    bool ok = true;
+    if (ys == w && us == w / 2 && vs == w / 2 && u == y + ysz && v == u + ysz / 4) {
+        const size_t piece = ((fb / 4) + 255) & ~(size_t)255;
+        for (size_t o = 0; o < fb && ok; o += piece) {
+            const size_t len = std::min(piece, fb - o);
+            memcpy(hs + o, y + o, len);
+            ok = hipMemcpyAsync(ds + o, hs + o, len, hipMemcpyHostToDevice, cs) == hipSuccess;
+        }
+    } else {
+        uint8_t* d = hs;
+        for (int r = 0; r < hh; r++) memcpy(d + (size_t)r * w, y + (size_t)r * ys, (size_t)w);
+        d += ysz;
+        for (int r = 0; r < hh / 2; r++) memcpy(d + (size_t)r * (w / 2), u + (size_t)r * us, (size_t)(w / 2));
+        d += ysz / 4;
+        for (int r = 0; r < hh / 2; r++) memcpy(d + (size_t)r * (w / 2), v + (size_t)r * vs, (size_t)(w / 2));
+        ok = hipMemcpyAsync(ds, hs, fb, hipMemcpyHostToDevice, cs) == hipSuccess;
+    }
+    ok = ok && hipEventRecord(it.copied, cs) == hipSuccess;
+    // 2. queue the picture; lead a step or wait for the one that takes it
+    std::unique_lock<std::mutex> lk(h->mu);
+    h->uploading--;
+    if (!ok) { h->cv.notify_all(); snprintf(it.err, sizeof(it.err), "upload of the picture failed"); return MI355X_H264_E_HIP; }
+    it.pending = true; it.done = false;
+    h->queue.push_back(s->item);
+    h->cv.notify_all();   // (a leader that is gathering counts the queue)
+    while (!it.done) {
+        HubCtx* c = !h->ctx[0].busy ? &h->ctx[0] : (!h->ctx[1].busy ? &h->ctx[1] : nullptr);
+        if (!h->collecting && c && !h->queue.empty()) {
+            h->collecting = true;
+            c->busy = true;
+            if (h->uploading > 0 && h->window_us > 0) {   // pictures on their way in join this step if they make it within the window
+                const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(h->window_us);
+                h->cv.wait_until(lk, deadline, [&] { return h->uploading == 0; });
+            }
+            std::vector<int> batch;
+            batch.swap(h->queue);
+            h->collecting = false;
+            h->steps++; h->pictures += batch.size(); h->max_batch = std::max<uint64_t>(h->max_batch, batch.size());
+            lk.unlock();
+            hub_run_step(h, *c, batch);
+            lk.lock();
+            for (int idx : batch) { h->items[idx].done = true; h->items[idx].pending = false; }
+            c->busy = false;
+            h->cv.notify_all();
+        } else {
+            h->cv.wait(lk);
+        }
+    }
+    *out = it.out; *out_len = it.out_len;
+    if (frame_type) *frame_type = it.frame_type;
+    return it.rc;
+}
+
+int mi355x_h264_stream_set_qp(mi355x_h264_stream* s, int qp)
+{
+    if (!s || qp < 10 || qp > 51) return MI355X_H264_E_ARG;
+    s->hub->items[s->item].qp = qp;
+    return MI355X_H264_OK;
+}
+
+int mi355x_h264_stream_force_idr(mi355x_h264_stream* s)
+{
+    if (!s) return MI355X_H264_E_ARG;
+    s->hub->items[s->item].force_idr = 1;
+    return MI355X_H264_OK;
+}
+
+int mi355x_h264_stream_set_idr_pic_id(mi355x_h264_stream* s, int next)
+{
+    if (!s) return MI355X_H264_E_ARG;
+    s->hub->items[s->item].idr_id = next & 0xFF;
+    return MI355X_H264_OK;
+}
+
+int mi355x_h264_stream_last_me_cost(const mi355x_h264_stream* s, uint32_t* cost)
+{
+    if (!s || !cost) return MI355X_H264_E_ARG;
+    *cost = s->hub->e->last_me_cost[s->item];
+    return MI355X_H264_OK;
+}
+
+const char* mi355x_h264_stream_last_error(const mi355x_h264_stream* s) { return s ? s->hub->items[s->item].err : "null stream"; }
+int mi355x_h264_stream_coded_width(const mi355x_h264_stream* s) { return s ? s->hub->e->cw : 0; }
+int mi355x_h264_stream_coded_height(const mi355x_h264_stream* s) { return s ? s->hub->e->ch : 0; }
+
+// reconstruction planes of the stream's last picture (MI355X_H264_DBG_RECON_Y / _U / _V); the stream's calls are synchronous, so
+// the picture is complete
+int64_t mi355x_h264_stream_debug_read(mi355x_h264_stream* s, int what, void* dst, size_t cap)
+{
+    if (!s || !dst || what < MI355X_H264_DBG_RECON_Y || what > MI355X_H264_DBG_RECON_V) return MI355X_H264_E_ARG;
+    Hub* h = s->hub;
+    const mi355x_h264_encoder* e = h->e;
+    if (hipSetDevice(h->cfg.device) != hipSuccess) return MI355X_H264_E_HIP;
+    const size_t ysz = (size_t)e->cw * e->ch, n = what ? ysz / 4 : ysz;
+    if (cap < n) return MI355X_H264_E_ARG;
+    const HubItem& it = h->items[s->item];
+    const uint8_t* src = e->d_plane_base[what] + (size_t)s->item * (what ? e->st_c : e->st_y) + (size_t)it.last_cur * (what ? e->st_ring_c : e->st_ring_y);
+    if (hipMemcpy(dst, src, n, hipMemcpyDeviceToHost) != hipSuccess) return MI355X_H264_E_HIP;
+    return (int64_t)n;
+}
+
+// how the hub of this stream has been batching: steps launched, pictures coded, the largest step
+int mi355x_h264_stream_hub_stats(const mi355x_h264_stream* s, uint64_t* steps, uint64_t* pictures, uint64_t* max_batch, int* open_streams)
+{
+    if (!s) return MI355X_H264_E_ARG;
+    Hub* h = s->hub;
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (steps) *steps = h->steps;
+    if (pictures) *pictures = h->pictures;
+    if (max_batch) *max_batch = h->max_batch;
+    if (open_streams) *open_streams = h->nopen;
     return MI355X_H264_OK;
 }
 

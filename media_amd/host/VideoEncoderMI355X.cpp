@@ -2,6 +2,7 @@
 #define LOG_TAG "VideoEncoderMI355X"
 #include "VideoEncoderMI355X.h"
 #include <algorithm>
+#include <cstdlib>
 #include "MediaLog.h"
 #include "Property.h"
 
@@ -54,6 +55,21 @@ bool VideoEncoderMI355X::EngineOpen(const Settings &s)
     // single slice (SM_SINGLE_SLICE, ref :247)
     const int32_t slices = GetIntEncParam("persist.vmi.video.encode.slices");
     cfg.slices = Within(slices, 2, 64) ? slices : 0;
+    // One engine per object (mi355x_h264_create) costs every picture its own launch sequence.  The default is a STREAM of the
+    // shared engine: the pictures that the encoder objects of one process hand over at about the same time are coded in one
+    // lockstep step (include/mi355x_h264.h, "streams"; same bitstream).  persist.vmi.video.encode.shared = 0 (or the environment
+    // variable MI355X_H264_HUB=0) keeps the engine of its own.
+    const char *hubEnv = getenv("MI355X_H264_HUB");
+    const bool shared = GetStrEncParam("persist.vmi.video.encode.shared") != "0" && !(hubEnv != nullptr && hubEnv[0] == '0');
+    if (shared) {
+        const int rc = mi355x_h264_stream_open(&cfg, &m_stream);
+        if (rc != MI355X_H264_OK) {
+            ERR("mi355x_h264_stream_open returned %d", rc);
+            m_stream = nullptr;
+            return false;
+        }
+        return true;
+    }
     const int rc = mi355x_h264_create(&cfg, &m_engine);
     if (rc != MI355X_H264_OK) {
         ERR("mi355x_h264_create returned %d", rc);
@@ -112,12 +128,19 @@ int VideoEncoderMI355X::EncodePicture(const uint8_t *i420, uint8_t **out, uint32
     const int pitch = static_cast<int>(Active().width);
     const uint8_t *u = i420 + LumaBytes();
     const uint8_t *v = u + LumaBytes() / 4;
+    if (m_stream != nullptr) {
+        return mi355x_h264_stream_encode(m_stream, i420, pitch, u, pitch / 2, v, pitch / 2, out, outLen, frameType);
+    }
     return mi355x_h264_encode(m_engine, i420, pitch, u, pitch / 2, v, pitch / 2, out, outLen, frameType);
 }
 
 bool VideoEncoderMI355X::EngineEncode(const uint8_t *i420, uint8_t **out, uint32_t *outLen)
 {
-    (void) mi355x_h264_set_qp(m_engine, m_qp);
+    if (m_stream != nullptr) {
+        (void) mi355x_h264_stream_set_qp(m_stream, m_qp);
+    } else {
+        (void) mi355x_h264_set_qp(m_engine, m_qp);
+    }
     m_lastQp = m_qp;
     int frameType = 0;
     int rc = EncodePicture(i420, out, outLen, &frameType);
@@ -125,16 +148,18 @@ bool VideoEncoderMI355X::EngineEncode(const uint8_t *i420, uint8_t **out, uint32
         // scene change: the motion search found no good match anywhere -> code this picture as IDR instead
         uint32_t cost = 0;
         const uint64_t mbs = static_cast<uint64_t>((Active().width + 15) / 16) * ((Active().height + 15) / 16);
-        if (mi355x_h264_last_me_cost(m_engine, &cost) == MI355X_H264_OK && cost > Rc::kSceneCutCostPerMb * mbs) {
+        const int crc = m_stream != nullptr ? mi355x_h264_stream_last_me_cost(m_stream, &cost) : mi355x_h264_last_me_cost(m_engine, &cost);
+        if (crc == MI355X_H264_OK && cost > Rc::kSceneCutCostPerMb * mbs) {
             INFO("scene change (motion cost %u over %llu macroblocks): picture re-coded as IDR", cost,
                  static_cast<unsigned long long>(mbs));
-            (void) mi355x_h264_force_idr(m_engine);
+            (void) EngineForceIdr();
             rc = EncodePicture(i420, out, outLen, &frameType);
             m_sceneCuts++;
         }
     }
     if (rc != MI355X_H264_OK) {
-        ERR("EncodeOneFrame: engine returned %d (%s)", rc, mi355x_h264_last_error(m_engine));
+        ERR("EncodeOneFrame: engine returned %d (%s)", rc,
+            m_stream != nullptr ? mi355x_h264_stream_last_error(m_stream) : mi355x_h264_last_error(m_engine));
         return false;
     }
     RateControlUpdate(*outLen, frameType == MI355X_H264_FRAME_IDR);
@@ -147,6 +172,29 @@ void VideoEncoderMI355X::EngineClose()
         mi355x_h264_destroy(m_engine);
         m_engine = nullptr;
     }
+    if (m_stream != nullptr) {
+        mi355x_h264_stream_close(m_stream);
+        m_stream = nullptr;
+    }
 }
 
-bool VideoEncoderMI355X::EngineForceIdr() { return m_engine != nullptr && mi355x_h264_force_idr(m_engine) == MI355X_H264_OK; }
+bool VideoEncoderMI355X::EngineForceIdr()
+{
+    if (m_stream != nullptr) {
+        return mi355x_h264_stream_force_idr(m_stream) == MI355X_H264_OK;
+    }
+    return m_engine != nullptr && mi355x_h264_force_idr(m_engine) == MI355X_H264_OK;
+}
+
+int64_t VideoEncoderMI355X::ReadReconY(void *dst, size_t cap, int32_t *codedWidth, int32_t *codedHeight)
+{
+    if (m_stream != nullptr) {
+        if (codedWidth != nullptr) *codedWidth = mi355x_h264_stream_coded_width(m_stream);
+        if (codedHeight != nullptr) *codedHeight = mi355x_h264_stream_coded_height(m_stream);
+        return mi355x_h264_stream_debug_read(m_stream, MI355X_H264_DBG_RECON_Y, dst, cap);
+    }
+    if (m_engine == nullptr) return -1;
+    if (codedWidth != nullptr) *codedWidth = mi355x_h264_coded_width(m_engine);
+    if (codedHeight != nullptr) *codedHeight = mi355x_h264_coded_height(m_engine);
+    return mi355x_h264_debug_read(m_engine, MI355X_H264_DBG_RECON_Y, dst, cap);
+}

@@ -24,13 +24,15 @@ public:
     // test hooks
     int32_t LastFrameQp() const { return m_lastQp; }
     uint32_t SceneCuts() const { return m_sceneCuts; }
-    mi355x_h264_encoder *Engine() const { return m_engine; }   // measurement hook (bench.py reads the reconstruction for PSNR)
+    // measurement hook (bench.py reads the reconstruction for PSNR): luma reconstruction of the last picture, coded size
+    int64_t ReadReconY(void *dst, size_t cap, int32_t *codedWidth, int32_t *codedHeight);
+    bool Shared() const { return m_stream != nullptr; }
 
 protected:
     const char *BackendName() const override { return "MI355X HIP"; }
     bool EngineOpen(const Settings &s) override;
     void EngineClose() override;
-    bool EngineReady() const override { return m_engine != nullptr; }
+    bool EngineReady() const override { return m_engine != nullptr || m_stream != nullptr; }
     bool EngineEncode(const uint8_t *i420, uint8_t **out, uint32_t *outLen) override;
     bool EngineForceIdr() override;
 
@@ -38,7 +40,8 @@ private:
     int EncodePicture(const uint8_t *i420, uint8_t **out, uint32_t *outLen, int *frameType);
     void RateControlUpdate(uint32_t frameBytes, bool isIdr);
 
-    mi355x_h264_encoder *m_engine = nullptr;
+    mi355x_h264_encoder *m_engine = nullptr;   // an engine of its own (persist.vmi.video.encode.shared = 0), or
+    mi355x_h264_stream *m_stream = nullptr;    // a stream of the process-wide shared engine (the default)
     // rate control (the reference preset runs RC_BITRATE_MODE, VideoEncoderOpenH264.cpp:274)
     int32_t m_fixedQp = -1;            // >= 0: extension property persist.vmi.video.encode.qp selects fixed QP
     int32_t m_qp = Rc::kQpStart, m_lastQp = 0;

@@ -33,10 +33,8 @@ uint32_t vc_scene_cuts(void *enc)
 int64_t vc_debug_recon_y(void *enc, void *dst, uint64_t cap, int32_t *codedWidth, int32_t *codedHeight)
 {
     auto *m = dynamic_cast<VideoEncoderMI355X *>(static_cast<VideoEncoder *>(enc));
-    if (m == nullptr || m->Engine() == nullptr) return -1;
-    if (codedWidth != nullptr) *codedWidth = mi355x_h264_coded_width(m->Engine());
-    if (codedHeight != nullptr) *codedHeight = mi355x_h264_coded_height(m->Engine());
-    return mi355x_h264_debug_read(m->Engine(), MI355X_H264_DBG_RECON_Y, dst, static_cast<size_t>(cap));
+    if (m == nullptr) return -1;
+    return m->ReadReconY(dst, static_cast<size_t>(cap), codedWidth, codedHeight);
 }
 void vc_prop_set(const char *key, const char *value) { SetEncParam(key, value); }
 int32_t vc_prop_get_int(const char *key) { return GetIntEncParam(key); }

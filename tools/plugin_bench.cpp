@@ -38,7 +38,7 @@ int main(int argc, char **argv)
             if (ok) {   // warm-up outside the clock: first IDR, allocations
                 uint8_t *au = nullptr;
                 uint32_t n = 0;
-                ok = encs[k]->EncodeOneFrame(pics.data(), (uint32_t)fsz, &au, &n) == VIDEO_ENCODER_SUCCESS;
+                ok = encs[k]->EncodeOneFrame(pics.data() + fsz * (size_t)(k % npic), (uint32_t)fsz, &au, &n) == VIDEO_ENCODER_SUCCESS;
             }
         }
         if (!ok) { printf("{\"streams\":%d,\"error\":\"an encoder could not be opened\"}\n", S); continue; }
@@ -48,7 +48,7 @@ int main(int argc, char **argv)
         auto work = [&](int k) {
             lat[k].reserve(frames);
             for (int i = 0; i < frames; i++) {
-                const uint8_t *f = pics.data() + fsz * ((i + 3 * k) % npic);
+                const uint8_t *f = pics.data() + fsz * (size_t)((k + 1 + i) % npic);   // (the pool holds frames + S + 1 pictures: no wrap)
                 uint8_t *au = nullptr;
                 uint32_t n = 0;
                 const auto t0 = std::chrono::steady_clock::now();
