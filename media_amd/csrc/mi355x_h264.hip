@@ -1188,9 +1188,9 @@ struct HubItem {
 
 struct HubCtx {
     hipStream_t st = nullptr, ec = nullptr;
-    hipEvent_t recon_ready[2] = {nullptr, nullptr}, entropy_done[2] = {nullptr, nullptr}, done[2] = {nullptr, nullptr};   // per picture type
+    hipEvent_t recon_ready = nullptr, entropy_done = nullptr, done = nullptr;
     unsigned* h_err = nullptr;       // pinned: hand-off time-out flag of the wavefront kernels
-    uint32_t* h_itemtab = nullptr;   // pinned, 2 * MAX_BATCH words (P positions, then IDR positions)
+    uint32_t* h_itemtab = nullptr;   // pinned, MAX_BATCH words
     uint32_t* d_itemtab = nullptr;
     bool busy = false;
 };
@@ -1203,16 +1203,30 @@ struct Hub {
     mi355x_h264_config cfg{};
     int cap = 0, nopen = 0, uploading = 0;
     HubItem items[MAX_BATCH];
-    std::vector<int> queue;
-    bool collecting = false;
-    HubCtx ctx[2];
+    // P pictures and IDR pictures never share a step: an IDR picture's row wavefront (k_intra_rows) runs for milliseconds, and
+    // the P pictures of other streams must not wait for it.  Contexts 0 and 1 take the P steps (one's loop filter overlaps the
+    // other's motion search), context 2 the IDR steps.
+    enum { MAX_CTX = 9 };
+    int nctx_p = 2;                  // contexts for P steps: ctx[0 .. nctx_p - 1]; ctx[nctx_p] takes the IDR steps
+    std::vector<int> queue[2];       // [0] P pictures, [1] IDR pictures waiting for a step
+    bool collecting = false;         // a leader is gathering a P step
+    HubCtx ctx[MAX_CTX];
+    bool any_busy() const { for (int i = 0; i <= nctx_p; i++) if (ctx[i].busy) return true; return false; }
     uint8_t* d_stage = nullptr;      // [cap] pictures as the callers hand them over (tight I420)
     uint8_t* h_stage = nullptr;      // pinned
     size_t st_stage = 0;
-    hipStream_t copy_st[2] = {nullptr, nullptr};
+    // uploads: item k on copy stream k % NCOPY.  Two streams fill most of the link (tools/ubench_h2d.hip: 1 stream 32 GB/s, 2: 46-51,
+    // 4+: 52-57); HIP streams are a scarce resource on this runtime - beyond about a dozen live streams in the process every launch
+    // gets slower (measured: 8 copy streams per hub halved the throughput at 64 streams)
+    enum { NCOPY = 2 };
+    hipStream_t copy_st[NCOPY] = {nullptr};
     int window_us = 200;
     uint64_t steps = 0, pictures = 0, max_batch = 0;
+    // where a picture's time goes (microseconds, summed; MI355X_H264_HUB_VERBOSE=1 prints them when the hub is freed)
+    std::atomic<uint64_t> us_upload{0}, us_queue{0}, us_launch{0}, us_gpu{0}, us_finish{0}, us_total{0};
+    bool verbose = false;
 };
+inline uint64_t now_us() { return (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 std::mutex g_hubs_mu;
 std::vector<Hub*> g_hubs;
@@ -1228,14 +1242,13 @@ void hub_free(Hub* h)
     if (!h) return;
     (void)hipSetDevice(h->cfg.device);
     for (auto& c : h->ctx) {
+        if (!c.st) continue;
         if (c.st) (void)hipStreamSynchronize(c.st);
         if (c.ec && c.ec != c.st) { (void)hipStreamSynchronize(c.ec); (void)hipStreamDestroy(c.ec); }
         if (c.st) (void)hipStreamDestroy(c.st);
-        for (int k = 0; k < 2; k++) {
-            if (c.recon_ready[k]) (void)hipEventDestroy(c.recon_ready[k]);
-            if (c.entropy_done[k]) (void)hipEventDestroy(c.entropy_done[k]);
-            if (c.done[k]) (void)hipEventDestroy(c.done[k]);
-        }
+        if (c.recon_ready) (void)hipEventDestroy(c.recon_ready);
+        if (c.entropy_done) (void)hipEventDestroy(c.entropy_done);
+        if (c.done) (void)hipEventDestroy(c.done);
         if (c.h_err) (void)hipHostFree(c.h_err);
         if (c.h_itemtab) (void)hipHostFree(c.h_itemtab);
         (void)hipFree(c.d_itemtab);
@@ -1244,6 +1257,12 @@ void hub_free(Hub* h)
     for (auto& it : h->items) if (it.copied) (void)hipEventDestroy(it.copied);
     (void)hipFree(h->d_stage);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
+    if (h->verbose && h->pictures)
+        fprintf(stderr, "mi355x_h264 hub %dx%d: %llu pictures in %llu steps (%.2f per step, largest %llu); per picture: upload %.0f us, queued %.0f us, "
+                        "whole call %.0f us; per step: launch %.0f us, GPU wait %.0f us, finish %.0f us\n", h->cfg.width, h->cfg.height,
+                (unsigned long long)h->pictures, (unsigned long long)h->steps, (double)h->pictures / h->steps, (unsigned long long)h->max_batch,
+                (double)h->us_upload / h->pictures, (double)h->us_queue / h->pictures, (double)h->us_total / h->pictures,
+                (double)h->us_launch / h->steps, (double)h->us_gpu / h->steps, (double)h->us_finish / h->steps);
     if (h->e) mi355x_h264_destroy(h->e);
     delete h;
 }
@@ -1257,6 +1276,11 @@ int hub_create(const mi355x_h264_config& cfg, Hub** out)
     h->cap = std::min((int)MAX_BATCH, std::max(1, ci ? atoi(ci) : 32));
     const char* wu = getenv("MI355X_H264_HUB_WINDOW_US");
     if (wu) h->window_us = std::max(0, atoi(wu));
+    h->verbose = getenv("MI355X_H264_HUB_VERBOSE") != nullptr;
+    // MI355X_H264_HUB_CTX = contexts for P steps (default 2, 1..8): one step's loop filter overlaps the other's motion search.  More
+    // contexts mean more HIP streams, and those cost more than they bring (measured: 4 contexts -5 %, 6 contexts -50 %)
+    const char* nc = getenv("MI355X_H264_HUB_CTX");
+    h->nctx_p = std::min((int)Hub::MAX_CTX - 1, std::max(1, nc ? atoi(nc) : 2));
     mi355x_h264_config ec = cfg;
     ec.batch = h->cap; ec.refs = 1; ec.band_index = 0; ec.band_count = 0; ec.input_format = MI355X_H264_INPUT_I420;
     int rc = create_engine(&ec, &h->e, true);
@@ -1268,19 +1292,19 @@ int hub_create(const mi355x_h264_config& cfg, Hub** out)
     HK(hipMalloc((void**)&h->d_stage, h->st_stage * h->cap));
     HK(hipHostMalloc((void**)&h->h_stage, h->st_stage * h->cap, hipHostMallocDefault));
     for (auto& cs : h->copy_st) HK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
-    for (auto& c : h->ctx) {
+    for (int ci = 0; ci <= h->nctx_p; ci++) {
+        HubCtx& c = h->ctx[ci];
         HK(hipStreamCreateWithFlags(&c.st, hipStreamNonBlocking));
         const char* one = getenv("MI355X_H264_ONE_STREAM");
-        if (one && one[0] == '1') c.ec = c.st; else HK(hipStreamCreateWithFlags(&c.ec, hipStreamNonBlocking));
-        for (int k = 0; k < 2; k++) {
-            HK(hipEventCreateWithFlags(&c.recon_ready[k], hipEventDisableTiming));
-            HK(hipEventCreateWithFlags(&c.entropy_done[k], hipEventDisableTiming));
-            HK(hipEventCreateWithFlags(&c.done[k], hipEventDisableTiming));
-        }
+        if ((one && one[0] == '1') || ci == h->nctx_p) c.ec = c.st;   // (the IDR context: its row wavefront dominates, nothing to overlap)
+        else HK(hipStreamCreateWithFlags(&c.ec, hipStreamNonBlocking));
+        HK(hipEventCreateWithFlags(&c.recon_ready, hipEventDisableTiming));
+        HK(hipEventCreateWithFlags(&c.entropy_done, hipEventDisableTiming));
+        HK(hipEventCreateWithFlags(&c.done, hipEventDisableTiming));
         HK(hipHostMalloc((void**)&c.h_err, sizeof(unsigned), hipHostMallocDefault));
         *c.h_err = 0;
-        HK(hipHostMalloc((void**)&c.h_itemtab, 2 * MAX_BATCH * sizeof(uint32_t), hipHostMallocDefault));
-        HK(hipMalloc((void**)&c.d_itemtab, 2 * MAX_BATCH * sizeof(uint32_t)));
+        HK(hipHostMalloc((void**)&c.h_itemtab, MAX_BATCH * sizeof(uint32_t), hipHostMallocDefault));
+        HK(hipMalloc((void**)&c.d_itemtab, MAX_BATCH * sizeof(uint32_t)));
     }
     for (int i = 0; i < h->cap; i++) HK(hipEventCreateWithFlags(&h->items[i].copied, hipEventDisableTiming));
 #undef HK
@@ -1288,71 +1312,73 @@ int hub_create(const mi355x_h264_config& cfg, Hub** out)
     return MI355X_H264_OK;
 }
 
-// one lockstep step for the queued pictures `batch` on context c: launch (P pictures, then IDR pictures), wait, finish
-void hub_run_step(Hub* h, HubCtx& c, const std::vector<int>& batch)
+// will the stream's next picture be an IDR picture?
+bool hub_next_is_idr(const HubItem& it) { return it.force_idr || it.frames == 0 || it.frame_in_gop >= it.gop; }
+
+// one lockstep step for the queued pictures `batch` (all of one type) on context c: launch, wait, finish
+void hub_run_step(Hub* h, HubCtx& c, const std::vector<int>& batch, bool idr)
 {
     mi355x_h264_encoder* e = h->e;
     (void)hipSetDevice(h->cfg.device);
-    ItemPic pics[2][MAX_BATCH];
-    int n[2] = {0, 0};   // [0] P pictures, [1] IDR pictures
-    for (int idx : batch) {
-        HubItem& it = h->items[idx];
-        const bool idr = it.force_idr || it.frames == 0 || it.frame_in_gop >= it.gop;
+    ItemPic pics[MAX_BATCH];
+    const int n = (int)batch.size();
+    for (int k = 0; k < n; k++) {
+        HubItem& it = h->items[batch[k]];
         if (idr) { it.frame_in_gop = 0; it.frame_num = 0; }
         it.force_idr = 0;
-        pics[idr][n[idr]++] = ItemPic{idx, it.cur, it.qp, it.frame_num, it.idr_id};
+        pics[k] = ItemPic{batch[k], it.cur, it.qp, it.frame_num, it.idr_id};
     }
-    Step T[2];
+    Step T;
     int rc = MI355X_H264_OK;
     char errtxt[256] = {0};
+    const uint64_t t0 = now_us();
     {
         std::lock_guard<std::mutex> lk(h->launch_mu);
-        for (int ty = 0; ty < 2 && rc == MI355X_H264_OK; ty++) {
-            if (!n[ty]) continue;
-            uint32_t* tab = c.h_itemtab + ty * MAX_BATCH;
-            for (int k = 0; k < n[ty]; k++) {
-                tab[k] = (uint32_t)pics[ty][k].item | ((uint32_t)pics[ty][k].cur << 8) | ((uint32_t)pics[ty][k].qp << 16);
-                if (hipStreamWaitEvent(c.st, h->items[pics[ty][k].item].copied, 0) != hipSuccess) rc = MI355X_H264_E_HIP;
-            }
-            if (hipMemcpyAsync(c.d_itemtab + ty * MAX_BATCH, tab, (size_t)n[ty] * sizeof(uint32_t), hipMemcpyHostToDevice, c.st) != hipSuccess) rc = MI355X_H264_E_HIP;
-            if (rc != MI355X_H264_OK) break;
-            Step& S = T[ty];
-            S.d_src = h->d_stage; S.src_item_stride = h->st_stage; S.nv12 = false; S.idr = ty == 1; S.n = n[ty];
-            S.items = pics[ty]; S.d_itemtab = c.d_itemtab + ty * MAX_BATCH;
-            S.st = c.st; S.ec = c.ec; S.recon_ready = c.recon_ready[ty]; S.entropy_done = c.entropy_done[ty]; S.done = c.done[ty]; S.h_err = c.h_err;
-            S.slot = &e->slots[0];
-            rc = submit_step(e, S);
+        for (int k = 0; k < n; k++) {
+            c.h_itemtab[k] = (uint32_t)pics[k].item | ((uint32_t)pics[k].cur << 8) | ((uint32_t)pics[k].qp << 16);
+            if (hipStreamWaitEvent(c.st, h->items[pics[k].item].copied, 0) != hipSuccess) rc = MI355X_H264_E_HIP;
+        }
+        if (hipMemcpyAsync(c.d_itemtab, c.h_itemtab, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, c.st) != hipSuccess) rc = MI355X_H264_E_HIP;
+        if (rc == MI355X_H264_OK) {
+            T.d_src = h->d_stage; T.src_item_stride = h->st_stage; T.nv12 = false; T.idr = idr; T.n = n;
+            T.items = pics; T.d_itemtab = c.d_itemtab;
+            // entropy coding beside the loop filter shortens a picture's latency; with many streams open the second HIP stream
+            // costs more than the overlap brings (64 streams: 10.9 k -> 12.1 k fps on one stream per step)
+            T.st = c.st; T.ec = h->nopen > 32 ? c.st : c.ec; T.recon_ready = c.recon_ready; T.entropy_done = c.entropy_done; T.done = c.done; T.h_err = c.h_err;
+            T.slot = &e->slots[0];
+            rc = submit_step(e, T);
         }
         if (rc != MI355X_H264_OK) snprintf(errtxt, sizeof(errtxt), "%s", e->err);
     }
+    const uint64_t t1 = now_us();
     if (rc == MI355X_H264_OK) {
-        const int last = n[1] ? 1 : 0;
-        if (hipEventSynchronize(c.done[last]) != hipSuccess) { rc = MI355X_H264_E_HIP; snprintf(errtxt, sizeof(errtxt), "hipEventSynchronize failed"); }
+        if (hipEventSynchronize(c.done) != hipSuccess) { rc = MI355X_H264_E_HIP; snprintf(errtxt, sizeof(errtxt), "hipEventSynchronize failed"); }
     } else (void)hipStreamSynchronize(c.st);
     if (rc == MI355X_H264_OK && *c.h_err) {
         snprintf(errtxt, sizeof(errtxt), "wavefront kernel hand-off timed out (flag %u)", *c.h_err);
         *c.h_err = 0;
         rc = MI355X_H264_E_INTERNAL;
     }
+    const uint64_t t2 = now_us();
     std::lock_guard<std::mutex> lk(h->launch_mu);   // (finish_item touches the engine's statistics and error text)
-    for (int ty = 0; ty < 2; ty++)
-        for (int k = 0; k < n[ty]; k++) {
-            HubItem& it = h->items[pics[ty][k].item];
-            it.rc = rc;
-            if (rc == MI355X_H264_OK) {
-                const AuLayout L{T[ty].au_start, T[ty].payload_off, ty == 1, T[ty].nal_hdr};
-                it.rc = finish_item(e, e->slots[0], L, pics[ty][k].item, &it.out, &it.out_len, &it.frame_type);
-                if (it.rc != MI355X_H264_OK) snprintf(it.err, sizeof(it.err), "%s", e->err);
-            } else snprintf(it.err, sizeof(it.err), "%s", errtxt);
-            if (it.rc == MI355X_H264_OK) {
-                it.last_cur = it.cur;
-                it.cur = (it.cur + 1) % e->nbuf;
-                if (ty == 1) it.idr_id = (it.idr_id + 1) & 0xFF;
-                it.frame_num = (it.frame_num + 1) & 255;
-                it.frame_in_gop++;
-                it.frames++;
-            } else it.force_idr = 1;   // the picture is missing from the stream (or not to be trusted): the next one must not refer to it
-        }
+    struct Acc { Hub* h; uint64_t a, b, c; ~Acc() { h->us_launch += b - a; h->us_gpu += c - b; h->us_finish += now_us() - c; } } acc{h, t0, t1, t2};
+    for (int k = 0; k < n; k++) {
+        HubItem& it = h->items[pics[k].item];
+        it.rc = rc;
+        if (rc == MI355X_H264_OK) {
+            const AuLayout L{T.au_start, T.payload_off, idr, T.nal_hdr};
+            it.rc = finish_item(e, e->slots[0], L, pics[k].item, &it.out, &it.out_len, &it.frame_type);
+            if (it.rc != MI355X_H264_OK) snprintf(it.err, sizeof(it.err), "%s", e->err);
+        } else snprintf(it.err, sizeof(it.err), "%s", errtxt);
+        if (it.rc == MI355X_H264_OK) {
+            it.last_cur = it.cur;
+            it.cur = (it.cur + 1) % e->nbuf;
+            if (idr) it.idr_id = (it.idr_id + 1) & 0xFF;
+            it.frame_num = (it.frame_num + 1) & 255;
+            it.frame_in_gop++;
+            it.frames++;
+        } else it.force_idr = 1;   // the picture is missing from the stream (or not to be trusted): the next one must not refer to it
+    }
 }
 
 }  // namespace
@@ -1404,7 +1430,7 @@ void mi355x_h264_stream_close(mi355x_h264_stream* s)
         std::unique_lock<std::mutex> lk(h->mu);
         h->items[s->item].open = false;
         last = --h->nopen == 0;
-        if (last) h->cv.wait(lk, [&] { return !h->ctx[0].busy && !h->ctx[1].busy; });
+        if (last) h->cv.wait(lk, [&] { return !h->any_busy(); });
     }
     if (last) {
         g_hubs.erase(std::find(g_hubs.begin(), g_hubs.end(), h));
@@ -1422,6 +1448,7 @@ int mi355x_h264_stream_encode(mi355x_h264_stream* s, const uint8_t* y, int ys, c
     const int w = h->cfg.width, hh = h->cfg.height;
     if (ys < w || us < w / 2 || vs < w / 2) { snprintf(it.err, sizeof(it.err), "stride smaller than width"); return MI355X_H264_E_ARG; }
     if (hipSetDevice(h->cfg.device) != hipSuccess) { snprintf(it.err, sizeof(it.err), "hipSetDevice"); return MI355X_H264_E_HIP; }
+    const uint64_t t_in = now_us();
     {
         std::lock_guard<std::mutex> lk(h->mu);
         h->uploading++;   // a step that is being gathered waits (briefly) for this picture
@@ -1430,11 +1457,14 @@ int mi355x_h264_stream_encode(mi355x_h264_stream* s, const uint8_t* y, int ys, c
     // runs while piece k is on the bus (the reference's tight layout, InitSrcPic ref :354-365; other layouts row by row)
     uint8_t* hs = h->h_stage + (size_t)s->item * h->st_stage;
     uint8_t* ds = h->d_stage + (size_t)s->item * h->st_stage;
-    hipStream_t cs = h->copy_st[s->item & 1];
+    hipStream_t cs = h->copy_st[s->item % Hub::NCOPY];
     const size_t ysz = (size_t)w * hh, fb = ysz * 3 / 2;
     bool ok = true;
     if (ys == w && us == w / 2 && vs == w / 2 && u == y + ysz && v == u + ysz / 4) {
-        const size_t piece = ((fb / 4) + 255) & ~(size_t)255;
+        // few streams: four pieces, so that the copy of piece k + 1 runs while piece k is on the bus (latency); many streams: one
+        // transfer per picture (every queued command costs, and other streams' transfers fill the bus anyway: 16 / 32 / 64 streams
+        // went from 7.3 / 8.0 / 8.6 k to 8.8 / 11.5 / 10.9 k fps with this alone, profiles/r03_hub_sweep_*.log)
+        const size_t piece = h->nopen > 4 ? fb : (((fb / 4) + 255) & ~(size_t)255);
         for (size_t o = 0; o < fb && ok; o += piece) {
             const size_t len = std::min(piece, fb - o);
             memcpy(hs + o, y + o, len);
@@ -1455,31 +1485,43 @@ int mi355x_h264_stream_encode(mi355x_h264_stream* s, const uint8_t* y, int ys, c
     h->uploading--;
     if (!ok) { h->cv.notify_all(); snprintf(it.err, sizeof(it.err), "upload of the picture failed"); return MI355X_H264_E_HIP; }
     it.pending = true; it.done = false;
-    h->queue.push_back(s->item);
-    h->cv.notify_all();   // (a leader that is gathering counts the queue)
+    const uint64_t t_q = now_us();
+    h->us_upload += t_q - t_in;
+    h->queue[hub_next_is_idr(it) ? 1 : 0].push_back(s->item);
+    h->cv.notify_all();   // (a leader that is gathering counts the uploads still on their way)
     while (!it.done) {
-        HubCtx* c = !h->ctx[0].busy ? &h->ctx[0] : (!h->ctx[1].busy ? &h->ctx[1] : nullptr);
-        if (!h->collecting && c && !h->queue.empty()) {
+        // lead a step if one can start: an IDR step when IDR pictures wait and the IDR context is free, else a P step
+        HubCtx* c = nullptr;
+        bool idr = false;
+        if (!h->queue[1].empty() && !h->ctx[h->nctx_p].busy) { c = &h->ctx[h->nctx_p]; idr = true; }
+        else if (!h->queue[0].empty() && !h->collecting)
+            for (int ci = 0; ci < h->nctx_p && !c; ci++) if (!h->ctx[ci].busy) c = &h->ctx[ci];
+        if (!c) { h->cv.wait(lk); continue; }
+        c->busy = true;
+        if (!idr && h->uploading > 0 && h->window_us > 0) {   // pictures on their way in join this step if they make it within the window
             h->collecting = true;
-            c->busy = true;
-            if (h->uploading > 0 && h->window_us > 0) {   // pictures on their way in join this step if they make it within the window
-                const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(h->window_us);
-                h->cv.wait_until(lk, deadline, [&] { return h->uploading == 0; });
-            }
-            std::vector<int> batch;
-            batch.swap(h->queue);
+            const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(h->window_us);
+            h->cv.wait_until(lk, deadline, [&] { return h->uploading == 0; });
             h->collecting = false;
-            h->steps++; h->pictures += batch.size(); h->max_batch = std::max<uint64_t>(h->max_batch, batch.size());
-            lk.unlock();
-            hub_run_step(h, *c, batch);
-            lk.lock();
-            for (int idx : batch) { h->items[idx].done = true; h->items[idx].pending = false; }
-            c->busy = false;
-            h->cv.notify_all();
-        } else {
-            h->cv.wait(lk);
         }
+        // A P step takes at most its share of the open streams: with nctx_p steps in flight and one share uploading, a context
+        // that frees finds pictures already uploaded instead of waiting for the streams it has just released to come back
+        std::vector<int> batch;
+        std::vector<int>& q = h->queue[idr ? 1 : 0];
+        const size_t share = idr ? q.size() : std::max<size_t>(1, ((size_t)h->nopen + h->nctx_p) / (h->nctx_p + 1));
+        if (q.size() <= share) batch.swap(q);
+        else { batch.assign(q.begin(), q.begin() + share); q.erase(q.begin(), q.begin() + share); }
+        h->steps++; h->pictures += batch.size(); h->max_batch = std::max<uint64_t>(h->max_batch, batch.size());
+        h->us_queue += (now_us() - t_q);   // (the leader's own wait; the followers' is within a step of it)
+        if (!q.empty()) h->cv.notify_all();   // what is left can start on another free context at once
+        lk.unlock();
+        hub_run_step(h, *c, batch, idr);
+        lk.lock();
+        for (int idx : batch) { h->items[idx].done = true; h->items[idx].pending = false; }
+        c->busy = false;
+        h->cv.notify_all();
     }
+    h->us_total += now_us() - t_in;
     *out = it.out; *out_len = it.out_len;
     if (frame_type) *frame_type = it.frame_type;
     return it.rc;

@@ -47,9 +47,12 @@ bool VideoEncoderMI355X::EngineOpen(const Settings &s)
     const int32_t qp = GetIntEncParam("persist.vmi.video.encode.qp");
     m_fixedQp = Within(qp, 10, 51) ? qp : -1;
     cfg.rc_mode = m_fixedQp >= 0 ? MI355X_H264_RC_FIXED_QP : MI355X_H264_RC_BITRATE;
-    cfg.qp = m_fixedQp >= 0 ? m_fixedQp : Rc::kQpStart;
+    cfg.qp = m_fixedQp >= 0 ? m_fixedQp : StartQp(s.bitrate, s.fps, s.width, s.height);
     m_qp = cfg.qp;
     m_bufferBits = 0;
+    m_gopLeft = 0;
+    m_picsLeft = 0;
+    m_meanP = 0;
     m_sceneDetect = GetStrEncParam("persist.vmi.video.encode.scenedetect") != "0";
     // extension: 2..64 slice bands per picture for a shorter per-picture latency; anything else keeps the preset's
     // single slice (SM_SINGLE_SLICE, ref :247)
@@ -79,47 +82,67 @@ bool VideoEncoderMI355X::EngineOpen(const Settings &s)
     return true;
 }
 
-// Frame-level rate control for the bitrate mode.  Integer arithmetic only, so a test can replay the QP
-// sequence on the oracle.  The picture budgets of a GOP add up to the GOP's share of the rate: an IDR picture is budgeted
-// kIdrWeight P pictures' worth, a P picture rate / fps * gop / (gop - 1 + kIdrWeight).  A picture that misses its budget moves
-// the QP by one or two steps; a quarter / half second of debt (credit) in the virtual buffer pushes one / two steps further.
+// Frame-level rate control for the bitrate mode: GOP budget + damped QP steps, the C++ statement of media_amd/ratecontrol.py
+// (integer for integer; a test replays the QP sequence on the oracle).  A GOP has target * gop bits, less the debt the virtual
+// buffer carries into it (within [1/2, 3/2] of that); the IDR picture is paid out of it and every P picture is budgeted (what is
+// left) / (pictures left).  The QP moves by one step when the running mean of the P pictures' bits (3/4 old + 1/4 new) is 15 %
+// over or 13 % under the next picture's budget, by two beyond 3/2 and 2/3.
 // PARITY UNPINNED: OpenH264's own rate-control model is not available.
 void VideoEncoderMI355X::RateControlUpdate(uint32_t frameBytes, bool isIdr)
 {
     if (m_fixedQp >= 0) {
         return;
     }
-    constexpr int64_t kIdrWeight = 4;
     const int64_t rate = static_cast<int64_t>(Active().bitrate);
     const int64_t target = rate / std::max<uint32_t>(1, Active().fps);
     const int64_t gop = std::max<int64_t>(1, static_cast<int64_t>(Active().gop));
-    const int64_t pBudget = gop > 1 ? target * gop / (gop - 1 + kIdrWeight) : target;
     const int64_t bits = static_cast<int64_t>(frameBytes) * 8;
+    const int64_t debt = m_bufferBits;
     m_bufferBits = std::max<int64_t>(m_bufferBits + bits - target, -rate);
-    const int64_t budget = (isIdr && gop > 1) ? kIdrWeight * pBudget : pBudget;
+    int64_t est;
+    if (isIdr || m_picsLeft <= 0) {
+        const int64_t full = target * gop;
+        const int64_t budget = std::min(std::max(full - debt, full / 2), full * 3 / 2);
+        m_gopLeft = budget - bits;
+        m_picsLeft = gop - 1;
+        est = m_meanP != 0 ? m_meanP : bits / 9;   // (no P picture yet: an IDR picture costs about nine of them)
+    } else {
+        m_gopLeft -= bits;
+        m_picsLeft -= 1;
+        m_meanP = m_meanP != 0 ? (m_meanP * 3 + bits) / 4 : bits;
+        est = m_meanP;
+    }
+    // (floor division as in the Python statement: m_gopLeft may be negative)
+    const int64_t n = std::max<int64_t>(1, m_picsLeft);
+    int64_t share = m_gopLeft / n;
+    if (m_gopLeft < 0 && m_gopLeft % n != 0) {
+        share -= 1;
+    }
+    const int64_t next = std::max(share, target / 4);
     int32_t step = 0;
-    if (bits * 2 > budget * 3) {
-        step = 2;   // more than 1.5x the budget
-    } else if (bits * 10 > budget * 11) {
-        step = 1;   // more than 1.1x
-    } else if (bits * 3 < budget * 2) {
-        step = -2;  // less than 2/3
-    } else if (bits * 10 < budget * 9) {
-        step = -1;  // less than 0.9x
-    }
-    if (m_bufferBits * 4 > rate) {
-        step += 1;
-    }
-    if (m_bufferBits * 2 > rate) {
-        step += 1;
-    }
-    if (m_bufferBits * 4 < -rate) {
-        step -= 1;
-    }
-    if (m_bufferBits * 2 < -rate) {
-        step -= 1;
+    if (est * 2 > next * 3) {
+        step = 2;
+    } else if (est * 100 > next * 115) {
+        step = 1;
+    } else if (est * 3 < next * 2) {
+        step = -2;
+    } else if (est * 100 < next * 87) {
+        step = -1;
     }
     m_qp = std::min(Rc::kQpMax, std::max(Rc::kQpMin, m_qp + step));
+}
+
+// QP of a stream's first picture from its bits per pixel (media_amd/ratecontrol.py start_qp)
+int32_t VideoEncoderMI355X::StartQp(uint32_t bitrate, uint32_t fps, uint32_t width, uint32_t height)
+{
+    const int64_t mbpp = static_cast<int64_t>(bitrate) * 1000 / std::max<int64_t>(1, static_cast<int64_t>(fps) * width * height);
+    static const struct { int64_t lim; int32_t qp; } table[] = {{200, 24}, {100, 27}, {50, 30}, {25, 34}, {12, 38}};
+    for (const auto &t : table) {
+        if (mbpp >= t.lim) {
+            return t.qp;
+        }
+    }
+    return 42;
 }
 
 int VideoEncoderMI355X::EncodePicture(const uint8_t *i420, uint8_t **out, uint32_t *outLen, int *frameType)

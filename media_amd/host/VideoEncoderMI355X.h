@@ -39,6 +39,7 @@ protected:
 private:
     int EncodePicture(const uint8_t *i420, uint8_t **out, uint32_t *outLen, int *frameType);
     void RateControlUpdate(uint32_t frameBytes, bool isIdr);
+    static int32_t StartQp(uint32_t bitrate, uint32_t fps, uint32_t width, uint32_t height);
 
     mi355x_h264_encoder *m_engine = nullptr;   // an engine of its own (persist.vmi.video.encode.shared = 0), or
     mi355x_h264_stream *m_stream = nullptr;    // a stream of the process-wide shared engine (the default)
@@ -46,6 +47,7 @@ private:
     int32_t m_fixedQp = -1;            // >= 0: extension property persist.vmi.video.encode.qp selects fixed QP
     int32_t m_qp = Rc::kQpStart, m_lastQp = 0;
     int64_t m_bufferBits = 0;          // virtual buffer fullness relative to the target rate
+    int64_t m_gopLeft = 0, m_picsLeft = 0, m_meanP = 0;   // GOP budget left, P pictures left in the GOP, running mean of the P pictures' bits
     bool m_sceneDetect = true;         // bEnableSceneChangeDetect = 1 in the reference preset (ref :283)
     uint32_t m_sceneCuts = 0;
 };

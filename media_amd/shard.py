@@ -31,14 +31,14 @@ def reassemble(parts):
 
 
 def broadcast_rc_state(rc, src, dist, device=None):
-    """every rank adopts rank `src`'s rate-control state (qp, virtual buffer): the one exchange step of
+    """every rank adopts rank `src`'s rate-control state (qp, virtual buffer, GOP budget left, pictures left, mean P picture: five integers): the one exchange step of
     bitrate-mode GOP sharding.  dist is torch.distributed (backend nccl = RCCL on GPUs, gloo on CPU) or None."""
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return rc.state()
     import torch
     t = torch.tensor(list(rc.state()), dtype=torch.int64, device=device)
     dist.broadcast(t, src=src)
-    rc.set_state((int(t[0].item()), int(t[1].item())))
+    rc.set_state(tuple(int(x) for x in t.tolist()))
     return rc.state()
 
 

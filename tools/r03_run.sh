@@ -1,0 +1,24 @@
+#!/bin/bash
+# usage: r03_run.sh <tag> ; one GPU-box call of round 3: the GPU test suite, the plugin measurement with and without the shared engine, the default line
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/r03
+mkdir -p $O
+cd $R
+timeout -k 10 600 python -m pytest tests -m gpu -x -q > $O/gpu_tests_$1.log 2>&1; echo "tests rc=$?"; tail -3 $O/gpu_tests_$1.log
+timeout -k 10 600 python bench.py --mode plugin --streams 1,4,16,64 > $O/plugin_hub_$1.json 2> $O/plugin_hub_$1.err; echo "plugin hub rc=$?"
+MI355X_H264_HUB=0 timeout -k 10 600 python bench.py --mode plugin --streams 1,4,16,64 > $O/plugin_nohub_$1.json 2> $O/plugin_nohub_$1.err; echo "plugin nohub rc=$?"
+timeout -k 10 600 python bench.py --no-plugin --no-cpu-baseline > $O/bench_$1.json 2> $O/bench_$1.err; echo "bench rc=$?"
+python - <<PY
+import json
+for n in ("plugin_hub_$1", "plugin_nohub_$1"):
+    try:
+        d = json.load(open("$O/%s.json" % n))
+        for r in d["plugin"]["results"]:
+            print(n, {k: r[k] for k in ("streams", "fps_aggregate", "latency_ms_p50", "latency_ms_p99", "bitrate_achieved", "bitrate_first_2s", "scene_cut_recodes", "h2d_GBps")})
+        for r in d["plugin"].get("native", {}).get("results", []):
+            print(n, "native", {k: r[k] for k in ("streams", "fps_aggregate", "latency_ms_p50", "latency_ms_p99")})
+    except Exception as ex:
+        print(n, "unreadable", ex)
+d = json.load(open("$O/bench_$1.json"))
+print({k: d[k] for k in ("value", "ms_per_step", "single_gop_in_flight_fps")}, d["roofline"]["frac"], d["kernels"])
+PY
