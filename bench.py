@@ -84,7 +84,7 @@ def cpu_limits():
     return info
 
 
-def cpu_baseline(frames, thread_counts, gop_frames):
+def cpu_baseline(frames, thread_counts, gop_frames, search=1):
     """time the CPU oracle (kind 'port') on host cores.  For every thread count T of the sweep: T independent encoder
     instances (one Python thread each; the C code runs outside the GIL) are created and warmed with one picture OUTSIDE the
     clock, then all start together on a barrier and each encodes ONE WHOLE closed GOP of the workload (1 IDR + gop_frames - 1
@@ -98,7 +98,7 @@ def cpu_baseline(frames, thread_counts, gop_frames):
         # share every further doubling only doubles the time of the run
         if len(rows) >= 2 and rows[-1]["fps"] < 0.85 * max(r["fps"] for r in rows):
             break
-        encs = [OracleEncoder(WIDTH, HEIGHT, qp=QP, gop=GOP) for _ in range(T)]
+        encs = [OracleEncoder(WIDTH, HEIGHT, qp=QP, gop=GOP, search=search) for _ in range(T)]
         for e in encs:            # warm-up: allocations, page faults, the first picture's tables
             e.encode(frames[0])
         start = threading.Barrier(T + 1)
@@ -387,6 +387,8 @@ def main():
     ap.add_argument("--fps", type=int, default=30, choices=[30, 60])
     ap.add_argument("--content", default="s1", choices=["s1", "s2", "s3", "scroll"],
                     help="synthetic input of SURVEY.md 8(d); s1 pan+noise is the headline workload")
+    ap.add_argument("--search", default="seeded", choices=["seeded", "exhaustive"],
+                    help="integer motion search (config.search): seeded by the previous picture's vector with the exhaustive pass as fall-back (default), or always exhaustive")
     ap.add_argument("--slices", type=int, default=0,
                     help="slices per picture (bands of macroblock rows, SURVEY.md 8e-3); 0/1 = one slice, the reference preset and the headline")
     ap.add_argument("--mode", default="gops", choices=["gops", "plugin", "decode"],
@@ -474,7 +476,8 @@ def main():
         del uv
     torch.cuda.synchronize()
     profile_idc = {"baseline": 66, "main": 77, "high": 100}[args.profile]
-    enc_kw = dict(qp=QP, gop=GOP, device=local_rank, fps=args.fps, profile_idc=profile_idc, input_format=1 if args.input == "nv12" else 0, slices=args.slices)
+    enc_kw = dict(qp=QP, gop=GOP, device=local_rank, fps=args.fps, profile_idc=profile_idc, input_format=1 if args.input == "nv12" else 0, slices=args.slices,
+                  search=1 if args.search == "seeded" else 0)
 
     # I encoder instances (own HIP stream each), each encoding G/I GOPs in lockstep: every kernel launch of an
     # instance covers all its pictures of one time step (grid.y = G/I); instances overlap each other's
@@ -629,7 +632,7 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "1080p%d %s synthetic S1 pan+noise, %s profile, fixed QP 26, closed GOPs of 30 " % (args.fps, args.input.upper(), args.profile) +
-                                   "(1 IDR + 29 P), %s, 1 ref, deblock on, CAVLC; per GPU one stream, %d of its "
+                                   "(1 IDR + 29 P), %s, 1 ref, " + args.search + " +-16 integer search, deblock on, CAVLC; per GPU one stream, %d of its "
                                    "closed GOPs per step on %d encoder instance(s), each encoding its %d GOPs in lockstep "
                                    "(grid.y) on its own HIP streams; pictures resident in HBM" % ("single slice" if args.slices < 2 else "%d slice bands (filter idc 2)" % args.slices, G, I, B),
                        "content": args.content, "width": WIDTH, "height": HEIGHT, "qp": QP, "gop": GOP, "frames_per_step": FRAMES_PER_STEP * G, "gops_in_flight": G, "instances": I, "lockstep_batch": B,
@@ -703,7 +706,7 @@ def main():
                 counts.append(avail)
             if args.cpu_threads:
                 counts = [int(x) for x in args.cpu_threads.split(",")]
-            rows, single = cpu_baseline(frames, counts, max(8, min(args.cpu_frames, GOP)))
+            rows, single = cpu_baseline(frames, counts, max(8, min(args.cpu_frames, GOP)), 1 if args.search == "seeded" else 0)
             best = max(rows, key=lambda r: r["fps"])
             per = max(8, min(args.cpu_frames, GOP))
             res["cpu_baseline"] = {"value": best["fps"], "unit": "frames/s", "cores": best["threads"], "kind": "port",

@@ -35,7 +35,7 @@ class Config(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("width", C.c_int32), ("height", C.c_int32), ("fps", C.c_int32),
                 ("bitrate", C.c_int32), ("gop", C.c_int32), ("profile_idc", C.c_int32), ("rc_mode", C.c_int32),
                 ("qp", C.c_int32), ("device", C.c_int32), ("disable_deblock", C.c_int32),
-                ("batch", C.c_int32), ("input_format", C.c_int32), ("slices", C.c_int32), ("band_index", C.c_int32), ("band_count", C.c_int32), ("refs", C.c_int32)]
+                ("batch", C.c_int32), ("input_format", C.c_int32), ("slices", C.c_int32), ("band_index", C.c_int32), ("band_count", C.c_int32), ("refs", C.c_int32), ("search", C.c_int32)]
 
 
 class Stats(C.Structure):
@@ -109,7 +109,7 @@ class Encoder:
     """thin object wrapper; argument meaning follows mi355x_h264_config"""
 
     def __init__(self, width, height, qp=26, gop=30, fps=30, profile_idc=66, device=0, disable_deblock=0,
-                 bitrate=5000000, rc_mode=0, batch=1, input_format=0, slices=0, band_index=0, band_count=0, refs=0):
+                 bitrate=5000000, rc_mode=0, batch=1, input_format=0, slices=0, band_index=0, band_count=0, refs=0, search=1):
         L = lib()
         cfg = Config()
         L.mi355x_h264_default_config(C.byref(cfg))
@@ -120,6 +120,7 @@ class Encoder:
         cfg.slices = slices               # > 1: that many bands of macroblock rows, one slice NAL unit each
         cfg.band_index, cfg.band_count = band_index, band_count   # band_count > 1: this instance codes its share of the slices
         cfg.refs = refs                                           # reference frames searched (0 / 1: one, the reference preset)
+        cfg.search = search                                       # 0 exhaustive integer search, 1 seeded by the previous picture's vector (the default)
         self.batch = batch
         self.h = C.c_void_p()
         rc = L.mi355x_h264_create(C.byref(cfg), C.byref(self.h))
@@ -248,12 +249,12 @@ class Stream:
     """a stream of the shared engine (include/mi355x_h264.h, "streams"): one picture per call, coded together with the pictures
     other streams of the same geometry deliver at about the same time; thread-safe across streams (one thread per stream)"""
 
-    def __init__(self, width, height, qp=26, gop=30, fps=30, profile_idc=66, device=0, disable_deblock=0, slices=0):
+    def __init__(self, width, height, qp=26, gop=30, fps=30, profile_idc=66, device=0, disable_deblock=0, slices=0, search=1):
         L = lib()
         cfg = Config()
         L.mi355x_h264_default_config(C.byref(cfg))
         cfg.width, cfg.height, cfg.qp, cfg.gop, cfg.fps = width, height, qp, gop, fps
-        cfg.profile_idc, cfg.device, cfg.disable_deblock, cfg.slices = profile_idc, device, disable_deblock, slices
+        cfg.profile_idc, cfg.device, cfg.disable_deblock, cfg.slices, cfg.search = profile_idc, device, disable_deblock, slices, search
         self.h = C.c_void_p()
         rc = L.mi355x_h264_stream_open(C.byref(cfg), C.byref(self.h))
         if rc != 0:

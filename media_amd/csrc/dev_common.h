@@ -86,6 +86,7 @@ struct FrameParams {
     Quant qy, qc;        // luma / chroma quantisers
     int lambda;
     int sad_nz;          // a luma SAD of this much or more cannot quantise to nothing (fill in submit(): exact bound)
+    int search;          // config.search: 0 exhaustive integer search, 1 seeded by the previous picture's vector (k_me section 1b)
     // lockstep batch (gridDim.y = number of independent closed GOPs / streams encoded together):
     // element strides between consecutive batch items
     size_t st_src;       // bytes between the source pictures of two batch items

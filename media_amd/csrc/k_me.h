@@ -281,10 +281,48 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ME_WAVES_MIN
         }
     }
 
+    // ---- 1b. seeded search (config.search = 1): the macroblock's previous-picture vector, rounded to integer samples, against
+    // its eight integer neighbours on the exhaustive pass's own key.  A strict local minimum inside the search range is the
+    // integer winner and the exhaustive pass is skipped; else it runs and the result is what it always was (oracle/h264_enc.c
+    // motion_search).  lane = (dy - sy + 1, source row): three SADs (dx = sx - 1, sx, sx + 1) of one row each, summed over the
+    // sixteen rows by DPP; the nine keys are compared on the scalar unit. ----
+    unsigned best = 0xFFFFFFFFu;
+    bool seeded = false;
+    if (P.search == 1) {
+        const int sx = (pmx + 2) >> 2, sy = (pmy + 2) >> 2;
+        if (sx >= -ME_R && sx < ME_R && sy >= -ME_R && sy < ME_R) {   // wave-uniform
+            const int g = lane >> 4, j = lane & 15;
+            const int dyc = sy - 1 + (g < 3 ? g : 0);
+            const uint4 sv = *(const uint4*)(s_src + 16 * j);
+            const int ob = (ME_R + ME_AP + dyc + j) * ME_WS + ME_R + ME_AP + sx - 1;
+            int sad3[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                uint32_t a = __builtin_amdgcn_sad_u8(lds_ld4(winb, ob + k), sv.x, 0u);
+                a = __builtin_amdgcn_sad_u8(lds_ld4(winb, ob + k + 4), sv.y, a);
+                a = __builtin_amdgcn_sad_u8(lds_ld4(winb, ob + k + 8), sv.z, a);
+                a = __builtin_amdgcn_sad_u8(lds_ld4(winb, ob + k + 12), sv.w, a);
+                sad3[k] = row_sum16_dpp((int)a);
+            }
+            unsigned ckey = 0, nmin = 0xFFFFFFFFu;
+#pragma unroll
+            for (int gy = 0; gy < 3; gy++)
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    const int dx = sx - 1 + k, dy = sy - 1 + gy;
+                    const unsigned sad = (unsigned)__builtin_amdgcn_readlane(sad3[k], 16 * gy);
+                    const unsigned key = ((sad + (unsigned)(P.lambda * (se_len(4 * dx - pmx) + se_len(4 * dy - pmy)))) << 10) | (unsigned)(((dy + ME_R) << 5) | (dx + ME_R));
+                    const bool inr = dx >= -ME_R && dx < ME_R && dy >= -ME_R && dy < ME_R;
+                    if (gy == 1 && k == 1) ckey = key;
+                    else if (inr && key < nmin) nmin = key;
+                }
+            if (ckey < nmin) { best = ckey; seeded = true; }
+        }
+    }
+
     // ---- 2. integer full search: lane = (dx, half of the dy range); 16 SAD accumulators per lane, one pass over
     // 31 window rows, every row feeding up to 16 candidates (v_sad_u8, four samples per instruction) ----
-    unsigned best;
-    {
+    if (!seeded) {
         const int dxi = lane & 31, half = lane >> 5;
         const int col = dxi + ME_AP, cdw = col >> 2, sh = col & 3;
         // motion-vector cost and candidate index of every dy, shifted into key position: one table per macroblock

@@ -381,6 +381,7 @@ int submit_step(mi355x_h264_encoder* e, Step& T)
     const unsigned pic_serial = e->pic_serial;
     const unsigned G = (unsigned)T.n;
     fill_qp(P.qy, P.qc, P.lambda, P.sad_nz, e->qp);   // (indirect launches take these from qtab by the item's own QP)
+    P.search = e->cfg.search;
     hipStream_t st = T.st;
     auto next_serial = [&]() { e->serial = e->serial == 0xFFFFFFFFu ? 1 : e->serial + 1; return e->serial; };
 
@@ -679,6 +680,7 @@ void mi355x_h264_default_config(mi355x_h264_config* c)
     c->width = 720; c->height = 1280;  // reference defaults, VideoEncoderOpenH264.h:13-24
     c->fps = 30; c->bitrate = 5000000; c->gop = 30; c->profile_idc = 66;
     c->rc_mode = MI355X_H264_RC_FIXED_QP; c->qp = 26; c->device = 0; c->disable_deblock = 0;
+    c->search = MI355X_H264_SEARCH_SEEDED;
 }
 
 // hub_engine: the engine of a stream hub (below) - one set of output buffers instead of NSLOT, never more than one HIP stream
@@ -696,6 +698,7 @@ static int create_engine(const mi355x_h264_config* cfg, mi355x_h264_encoder** ou
     if (cfg->input_format != MI355X_H264_INPUT_I420 && cfg->input_format != MI355X_H264_INPUT_NV12) return MI355X_H264_E_ARG;
     if (cfg->slices < 0 || cfg->slices > 64) return MI355X_H264_E_ARG;
     if (cfg->refs < 0 || cfg->refs > mi355x_h264_encoder::MAX_REFS) return MI355X_H264_E_ARG;
+    if (cfg->search != MI355X_H264_SEARCH_EXHAUSTIVE && cfg->search != MI355X_H264_SEARCH_SEEDED) return MI355X_H264_E_ARG;
     if (cfg->band_count < 0 || cfg->band_index < 0 || (cfg->band_count > 1 && (cfg->band_index >= cfg->band_count || cfg->batch > 1))) return MI355X_H264_E_ARG;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev) return MI355X_H264_E_NODEVICE;
@@ -1234,7 +1237,7 @@ std::vector<Hub*> g_hubs;
 bool same_geometry(const mi355x_h264_config& a, const mi355x_h264_config& b)
 {
     return a.width == b.width && a.height == b.height && a.fps == b.fps && a.profile_idc == b.profile_idc && a.device == b.device &&
-           a.disable_deblock == b.disable_deblock && a.slices == b.slices;
+           a.disable_deblock == b.disable_deblock && a.slices == b.slices && a.search == b.search;
 }
 
 void hub_free(Hub* h)

@@ -58,6 +58,10 @@ bool VideoEncoderMI355X::EngineOpen(const Settings &s)
     // single slice (SM_SINGLE_SLICE, ref :247)
     const int32_t slices = GetIntEncParam("persist.vmi.video.encode.slices");
     cfg.slices = Within(slices, 2, 64) ? slices : 0;
+    // extension: "0" = exhaustive integer motion search instead of the default seeded one (include/mi355x_h264.h config.search)
+    if (GetStrEncParam("persist.vmi.video.encode.search") == "0") {
+        cfg.search = MI355X_H264_SEARCH_EXHAUSTIVE;
+    }
     // One engine per object (mi355x_h264_create) costs every picture its own launch sequence.  The default is a STREAM of the
     // shared engine: the pictures that the encoder objects of one process hand over at about the same time are coded in one
     // lockstep step (include/mi355x_h264.h, "streams"; same bitstream).  persist.vmi.video.encode.shared = 0 (or the environment

@@ -893,7 +893,28 @@ static int motion_search(h264o_enc *e, int mx, int my, mv_t pmv, const uint8_t *
     for (int y = 0; y < WS; y++)
         for (int x = 0; x < WS; x++) win[y * WS + x] = (uint8_t)refpx(refy, cw, cw, ch, bx - R - AP + x, by - R - AP + y);
     uint32_t best_key = 0xFFFFFFFFu;
-    for (int dy = -R; dy < R; dy++)
+    int seeded = 0;
+    if (e->cfg.search == 1) {
+        /* seeded search: the previous picture's vector of this macroblock, rounded to integer samples (the same rounding as
+         * the "nothing left to code" test), against its eight integer neighbours, on the exhaustive pass's own key (SAD +
+         * lambda * bits(mv - pmv), then the candidate index).  A strict local minimum inside the search range is taken as the
+         * integer winner; anything else falls through to the exhaustive pass, whose result is then what it always was. */
+        const int sx = (pmv.x + 2) >> 2, sy = (pmv.y + 2) >> 2;
+        if (sx >= -R && sx < R && sy >= -R && sy < R) {
+            uint32_t ckey = 0, nmin = 0xFFFFFFFFu;
+            for (int dy = sy - 1; dy <= sy + 1; dy++)
+                for (int dx = sx - 1; dx <= sx + 1; dx++) {
+                    if (dx < -R || dx >= R || dy < -R || dy >= R) continue;
+                    int sad = h264o_sad16x16(s, cw, win + (dy + R + AP) * WS + dx + R + AP, WS);
+                    uint32_t cost = (uint32_t)(sad + lambda * (se_len(4 * dx - pmv.x) + se_len(4 * dy - pmv.y)));
+                    uint32_t key = (cost << 10) | (uint32_t)(((dy + R) << 5) | (dx + R));
+                    if (dx == sx && dy == sy) ckey = key;
+                    else if (key < nmin) nmin = key;
+                }
+            if (ckey < nmin) { best_key = ckey; seeded = 1; }
+        }
+    }
+    for (int dy = -R; dy < R && !seeded; dy++)
         for (int dx = -R; dx < R; dx++) {
             int sad = h264o_sad16x16(s, cw, win + (dy + R + AP) * WS + dx + R + AP, WS);
             uint32_t cost = (uint32_t)(sad + lambda * (se_len(4 * dx - pmv.x) + se_len(4 * dy - pmv.y)));

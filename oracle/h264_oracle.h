@@ -51,6 +51,10 @@ typedef struct {
     int32_t band_count;     /* picture on several instances / GPUs, mirrors mi355x_h264_config)                       */
     int32_t refs;           /* 0/1: one reference frame (the reference preset, iNumRefFrame = 1 :290); 2, 3: the motion
                              * search runs on the last `refs` pictures (BASELINE.json configs[4]), ref_idx_l0 is coded      */
+    int32_t search;         /* integer motion search (mirrors mi355x_h264_config.search): 0 = exhaustive +-16 around the co-located
+                             * macroblock; 1 = seeded - when the macroblock's previous-picture vector, rounded to integer samples,
+                             * is a strict local minimum of the search cost among its eight integer neighbours, it is taken as
+                             * the integer winner and the exhaustive pass is skipped (it runs whenever the test fails)         */
 } h264o_config;
 
 typedef struct h264o_enc h264o_enc;

@@ -38,18 +38,26 @@ CASES = [
     ("qvga_cut_2refs_high", 320, 240, "cut", 28, 30, 6, 100, 2, 2),
     ("qcif_split_partitions", 176, 144, "split", 26, 30, 4, 66),      # 16x8 / 8x16 / 8x8 partitions
     ("cif_split_3refs_high_2slices", 352, 288, "split", 30, 30, 4, 100, 2, 3),
+    # the cases above run the EXHAUSTIVE integer search (search = 0: their vectors are those of rounds 1 and 2); the ones below the
+    # seeded search, the default since round 3 (config.search = 1): name, ..., slices, refs, search
+    ("seeded_qvga_s1", 320, 240, "s1", 26, 30, 6, 66, 0, 0, 1),
+    ("seeded_cif_scroll_main", 352, 288, "scroll", 30, 30, 5, 77, 0, 0, 1),
+    ("seeded_qcif_cut_qp28", 176, 144, "cut", 28, 30, 5, 66, 0, 0, 1),
+    ("seeded_cif_split_3refs_high_2slices", 352, 288, "split", 30, 30, 4, 100, 2, 3, 1),
+    ("seeded_qvga_ramp_qp32", 320, 240, "ramp", 32, 30, 5, 66, 0, 0, 1),
+    ("seeded_edge_130x98_s1", 130, 98, "s1", 28, 30, 5, 66, 0, 0, 1),
 ]
 
 
-def run_case(name, w, h, kind, qp, gop, n, prof, slices=0, refs=0):
-    enc = OracleEncoder(w, h, qp=qp, gop=gop, profile_idc=prof, slices=slices, refs=refs)
+def run_case(name, w, h, kind, qp, gop, n, prof, slices=0, refs=0, search=0):
+    enc = OracleEncoder(w, h, qp=qp, gop=gop, profile_idc=prof, slices=slices, refs=refs, search=search)
     frames = []
     for f in synth.sequence(kind, w, h, n):
         bs, idr = enc.encode(f)
         rec = hashlib.sha256(b"".join(enc.recon(p).tobytes() for p in range(3))).hexdigest()
         frames.append({"idr": bool(idr), "bytes": len(bs), "sha256": hashlib.sha256(bs).hexdigest(), "recon_sha256": rec})
     enc.close()
-    return {"name": name, "width": w, "height": h, "kind": kind, "qp": qp, "gop": gop, "profile_idc": prof, "slices": slices, "refs": refs, "frames": frames}
+    return {"name": name, "width": w, "height": h, "kind": kind, "qp": qp, "gop": gop, "profile_idc": prof, "slices": slices, "refs": refs, "search": search, "frames": frames}
 
 
 # Streams of random syntax for the decoder peer (oracle/h264_enc.c h264o_enc_random_picture): what is pinned is the stream

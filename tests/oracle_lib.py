@@ -14,7 +14,7 @@ LV_LUMA_DC, LV_LUMA, LV_CHROMA_DC, LV_CHROMA_AC = 0, 16, 272, 280
 
 class Config(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("fps", C.c_int32), ("qp", C.c_int32),
-                ("gop", C.c_int32), ("profile_idc", C.c_int32), ("disable_deblock", C.c_int32), ("slices", C.c_int32), ("band_index", C.c_int32), ("band_count", C.c_int32), ("refs", C.c_int32)]
+                ("gop", C.c_int32), ("profile_idc", C.c_int32), ("disable_deblock", C.c_int32), ("slices", C.c_int32), ("band_index", C.c_int32), ("band_count", C.c_int32), ("refs", C.c_int32), ("search", C.c_int32)]
 
 
 MBINFO_DTYPE = np.dtype([("mvx", "<i2"), ("mvy", "<i2"), ("type", "u1"), ("i16_mode", "u1"),
@@ -116,8 +116,8 @@ def _ptr(a):
 
 
 class OracleEncoder:
-    def __init__(self, width, height, qp=26, gop=30, fps=30, profile_idc=66, disable_deblock=0, slices=0, band_index=0, band_count=0, refs=0):
-        self.cfg = Config(width, height, fps, qp, gop, profile_idc, disable_deblock, slices, band_index, band_count, refs)
+    def __init__(self, width, height, qp=26, gop=30, fps=30, profile_idc=66, disable_deblock=0, slices=0, band_index=0, band_count=0, refs=0, search=1):
+        self.cfg = Config(width, height, fps, qp, gop, profile_idc, disable_deblock, slices, band_index, band_count, refs, search)
         self.h = lib().h264o_enc_create(C.byref(self.cfg))
         if not self.h:
             raise ValueError("oracle rejected config")

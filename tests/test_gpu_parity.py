@@ -48,9 +48,9 @@ def _compare_all(enc, orc, tag):
 @pytest.mark.parametrize("case", GOLD["cases"], ids=[c["name"] for c in GOLD["cases"]])
 def test_golden_cases_bit_exact(case):
     w, h = case["width"], case["height"]
-    enc = capi.Encoder(w, h, qp=case["qp"], gop=case["gop"], profile_idc=case["profile_idc"], slices=case.get("slices", 0), refs=case.get("refs", 0))
+    enc = capi.Encoder(w, h, qp=case["qp"], gop=case["gop"], profile_idc=case["profile_idc"], slices=case.get("slices", 0), refs=case.get("refs", 0), search=case.get("search", 0))
     enc.keep_pre(True)
-    orc = OracleEncoder(w, h, qp=case["qp"], gop=case["gop"], profile_idc=case["profile_idc"], slices=case.get("slices", 0), refs=case.get("refs", 0))
+    orc = OracleEncoder(w, h, qp=case["qp"], gop=case["gop"], profile_idc=case["profile_idc"], slices=case.get("slices", 0), refs=case.get("refs", 0), search=case.get("search", 0))
     for i, (f, g) in enumerate(zip(synth.sequence(case["kind"], w, h, len(case["frames"])), case["frames"])):
         bs, ft = enc.encode(f)
         obs, idr = orc.encode(f)

@@ -16,7 +16,7 @@ GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "oracle_
 @pytest.mark.parametrize("case", GOLD["cases"], ids=[c["name"] for c in GOLD["cases"]])
 def test_golden_and_roundtrip(case):
     w, h = case["width"], case["height"]
-    enc = OracleEncoder(w, h, qp=case["qp"], gop=case["gop"], profile_idc=case["profile_idc"], slices=case.get("slices", 0), refs=case.get("refs", 0))
+    enc = OracleEncoder(w, h, qp=case["qp"], gop=case["gop"], profile_idc=case["profile_idc"], slices=case.get("slices", 0), refs=case.get("refs", 0), search=case.get("search", 0))
     dec = OracleDecoder()
     for i, (f, g) in enumerate(zip(synth.sequence(case["kind"], w, h, len(case["frames"])), case["frames"])):
         bs, idr = enc.encode(f)

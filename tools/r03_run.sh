@@ -8,6 +8,8 @@ timeout -k 10 600 python -m pytest tests -m gpu -x -q > $O/gpu_tests_$1.log 2>&1
 timeout -k 10 600 python bench.py --mode plugin --streams 1,4,16,64 > $O/plugin_hub_$1.json 2> $O/plugin_hub_$1.err; echo "plugin hub rc=$?"
 MI355X_H264_HUB=0 timeout -k 10 600 python bench.py --mode plugin --streams 1,4,16,64 > $O/plugin_nohub_$1.json 2> $O/plugin_nohub_$1.err; echo "plugin nohub rc=$?"
 timeout -k 10 600 python bench.py --no-plugin --no-cpu-baseline > $O/bench_$1.json 2> $O/bench_$1.err; echo "bench rc=$?"
+timeout -k 10 600 python bench.py --no-plugin --no-cpu-baseline --search exhaustive > $O/bench_exh_$1.json 2> $O/bench_exh_$1.err; echo "bench exhaustive rc=$?"
+for c in scroll s2 s3; do timeout -k 10 300 python bench.py --no-plugin --no-cpu-baseline --steps 4 --content $c > $O/bench_${c}_$1.json 2> /dev/null; timeout -k 10 300 python bench.py --no-plugin --no-cpu-baseline --steps 4 --content $c --search exhaustive > $O/bench_${c}_exh_$1.json 2> /dev/null; done
 python - <<PY
 import json
 for n in ("plugin_hub_$1", "plugin_nohub_$1"):
@@ -19,6 +21,10 @@ for n in ("plugin_hub_$1", "plugin_nohub_$1"):
             print(n, "native", {k: r[k] for k in ("streams", "fps_aggregate", "latency_ms_p50", "latency_ms_p99")})
     except Exception as ex:
         print(n, "unreadable", ex)
-d = json.load(open("$O/bench_$1.json"))
-print({k: d[k] for k in ("value", "ms_per_step", "single_gop_in_flight_fps")}, d["roofline"]["frac"], d["kernels"])
+for n in ("bench_$1", "bench_exh_$1", "bench_scroll_$1", "bench_scroll_exh_$1", "bench_s2_$1", "bench_s2_exh_$1", "bench_s3_$1", "bench_s3_exh_$1"):
+    try:
+        d = json.load(open("$O/%s.json" % n))
+        print(n, {k: d[k] for k in ("value", "ms_per_step", "single_gop_in_flight_fps")}, d["roofline"]["frac"], d["config"]["bytes_per_gop"], {k: v["ms_per_launch"] for k, v in d["kernels"].items()})
+    except Exception as ex:
+        print(n, "unreadable", ex)
 PY
