@@ -10,6 +10,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libmi355x_h264.so")
+if os.environ.get("MI355X_H264_LIB"):   # A/B measurements: another build of the same library (media_amd/csrc/Makefile target `ab`)
+    LIB_PATH = os.environ["MI355X_H264_LIB"]
 
 LV_STRIDE = 416
 MBINFO_DTYPE = np.dtype([("mvx", "<i2"), ("mvy", "<i2"), ("type", "u1"), ("i16_mode", "u1"),

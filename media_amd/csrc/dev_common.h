@@ -391,6 +391,11 @@ __device__ __forceinline__ int group_sum8_dpp(int v)   // sum over aligned group
     v += __builtin_amdgcn_mov_dpp(v, 0x141, 0xf, 0xf, false);   // row_half_mirror
     return v;
 }
+__device__ __forceinline__ int wave_sum_dpp(int v)   // sum over the 64 lanes, wave-uniform result
+{
+    v = row_sum16_dpp(v);
+    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
+}
 __device__ __forceinline__ unsigned wave_min_u32_dpp(unsigned v)   // minimum over the 64 lanes, wave-uniform result
 {
     auto step = [](unsigned x, unsigned t) { return t < x ? t : x; };

@@ -247,6 +247,17 @@ __device__ __forceinline__ void filt_uni(const int p3, int& p2, int& p1, int& p0
 }
 
 enum { DR_LP = 40, DR_CP = 24 };  // LDS pitches; luma tile cols -16..15 (+4 pad), rows -4..15; chroma cols -8..7, rows -4..15
+// One tile holds luma and both chroma planes at offsets chosen for the LDS banks (64 x 4 B; ds_read / write_b32 serve 32 lanes at
+// a time by (address / 4) mod 32).  The vertical-edge phase has 16 luma and 16 chroma lanes each read and write dword w of ITS
+// line: luma lines are 10 dwords apart and take the 16 banks of one parity; chroma lines 6 dwords apart take 8 banks of the other
+// parity when the plane starts at an odd dword (DR_CB), and the second plane the remaining 8 when it lies 16 mod 32 dwords
+// after the first (DR_CPS) - 32 lanes, 32 banks.  (Separate arrays had put all 32 lines on the 16 odd banks, the two chroma
+// planes partly on each other's: 2- and 3-way conflicts on every access of the phase)
+#ifdef MI355X_AB_OLD_DB_TILE   // A/B builds only (media_amd/csrc/Makefile target `ab`): the layout before round 3, chroma straight behind luma
+enum { DR_CB = 4 * 200, DR_CPS = 4 * 120, DR_TILE = DR_CB + 2 * DR_CPS + 12 };
+#else
+enum { DR_CB = 4 * 201, DR_CPS = 4 * 144, DR_TILE = DR_CB + 2 * DR_CPS + 12 };
+#endif
 
 // PERMB (the decoder peer, streams of other encoders): qPp / qPq are the two macroblocks' own QPs (mb_qp_delta, I_PCM = 0),
 // the chroma QPs go through chroma_qp_index_offset, indexA / indexB through the slice's filter offsets - three threshold
@@ -282,10 +293,9 @@ __global__ __launch_bounds__(64) void k_deblock_rows(DbRowParams R)
     // filtered), its last row stores all sixteen sample rows itself
     const bool first_row = !D.sl.has_top(my);
     const bool last_row = my == D.mbh - 1 || !D.sl.has_top(my + 1);
-    __shared__ __attribute__((aligned(16))) uint8_t s_y[20 * DR_LP];     // [row+4][col+16]
-    __shared__ __attribute__((aligned(16))) uint8_t s_c[2][20 * DR_CP];  // [row+4][col+8] (rows 8.. unused padding)
+    __shared__ __attribute__((aligned(16))) uint8_t s_y[DR_TILE];        // luma [row+4][col+16], then the chroma planes [row+4][col+8] at DR_CB + plane * DR_CPS
 #define SY(r, c) s_y[((r) + 4) * DR_LP + (c) + 16]
-#define SC(pl, r, c) s_c[pl][((r) + 4) * DR_CP + (c) + 8]
+#define SC(pl, r, c) s_y[DR_CB + (pl) * DR_CPS + ((r) + 4) * DR_CP + (c) + 8]
     bool timed_out = false;
     const int yr = lane >> 2, yc4 = (lane & 3) * 4;                                   // luma dword owned by this lane
     const int cpl_l = (lane >> 4) & 1, cr_l = (lane >> 1) & 7, cc4 = (lane & 1) * 4;  // chroma dword (lanes < 32)
@@ -520,12 +530,11 @@ __global__ __launch_bounds__(64) void k_deblock_pairs(DbRowParams R)
     const bool first_row = half == 0 && rowA == 0;  // (one slice: only picture row 0 has nothing above)
     const bool last_row = my == D.mbh - 1;
     const bool from_lds = half == 1;                // the lower row's top apron comes from the upper row through LDS
-    __shared__ __attribute__((aligned(16))) uint8_t s_yy[2][20 * DR_LP];
-    __shared__ __attribute__((aligned(16))) uint8_t s_cc[2][2][20 * DR_CP];
+    __shared__ __attribute__((aligned(16))) uint8_t s_yy[2][(DR_TILE + 127) / 128 * 128];   // one tile per row of the pair (a multiple of 32 dwords apart: the same banks)
     __shared__ __attribute__((aligned(16))) uint32_t s_ring[2][24];   // bottom rows of the upper row's macroblock (parity of its index): 16 luma + 8 chroma dwords
     uint8_t* const s_y = s_yy[half];
 #define SY(r, c) s_y[((r) + 4) * DR_LP + (c) + 16]
-#define SC(pl, r, c) s_cc[half][pl][((r) + 4) * DR_CP + (c) + 8]
+#define SC(pl, r, c) s_y[DR_CB + (pl) * DR_CPS + ((r) + 4) * DR_CP + (c) + 8]
     bool timed_out = false;
     // luma dwords owned by this lane: two of the 64 of a macroblock (rows yr0 and yr0 + 8); chroma dword as in the row form
     const int yr0 = hl >> 2, yc4 = (hl & 3) * 4;
