@@ -336,35 +336,51 @@ def latest_profile(suffix):
 def valu_issue_bound(nmb):
     """What actually bounds the pipeline: VALU instruction issue.  From the committed PMC pass
     (profiles/rNN?_summary.json, SQ_INSTS_VALU of the lockstep launches of this same default workload): instructions per
-    macroblock over all kernels, averaged over a GOP of 1 IDR + 29 P pictures -> pictures per second 1 024 SIMDs can
-    issue (one VALU instruction per wave per 4 cycles at 2.4 GHz).  Informational; None when no summary is committed."""
+    macroblock over all kernels, averaged over a GOP of 1 IDR + 29 P pictures -> pictures per second 1 024 SIMDs can issue.
+    Priced two ways: every instruction at 4 cycles (`bound_fps_4cycles`, the round-2 figure), and by the MEASURED issue classes
+    (tools/ubench_issue.hip: ~2.3 cycles for plain 32-bit-encoded VOP1/VOP2 on VGPR / constant operands, ~4.15 for everything
+    else) with each kernel's static class mix from profiles/rNN_valu_classes.json (tools/valu_classes.py) applied to its
+    dynamic count - `bound_fps`.  Informational; None when no summary is committed."""
     f = latest_profile("summary.json")
     if f is None:
         return None
     try:
         sq = json.load(open(f)).get("sq", {})
-        per = {}
+        cf = latest_profile("valu_classes.json")
+        classes = json.load(open(cf))["kernels"] if cf else {}
+        per, cyc = {}, {}
         for name, v in sq.items():
             k = name.split(" grid=")[0]
             if not k.startswith("k_") or not v.get("SQ_WAVES"):
                 continue
             if k not in per or v["SQ_INSTS_VALU"] > per[k]:              # the lockstep (largest) launch of each kernel
                 per[k] = v["SQ_INSTS_VALU"]
-        entropy = sum(per.get(k, 0) for k in ("k_bs", "k_cavlc<false>", "k_cavlc<true>", "k_bit_scan", "k_pack"))
-        # (the loop filter's name carries its template arguments: <BS4> until r02c, <BS4, PERMB> since)
-        # (lockstep batches of 8 pictures or more run the pair form of the filter since r02f)
-        db_p = per.get("k_deblock_pairs<false>") or per.get("k_deblock_rows<false, false>", per.get("k_deblock_rows<false>", 0))
-        db_i = per.get("k_deblock_pairs<true>") or per.get("k_deblock_rows<true, false>", per.get("k_deblock_rows<true>", 0))
-        p_pic = entropy + db_p + sum(per.get(k, 0) for k in ("k_me", "k_tq", "k_mvpred", "k_skip_scan", "k_pintra_rows", "k_pintra_rows<false>"))
-        idr = entropy + db_i + sum(per.get(k, 0) for k in ("k_i4_decide", "k_intra_rows"))
-        if not per.get("k_me") or not per.get("k_tq"):
+                cyc[k] = per[k] * classes.get(k, {}).get("cycles_per_valu", 4.15)
+        if not per.get("k_me<false>") and not per.get("k_me"):
             return None
+
+        def total(d):
+            g = lambda *names: sum(d.get(n, 0) for n in names)
+            entropy = g("k_bs<false>", "k_cavlc<false, false>", "k_cavlc<true, false>", "k_bit_scan<false>", "k_pack<false>", "k_skip_scan<false>", "k_mvpred<false>",
+                        "k_bs", "k_cavlc<false>", "k_cavlc<true>", "k_bit_scan", "k_pack", "k_skip_scan", "k_mvpred")
+            db_p = d.get("k_deblock_pairs<false, false>") or d.get("k_deblock_pairs<false>") or d.get("k_deblock_rows<false, false, false>", 0)
+            db_i = d.get("k_deblock_pairs<true, false>") or d.get("k_deblock_pairs<true>") or d.get("k_deblock_rows<true, false, false>", 0)
+            p_pic = entropy + db_p + g("k_me<false>", "k_me", "k_tq<false>", "k_tq", "k_pintra_rows<false, false>", "k_pintra_rows<false>")
+            idr = entropy + db_i + g("k_i4_decide<false>", "k_i4_decide", "k_intra_rows<false>", "k_intra_rows")
+            return p_pic, idr
+
         mbs = 32 * nmb                                                   # the profiled launches cover 32 pictures
-        total = ((GOP - 1) * p_pic + idr) / GOP / mbs
-        return {"valu_per_macroblock": round(total, 1), "p_picture": round(p_pic / mbs, 1), "idr_picture": round(idr / mbs, 1),
-                "source": os.path.basename(f),
-                "bound_fps": round(1024 * 2.4e9 / 4 / (total * nmb), 1),
-                "note": "all kernels, GOP average (1 IDR + %d P); 256 CUs x 4 SIMDs, one VALU instruction per wave per 4 cycles at 2.4 GHz" % (GOP - 1)}
+        p_pic, idr = total(per)
+        p_cyc, i_cyc = total(cyc)
+        tot = ((GOP - 1) * p_pic + idr) / GOP / mbs
+        tot_cyc = ((GOP - 1) * p_cyc + i_cyc) / GOP / mbs
+        return {"valu_per_macroblock": round(tot, 1), "p_picture": round(p_pic / mbs, 1), "idr_picture": round(idr / mbs, 1),
+                "issue_cycles_per_macroblock": round(tot_cyc, 1), "mean_cycles_per_valu": round(tot_cyc / tot, 3),
+                "source": os.path.basename(f), "classes_source": os.path.basename(cf) if cf else None,
+                "bound_fps_4cycles": round(1024 * 2.4e9 / 4 / (tot * nmb), 1),
+                "bound_fps": round(1024 * 2.4e9 / (tot_cyc * nmb), 1),
+                "note": "all kernels, GOP average (1 IDR + %d P); 256 CUs x 4 SIMDs at 2.4 GHz; bound_fps prices each kernel's dynamic VALU count by its static "
+                        "mix of the two measured issue classes (2.3 / 4.15 cycles per wave-instruction with the SIMD saturated)" % (GOP - 1)}
     except Exception:
         return None
 
