@@ -44,19 +44,21 @@ if sq:
 json.dump(out, open("profiles/%s_summary.json" % tag, "w"), indent=1)
 print(json.dumps({k: v for k, v in out["pmc"].items() if "k_tq" in k or "k_me" in k}, indent=1))
 print(json.dumps({k: v for k, v in split.items() if "k_tq" in k or "k_me" in k or "deblock" in k}, indent=1))
-# HBM traffic of the roofline kernel (k_tq), corrected as MI355X_MICROARCH.md prescribes: FETCH_SIZE x 2 (gfx950 tallies
-# 128-B requests at 64 B), WRITE_SIZE as is; both counters are in KB -> bytes.  The lockstep launch = the largest grid.
-tq = [(k, v) for k, v in out["pmc"].items() if k.startswith("k_tq ") and v["FETCH_SIZE_KB_raw"] and v["WRITE_SIZE_KB"]]
+# HBM traffic of the roofline kernel (k_tq).  MI355X_MICROARCH.md: FETCH_SIZE reads half the bytes of a wide coalesced stream and
+# "other access widths are uncalibrated: calibrate on a known byte count in your own access pattern".  tools/ubench_fetch.hip did
+# (profiles/r03_ubench_fetch.json): for k_tq's loads (four 64-byte row segments per wave instruction) FETCH_SIZE / bytes = 1.0, for
+# its stores WRITE_SIZE / bytes = 1.0 - both counters are taken as they are (KB -> bytes).  The lockstep launch = the largest grid.
+tq = [(k, v) for k, v in out["pmc"].items() if k.startswith("k_tq") and not k.startswith("k_tq8") and not k.startswith("k_tq_list") and v["FETCH_SIZE_KB_raw"] and v["WRITE_SIZE_KB"]]
 if tq:
     k, v = max(tq, key=lambda kv: int(kv[0].split("grid=")[1].split()[0]))
     threads = int(k.split("grid=")[1].split()[0])
     mbs = threads // 64 * 8
     tr_ = {"kernel": "k_tq", "lockstep_batch": mbs // 8160, "macroblocks_per_launch": mbs,
-           "FETCH_SIZE_bytes_raw": int(v["FETCH_SIZE_KB_raw"] * 1024), "FETCH_SIZE_bytes_corrected_x2": int(v["FETCH_SIZE_KB_raw"] * 2048),
-           "WRITE_SIZE_bytes": int(v["WRITE_SIZE_KB"] * 1024),
-           "traffic_bytes_per_launch": int(v["FETCH_SIZE_KB_raw"] * 2048 + v["WRITE_SIZE_KB"] * 1024),
-           "algorithmic_bytes_per_launch": 1952 * mbs,
+           "FETCH_SIZE_bytes": int(v["FETCH_SIZE_KB_raw"] * 1024), "WRITE_SIZE_bytes": int(v["WRITE_SIZE_KB"] * 1024),
+           "fetch_ratio_calibrated": 1.0, "write_ratio_calibrated": 1.0, "calibration": "profiles/r03_ubench_fetch.json (rd4_tq, wr4_tq, wr32_lv)",
+           "traffic_bytes_per_launch": int(v["FETCH_SIZE_KB_raw"] * 1024 + v["WRITE_SIZE_KB"] * 1024),
            "note": "separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of `python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-plugin` "
-                   "(profiles/%s_summary.json); FETCH_SIZE doubled per MI355X_MICROARCH.md, WRITE_SIZE taken as is" % tag}
+                   "(profiles/%s_summary.json); counters taken as they are: the x2 of the guide applies to >= 256-byte contiguous reads, not to this "
+                   "kernel's 64-byte segments (measured).  bench.py compares this with coded x 1952 + settled x 2 bytes of the same launch" % tag}
     json.dump(tr_, open("profiles/%s_traffic.json" % tag, "w"), indent=1)
     print(json.dumps(tr_, indent=1))
