@@ -10,6 +10,15 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// wave priorities of the entropy-coding kernels and of the motion search (row wavefronts run at 3, the transform at 2).
+// A/B builds (media_amd/csrc/Makefile target `ab`) may swap them: -DAB_PRIO_EC=0 -DAB_PRIO_ME=1
+#ifndef AB_PRIO_EC
+#define AB_PRIO_EC 1
+#endif
+#ifndef AB_PRIO_ME
+#define AB_PRIO_ME 0
+#endif
+
 namespace h264 {
 
 enum { MB_I16 = 0, MB_P16 = 1, MB_PSKIP = 2, MB_IPCM = 3, MB_I4 = 4, MB_P16X8 = 5, MB_P8X16 = 6, MB_P8X8 = 7 };   // 5..7: two 16x8, two 8x16, four 8x8 partitions

@@ -453,7 +453,7 @@ __global__ __launch_bounds__(256) void k_skip_scan(CavlcParams C0)
 template <bool WRITE, bool IND = false>
 __global__ __launch_bounds__(64) void k_cavlc(CavlcParams C0)
 {
-    __builtin_amdgcn_s_setprio(1);
+    __builtin_amdgcn_s_setprio(AB_PRIO_EC);
     const CavlcParams C = batch_view<IND>(C0, blockIdx.y);
     const int lane = threadIdx.x, slot = lane & 31;
     const int mbi = C.mb_first + blockIdx.x * 2 + (lane >> 5);
@@ -527,7 +527,7 @@ template <bool IND = false>
 __global__ __launch_bounds__(SCAN_NT) void k_bit_scan(CavlcParams C0, HdrBatch H, HdrBatch Hpcm, const unsigned* anypcm, unsigned pic_serial, SliceInfo* info0,
                                                    const uint16_t* me_cost0, int nsl, int sl0, unsigned slice_cap)
 {   // nsl slices of this instance's band per picture, the first of them is slice sl0 of the picture
-    __builtin_amdgcn_s_setprio(1);
+    __builtin_amdgcn_s_setprio(AB_PRIO_EC);
     const int pos = blockIdx.x / nsl, sl = sl0 + blockIdx.x - pos * nsl;
     const int pic = batch_item<IND>(C0.itemtab, pos), item = pic * nsl + (sl - sl0);
     const CavlcParams C = batch_view(C0, pic);

@@ -89,6 +89,7 @@ __device__ __forceinline__ uint32_t chroma_pred4(const uint8_t* cp, int cs2, int
 template <bool IND = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ME_WAVES_MIN, 8))) void k_me(FrameParams P0)
 {
+    if (AB_PRIO_ME) __builtin_amdgcn_s_setprio(AB_PRIO_ME);
     const FrameParams P = batch_view<IND>(P0, blockIdx.y);
     const int lane = threadIdx.x;
     const int mbi = P.band.row0 * P.mbw + xcd_mb_index(blockIdx.x, P.mbw * P.band.rows), my = P.mbdiv.row(mbi), mx = mbi - my * P.mbw;

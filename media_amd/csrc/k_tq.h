@@ -419,7 +419,7 @@ __global__ __launch_bounds__(64) void k_tq8(FrameParams P0)
 template <bool IND = false>
 __global__ __launch_bounds__(64) void k_mvpred(FrameParams P0)
 {
-    __builtin_amdgcn_s_setprio(1);
+    __builtin_amdgcn_s_setprio(AB_PRIO_EC);
     const FrameParams P = batch_view<IND>(P0, blockIdx.y);
     const int nmb = P.mbw * P.band.rows, mb0 = P.band.row0 * P.mbw;
     const int i = blockIdx.x * 64 + threadIdx.x;
