@@ -410,15 +410,21 @@ __global__ __launch_bounds__(64) void k_bs(CavlcParams C0, unsigned* anybs, unsi
     __builtin_amdgcn_s_setprio(2);
     const CavlcParams C = batch_view<IND>(C0, blockIdx.y);
     const int lane = threadIdx.x, slot = lane & 31;
-    const int mbi = C.mb_first + blockIdx.x * 2 + (lane >> 5);
-    int bs = 0;
-    if (mbi < C.mb_end) {
-        const int my = C.mbdiv.row(mbi);
-        bs = mb_edge_strength(C.mb + mbi, C.mvq + (size_t)mbi * 8, mbi - my * C.mbw, C.sl.has_top(my), C.mbw, slot);
-        C.bs[(size_t)mbi * 32 + slot] = (uint8_t)bs;
+    // a wave walks its share of the macroblock pairs (the host launches at most BS_WAVES waves per picture): 130 560 tiny waves
+    // per launch of 32 pictures cost more to dispatch beside the other instance's motion search than their loads take
+    int any = 0;
+    for (int pair = blockIdx.x; 2 * pair < C.mb_end - C.mb_first; pair += gridDim.x) {
+        const int mbi = C.mb_first + pair * 2 + (lane >> 5);
+        if (mbi < C.mb_end) {
+            const int my = C.mbdiv.row(mbi);
+            const int bs = mb_edge_strength(C.mb + mbi, C.mvq + (size_t)mbi * 8, mbi - my * C.mbw, C.sl.has_top(my), C.mbw, slot);
+            C.bs[(size_t)mbi * 32 + slot] = (uint8_t)bs;
+            any |= bs;
+        }
     }
-    if (__ballot(bs != 0) != 0ull && lane == 0) anybs[batch_item<IND>(C0.itemtab, blockIdx.y)] = serial;   // same value from every writer: a plain store
+    if (__ballot(any != 0) != 0ull && lane == 0) anybs[batch_item<IND>(C0.itemtab, blockIdx.y)] = serial;   // same value from every writer: a plain store
 }
+enum { BS_WAVES = 1020 };
 
 // P slices: prevcoded[i] = index of the last macroblock before i that is not P_Skip (a prefix maximum over the
 // picture, one 256-thread workgroup per picture), so that mb_skip_run costs no walk over the skipped macroblocks

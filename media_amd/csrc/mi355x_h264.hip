@@ -420,7 +420,7 @@ int submit_step(mi355x_h264_encoder* e, Step& T)
             IntraRowParams R{};
             R.p = P; R.handoff = e->d_handoff; R.st_handoff = e->st_handoff; R.err = T.h_err;
             R.serial = next_serial();
-            LAUNCH2(ind, k_i4_decide<true>, k_i4_decide<false>, dim3((e->b_nmb + 3) / 4, G), dim3(64), st, P, 1);
+            LAUNCH2(ind, k_i4_decide<true>, k_i4_decide<false>, dim3(std::min((e->b_nmb + 3) / 4, (int)I4_MARKED_WAVES), G), dim3(64), st, P, 1);
             LAUNCH2(ind, (k_pintra_rows<false, true>), (k_pintra_rows<false, false>), dim3(e->b_rows, G), dim3(64), st, R);
         }
     }
@@ -455,7 +455,7 @@ int submit_step(mi355x_h264_encoder* e, Step& T)
     unsigned db_serial = 0;
     if (!e->cfg.disable_deblock) {   // (the diagonal debug form of the filter reads the strengths too)
         db_serial = next_serial();   // the serial the loop filter of this picture will run under
-        LAUNCH2(ind, k_bs<true>, k_bs<false>, dim3(cavlc_grid, G), dim3(64), st, C, e->d_anybs, db_serial);
+        LAUNCH2(ind, k_bs<true>, k_bs<false>, dim3(std::min(cavlc_grid, (int)BS_WAVES), G), dim3(64), st, C, e->d_anybs, db_serial);
     }
     const bool fork = ec != st;
     if (fork) {
