@@ -1460,9 +1460,11 @@ int mi355x_h264_stream_encode(mi355x_h264_stream* s, const uint8_t* y, int ys, c
     if (ys < w || us < w / 2 || vs < w / 2) { snprintf(it.err, sizeof(it.err), "stride smaller than width"); return MI355X_H264_E_ARG; }
     if (hipSetDevice(h->cfg.device) != hipSuccess) { snprintf(it.err, sizeof(it.err), "hipSetDevice"); return MI355X_H264_E_HIP; }
     const uint64_t t_in = now_us();
+    int nopen;
     {
         std::lock_guard<std::mutex> lk(h->mu);
         h->uploading++;   // a step that is being gathered waits (briefly) for this picture
+        nopen = h->nopen;
     }
     // 1. the picture into the stream's staging slot: pinned copy, then the transfer - in pieces, so that the copy of piece k + 1
     // runs while piece k is on the bus (the reference's tight layout, InitSrcPic ref :354-365; other layouts row by row)
@@ -1475,7 +1477,7 @@ int mi355x_h264_stream_encode(mi355x_h264_stream* s, const uint8_t* y, int ys, c
         // few streams: four pieces, so that the copy of piece k + 1 runs while piece k is on the bus (latency); many streams: one
         // transfer per picture (every queued command costs, and other streams' transfers fill the bus anyway: 16 / 32 / 64 streams
         // went from 7.3 / 8.0 / 8.6 k to 8.8 / 11.5 / 10.9 k fps with this alone, profiles/r03_hub_sweep_*.log)
-        const size_t piece = h->nopen > 4 ? fb : (((fb / 4) + 255) & ~(size_t)255);
+        const size_t piece = nopen > 4 ? fb : (((fb / 4) + 255) & ~(size_t)255);
         for (size_t o = 0; o < fb && ok; o += piece) {
             const size_t len = std::min(piece, fb - o);
             memcpy(hs + o, y + o, len);
