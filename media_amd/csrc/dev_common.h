@@ -9,6 +9,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 // wave priorities of the entropy-coding kernels and of the motion search (row wavefronts run at 3, the transform at 2).
 // A/B builds (media_amd/csrc/Makefile target `ab`) may swap them: -DAB_PRIO_EC=0 -DAB_PRIO_ME=1
@@ -202,6 +203,16 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// compile-time loop: f(std::integral_constant<int, I>) for I = A .. B - 1
+template <int A, int B, class F>
+__device__ __forceinline__ void static_for(F&& f)
+{
+    if constexpr (A < B) {
+        f(std::integral_constant<int, A>{});
+        static_for<A + 1, B>(f);
+    }
+}
+
 __device__ __forceinline__ int clip3(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
 __device__ __forceinline__ int clip255(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
 __device__ __forceinline__ int iabs(int v) { return v < 0 ? -v : v; }
@@ -216,7 +227,7 @@ __device__ __forceinline__ int pos_class(int i)
 // 6.4.3: blkIdx <-> 4x4 raster position
 __device__ __forceinline__ int blk_x(int b) { return (b & 1) | ((b >> 1) & 2); }
 __device__ __forceinline__ int blk_y(int b) { return ((b >> 1) & 1) | ((b >> 2) & 2); }
-__device__ __forceinline__ int xy2blk(int x, int y) { return (x & 1) | ((y & 1) << 1) | ((x & 2) << 1) | ((y & 2) << 2); }
+__device__ __forceinline__ constexpr int xy2blk(int x, int y) { return (x & 1) | ((y & 1) << 1) | ((x & 2) << 1) | ((y & 2) << 2); }
 
 __constant__ const uint8_t c_zigzag[16] = {0, 1, 4, 8, 5, 2, 3, 6, 9, 12, 13, 10, 7, 11, 14, 15};
 // raster position -> zig-zag index
@@ -361,6 +372,22 @@ __device__ __forceinline__ int blk_bits_bound_packed(const uint32_t lvp[8], int 
     }
     // the 16 - tc zero positions were counted as h each, the non-zero ones lack their + 1
     return tc ? (int)sum - (16 - tc) * h + tc + pcm_blk_tail(tc) : 6;
+}
+
+// number of non-zero levels among 16 int16 (two per word)
+__device__ __forceinline__ int count_nz16_packed(const uint32_t lvp[8])
+{
+    typedef short s2 __attribute__((ext_vector_type(2)));
+    typedef unsigned short u2 __attribute__((ext_vector_type(2)));
+    const u2 one = {1, 1};
+    uint32_t n = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const s2 p = __builtin_bit_cast(s2, lvp[k]);
+        const u2 a = __builtin_bit_cast(u2, __builtin_elementwise_max(p, -p));
+        n = __builtin_amdgcn_sad_u16(__builtin_bit_cast(uint32_t, __builtin_elementwise_min(a, one)), 0u, n);
+    }
+    return (int)n;
 }
 
 // wave-wide reductions over 64 lanes

@@ -180,21 +180,20 @@ __device__ __forceinline__ void intra_mb_core(const FrameParams& P, int mx, int 
             return;
         }
     } else
-        for (int i = lane; i < LV_STRIDE / 2; i += 64) ((uint32_t*)S.lv)[i] = 0;
+        if (lane < LV_STRIDE * 2 / 16) ((uint4*)S.lv)[lane] = make_uint4(0u, 0u, 0u, 0u);
 
     // ---- Intra4x4 (type and modes chosen by k_i4_decide; use_i4 is wave-uniform, auxw = lanes 0..3: the sixteen modes) ----
-    int cbp_luma_i4 = 0;
+    int cbp_luma_i4 = 0, tc_i4 = 0;   // tc_i4: TotalCoeff of luma block blkIdx = lane
     if (use_i4) {
-        const uint32_t m0 = (uint32_t)__builtin_amdgcn_readlane((int)auxw, 0), m1 = (uint32_t)__builtin_amdgcn_readlane((int)auxw, 1);
-        const uint32_t m2 = (uint32_t)__builtin_amdgcn_readlane((int)auxw, 2), m3 = (uint32_t)__builtin_amdgcn_readlane((int)auxw, 3);
-        cbp_luma_i4 = i4_code_luma<DEC>(QY, S.i4, S.top, S.left, S.src, m0, m1, m2, m3, S.lv, S.dc, DEC ? (int)left : mx, top, topright, lane);   // (S.dc: TotalCoeff of the 16 blocks)
+        cbp_luma_i4 = i4_code_luma<DEC>(QY, S.i4, S.top, S.left, S.src, auxw, S.lv, tc_i4, DEC ? (int)left : mx, top, topright, lane);
         const uint32_t o = *(const uint32_t*)(S.i4.rb + (1 + (lane >> 2)) * 32 + 4 + (lane & 3) * 4);
         *(uint32_t*)(S.rec_y + (lane >> 2) * 16 + (lane & 3) * 4) = o;
         *(uint32_t*)(P.rec[0] + (size_t)(by + (lane >> 2)) * P.cw + bx + (lane & 3) * 4) = o;
     }
 
     // ---- luma mode decision: lane = (mode, 4x4 block), SATD per mode ----
-    const I16Params ip = i16_params(S.top, S.left, avail);
+    I16Params ip = {0, 0, 0, 0};
+    if (!use_i4) ip = i16_params(S.top, S.left, avail);
     int best_mode = DEC ? (int)mbp->i16_mode : 0;
     if (!DEC && !use_i4) {
         const int mode = lane >> 4, blk = lane & 15, x0 = (blk & 3) * 4, y0 = (blk >> 2) * 4;
@@ -417,11 +416,15 @@ __device__ __forceinline__ void intra_mb_core(const FrameParams& P, int mx, int 
     MbInfo* m = P.mb + mbi;
     {   // I_PCM fallback (dev_common.h): bit bound of the 27 blocks, one per lane; above the limit of A.3.1 the macroblock is
         // re-written as I_PCM: reconstruction = source, for the picture and for this row's next prediction alike
-        int bb = 0;
-        if (lane < 16) bb = blk_bits_bound(S.lv + LV_LUMA + lane * 16, 16);
-        else if (lane < 24) bb = blk_bits_bound(S.lv + LV_CHROMA_AC + (lane - 16) * 16, 16);
-        else if (lane == 24) bb = use_i4 ? 0 : blk_bits_bound(S.lv + LV_LUMA_DC, 16);
-        else if (lane < 27) bb = blk_bits_bound(S.lv + LV_CHROMA_DC + (lane - 25) * 4, 4);
+        // one block per lane, every lane the same code: 0..15 luma, 16..23 chroma AC, 24 luma DC (Intra16x16 only), 25, 26 chroma DC
+        // (four levels: the other twelve of the sixteen count as zero)
+        const int off = lane < 16 ? 2 * LV_LUMA + 32 * lane : (lane < 24 ? 2 * LV_CHROMA_AC + 32 * (lane - 16) : (lane == 24 ? 2 * LV_LUMA_DC : 2 * LV_CHROMA_DC));
+        const uint4 qa = *(const uint4*)((const uint8_t*)S.lv + off), qb = *(const uint4*)((const uint8_t*)S.lv + off + 16);
+        const bool cdc = lane >= 25;
+        uint32_t lvp[8] = {cdc ? (lane == 26 ? qa.z : qa.x) : qa.x, cdc ? (lane == 26 ? qa.w : qa.y) : qa.y, cdc ? 0u : qa.z, cdc ? 0u : qa.w,
+                           cdc ? 0u : qb.x, cdc ? 0u : qb.y, cdc ? 0u : qb.z, cdc ? 0u : qb.w};
+        const int bbv = blk_bits_bound_packed(lvp, count_nz16_packed(lvp));
+        const int bb = (lane < 27 && !(lane == 24 && use_i4)) ? bbv : 0;
         const int s16 = row_sum16_dpp(bb);
         const int tot = MB_HEADER_BOUND + __builtin_amdgcn_readlane(s16, 0) + __builtin_amdgcn_readlane(s16, 16);
         if (tot > MB_BITS_LIMIT) {   // wave-uniform
@@ -448,7 +451,7 @@ __device__ __forceinline__ void intra_mb_core(const FrameParams& P, int mx, int 
             return;
         }
     }
-    const int tcv = lane < 16 ? (use_i4 ? S.dc[lane] : (cbp_luma != 0 ? nnz : 0)) : (cbp_chroma == 2 ? nnz : 0);
+    const int tcv = lane < 16 ? (use_i4 ? tc_i4 : (cbp_luma != 0 ? nnz : 0)) : (cbp_chroma == 2 ? nnz : 0);
     if (lane < 24) m->tc[lane] = (uint8_t)tcv;
     if (lane == 0) {
         m->mvx = 0; m->mvy = 0; m->type = use_i4 ? MB_I4 : MB_I16;

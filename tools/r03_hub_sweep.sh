@@ -17,9 +17,11 @@ export PERSIST_VMI_VIDEO_ENCODE_BITRATE=5000000 PERSIST_VMI_VIDEO_ENCODE_GOPSIZE
 export PERSIST_VMI_VIDEO_ENCODE_PARAM_ADJUSTING=0 PERSIST_VMI_VIDEO_ENCODE_KEYFRAME=0 PERSIST_VMI_VIDEO_ENCODE_SCENEDETECT=1 PERSIST_VMI_VIDEO_ENCODE_DEVICE=0 MEDIA_LOG_QUIET=1
 export GPU_MAX_HW_QUEUES=32 MI355X_H264_HUB_VERBOSE=1
 run() { echo "== $*"; env "$@" timeout -k 10 300 $R/media_amd/lib/plugin_bench /tmp/pool.i420 1920 1080 265 200 ${STREAMS:-16,64} 2>&1 | grep -E "fps_aggregate|hub " | cut -c1-330; }
-export STREAMS=16,32,64
+export STREAMS=2,4,8,16
 run X=1
-run MI355X_H264_HUB_NOUPLOAD=1
-run MI355X_H264_HUB_NOUPLOAD=2
-run MI355X_H264_ONE_STREAM=1
-run MI355X_H264_ONE_STREAM=1 MI355X_H264_HUB_NOUPLOAD=2
+run MI355X_H264_HUB_WINDOW_US=0
+run MI355X_H264_HUB_WINDOW_US=0 MI355X_H264_HUB_CTX=3
+run MI355X_H264_HUB_WINDOW_US=0 MI355X_H264_HUB_CTX=4
+run MI355X_H264_HUB=0
+STREAMS=32,64 run MI355X_H264_HUB_WINDOW_US=0
+STREAMS=32,64 run X=1
