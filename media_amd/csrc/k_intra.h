@@ -128,7 +128,15 @@ struct IntraLds {
     uint8_t top[24], left[16];        // luma neighbours; top[0] = top-left, top[1..16] above, top[17..20] above-right (decoder only)
     uint8_t ctop[2][12], cleft[2][8];
     I4Lds i4;                         // Intra4x4 macroblocks (k_intra4.h)
+    int xchg[2][2][4];                // k_intra_rows' two waves, [macroblock & 1][luma, chroma]: {bit bound of its blocks, cbp, mode}
 };
+
+// the two waves of k_intra_rows meet: LDS traffic drained, not the global loads and stores in flight (__syncthreads() would wait
+// for the reconstruction stores just issued and the source requested ahead)
+__device__ __forceinline__ void pair_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 
 // Mode decision, transform, quantisation and reconstruction of one intra macroblock (Intra16x16, or Intra4x4 with the
 // modes k_i4_decide chose) whose source and
@@ -136,9 +144,14 @@ struct IntraLds {
 // levels, MbInfo, mvd.
 // DEC (the decoder peer, k_dec.h): types, modes and levels are given (MbInfo, aux, levels); prediction, scaling, inverse
 // transforms and reconstruction are the code the encoder runs, nothing is decided, transformed forward or written back.
-template <bool DEC = false>
+// PART: 0 the whole macroblock in this wave; 1 its luma, 2 its chroma - the two waves of one workgroup of k_intra_rows, which
+// share S, work on the same macroblock side by side and meet once (pair_barrier) to add up the bit bound and to exchange what the
+// macroblock's header needs.  Luma and chroma predict from their own planes only, so nothing else passes between them.
+template <bool DEC = false, int PART = 0>
 __device__ __forceinline__ void intra_mb_core(const FrameParams& P, int mx, int my, IntraLds& S, int lane, bool use_i4, uint32_t auxw)
 {
+    static_assert(!DEC || PART == 0, "the decoder runs the macroblock in one wave");
+    constexpr bool LUMA = PART != 2, CHROMA = PART != 1;
     const int mbi = my * P.mbw + mx, bx = 16 * mx, by = 16 * my, cs = P.cw / 2;
     // neighbouring macroblocks available for prediction (6.4.9: in the picture, in this slice, decoded before).  Encoder: slices are
     // bands of whole rows.  DEC: the parser's bits per macroblock (16 left, 32 above, 64 above-right, 128 above-left) - slices of any shape, constrained_intra_pred_flag
@@ -179,12 +192,14 @@ __device__ __forceinline__ void intra_mb_core(const FrameParams& P, int mx, int 
             wave_sync();
             return;
         }
-    } else
-        if (lane < LV_STRIDE * 2 / 16) ((uint4*)S.lv)[lane] = make_uint4(0u, 0u, 0u, 0u);
+    } else {   // (luma DC + luma: 34 x 16 bytes, then the chroma lists)
+        const int zi = (LUMA ? 0 : 2 * LV_CHROMA_DC / 16) + lane;
+        if (zi < (CHROMA ? LV_STRIDE * 2 / 16 : 2 * LV_CHROMA_DC / 16)) ((uint4*)S.lv)[zi] = make_uint4(0u, 0u, 0u, 0u);
+    }
 
     // ---- Intra4x4 (type and modes chosen by k_i4_decide; use_i4 is wave-uniform, auxw = lanes 0..3: the sixteen modes) ----
     int cbp_luma_i4 = 0, tc_i4 = 0;   // tc_i4: TotalCoeff of luma block blkIdx = lane
-    if (use_i4) {
+    if (LUMA && use_i4) {
         cbp_luma_i4 = i4_code_luma<DEC>(QY, S.i4, S.top, S.left, S.src, auxw, S.lv, tc_i4, DEC ? (int)left : mx, top, topright, lane);
         const uint32_t o = *(const uint32_t*)(S.i4.rb + (1 + (lane >> 2)) * 32 + 4 + (lane & 3) * 4);
         *(uint32_t*)(S.rec_y + (lane >> 2) * 16 + (lane & 3) * 4) = o;
@@ -193,9 +208,9 @@ __device__ __forceinline__ void intra_mb_core(const FrameParams& P, int mx, int 
 
     // ---- luma mode decision: lane = (mode, 4x4 block), SATD per mode ----
     I16Params ip = {0, 0, 0, 0};
-    if (!use_i4) ip = i16_params(S.top, S.left, avail);
+    if (LUMA && !use_i4) ip = i16_params(S.top, S.left, avail);
     int best_mode = DEC ? (int)mbp->i16_mode : 0;
-    if (!DEC && !use_i4) {
+    if (LUMA && !DEC && !use_i4) {
         const int mode = lane >> 4, blk = lane & 15, x0 = (blk & 3) * 4, y0 = (blk >> 2) * 4;
         // this lane's block: four source dwords, the four top and left neighbours, the plane value of its corner -
         // fetched once instead of per sample
@@ -218,7 +233,7 @@ __device__ __forceinline__ void intra_mb_core(const FrameParams& P, int mx, int 
         unsigned key = ok ? (((unsigned)sum << 2) | (unsigned)mode) : 0xFFFFFFFFu;
         best_mode = (int)(wave_min_u32_dpp(key) & 3);
     }
-    if (!use_i4) {
+    if (LUMA && !use_i4) {
         const int y = lane >> 2, xs = (lane & 3) * 4;
         uint32_t o = 0;
         if (best_mode == 0) {          // vertical: the four samples above (best_mode is wave-uniform)
@@ -235,8 +250,9 @@ __device__ __forceinline__ void intra_mb_core(const FrameParams& P, int mx, int 
     }
     // ---- chroma mode decision: lane<32 = (mode, plane, block) ----
     int best_cmode = DEC ? (int)mbp->chroma_mode : 0;
-    C8Params cp[2] = {c8_params(S.ctop[0], S.cleft[0], avail), c8_params(S.ctop[1], S.cleft[1], avail)};
-    if (!DEC) {
+    C8Params cp[2] = {};
+    if (CHROMA) { cp[0] = c8_params(S.ctop[0], S.cleft[0], avail); cp[1] = c8_params(S.ctop[1], S.cleft[1], avail); }
+    if (CHROMA && !DEC) {
         const int mode = (lane >> 3) & 3, pl = (lane >> 2) & 1, blk = lane & 3, x0 = (blk & 1) * 4, y0 = (blk >> 1) * 4;
         int tp[4], lf[4];
 #pragma unroll
@@ -264,7 +280,7 @@ __device__ __forceinline__ void intra_mb_core(const FrameParams& P, int mx, int 
         unsigned key = (ok && lane < 32) ? (((unsigned)sum << 2) | (unsigned)mode) : 0xFFFFFFFFu;
         best_cmode = (int)(wave_min_u32_dpp(key) & 3);
     }
-    if (lane < 32) {
+    if (CHROMA && lane < 32) {
         const int pl = lane >> 4, y = (lane >> 1) & 7, xs = (lane & 1) * 4;
         uint32_t o = 0;
         if (best_cmode == 0) o = 0x01010101u * (uint32_t)(pl ? pick4(cp[1].dc, (y >> 2) * 2 + (xs >> 2)) : pick4(cp[0].dc, (y >> 2) * 2 + (xs >> 2)));
@@ -285,7 +301,7 @@ __device__ __forceinline__ void intra_mb_core(const FrameParams& P, int mx, int 
     // ---- transform / quant: lanes 0..15 luma AC (+DC via Hadamard), 16..23 chroma ----
     int nnz = 0, dcw = 0;
     int d[16];
-    const bool is_luma = lane < 16 && !use_i4, is_chroma = lane >= 16 && lane < 24;
+    const bool is_luma = LUMA && lane < 16 && !use_i4, is_chroma = CHROMA && lane >= 16 && lane < 24;
     const int cpl = (lane - 16) >> 2, cb = lane & 3;
     if (is_luma) {
         const int x = blk_x(lane) * 4, y = blk_y(lane) * 4;
@@ -323,7 +339,7 @@ __device__ __forceinline__ void intra_mb_core(const FrameParams& P, int mx, int 
             nnz = tq4x4(d, P.qc, P.qc.f_intra, 1, S.lv + LV_CHROMA_AC + (cpl * 4 + cb) * 16, &dcw, 0, false);
     }
     wave_sync();
-    if (!use_i4) {
+    if (LUMA && !use_i4) {
         // luma DC (8.5.10): 4x4 Hadamard of the sixteen transformed DCs, quantised at qbits + 2, inverse Hadamard, scaling.
         // Lane = raster position of the block; each transform is four exchange stages (lane ^ 1, ^ 2: DPP quad permutes,
         // ^ 4, ^ 8: DPP row moves).  After the forward pass lane (i, j) holds coefficient (sg(i), sg(j)), sg = [0 3 1 2] (the
@@ -360,7 +376,7 @@ __device__ __forceinline__ void intra_mb_core(const FrameParams& P, int mx, int 
             d[0] = qp >= 36 ? (fi * ls) << (qp / 6 - 6) : (fi * ls + (1 << (5 - qp / 6))) >> (6 - qp / 6);
         }
     }
-    {   // chroma DC
+    if (CHROMA) {   // chroma DC
         const int base = 16 + ((lane - 16) & 4);
         const int w4[4] = {__shfl(dcw, base), __shfl(dcw, base + 1), __shfl(dcw, base + 2), __shfl(dcw, base + 3)};
         int lv[4], deq[4];
@@ -414,6 +430,7 @@ __device__ __forceinline__ void intra_mb_core(const FrameParams& P, int mx, int 
     wave_sync();
     if (DEC) return;
     MbInfo* m = P.mb + mbi;
+    int cbp_l = cbp_luma, cbp_c = cbp_chroma, mode_l = best_mode, mode_c = best_cmode;
     {   // I_PCM fallback (dev_common.h): bit bound of the 27 blocks, one per lane; above the limit of A.3.1 the macroblock is
         // re-written as I_PCM: reconstruction = source, for the picture and for this row's next prediction alike
         // one block per lane, every lane the same code: 0..15 luma, 16..23 chroma AC, 24 luma DC (Intra16x16 only), 25, 26 chroma DC
@@ -424,25 +441,35 @@ __device__ __forceinline__ void intra_mb_core(const FrameParams& P, int mx, int 
         uint32_t lvp[8] = {cdc ? (lane == 26 ? qa.z : qa.x) : qa.x, cdc ? (lane == 26 ? qa.w : qa.y) : qa.y, cdc ? 0u : qa.z, cdc ? 0u : qa.w,
                            cdc ? 0u : qb.x, cdc ? 0u : qb.y, cdc ? 0u : qb.z, cdc ? 0u : qb.w};
         const int bbv = blk_bits_bound_packed(lvp, count_nz16_packed(lvp));
-        const int bb = (lane < 27 && !(lane == 24 && use_i4)) ? bbv : 0;
-        const int s16 = row_sum16_dpp(bb);
-        const int tot = MB_HEADER_BOUND + __builtin_amdgcn_readlane(s16, 0) + __builtin_amdgcn_readlane(s16, 16);
+        const bool luma_blk = lane < 16 || lane == 24;
+        const bool mine = lane < 27 && !(lane == 24 && use_i4) && (PART == 0 || (PART == 1) == luma_blk);
+        const int s16 = row_sum16_dpp(mine ? bbv : 0);
+        int tot = MB_HEADER_BOUND + __builtin_amdgcn_readlane(s16, 0) + __builtin_amdgcn_readlane(s16, 16);
+        if (PART != 0) {   // the other wave's blocks, and what the header needs of it
+            int* const out = S.xchg[mx & 1][PART - 1];
+            const int* const in = S.xchg[mx & 1][2 - PART];
+            if (lane == 0) { out[0] = tot - MB_HEADER_BOUND; out[1] = LUMA ? cbp_luma : cbp_chroma; out[2] = LUMA ? best_mode : best_cmode; }
+            pair_barrier();
+            tot += __builtin_amdgcn_readfirstlane(in[0]);
+            if (LUMA) { cbp_c = in[1]; mode_c = in[2]; }
+            else { cbp_l = in[1]; mode_l = in[2]; }
+        }
         if (tot > MB_BITS_LIMIT) {   // wave-uniform
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            {
+            if (LUMA) {
                 const int row = lane >> 2, xs = (lane & 3) * 4;
                 const uint32_t v = *(const uint32_t*)(S.src + row * 16 + xs);
                 *(uint32_t*)(P.rec[0] + (size_t)(by + row) * P.cw + bx + xs) = v;
                 *(uint32_t*)(S.rec_y + row * 16 + xs) = v;
             }
-            if (lane < 32) {
+            if (CHROMA && lane < 32) {
                 const int pl = lane >> 4, row = (lane >> 1) & 7, xs = (lane & 1) * 4;
                 const uint32_t v = *(const uint32_t*)(S.srcc + pl * 64 + row * 8 + xs);
                 *(uint32_t*)(rec_chroma(P, pl) + (size_t)(8 * my + row) * cs + 8 * mx + xs) = v;
                 *(uint32_t*)(S.rec_c + pl * 64 + row * 8 + xs) = v;
             }
-            if (lane < 6) ((uint32_t*)m)[2 + lane] = 0x10101010u;
-            if (lane == 6) {
+            if (LUMA && lane < 6) ((uint32_t*)m)[2 + lane] = 0x10101010u;
+            if (LUMA && lane == 6) {
                 *(uint2*)m = make_uint2(0u, (uint32_t)MB_IPCM | (0x2Fu << 24));
                 *(uint32_t*)(P.mvd + 8 * (size_t)mbi) = 0u;
                 *P.anypcm = P.pic_serial;
@@ -451,18 +478,19 @@ __device__ __forceinline__ void intra_mb_core(const FrameParams& P, int mx, int 
             return;
         }
     }
-    const int tcv = lane < 16 ? (use_i4 ? tc_i4 : (cbp_luma != 0 ? nnz : 0)) : (cbp_chroma == 2 ? nnz : 0);
-    if (lane < 24) m->tc[lane] = (uint8_t)tcv;
-    if (lane == 0) {
+    const int tcv = lane < 16 ? (use_i4 ? tc_i4 : (cbp_l != 0 ? nnz : 0)) : (cbp_c == 2 ? nnz : 0);
+    if (lane < 24 && (PART == 0 || (PART == 1) == (lane < 16))) m->tc[lane] = (uint8_t)tcv;
+    if (LUMA && lane == 0) {
         m->mvx = 0; m->mvy = 0; m->type = use_i4 ? MB_I4 : MB_I16;
-        m->i16_mode = (uint8_t)best_mode; m->chroma_mode = (uint8_t)best_cmode;
-        m->cbp = (uint8_t)(cbp_luma | (cbp_chroma << 4));
+        m->i16_mode = (uint8_t)mode_l; m->chroma_mode = (uint8_t)mode_c;
+        m->cbp = (uint8_t)(cbp_l | (cbp_c << 4));
         *(uint32_t*)(P.mvd + 8 * (size_t)mbi) = 0u;
     }
-    {
+    {   // the level lists: luma DC + luma, then chroma
         uint4* g = (uint4*)(P.levels + (size_t)mbi * LV_STRIDE);
         const uint4* sl = (const uint4*)S.lv;
-        if (lane < LV_STRIDE * 2 / 16) g[lane] = sl[lane];
+        const int li = (LUMA ? 0 : 2 * LV_CHROMA_DC / 16) + lane;
+        if (li < (CHROMA ? LV_STRIDE * 2 / 16 : 2 * LV_CHROMA_DC / 16)) g[li] = sl[li];
     }
 }
 
@@ -516,29 +544,45 @@ struct IntraRowParams {
     unsigned serial;
 };
 
+// Two waves per row (one workgroup): wave 0 codes the luma of the row's macroblocks, wave 1 their chroma, the same macroblock at the
+// same time (intra_mb_core PART 1 / 2; one pair_barrier per macroblock).  Each waits for its own granules of the row above
+// (0..3 luma, 4..7 chroma) and publishes its own.  What an IDR picture waits for is the chain of dependent macroblocks along the
+// wavefront, 120 + 67 of them at 1080p, and a lone wave issues one instruction every five to eight cycles whatever the other
+// SIMDs do: halving the instructions in the chain is worth more than the second wave costs.
 template <bool IND = false>
-__global__ __launch_bounds__(64) void k_intra_rows(IntraRowParams R)
+__global__ __launch_bounds__(128) void k_intra_rows(IntraRowParams R)
 {
     __builtin_amdgcn_s_setprio(3);   // dependency-bound row wavefront: issue ahead of co-resident throughput kernels
     const FrameParams P = batch_view<IND>(R.p, blockIdx.y);
     unsigned long long* const handoff = R.handoff + (size_t)batch_item<IND>(R.p.itemtab, blockIdx.y) * R.st_handoff;
-    const int lane = threadIdx.x, my = P.band.row0 + blockIdx.x;
+    const int lane = threadIdx.x & 63, my = P.band.row0 + blockIdx.x;
+    const bool chroma_wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) != 0;
     const bool top = P.sl.has_top(my);   // first row of a slice: nothing above to wait for, the slices' wavefronts run side by side
     __shared__ IntraLds S;
     bool timed_out = false;
-    const uint8_t* Y = P.src;
-    // source fetch of one macroblock into registers (same clamping as load_src_mb)
-    uint32_t pf_y = 0, pf_c = 0, pf_aux = 0;
-    int pf_type = 0;
-    unsigned long long pf_g = 0;
-    i4_lds_init(S.i4, lane);
-    auto prefetch = [&](int mx) {
-        {   // k_i4_decide's verdict for the macroblock: type and, lanes 0..3, the sixteen Intra4x4 modes
+    // this wave's four granules of macroblock mx of the row above / of this row
+    const int gl = (chroma_wave ? 4 : 0) + (lane & 3);
+    auto wait_above = [&](unsigned long long g, int mx) {
+        unsigned spins = 0;
+        while (!timed_out) {
+            const bool bad = lane < 4 && (unsigned)(g >> 32) != R.serial;
+            if (__ballot(bad) == 0ull) break;
+            if (++spins > (1u << 20)) { timed_out = true; break; }
+            __builtin_amdgcn_s_sleep(1);
+            if (lane < 4) g = __hip_atomic_load(handoff + ((size_t)(my - 1) * P.mbw + mx) * 8 + gl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return g;
+    };
+    if (!chroma_wave) {
+        const uint8_t* Y = P.src;
+        uint32_t pf_y = 0, pf_aux = 0;
+        int pf_type = 0;
+        unsigned long long pf_g = 0;
+        i4_lds_init(S.i4, lane);
+        auto prefetch = [&](int mx) {   // source, k_i4_decide's verdict (type and, lanes 0..3, the sixteen Intra4x4 modes), the row above
             const int mbi = my * P.mbw + mx;
             pf_type = ((const uint8_t*)(P.mb + mbi))[4];
             if (lane < 4) pf_aux = *(const uint32_t*)(P.aux + (size_t)mbi * 16 + 4 * lane);
-        }
-        {
             const int row = lane >> 2, xs = (lane & 3) * 4;
             const int gy = 16 * my + row, gx = 16 * mx + xs;
             const uint8_t* p = Y + (size_t)(gy < P.h ? gy : P.h - 1) * P.w + gx;
@@ -548,58 +592,74 @@ __global__ __launch_bounds__(64) void k_intra_rows(IntraRowParams R)
 #pragma unroll
                 for (int k = 0; k < 4; k++) pf_y |= (uint32_t)src_px(Y, P.w, P.h, gx + k, gy) << (8 * k);
             }
-        }
-        if (lane < 32) {
-            const int pl = lane >> 4, row = (lane >> 1) & 7, xs = (lane & 1) * 4;
-            pf_c = src_chroma4(P, pl, 8 * mx + xs, 8 * my + row);
-        }
-        if (top && lane < 8) pf_g = __hip_atomic_load(handoff + ((size_t)(my - 1) * P.mbw + mx) * 8 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    };
-    prefetch(0);
-    for (int mx = 0; mx < P.mbw; mx++) {
-        const uint32_t cur_y = pf_y, cur_c = pf_c, cur_aux = pf_aux;
-        const bool cur_i4 = __builtin_amdgcn_readfirstlane(pf_type) == MB_I4;
-        unsigned long long g = pf_g;
-        if (mx + 1 < P.mbw) prefetch(mx + 1);
-        // left neighbours = last column of the previous reconstruction; corner = last sample of the previous top row
-        if (mx > 0) {
-            if (lane < 16) S.left[lane] = S.rec_y[lane * 16 + 15];
-            else if (lane < 32) S.cleft[(lane >> 3) & 1][lane & 7] = S.rec_c[((lane >> 3) & 1) * 64 + (lane & 7) * 8 + 7];
-            else if (lane == 32) S.top[0] = S.top[16];
-            else if (lane == 33) S.ctop[0][0] = S.ctop[0][8];
-            else if (lane == 34) S.ctop[1][0] = S.ctop[1][8];
-        }
-        *(uint32_t*)(S.src + (lane >> 2) * 16 + (lane & 3) * 4) = cur_y;
-        if (lane < 32) *(uint32_t*)(S.srcc + (lane >> 4) * 64 + ((lane >> 1) & 7) * 8 + (lane & 1) * 4) = cur_c;
-        wave_sync();   // corner moved before the top row is overwritten
-        if (top) {
-            unsigned spins = 0;
-            while (!timed_out) {
-                const bool bad = lane < 8 && (unsigned)(g >> 32) != R.serial;
-                if (__ballot(bad) == 0ull) break;
-                if (++spins > (1u << 20)) { timed_out = true; break; }
-                __builtin_amdgcn_s_sleep(1);
-                if (lane < 8) g = __hip_atomic_load(handoff + ((size_t)(my - 1) * P.mbw + mx) * 8 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (top && lane < 4) pf_g = __hip_atomic_load(handoff + ((size_t)(my - 1) * P.mbw + mx) * 8 + gl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        };
+        prefetch(0);
+        for (int mx = 0; mx < P.mbw; mx++) {
+            const uint32_t cur_y = pf_y, cur_aux = pf_aux;
+            const bool cur_i4 = __builtin_amdgcn_readfirstlane(pf_type) == MB_I4;
+            unsigned long long g = pf_g;
+            if (mx + 1 < P.mbw) prefetch(mx + 1);
+            // left neighbours = last column of the previous reconstruction; corner = last sample of the previous top row
+            if (mx > 0) {
+                if (lane < 16) S.left[lane] = S.rec_y[lane * 16 + 15];
+                else if (lane == 32) S.top[0] = S.top[16];
             }
-            // granules 0..3 luma samples 0..15 -> top[1..16]; 4,5 Cb -> ctop[0][1..8]; 6,7 Cr -> ctop[1][1..8]
-            if (lane < 8) {
-                const uint32_t v = (uint32_t)g;
-                uint8_t* dst = lane < 4 ? S.top + 1 + 4 * lane : S.ctop[(lane - 4) >> 1] + 1 + 4 * (lane & 1);
+            *(uint32_t*)(S.src + (lane >> 2) * 16 + (lane & 3) * 4) = cur_y;
+            wave_sync();   // corner moved before the top row is overwritten
+            if (top) {
+                g = wait_above(g, mx);
+                if (lane < 4) {   // granules 0..3: luma samples 0..15 -> top[1..16]
+                    const uint32_t v = (uint32_t)g;
 #pragma unroll
-                for (int k = 0; k < 4; k++) dst[k] = (uint8_t)(v >> (8 * k));
+                    for (int k = 0; k < 4; k++) S.top[1 + 4 * lane + k] = (uint8_t)(v >> (8 * k));
+                }
             }
+            wave_sync();
+            intra_mb_core<false, 1>(P, mx, my, S, lane, cur_i4, cur_aux);
+            if (my + 1 < P.mbh && lane < 4)   // publish this macroblock's bottom sample row for the row below
+                __hip_atomic_store(handoff + ((size_t)my * P.mbw + mx) * 8 + gl, ((unsigned long long)R.serial << 32) | *(const uint32_t*)(S.rec_y + 15 * 16 + 4 * lane),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            wave_sync();
         }
-        wave_sync();
-        intra_mb_core(P, mx, my, S, lane, cur_i4, cur_aux);
-        // publish this macroblock's bottom sample row for the row below
-        if (my + 1 < P.mbh && lane < 8) {
-            uint32_t v;
-            if (lane < 4) v = *(const uint32_t*)(S.rec_y + 15 * 16 + 4 * lane);
-            else v = *(const uint32_t*)(S.rec_c + ((lane - 4) >> 1) * 64 + 7 * 8 + 4 * (lane & 1));
-            __hip_atomic_store(handoff + ((size_t)my * P.mbw + mx) * 8 + lane, ((unsigned long long)R.serial << 32) | v,
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        uint32_t pf_c = 0;
+        unsigned long long pf_g = 0;
+        auto prefetch = [&](int mx) {
+            if (lane < 32) {
+                const int pl = lane >> 4, row = (lane >> 1) & 7, xs = (lane & 1) * 4;
+                pf_c = src_chroma4(P, pl, 8 * mx + xs, 8 * my + row);
+            }
+            if (top && lane < 4) pf_g = __hip_atomic_load(handoff + ((size_t)(my - 1) * P.mbw + mx) * 8 + gl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        };
+        prefetch(0);
+        for (int mx = 0; mx < P.mbw; mx++) {
+            const uint32_t cur_c = pf_c;
+            unsigned long long g = pf_g;
+            if (mx + 1 < P.mbw) prefetch(mx + 1);
+            if (mx > 0) {
+                if (lane < 16) S.cleft[lane >> 3][lane & 7] = S.rec_c[(lane >> 3) * 64 + (lane & 7) * 8 + 7];
+                else if (lane == 32) S.ctop[0][0] = S.ctop[0][8];
+                else if (lane == 33) S.ctop[1][0] = S.ctop[1][8];
+            }
+            if (lane < 32) *(uint32_t*)(S.srcc + (lane >> 4) * 64 + ((lane >> 1) & 7) * 8 + (lane & 1) * 4) = cur_c;
+            wave_sync();
+            if (top) {
+                g = wait_above(g, mx);
+                if (lane < 4) {   // granules 4, 5: Cb samples 0..7 -> ctop[0][1..8]; 6, 7: Cr -> ctop[1][1..8]
+                    const uint32_t v = (uint32_t)g;
+                    uint8_t* dst = S.ctop[lane >> 1] + 1 + 4 * (lane & 1);
+#pragma unroll
+                    for (int k = 0; k < 4; k++) dst[k] = (uint8_t)(v >> (8 * k));
+                }
+            }
+            wave_sync();
+            intra_mb_core<false, 2>(P, mx, my, S, lane, false, 0u);
+            if (my + 1 < P.mbh && lane < 4)
+                __hip_atomic_store(handoff + ((size_t)my * P.mbw + mx) * 8 + gl, ((unsigned long long)R.serial << 32) | *(const uint32_t*)(S.rec_c + (lane >> 1) * 64 + 7 * 8 + 4 * (lane & 1)),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            wave_sync();
         }
-        wave_sync();
     }
     if (timed_out && lane == 0) *R.err = 2u;
 }

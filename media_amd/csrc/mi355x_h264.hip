@@ -402,7 +402,7 @@ int submit_step(mi355x_h264_encoder* e, Step& T)
             IntraRowParams R{};
             R.p = P; R.handoff = e->d_handoff; R.st_handoff = e->st_handoff; R.err = T.h_err;
             R.serial = next_serial();
-            LAUNCH2(ind, k_intra_rows<true>, k_intra_rows<false>, dim3(e->b_rows, G), dim3(64), st, R);
+            LAUNCH2(ind, k_intra_rows<true>, k_intra_rows<false>, dim3(e->b_rows, G), dim3(128), st, R);
         }
     } else {
         { StatScope sc(e, &S, MI355X_H264_K_ME, (uint32_t)P.nref, (uint32_t)(e->b_nmb * T.n), st);
