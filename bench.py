@@ -393,6 +393,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gops-in-flight", type=int, default=int(os.environ.get("BENCH_GOPS_IN_FLIGHT", "64")),
                     help="closed GOPs of the stream resident and encoded per step per GPU")
+    ap.add_argument("--stagger-ms", type=float, default=float(os.environ.get("BENCH_STAGGER_MS", "0")),
+                    help="instance i starts i x this many milliseconds after instance 0 (inside the timed region)")
     ap.add_argument("--instances", type=int, default=int(os.environ.get("BENCH_INSTANCES", "2")),
                     help="encoder instances (HIP streams) the GOPs in flight are split over; each encodes its share in lockstep")
     ap.add_argument("--cpu-frames", type=int, default=30, help="pictures per CPU-baseline thread (8..30: one closed GOP, 1 IDR + the rest P)")
@@ -525,6 +527,8 @@ def main():
                 run_inst(0)
         else:
             def work(i):
+                if args.stagger_ms > 0 and i:
+                    time.sleep(i * args.stagger_ms * 1e-3)
                 for _ in range(n):
                     run_inst(i)
             ths = [threading.Thread(target=work, args=(i,)) for i in range(I)]

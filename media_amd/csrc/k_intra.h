@@ -542,6 +542,7 @@ struct IntraRowParams {
     size_t st_handoff;            // u64 words between batch items
     unsigned* err;                // pinned host word
     unsigned serial;
+    int npic;                     // pictures of the step (gridDim.y of them at a time)
 };
 
 // Two waves per row (one workgroup): wave 0 codes the luma of the row's macroblocks, wave 1 their chroma, the same macroblock at the
@@ -553,24 +554,41 @@ template <bool IND = false>
 __global__ __launch_bounds__(128) void k_intra_rows(IntraRowParams R)
 {
     __builtin_amdgcn_s_setprio(3);   // dependency-bound row wavefront: issue ahead of co-resident throughput kernels
-    const FrameParams P = batch_view<IND>(R.p, blockIdx.y);
-    unsigned long long* const handoff = R.handoff + (size_t)batch_item<IND>(R.p.itemtab, blockIdx.y) * R.st_handoff;
-    const int lane = threadIdx.x & 63, my = P.band.row0 + blockIdx.x;
+    const int lane = threadIdx.x & 63;
     const bool chroma_wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) != 0;
-    const bool top = P.sl.has_top(my);   // first row of a slice: nothing above to wait for, the slices' wavefronts run side by side
     __shared__ IntraLds S;
     bool timed_out = false;
+    if (!chroma_wave) i4_lds_init(S.i4, lane);
+    // The launch holds gridDim.y pictures at a time, not all of them: workgroup (row, y) takes pictures y, y + gridDim.y, ...  A row
+    // wavefront is bound by its dependencies, not by the machine, and every resident wave holds registers the other instance's
+    // kernels could run in: with all 32 pictures of a lockstep batch resident (4 352 waves of ~150 registers, three to a SIMD) neither
+    // k_me nor the loop filter of the other instance found room beside them, and what the faster IDR step gained they lost.
+    // (Row r of a picture waits for row r - 1 of the same picture, which the workgroup dispatched just before handles: whatever part of the
+    // grid is resident, the row being waited for is in it.)
+    for (int pic = blockIdx.y; pic < R.npic; pic += gridDim.y) {
+    const FrameParams P = batch_view<IND>(R.p, pic);
+    unsigned long long* const handoff = R.handoff + (size_t)batch_item<IND>(R.p.itemtab, pic) * R.st_handoff;
+    const int my = P.band.row0 + blockIdx.x;
+    const bool top = P.sl.has_top(my);   // first row of a slice: nothing above to wait for, the slices' wavefronts run side by side
     // this wave's four granules of macroblock mx of the row above / of this row
     const int gl = (chroma_wave ? 4 : 0) + (lane & 3);
+    // A row that is not due yet polls at priority 0 and ever more rarely (all rows of all pictures are resident from the start, most
+    // of them waiting: at the row wavefront's priority their polling took issue slots from the other instance's kernels); once
+    // the row above is a macroblock ahead the granules requested one macroblock earlier are there and nothing is polled.
     auto wait_above = [&](unsigned long long g, int mx) {
         unsigned spins = 0;
+        bool low = false;
         while (!timed_out) {
             const bool bad = lane < 4 && (unsigned)(g >> 32) != R.serial;
             if (__ballot(bad) == 0ull) break;
-            if (++spins > (1u << 20)) { timed_out = true; break; }
-            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1u << 19)) { timed_out = true; break; }
+            if (!low) { __builtin_amdgcn_s_setprio(0); low = true; }
+            if (spins < 4) __builtin_amdgcn_s_sleep(1);
+            else if (spins < 64) __builtin_amdgcn_s_sleep(8);
+            else __builtin_amdgcn_s_sleep(32);
             if (lane < 4) g = __hip_atomic_load(handoff + ((size_t)(my - 1) * P.mbw + mx) * 8 + gl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        if (low) __builtin_amdgcn_s_setprio(3);
         return g;
     };
     if (!chroma_wave) {
@@ -578,7 +596,6 @@ __global__ __launch_bounds__(128) void k_intra_rows(IntraRowParams R)
         uint32_t pf_y = 0, pf_aux = 0;
         int pf_type = 0;
         unsigned long long pf_g = 0;
-        i4_lds_init(S.i4, lane);
         auto prefetch = [&](int mx) {   // source, k_i4_decide's verdict (type and, lanes 0..3, the sixteen Intra4x4 modes), the row above
             const int mbi = my * P.mbw + mx;
             pf_type = ((const uint8_t*)(P.mb + mbi))[4];
@@ -661,6 +678,7 @@ __global__ __launch_bounds__(128) void k_intra_rows(IntraRowParams R)
             wave_sync();
         }
     }
+    }
     if (timed_out && lane == 0) *R.err = 2u;
 }
 
@@ -679,14 +697,19 @@ template <bool DEC, bool IND = false>
 __global__ __launch_bounds__(64) void k_pintra_rows(IntraRowParams R)
 {
     __builtin_amdgcn_s_setprio(3);
-    const FrameParams P = batch_view<IND>(R.p, blockIdx.y);
-    if (!DEC && *P.anyintra != P.pic_serial) return;
-    unsigned long long* const handoff = R.handoff + (size_t)batch_item<IND>(R.p.itemtab, blockIdx.y) * R.st_handoff;
-    const int lane = threadIdx.x, my = P.band.row0 + blockIdx.x, cs = P.cw / 2;
-    const bool top = P.sl.has_top(my);
+    const int lane = threadIdx.x;
     __shared__ IntraLds S;
-    i4_lds_init(S.i4, lane);
+    bool tab_ready = false;   // the Intra4x4 address table is built by the first macroblock that needs this wave: most rows of most P pictures have none
     bool timed_out = false;
+    // gridDim.y pictures at a time, workgroup (row, y) taking pictures y, y + gridDim.y, ... (as k_intra_rows): this kernel is on every P
+    // step's chain, nearly all of its waves find nothing to do, and each needs ~200 registers to be placed - 2 176 of them per
+    // step beside the other instance's motion search (80 registers a wave, six to a SIMD) cost 7 % of the throughput, 272 cost nothing.
+    for (int pic = blockIdx.y; pic < R.npic; pic += gridDim.y) {
+    const FrameParams P = batch_view<IND>(R.p, pic);
+    if (!DEC && *P.anyintra != P.pic_serial) continue;
+    unsigned long long* const handoff = R.handoff + (size_t)batch_item<IND>(R.p.itemtab, pic) * R.st_handoff;
+    const int my = P.band.row0 + blockIdx.x, cs = P.cw / 2;
+    const bool top = P.sl.has_top(my);
     int last_done = -2;   // the macroblock whose reconstruction S.rec_* holds
     // bit 15 of me_cost = "handed to this pass by k_me": unlike MbInfo.type (an I_PCM conversion changes it, here or in k_tq)
     // it does not change during the launch, so every row sees the same set of macroblocks to wait for
@@ -769,6 +792,7 @@ __global__ __launch_bounds__(64) void k_pintra_rows(IntraRowParams R)
                 const int mbi = my * P.mbw + mx;
                 const bool use_i4 = ((const uint8_t*)(P.mb + mbi))[4] == MB_I4;
                 const uint32_t auxw = lane < 4 ? *(const uint32_t*)(P.aux + (size_t)mbi * 16 + 4 * lane) : 0u;
+                if (!tab_ready) { i4_lds_init(S.i4, lane); tab_ready = true; wave_sync(); }
                 intra_mb_core<DEC>(P, mx, my, S, lane, __builtin_amdgcn_readfirstlane((int)use_i4) != 0, auxw);
             }
             last_done = mx;
@@ -782,6 +806,7 @@ __global__ __launch_bounds__(64) void k_pintra_rows(IntraRowParams R)
             }
             wave_sync();
         }
+    }
     }
     if (timed_out && lane == 0) *R.err = 3u;
 }

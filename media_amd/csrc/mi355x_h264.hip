@@ -225,9 +225,14 @@ struct mi355x_h264_encoder {
     int qp = 26;
     bool keep_pre = false, stats_on = false;
     std::vector<hipEvent_t> ev_pool;
+    uint32_t p_intra_x16 = 0;                // intra macroblocks per P picture, recent pictures (x 16, a running mean): sizes k_pintra_rows' grid
     mi355x_h264_stats stats{};
     char err[256] = {0};
 };
+
+namespace {
+enum { PINTRA_SPARSE_MBS = 8 };   // intra macroblocks per P picture up to which k_pintra_rows takes the step's pictures one after the other
+}  // namespace
 
 namespace {
 
@@ -402,7 +407,11 @@ int submit_step(mi355x_h264_encoder* e, Step& T)
             IntraRowParams R{};
             R.p = P; R.handoff = e->d_handoff; R.st_handoff = e->st_handoff; R.err = T.h_err;
             R.serial = next_serial();
-            LAUNCH2(ind, k_intra_rows<true>, k_intra_rows<false>, dim3(e->b_rows, G), dim3(128), st, R);
+            {   // MI355X_H264_INTRA_SLOTS: pictures the row wavefront holds at a time (k_intra_rows)
+                static const int slots = getenv("MI355X_H264_INTRA_SLOTS") ? std::max(1, atoi(getenv("MI355X_H264_INTRA_SLOTS"))) : 16;
+                R.npic = (int)G;
+                LAUNCH2(ind, k_intra_rows<true>, k_intra_rows<false>, dim3(e->b_rows, std::min(G, (unsigned)slots)), dim3(128), st, R);
+            }
         }
     } else {
         { StatScope sc(e, &S, MI355X_H264_K_ME, (uint32_t)P.nref, (uint32_t)(e->b_nmb * T.n), st);
@@ -421,7 +430,12 @@ int submit_step(mi355x_h264_encoder* e, Step& T)
             R.p = P; R.handoff = e->d_handoff; R.st_handoff = e->st_handoff; R.err = T.h_err;
             R.serial = next_serial();
             LAUNCH2(ind, k_i4_decide<true>, k_i4_decide<false>, dim3(std::min((e->b_nmb + 3) / 4, (int)I4_MARKED_WAVES), G), dim3(64), st, P, 1);
-            LAUNCH2(ind, (k_pintra_rows<false, true>), (k_pintra_rows<false, false>), dim3(e->b_rows, G), dim3(64), st, R);
+            // Its grid holds ONE picture at a time (the workgroups walk the step's pictures) while the recent P pictures had next to no
+            // intra macroblocks, all of them once they have: see k_pintra_rows.  MI355X_H264_PINTRA_SLOTS fixes the number.
+            static const int pslots_env = getenv("MI355X_H264_PINTRA_SLOTS") ? std::max(1, atoi(getenv("MI355X_H264_PINTRA_SLOTS"))) : 0;
+            const unsigned pslots = pslots_env ? (unsigned)pslots_env : (e->p_intra_x16 > 16u * PINTRA_SPARSE_MBS ? G : 1u);
+            R.npic = (int)G;
+            LAUNCH2(ind, (k_pintra_rows<false, true>), (k_pintra_rows<false, false>), dim3(e->b_rows, std::min(G, pslots)), dim3(64), st, R);
         }
     }
     // entropy coding: slice headers per position
@@ -599,7 +613,7 @@ int finish_item(mi355x_h264_encoder* e, Slot& S, const AuLayout& L, int g, uint8
         // several slices: one NAL unit each, put together here (the payloads lie slice_cap apart in the pinned buffer)
         std::vector<uint8_t>& eb = e->esc_buf[g];
         size_t need = e->sps_pps.size() + 16;
-        uint32_t cost = 0;
+        uint32_t cost = 0, p_intra = 0;
         for (int sl = 0; sl < e->b_nsl; sl++) {
             const SliceInfo& si = S.h_info[(size_t)g * e->b_nsl + sl];
             if (si.error) {
@@ -608,10 +622,10 @@ int finish_item(mi355x_h264_encoder* e, Slot& S, const AuLayout& L, int g, uint8
             }
             need += 5 + (size_t)si.total_bytes * 3 / 2 + 16;
             cost += si.me_cost;
-            if (!L.idr) { e->stats.me_searched_mbs += si.searched; e->stats.tq_coded_mbs += si.tq_coded; }
+            if (!L.idr) { e->stats.me_searched_mbs += si.searched; e->stats.tq_coded_mbs += si.tq_coded; p_intra += si.searched - si.tq_coded; }
         }
         e->last_me_cost[g] = cost;
-        if (!L.idr) e->stats.p_mbs += (uint64_t)e->b_nmb;
+        if (!L.idr) { e->stats.p_mbs += (uint64_t)e->b_nmb; e->p_intra_x16 = (3 * e->p_intra_x16 + 16 * p_intra) / 4; }
         eb.resize(need);
         size_t pos = 0;
         if (L.idr && e->b_sl0 == 0) { memcpy(eb.data(), e->sps_pps.data(), e->sps_pps.size()); pos = e->sps_pps.size(); }   // parameter sets go with the first band
@@ -631,7 +645,10 @@ int finish_item(mi355x_h264_encoder* e, Slot& S, const AuLayout& L, int g, uint8
     }
     const SliceInfo info = S.h_info[g];
     e->last_me_cost[g] = info.me_cost;
-    if (!L.idr) { e->stats.p_mbs += (uint64_t)e->b_nmb; e->stats.me_searched_mbs += info.searched; e->stats.tq_coded_mbs += info.tq_coded; }
+    if (!L.idr) {
+        e->stats.p_mbs += (uint64_t)e->b_nmb; e->stats.me_searched_mbs += info.searched; e->stats.tq_coded_mbs += info.tq_coded;
+        e->p_intra_x16 = (3 * e->p_intra_x16 + 16 * (info.searched - info.tq_coded)) / 4;
+    }
     if (info.error) {
         e->force_idr = 1;   // the refused picture is missing from the stream: the next one must not refer to it
         return fail(e, info.error == 1 ? MI355X_H264_E_OVERFLOW : MI355X_H264_E_INTERNAL, "device reported error %u", info.error);
@@ -1753,6 +1770,7 @@ int dec_submit(mi355x_h264_decoder* d, const h264dec::Picture& pic)
         R.p = P; R.handoff = e->d_handoff; R.st_handoff = e->st_handoff; R.err = S.h_err;
         e->serial = e->serial == 0xFFFFFFFFu ? 1 : e->serial + 1;
         R.serial = e->serial;
+        R.npic = 1;
         hipLaunchKernelGGL(k_pintra_rows<true>, dim3(e->mbh, 1), dim3(64), 0, st, R);
     }
     if (pic.deblock_idc != 1) {
