@@ -197,6 +197,7 @@ struct DbRowParams {
     const unsigned* anypcm;  // [item] == pic_serial: the picture holds an I_PCM macroblock and is not filtered (slice header idc 1)
     const unsigned* anyintra;   // [item] == pic_serial: a P picture with intra macroblocks (bS 3 / 4 edges)
     unsigned pic_serial;
+    int npic;                // pictures of the step (gridDim.y of them at a time)
     int need_intra;          // P pictures are launched in both forms: < 0 this form runs when the picture has no intra
                              // macroblock, > 0 when it has, 0 = unconditional (IDR)
     // lockstep batch strides (gridDim.y items)
@@ -263,12 +264,10 @@ enum { DR_CB = 4 * 201, DR_CPS = 4 * 144, DR_TILE = DR_CB + 2 * DR_CPS + 12 };
 // the chroma QPs go through chroma_qp_index_offset, indexA / indexB through the slice's filter offsets - three threshold
 // sets per macroblock (left edge, top edge, inner edges), looked up in LDS copies of Tables 8-15 / 8-16.  PERMB = false is
 // the encoder's form: one set per picture, prepared on the host.
-template <bool BS4, bool PERMB = false, bool IND = false>
-__global__ __launch_bounds__(64) void k_deblock_rows(DbRowParams R)
+template <bool BS4, bool PERMB, bool IND>
+__device__ __forceinline__ void deblock_rows_picture(const DbRowParams& R, const int pos)   // pos: the picture's position in the step (blockIdx.y, or the one this workgroup walks to)
 {
-    // dependency-bound: when a throughput kernel of another stream shares the SIMD, this wave issues first
-    __builtin_amdgcn_s_setprio(3);
-    const int bitem = batch_item<IND>(R.itemtab, blockIdx.y);
+    const int bitem = batch_item<IND>(R.itemtab, pos);
     if (R.anybs[bitem] != R.serial) return;   // no edge of this picture is filtered: nothing to do, nobody waits
     if (R.anypcm[bitem] == R.pic_serial) return;
     if (R.need_intra != 0 && (R.anyintra[bitem] == R.pic_serial) != (R.need_intra > 0)) return;
@@ -277,7 +276,7 @@ __global__ __launch_bounds__(64) void k_deblock_rows(DbRowParams R)
         const size_t g = (size_t)bitem;
         D.pl[0] += g * R.st_y; D.pl[1] += g * R.st_c; D.pl[2] += g * R.st_c; D.mb += g * R.st_mb;
         if constexpr (IND) {   // the item's own ring slot and its own QP's thresholds (Tables 8-16 / 8-17, chroma through Table 8-15)
-            const ItemRef it = item_ref(R.itemtab, blockIdx.y);
+            const ItemRef it = item_ref(R.itemtab, pos);
             D.pl[0] += (size_t)it.cur * R.st_ring_y; D.pl[1] += (size_t)it.cur * R.st_ring_c; D.pl[2] += (size_t)it.cur * R.st_ring_c;
             const int qpc = c_chroma_qp[it.qp];
             D.alpha_y = c_alpha[it.qp]; D.beta_y = c_beta[it.qp]; D.alpha_c = c_alpha[qpc]; D.beta_c = c_beta[qpc];
@@ -480,6 +479,16 @@ __global__ __launch_bounds__(64) void k_deblock_rows(DbRowParams R)
 #undef SY
 #undef SC
 }
+// The kernels: workgroup (row, y) filters its row of pictures y, y + gridDim.y, ... of the step's R.npic pictures.  A launch whose
+// pictures nearly all return at once - the bS 4 form on P steps of content without intra macroblocks - is made with gridDim.y = 1: placing
+// a thousand 120-register waves beside the other instance's kernels for nothing is what costs, not the walk (see k_pintra_rows).
+template <bool BS4, bool PERMB = false, bool IND = false>
+__global__ __launch_bounds__(64) void k_deblock_rows(DbRowParams R)
+{
+    // dependency-bound: when a throughput kernel of another stream shares the SIMD, this wave issues first
+    __builtin_amdgcn_s_setprio(3);
+    for (int pos = blockIdx.y; pos < R.npic; pos += gridDim.y) deblock_rows_picture<BS4, PERMB, IND>(R, pos);
+}
 
 
 // ===========================================================================
@@ -499,11 +508,10 @@ __global__ __launch_bounds__(64) void k_deblock_rows(DbRowParams R)
 // (pictures of one slice; MI355X_H264_PAIR_FILTER=N moves the threshold, 0 turns it off); smaller batches, the latency mode and
 // the decoder use the row form.  tests/test_gpu_parity.py runs both forms at batch 8 and this one forced on single pictures.
 // ===========================================================================
-template <bool BS4, bool IND = false>
-__global__ __launch_bounds__(64) void k_deblock_pairs(DbRowParams R)
+template <bool BS4, bool IND>
+__device__ __forceinline__ void deblock_pairs_picture(const DbRowParams& R, const int pos)
 {
-    __builtin_amdgcn_s_setprio(3);
-    const int bitem = batch_item<IND>(R.itemtab, blockIdx.y);
+    const int bitem = batch_item<IND>(R.itemtab, pos);
     if (R.anybs[bitem] != R.serial) return;
     if (R.anypcm[bitem] == R.pic_serial) return;
     if (R.need_intra != 0 && (R.anyintra[bitem] == R.pic_serial) != (R.need_intra > 0)) return;
@@ -512,7 +520,7 @@ __global__ __launch_bounds__(64) void k_deblock_pairs(DbRowParams R)
         const size_t g = (size_t)bitem;
         D.pl[0] += g * R.st_y; D.pl[1] += g * R.st_c; D.pl[2] += g * R.st_c; D.mb += g * R.st_mb;
         if constexpr (IND) {   // the item's own ring slot and its own QP's thresholds (Tables 8-16 / 8-17, chroma through Table 8-15)
-            const ItemRef it = item_ref(R.itemtab, blockIdx.y);
+            const ItemRef it = item_ref(R.itemtab, pos);
             D.pl[0] += (size_t)it.cur * R.st_ring_y; D.pl[1] += (size_t)it.cur * R.st_ring_c; D.pl[2] += (size_t)it.cur * R.st_ring_c;
             const int qpc = c_chroma_qp[it.qp];
             D.alpha_y = c_alpha[it.qp]; D.beta_y = c_beta[it.qp]; D.alpha_c = c_alpha[qpc]; D.beta_c = c_beta[qpc];
@@ -690,6 +698,12 @@ __global__ __launch_bounds__(64) void k_deblock_pairs(DbRowParams R)
     if (timed_out && lane == 0) *R.err = 1u;
 #undef SY
 #undef SC
+}
+template <bool BS4, bool IND = false>
+__global__ __launch_bounds__(64) void k_deblock_pairs(DbRowParams R)
+{
+    __builtin_amdgcn_s_setprio(3);
+    for (int pos = blockIdx.y; pos < R.npic; pos += gridDim.y) deblock_pairs_picture<BS4, IND>(R, pos);
 }
 
 }  // namespace h264

@@ -225,12 +225,51 @@ struct mi355x_h264_encoder {
     int qp = 26;
     bool keep_pre = false, stats_on = false;
     std::vector<hipEvent_t> ev_pool;
+    int me_turn = 0;                         // this engine's id at the GPU's motion-search lock (0: takes no part)
     uint32_t p_intra_x16 = 0;                // intra macroblocks per P picture, recent pictures (x 16, a running mean): sizes k_pintra_rows' grid
     mi355x_h264_stats stats{};
     char err[256] = {0};
 };
 
+// ---------------------------------------------------------------------------------------------------------------
+// One motion search of a lockstep batch at a time per GPU.
+// Two instances beside each other are worth more than one because the dependency-bound kernels of one (loop filter, entropy
+// coding, row wavefronts) run in the issue slots the other's motion search leaves.  Left to themselves the instances settle in
+// whatever phase their first steps put them - search beside filter (good), or search beside search and filter beside filter (2 - 5 %
+// less, run by run: section 7 of DESIGN.md).  A lock word in device memory per GPU keeps the searches apart: a one-wave kernel in
+// front of a search takes it (compare-and-swap, sleeping between tries), a one-thread kernel behind the search gives it back.
+// Whoever comes first goes first - no order is imposed, so an engine in its IDR step, or gone, holds nobody up (an ORDER between the
+// engines' searches, by events or by counters, follows the order in which the host threads happened to queue them and left one
+// instance idle for 1.4 ms of every step) - and the holder's search is already queued behind its acquire, so the lock is always given
+// back; the wait gives up after TURN_TIMEOUT_US all the same.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void k_turn_acquire(unsigned* lock, unsigned id, int timeout_us)
+{
+    if (threadIdx.x) return;
+    const long long t0 = wall_clock64();   // 100 MHz
+    for (;;) {
+        unsigned expect = 0u;
+        if (__hip_atomic_compare_exchange_strong(lock, &expect, id, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+        if (wall_clock64() - t0 > (long long)timeout_us * 100) { __hip_atomic_store(lock, id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
+        __builtin_amdgcn_s_sleep(16);
+    }
+}
+__global__ void k_turn_release(unsigned* lock, unsigned id)
+{
+    unsigned expect = id;
+    (void)__hip_atomic_compare_exchange_strong(lock, &expect, 0u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 namespace {
+enum { TURN_MIN_BATCH = 16, TURN_DEVICES = 16, TURN_TIMEOUT_US = 3000 };
+struct MeTurns {
+    std::mutex mu;
+    unsigned* d_lock[TURN_DEVICES] = {};   // allocated with the first engine of the device, kept for the life of the process
+    unsigned next_id = 1;
+};
+MeTurns g_turns;
+const bool g_turns_on = !(getenv("MI355X_H264_ME_TURNS") && atoi(getenv("MI355X_H264_ME_TURNS")) == 0);
+
 enum { PINTRA_SPARSE_MBS = 8 };   // intra macroblocks per P picture up to which k_pintra_rows takes the step's pictures one after the other
 }  // namespace
 
@@ -414,14 +453,18 @@ int submit_step(mi355x_h264_encoder* e, Step& T)
             }
         }
     } else {
-        { StatScope sc(e, &S, MI355X_H264_K_ME, (uint32_t)P.nref, (uint32_t)(e->b_nmb * T.n), st);
-          FrameParams Q = P;   // one launch per reference picture (config.refs): Q.ref = the planes of ref_idx_l0 = Q.rf
-          Q.rf_last = P.nref - 1;
-          for (int r = 0; r < P.nref; r++) {
-              Q.rf = r;
-              for (int p = 0; p < 3; p++) Q.ref[p] = P.refs[r][p];
-              LAUNCH2(ind, k_me<true>, k_me<false>, dim3(e->b_nmb, G), dim3(64), st, Q);
-          } }
+        { const bool turns = g_turns_on && !ind && e->me_turn > 0 && T.n >= TURN_MIN_BATCH;
+          if (turns) hipLaunchKernelGGL(k_turn_acquire, dim3(1), dim3(64), 0, st, g_turns.d_lock[e->device], (unsigned)e->me_turn, (int)TURN_TIMEOUT_US);
+          { StatScope sc(e, &S, MI355X_H264_K_ME, (uint32_t)P.nref, (uint32_t)(e->b_nmb * T.n), st);
+            FrameParams Q = P;   // one launch per reference picture (config.refs): Q.ref = the planes of ref_idx_l0 = Q.rf
+            Q.rf_last = P.nref - 1;
+            for (int r = 0; r < P.nref; r++) {
+                Q.rf = r;
+                for (int p = 0; p < 3; p++) Q.ref[p] = P.refs[r][p];
+                LAUNCH2(ind, k_me<true>, k_me<false>, dim3(e->b_nmb, G), dim3(64), st, Q);
+            } }
+          if (turns) hipLaunchKernelGGL(k_turn_release, dim3(1), dim3(1), 0, st, g_turns.d_lock[e->device], (unsigned)e->me_turn);
+        }
         { StatScope sc(e, &S, MI355X_H264_K_PMB, 1, (uint32_t)(e->b_nmb * T.n), st);
           if (e->cfg.profile_idc == 100) LAUNCH2(ind, k_tq8<true>, k_tq8<false>, dim3((e->b_nmb + 15) / 16, G), dim3(64), st, P);   // High: 8x8 transform, sixteen macroblocks per wave
           else LAUNCH2(ind, k_tq<true>, k_tq<false>, dim3((e->b_nmb + 7) / 8, G), dim3(64), st, P); }   // one wave per eight macroblocks
@@ -429,13 +472,13 @@ int submit_step(mi355x_h264_encoder* e, Step& T)
             IntraRowParams R{};
             R.p = P; R.handoff = e->d_handoff; R.st_handoff = e->st_handoff; R.err = T.h_err;
             R.serial = next_serial();
-            LAUNCH2(ind, k_i4_decide<true>, k_i4_decide<false>, dim3(std::min((e->b_nmb + 3) / 4, (int)I4_MARKED_WAVES), G), dim3(64), st, P, 1);
-            // Its grid holds ONE picture at a time (the workgroups walk the step's pictures) while the recent P pictures had next to no
-            // intra macroblocks, all of them once they have: see k_pintra_rows.  MI355X_H264_PINTRA_SLOTS fixes the number.
+            // Their grids hold ONE picture at a time (the workgroups walk the step's pictures) while the recent P pictures had next to
+            // no intra macroblocks, all of them once they have: see k_pintra_rows.  MI355X_H264_PINTRA_SLOTS fixes the number.
             static const int pslots_env = getenv("MI355X_H264_PINTRA_SLOTS") ? std::max(1, atoi(getenv("MI355X_H264_PINTRA_SLOTS"))) : 0;
-            const unsigned pslots = pslots_env ? (unsigned)pslots_env : (e->p_intra_x16 > 16u * PINTRA_SPARSE_MBS ? G : 1u);
+            const unsigned pslots = std::min(G, pslots_env ? (unsigned)pslots_env : (e->p_intra_x16 > 16u * PINTRA_SPARSE_MBS ? G : 1u));
             R.npic = (int)G;
-            LAUNCH2(ind, (k_pintra_rows<false, true>), (k_pintra_rows<false, false>), dim3(e->b_rows, std::min(G, pslots)), dim3(64), st, R);
+            LAUNCH2(ind, k_i4_decide<true>, k_i4_decide<false>, dim3(std::min((e->b_nmb + 3) / 4, (int)I4_MARKED_WAVES), pslots), dim3(64), st, P, (int)G);
+            LAUNCH2(ind, (k_pintra_rows<false, true>), (k_pintra_rows<false, false>), dim3(e->b_rows, pslots), dim3(64), st, R);
         }
     }
     // entropy coding: slice headers per position
@@ -528,17 +571,20 @@ int submit_step(mi355x_h264_encoder* e, Step& T)
             R.itemtab = T.d_itemtab; R.st_ring_y = e->st_ring_y; R.st_ring_c = e->st_ring_c;
             // two macroblock rows per wave (k_deblock_pairs) for lockstep batches of pictures of one slice; else one row per wave
             const bool pairs = e->pair_filter && T.n >= e->pair_min_batch && e->nsl == 1 && e->b_rows == e->mbh;
-            const dim3 grid(pairs ? (unsigned)((e->b_rows + 1) / 2) : (unsigned)e->b_rows, G);
-            auto filter = [&](bool bs4) {
+            R.npic = (int)G;
+            const unsigned grid_x = pairs ? (unsigned)((e->b_rows + 1) / 2) : (unsigned)e->b_rows;
+            auto filter = [&](bool bs4, unsigned at_a_time) {
+                const dim3 grid(grid_x, std::min(G, at_a_time));
                 if (pairs) { if (bs4) LAUNCH2(ind, (k_deblock_pairs<true, true>), (k_deblock_pairs<true, false>), grid, dim3(64), st, R);
                              else LAUNCH2(ind, (k_deblock_pairs<false, true>), (k_deblock_pairs<false, false>), grid, dim3(64), st, R); }
                 else { if (bs4) LAUNCH2(ind, (k_deblock_rows<true, false, true>), (k_deblock_rows<true, false, false>), grid, dim3(64), st, R);
                        else LAUNCH2(ind, (k_deblock_rows<false, false, true>), (k_deblock_rows<false, false, false>), grid, dim3(64), st, R); }
             };
-            if (idr) { R.need_intra = 0; filter(true); }
+            if (idr) { R.need_intra = 0; filter(true, G); }
             else {   // P pictures: the form without the bS 4 filter, or - when the picture has intra macroblocks - the one with it
-                R.need_intra = -1; filter(false);
-                R.need_intra = 1; filter(true);
+                // (while the recent P pictures had next to none, the second launch holds one picture at a time: see k_deblock_rows)
+                R.need_intra = -1; filter(false, G);
+                R.need_intra = 1; filter(true, e->p_intra_x16 > 16u * PINTRA_SPARSE_MBS ? G : 1u);
             }
         }
     }
@@ -847,6 +893,14 @@ static int create_engine(const mi355x_h264_config* cfg, mi355x_h264_encoder** ou
     e->au_cap = e->bitbuf_cap + e->sps_pps.size() + 64;
     e->st_au = (e->au_cap + 256 + 255) & ~(size_t)255;
     e->nslots = hub_engine ? 1 : NSLOT;
+    if (!hub_engine && e->G >= TURN_MIN_BATCH && e->device >= 0 && e->device < TURN_DEVICES) {   // takes part in the turn-taking of the motion searches
+        std::lock_guard<std::mutex> tl(g_turns.mu);
+        if (!g_turns.d_lock[e->device]) {
+            CK(hipMalloc((void**)&g_turns.d_lock[e->device], sizeof(unsigned)));
+            CK(hipMemset(g_turns.d_lock[e->device], 0, sizeof(unsigned)));
+        }
+        e->me_turn = (int)g_turns.next_id++;
+    }
     for (int si = 0; si < e->nslots; si++) {
         Slot& S = e->slots[si];
         CK(hipMalloc((void**)&S.d_bitbuf, e->st_bitbuf_bytes * Gn));
@@ -1794,6 +1848,7 @@ int dec_submit(mi355x_h264_decoder* d, const h264dec::Picture& pic)
         D.alpha_y = h_alpha[qp]; D.beta_y = h_beta[qp]; D.alpha_c = h_alpha[qpc]; D.beta_c = h_beta[qpc];
         for (int i = 0; i < 3; i++) { D.tc0_y[i] = h_tc0[qp][i]; D.tc0_c[i] = h_tc0[qpc][i]; }
         DbRowParams R{};
+        R.npic = 1;
         R.d = D; R.handoff = e->d_handoff; R.err = S.h_err;
         R.st_y = e->st_y; R.st_c = e->st_c; R.st_handoff = e->st_handoff; R.st_mb = e->nmb;
         R.serial = db_serial; R.row0 = 0;

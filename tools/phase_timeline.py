@@ -28,3 +28,8 @@ offs.sort()
 print("offset between the instances' k_me starts (us): median %.0f, quartiles %.0f / %.0f" % (offs[len(offs) // 2], offs[len(offs) // 4], offs[3 * len(offs) // 4]))
 per = [(b - a) / 1e3 for a, b in zip(me[main[0]], me[main[0]][1:])]
 per.sort(); print("k_me period of one instance (us): median %.0f" % per[len(per) // 2])
+if len(sys.argv) > 2:   # a stretch of the timeline, both queues side by side
+    t0 = me[main[0]][len(me[main[0]]) // 2]
+    for s, e, q, n in sorted(ev):
+        if q in main and t0 <= s < t0 + int(float(sys.argv[2]) * 1e6):
+            print("%s%-18s %8.1f -> %8.1f (%6.1f)" % ("" if q == main[0] else " " * 44, n, (s - t0) / 1e3, (e - t0) / 1e3, (e - s) / 1e3))

@@ -1,28 +1,26 @@
 #!/bin/bash
-# usage: r03_prio_sweep.sh ; the default line and three other contents: shipped library (adaptive k_pintra_rows grid), the grid fixed at 1 and at 32 pictures, library B
+# usage: r03_prio_sweep.sh ; the default line with the motion-search lock on (default) / off (MI355X_H264_ME_TURNS=0), instance 1 started 0 / 1.6 ms after instance 0
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r03
 mkdir -p $O
 cd $R
-for c in s1 s2 s3 scroll; do
-for rep in 1 2; do
-  timeout -k 10 300 python bench.py --no-plugin --no-cpu-baseline --steps 5 --content $c > $O/pc_${c}_A_$rep.json 2> /dev/null
-  MI355X_H264_PINTRA_SLOTS=1 timeout -k 10 300 python bench.py --no-plugin --no-cpu-baseline --steps 5 --content $c > $O/pc_${c}_K1_$rep.json 2> /dev/null
-  MI355X_H264_PINTRA_SLOTS=32 timeout -k 10 300 python bench.py --no-plugin --no-cpu-baseline --steps 5 --content $c > $O/pc_${c}_K32_$rep.json 2> /dev/null
-  MI355X_H264_LIB=$R/media_amd/lib/libmi355x_h264_ab.so timeout -k 10 300 python bench.py --no-plugin --no-cpu-baseline --steps 5 --content $c > $O/pc_${c}_B_$rep.json 2> /dev/null
-done
+for rep in 1 2 3 4; do
+ for sg in 0 1.6; do
+  timeout -k 10 300 python bench.py --no-plugin --no-cpu-baseline --steps 5 --stagger-ms $sg > $O/turn_on_${sg}_$rep.json 2> /dev/null
+  MI355X_H264_ME_TURNS=0 timeout -k 10 300 python bench.py --no-plugin --no-cpu-baseline --steps 5 --stagger-ms $sg > $O/turn_off_${sg}_$rep.json 2> /dev/null
+ done
 done
 python - <<PY
 import json
-for c in ("s1", "s2", "s3", "scroll"):
-  for v in ["A", "K1", "K32", "B"]:
+for sg in ("0", "1.6"):
+  for v in ("on", "off"):
     out = []
-    for rep in (1, 2):
+    for rep in (1, 2, 3, 4):
         try:
-            d = json.load(open("$O/pc_%s_%s_%d.json" % (c, v, rep)))
-            k = d.get("kernels") or {}
-            out.append("%.0f/%.0f %s" % (d["value"], d["single_gop_in_flight_fps"], {a: round(b["ms_per_launch"], 3) for a, b in k.items()}))
+            d = json.load(open("$O/turn_%s_%s_%d.json" % (v, sg, rep)))
+            k = d["kernels"]
+            out.append("%.0f (me %.2f tq %.3f cavlc %.3f db %.2f)" % (d["value"], k["me"]["ms_per_launch"], k["tq"]["ms_per_launch"], k["cavlc"]["ms_per_launch"], k["deblock"]["ms_per_launch"]))
         except Exception as ex:
-            out.append("unreadable %s" % ex)
-    print(c, v, " ".join(out))
+            out.append("unreadable")
+    print("stagger", sg, "lock", v, " ".join(out))
 PY
