@@ -447,7 +447,7 @@ int submit_step(mi355x_h264_encoder* e, Step& T)
             R.p = P; R.handoff = e->d_handoff; R.st_handoff = e->st_handoff; R.err = T.h_err;
             R.serial = next_serial();
             {   // MI355X_H264_INTRA_SLOTS: pictures the row wavefront holds at a time (k_intra_rows)
-                static const int slots = getenv("MI355X_H264_INTRA_SLOTS") ? std::max(1, atoi(getenv("MI355X_H264_INTRA_SLOTS"))) : 16;
+                static const int slots = getenv("MI355X_H264_INTRA_SLOTS") ? std::max(1, atoi(getenv("MI355X_H264_INTRA_SLOTS"))) : 24;
                 R.npic = (int)G;
                 LAUNCH2(ind, k_intra_rows<true>, k_intra_rows<false>, dim3(e->b_rows, std::min(G, (unsigned)slots)), dim3(128), st, R);
             }
