@@ -368,6 +368,53 @@ def test_lockstep_batch_equals_serial():
     enc.close()
 
 
+def test_two_instances_of_sixteen_gops_side_by_side_with_cuts():
+    """Two engines of 16 closed GOPs each on two host threads (the bench's arrangement, from the size on where the GPU's
+    motion-search lock and the picture-walking grids of k_pintra_rows / k_i4_decide / the bS-4 loop filter are in use): every other
+    GOP has a cut after its second picture, so one lockstep step mixes P pictures with and without intra macroblocks, and the
+    second call finds the engine's intra statistics above the sparse threshold (all pictures of the step resident).  Every GOP ==
+    the oracle's serial stream."""
+    import threading
+    import torch
+    w, h, gop, G = 320, 240, 4, 16
+    fbytes = w * h * 3 // 2
+
+    def gops(first):   # GOP k: cut content when k is odd
+        out = []
+        for k in range(first, first + G):
+            out += synth.sequence("cut" if k & 1 else "s1", w, h, gop, start=0 if k & 1 else 3 * k)
+        return out
+
+    errors = []
+
+    def run(inst):
+        try:
+            orc = OracleEncoder(w, h, qp=27 + inst, gop=gop)
+            enc = capi.Encoder(w, h, qp=27 + inst, gop=gop, batch=G)
+            cap = gop * fbytes
+            out = np.zeros(G * cap, np.uint8)
+            sizes = np.zeros(G * gop, np.uint32)
+            gb = np.zeros(G, np.uint64)
+            for call in range(3):
+                frames = gops(call * G + inst)
+                want = [orc.encode(f)[0] for f in frames]
+                dev = torch.from_numpy(np.stack(frames)).cuda()
+                enc.encode_gops_device(dev.data_ptr(), fbytes, gop * fbytes, gop, out, cap, sizes, gb)
+                for g in range(G):
+                    if out[g * cap: g * cap + int(gb[g])].tobytes() != b"".join(want[g * gop:(g + 1) * gop]):
+                        errors.append((inst, call, g))
+            enc.close()
+        except Exception as ex:  # noqa: BLE001
+            errors.append((inst, repr(ex)))
+
+    ths = [threading.Thread(target=run, args=(i,)) for i in range(2)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errors, errors
+
+
 def test_concurrent_instances_under_uneven_load():
     """the row-wavefront kernels hand samples between workgroups inside one launch; run several encoder
     instances of different geometry concurrently (uneven load on the chip, L1-warm consumers) and check
