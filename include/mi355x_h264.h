@@ -125,6 +125,19 @@ int mi355x_h264_encode_nv12(mi355x_h264_encoder *enc, const uint8_t *y, int y_st
 int mi355x_h264_encode_nv12_device(mi355x_h264_encoder *enc, const void *d_nv12, uint8_t **out,
                                    uint32_t *out_len, int *frame_type);
 
+/* RGBA ingest (the reference's own interface names the layout only on its decoder side,
+ * video_decoder/include/VideoDecoder.h:40-47 PIXEL_FORMAT_RGBA_8888 - no reference ENCODER path takes it, so the conversion
+ * is this library's definition, stated in oracle/h264_rgba.c): 8-bit R, G, B, A bytes per sample, alpha ignored.  One
+ * conversion kernel writes the I420 picture the encoder then reads: BT.601 studio swing in the usual integer form,
+ *   Y = ((66 R + 129 G + 25 B + 128) >> 8) + 16,
+ *   Cb = ((-38 r - 74 g + 112 b + 128) >> 8) + 128,  Cr = ((112 r - 94 g - 18 b + 128) >> 8) + 128
+ * with r, g, b the rounded mean of the four samples of a 2x2 block.  stride in bytes (>= 4 * width).  Batch-1 encoders. */
+int mi355x_h264_encode_rgba(mi355x_h264_encoder *enc, const uint8_t *rgba, int stride, uint8_t **out,
+                            uint32_t *out_len, int *frame_type);
+/* tightly packed RGBA in device memory (4 * width bytes per row) */
+int mi355x_h264_encode_rgba_device(mi355x_h264_encoder *enc, const void *d_rgba, uint8_t **out,
+                                   uint32_t *out_len, int *frame_type);
+
 /* Encode `count` device-resident pictures back to back; picture i starts at
  * d_frames + i*frame_stride_bytes.  Access units are appended to host_out
  * (capacity out_cap); sizes[i] receives the byte length of picture i.  The

@@ -26,7 +26,7 @@ EXPORTS = [
     "mi355x_h264_force_idr", "mi355x_h264_last_error", "mi355x_h264_coded_width", "mi355x_h264_coded_height",
     "mi355x_h264_debug_keep_pre", "mi355x_h264_debug_read", "mi355x_h264_stats_enable", "mi355x_h264_stats_read",
     "mi355x_h264_set_qp", "mi355x_h264_set_idr_pic_id", "mi355x_h264_encode_nv12", "mi355x_h264_encode_nv12_device",
-    "mi355x_h264_encode_gops_device", "mi355x_h264_last_me_cost",
+    "mi355x_h264_encode_gops_device", "mi355x_h264_last_me_cost", "mi355x_h264_encode_rgba", "mi355x_h264_encode_rgba_device",
     "mi355x_h264_stream_open", "mi355x_h264_stream_close", "mi355x_h264_stream_encode", "mi355x_h264_stream_set_qp",
     "mi355x_h264_stream_force_idr", "mi355x_h264_stream_set_idr_pic_id", "mi355x_h264_stream_last_me_cost",
     "mi355x_h264_stream_last_error", "mi355x_h264_stream_debug_read", "mi355x_h264_stream_hub_stats",
@@ -65,6 +65,8 @@ def lib():
         L.mi355x_h264_encode_device.argtypes = [vp, vp, C.POINTER(vp), C.POINTER(C.c_uint32), C.POINTER(C.c_int)]
         L.mi355x_h264_encode_nv12.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_uint32), C.POINTER(C.c_int)]
         L.mi355x_h264_encode_nv12_device.argtypes = [vp, vp, C.POINTER(vp), C.POINTER(C.c_uint32), C.POINTER(C.c_int)]
+        L.mi355x_h264_encode_rgba.argtypes = [vp, vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_uint32), C.POINTER(C.c_int)]
+        L.mi355x_h264_encode_rgba_device.argtypes = [vp, vp, C.POINTER(vp), C.POINTER(C.c_uint32), C.POINTER(C.c_int)]
         L.mi355x_h264_encode_batch_device.argtypes = [vp, vp, C.c_size_t, C.c_int, vp, C.c_size_t, vp,
                                                       C.POINTER(C.c_size_t)]
         L.mi355x_h264_encode_gops_device.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_int, vp, C.c_size_t, vp, vp]
@@ -154,6 +156,18 @@ class Encoder:
         out, n, ft = C.c_void_p(), C.c_uint32(), C.c_int()
         self._check(lib().mi355x_h264_encode_nv12(self.h, f.ctypes.data, w, f.ctypes.data + w * h, w,
                                                   C.byref(out), C.byref(n), C.byref(ft)))
+        return C.string_at(out.value, n.value), ft.value
+
+    def encode_rgba(self, rgba, stride=None):
+        """host RGBA (height x width x 4 bytes, or rows `stride` bytes apart) -> (bytes, frame_type)"""
+        f = np.ascontiguousarray(rgba, dtype=np.uint8)
+        out, n, ft = C.c_void_p(), C.c_uint32(), C.c_int()
+        self._check(lib().mi355x_h264_encode_rgba(self.h, f.ctypes.data, int(stride or 4 * self.width), C.byref(out), C.byref(n), C.byref(ft)))
+        return C.string_at(out.value, n.value), ft.value
+
+    def encode_rgba_device(self, dev_ptr):
+        out, n, ft = C.c_void_p(), C.c_uint32(), C.c_int()
+        self._check(lib().mi355x_h264_encode_rgba_device(self.h, C.c_void_p(dev_ptr), C.byref(out), C.byref(n), C.byref(ft)))
         return C.string_at(out.value, n.value), ft.value
 
     def encode_device(self, dev_ptr):

@@ -215,6 +215,7 @@ struct mi355x_h264_encoder {
     bool diag_mode = false;                  // debug: one launch per wavefront step instead
     uint8_t* d_stage = nullptr;              // device copy of a host-supplied picture
     uint8_t* h_stage = nullptr;              // pinned staging for strided host input
+    uint8_t* d_rgba = nullptr, *h_rgba = nullptr;   // RGBA pictures on their way to the conversion kernel (allocated with the first)
     size_t frame_bytes = 0, bitbuf_cap = 0, au_cap = 0;
     Slot slots[NSLOT];
     int next_slot = 0;
@@ -931,6 +932,8 @@ void mi355x_h264_destroy(mi355x_h264_encoder* e)
     (void)hipFree(e->d_slotbits); (void)hipFree(e->d_slotcode); (void)hipFree(e->d_mbbits); (void)hipFree(e->d_prevcoded); (void)hipFree(e->d_anybs); (void)hipFree(e->d_anypcm); (void)hipFree(e->d_anyintra); (void)hipFree(e->d_stage);
     (void)hipFree(e->d_handoff); (void)hipFree(e->d_bs); (void)hipFree(e->d_me_cost);
     if (e->h_stage) (void)hipHostFree(e->h_stage);
+    (void)hipFree(e->d_rgba);
+    if (e->h_rgba) (void)hipHostFree(e->h_rgba);
     for (auto& S : e->slots) {
         (void)hipFree(S.d_bitbuf); (void)hipFree(S.d_info);
         if (S.h_info) (void)hipHostFree(S.h_info);
@@ -1014,6 +1017,66 @@ int mi355x_h264_encode_nv12(mi355x_h264_encoder* e, const uint8_t* y, int ys, co
     for (int r = 0; r < h / 2; r++) memcpy(d + (size_t)r * w, uv + (size_t)r * uvs, (size_t)w);
     HIPCHK(e, hipMemcpyAsync(e->d_stage, e->h_stage, e->frame_bytes, hipMemcpyHostToDevice, e->stream));
     return encode_one_device(e, e->d_stage, true, out, out_len, frame_type);
+}
+
+// RGBA ingest: one conversion pass into the I420 staging picture (include/mi355x_h264.h states the arithmetic;
+// oracle/h264_rgba.c is its CPU restatement).  Thread = one 2x2 block: two 8-byte loads, two 2-byte luma stores, one Cb, one Cr.
+__global__ __launch_bounds__(256) void k_rgba_to_i420(const uint8_t* __restrict__ rgba, size_t stride, uint8_t* __restrict__ i420, int w, int h)
+{
+    const int bx = blockIdx.x * blockDim.x + threadIdx.x, by = blockIdx.y;
+    if (bx >= w / 2) return;
+    uint8_t* const Y = i420;
+    uint8_t* const U = i420 + (size_t)w * h;
+    uint8_t* const V = U + (size_t)(w / 2) * (h / 2);
+    int sr = 0, sg = 0, sb = 0;
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        const uint2 p = *(const uint2*)(rgba + (size_t)(2 * by + r) * stride + 8 * (size_t)bx);   // (rows start on 8 bytes: stride % 8 == 0 checked by the host)
+        const int r0 = p.x & 255, g0 = (p.x >> 8) & 255, b0 = (p.x >> 16) & 255;
+        const int r1 = p.y & 255, g1 = (p.y >> 8) & 255, b1 = (p.y >> 16) & 255;
+        const int y0 = ((66 * r0 + 129 * g0 + 25 * b0 + 128) >> 8) + 16, y1 = ((66 * r1 + 129 * g1 + 25 * b1 + 128) >> 8) + 16;
+        *(uint16_t*)(Y + (size_t)(2 * by + r) * w + 2 * bx) = (uint16_t)(y0 | (y1 << 8));
+        sr += r0 + r1; sg += g0 + g1; sb += b0 + b1;
+    }
+    const int r = (sr + 2) >> 2, g = (sg + 2) >> 2, b = (sb + 2) >> 2;
+    U[(size_t)by * (w / 2) + bx] = (uint8_t)(((-38 * r - 74 * g + 112 * b + 128) >> 8) + 128);
+    V[(size_t)by * (w / 2) + bx] = (uint8_t)(((112 * r - 94 * g - 18 * b + 128) >> 8) + 128);
+}
+
+static int encode_rgba_from_device(mi355x_h264_encoder* e, const uint8_t* d_rgba, size_t stride, uint8_t** out, uint32_t* out_len, int* frame_type)
+{
+    const int w = e->cfg.width, h = e->cfg.height;
+    hipLaunchKernelGGL(k_rgba_to_i420, dim3((unsigned)((w / 2 + 255) / 256), (unsigned)(h / 2)), dim3(256), 0, e->stream, d_rgba, stride, e->d_stage, w, h);
+    HIPCHK(e, hipGetLastError());
+    return encode_one_device(e, e->d_stage, false, out, out_len, frame_type);
+}
+
+int mi355x_h264_encode_rgba_device(mi355x_h264_encoder* e, const void* d_rgba, uint8_t** out, uint32_t* out_len, int* frame_type)
+{
+    if (!e || !d_rgba || !out || !out_len) return fail(e, MI355X_H264_E_ARG, "null argument");
+    if (e->G != 1) return fail(e, MI355X_H264_E_ARG, "single-picture calls need a batch-1 encoder");
+    if (((uintptr_t)d_rgba & 7) != 0) return fail(e, MI355X_H264_E_ARG, "RGBA picture not aligned to 8 bytes");
+    HIPCHK(e, hipSetDevice(e->device));
+    return encode_rgba_from_device(e, (const uint8_t*)d_rgba, (size_t)e->cfg.width * 4, out, out_len, frame_type);
+}
+
+int mi355x_h264_encode_rgba(mi355x_h264_encoder* e, const uint8_t* rgba, int stride, uint8_t** out, uint32_t* out_len, int* frame_type)
+{
+    if (!e || !rgba || !out || !out_len) return fail(e, MI355X_H264_E_ARG, "null argument");
+    if (e->G != 1) return fail(e, MI355X_H264_E_ARG, "single-picture calls need a batch-1 encoder");
+    const int w = e->cfg.width, h = e->cfg.height;
+    if (stride < 4 * w) return fail(e, MI355X_H264_E_ARG, "stride smaller than 4 * width");
+    HIPCHK(e, hipSetDevice(e->device));
+    const size_t row = (size_t)w * 4, n = row * h;
+    if (!e->d_rgba) {   // staging for RGBA pictures: allocated with the first one
+        HIPCHK(e, hipMalloc((void**)&e->d_rgba, n + 256));
+        HIPCHK(e, hipHostMalloc((void**)&e->h_rgba, n + 256, hipHostMallocDefault));
+    }
+    // (the previous picture's use of the staging buffers has completed: encode is synchronous)
+    if ((size_t)stride == row) memcpy(e->h_rgba, rgba, n);
+    else for (int r = 0; r < h; r++) memcpy(e->h_rgba + (size_t)r * row, rgba + (size_t)r * stride, row);
+    HIPCHK(e, hipMemcpyAsync(e->d_rgba, e->h_rgba, n, hipMemcpyHostToDevice, e->stream));
+    return encode_rgba_from_device(e, e->d_rgba, row, out, out_len, frame_type);
 }
 
 int mi355x_h264_encode_batch_device(mi355x_h264_encoder* e, const void* d_frames, size_t stride, int count, uint8_t* host_out,

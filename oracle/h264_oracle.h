@@ -152,6 +152,8 @@ void h264o_pred_chroma8x8(const uint8_t *rec, int stride, int mode, int avail, u
 void h264o_deblock_picture(uint8_t *y, uint8_t *u, uint8_t *v, int cw, int ch,
                            const h264o_mbinfo *mbs, const int16_t *mvq, int qp, const int16_t *slice_of, int row0, int row1);
 /* Exp-Golomb / CAVLC helpers for known-answer tests */
+/* RGBA ingest (h264_rgba.c): rgba = R, G, B, A bytes per sample, stride in bytes; i420 = w*h*3/2 bytes */
+void h264o_rgba_to_i420(const uint8_t *rgba, int stride, int w, int h, uint8_t *i420);
 int h264o_ue_bits(uint32_t v, uint32_t *code); /* returns length, *code = bit pattern */
 int h264o_se_bits(int32_t v, uint32_t *code);
 /* writes one residual block with CAVLC; returns number of bits appended to buf

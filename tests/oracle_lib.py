@@ -91,6 +91,8 @@ def lib():
         L.h264o_dec_table_run_before.argtypes = [C.c_int, C.c_int, ip, up]
         L.h264o_dec_table_misc.argtypes = [C.c_int, C.c_int, C.c_int]
         L.h264o_fdct4x4.argtypes = [vp, vp]
+        L.h264o_rgba_to_i420.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp]
+        L.h264o_rgba_to_i420.restype = None
         L.h264o_idct4x4_add.argtypes = [vp, vp, C.c_int]
         L.h264o_quant4x4.argtypes = [vp, C.c_int, C.c_int, vp]
         L.h264o_dequant4x4.argtypes = [vp, C.c_int, vp]
@@ -113,6 +115,14 @@ def lib():
 
 def _ptr(a):
     return a.ctypes.data_as(C.c_void_p)
+
+
+def rgba_to_i420(rgba, width, height, stride=None):
+    """the oracle's RGBA ingest (oracle/h264_rgba.c): uint8 RGBA rows -> tight I420 as a flat uint8 array"""
+    a = np.ascontiguousarray(rgba, dtype=np.uint8)
+    out = np.zeros(width * height * 3 // 2, np.uint8)
+    lib().h264o_rgba_to_i420(a.ctypes.data, int(stride or 4 * width), width, height, out.ctypes.data)
+    return out
 
 
 class OracleEncoder:

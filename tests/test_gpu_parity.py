@@ -166,6 +166,37 @@ def _to_nv12(f, w, h):
     return np.concatenate([y, np.stack([u, v], axis=1).ravel()])
 
 
+def test_rgba_ingest_host_strided_and_device():
+    """RGBA pictures (row f3): the conversion kernel + encoder against the oracle's conversion + encoder, from host memory
+    (tight rows, and rows with a stride), and from device memory; odd geometry (width not a multiple of 16)."""
+    import torch
+    from oracle_lib import rgba_to_i420
+    rng = np.random.default_rng(5)
+    for (w, h) in ((320, 240), (1920, 1080), (200, 120)):
+        enc = capi.Encoder(w, h, qp=26, gop=30)
+        orc = OracleEncoder(w, h, qp=26, gop=30)
+        # a moving colour texture: smooth gradients + noise, alpha random (must not matter)
+        yy, xx = np.mgrid[0:h, 0:w]
+        for i in range(3):
+            pic = np.empty((h, w, 4), np.uint8)
+            pic[..., 0] = (xx * 2 + 3 * i) & 255
+            pic[..., 1] = (yy * 3 + xx + 5 * i) & 255
+            pic[..., 2] = ((xx ^ yy) + 7 * i) & 255
+            pic[..., :3] = np.clip(pic[..., :3].astype(np.int16) + rng.integers(-6, 7, (h, w, 3)), 0, 255).astype(np.uint8)
+            pic[..., 3] = rng.integers(0, 256, (h, w))
+            want = orc.encode(rgba_to_i420(pic, w, h))[0]
+            if i == 0:
+                got = enc.encode_rgba(pic)[0]
+            elif i == 1:
+                wide = np.zeros((h, w + 10, 4), np.uint8)
+                wide[:, :w] = pic
+                got = enc.encode_rgba(wide, stride=4 * (w + 10))[0]
+            else:
+                got = enc.encode_rgba_device(torch.from_numpy(pic).cuda().data_ptr())[0]
+            assert got == want, "%dx%d picture %d" % (w, h, i)
+        enc.close()
+
+
 def test_nv12_device_pictures_in_lockstep_batch():
     """config.input_format = NV12: device-resident NV12 pictures go through the lockstep batch (and the
     batch-1 device entry points) with no conversion pass and give the I420 stream"""

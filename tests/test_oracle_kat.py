@@ -237,6 +237,31 @@ def test_deblock_known_answers():
     assert list(y[3, 13:19]) == [60, 62, 64, 66, 67, 70]
 
 
+def test_rgba_ingest_known_answers():
+    """The RGBA ingest's arithmetic (include/mi355x_h264.h, oracle/h264_rgba.c) against the published BT.601 studio-swing values of
+    the primaries (white, black, red, green, blue: the values every BT.601 table lists), the secondaries as the integer form gives
+    them (cyan's luma is 169 where the rounded real-valued matrix gives 170), the 2x2 chroma mean, the alpha byte ignored and a row
+    stride."""
+    from oracle_lib import rgba_to_i420
+    for rgb, yuv in (((255, 255, 255), (235, 128, 128)), ((0, 0, 0), (16, 128, 128)), ((255, 0, 0), (82, 90, 240)),
+                     ((0, 255, 0), (144, 54, 34)), ((0, 0, 255), (41, 240, 110)), ((255, 255, 0), (210, 16, 146)),
+                     ((0, 255, 255), (169, 166, 16)), ((255, 0, 255), (107, 202, 222))):
+        for alpha in (0, 255):
+            pic = np.tile(np.array(rgb + (alpha,), np.uint8), (4, 6, 1))
+            out = rgba_to_i420(pic, 6, 4)
+            assert set(out[:24]) == {yuv[0]} and set(out[24:30]) == {yuv[1]} and set(out[30:]) == {yuv[2]}, (rgb, out)
+    # a 2x2 block of black, black, white, white: luma per sample, chroma from the mean (128, 128, 128) -> Y 126, neutral chroma
+    pic = np.zeros((2, 2, 4), np.uint8)
+    pic[1] = 255
+    out = rgba_to_i420(pic, 2, 2)
+    assert list(out) == [16, 16, 235, 235, 128, 128]
+    # rounding of the mean: three samples at 1, one at 0 -> (3 + 2) >> 2 = 1; rows 24 bytes apart
+    pic = np.zeros((2, 6, 4), np.uint8)
+    pic[0, 0, :3] = 1; pic[0, 1, :3] = 1; pic[1, 0, :3] = 1
+    out = rgba_to_i420(pic, 2, 2, stride=24)
+    assert list(out[:4]) == [17, 17, 17, 16] and list(out[4:]) == [128, 128]
+
+
 def test_emulation_prevention():
     L = lib()
 
