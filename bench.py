@@ -654,8 +654,9 @@ def main():
             "config": {"workload": "1080p%d %s synthetic S1 pan+noise, %s profile, fixed QP 26, closed GOPs of 30 " % (args.fps, args.input.upper(), args.profile) +
                                    "(1 IDR + 29 P), %s, 1 ref, %s +-16 integer search, deblock on, CAVLC; per GPU one stream, %d of its "
                                    "closed GOPs per step on %d encoder instance(s), each encoding its %d GOPs in lockstep "
-                                   "(grid.y) on its own HIP streams; pictures resident in HBM" % ("single slice" if args.slices < 2 else "%d slice bands (filter idc 2)" % args.slices, args.search, G, I, B),
-                       "content": args.content, "width": WIDTH, "height": HEIGHT, "qp": QP, "gop": GOP, "frames_per_step": FRAMES_PER_STEP * G, "gops_in_flight": G, "instances": I, "lockstep_batch": B,
+                                   "(grid.y) on its own HIP streams, the instances' motion searches taking turns (one at a time per GPU: device-side lock, "
+                                   "MI355X_H264_ME_TURNS); pictures resident in HBM" % ("single slice" if args.slices < 2 else "%d slice bands (filter idc 2)" % args.slices, args.search, G, I, B),
+                       "content": args.content, "width": WIDTH, "height": HEIGHT, "qp": QP, "gop": GOP, "frames_per_step": FRAMES_PER_STEP * G, "gops_in_flight": G, "instances": I, "lockstep_batch": B, "me_turns": os.environ.get("MI355X_H264_ME_TURNS", "1") != "0", "stagger_ms": args.stagger_ms,
                        "streams": world, "bytes_per_gop": int(nbytes), "selfcheck_batch_equals_single": selfcheck, "parity": "bit-exact vs CPU oracle "
                        "(oracle unpinned vs OpenH264: no libopenh264 available)"},
             "roofline": {"kernel": "k_tq (residual + fDCT + quant + dequant + iDCT + recon, 8 macroblocks per wave)", "bound": "hbm",

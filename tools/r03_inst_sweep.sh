@@ -1,17 +1,24 @@
 #!/bin/bash
+# usage: r03_inst_sweep.sh ; the default workload with 2 / 3 / 4 instances of 32 or 24 GOPs (final build: picture-walking grids, motion-search lock)
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r03
 mkdir -p $O
 cd $R
-for cfg in "64 2 1" "64 2 0" "96 3 1" "64 4 1" "128 4 1" "128 2 1" "96 2 1" "64 2 1" "64 2 0"; do
+for rep in 1 2; do
+for cfg in "2 64" "3 96" "4 128" "3 72" "4 96" "4 64"; do
   set -- $cfg
-  timeout -k 10 300 python bench.py --no-plugin --no-cpu-baseline --steps 5 --gops-in-flight $1 --instances $2 --phase-lock $3 > $O/inst_$1_$2_$3.json 2> $O/inst_$1_$2_$3.err
-  python - <<PY
-import json
-try:
-    d = json.load(open("$O/inst_$1_$2_$3.json"))
-    print("G=$1 I=$2 lock=$3", d["value"], d["ms_per_step"], d["config"]["selfcheck_batch_equals_single"], {k: x["ms_per_launch"] for k, x in d["kernels"].items()})
-except Exception as ex:
-    print("G=$1 I=$2 lock=$3 failed", ex)
-PY
+  timeout -k 10 300 python bench.py --no-plugin --no-cpu-baseline --steps 4 --instances $1 --gops-in-flight $2 > $O/isw_$1_$2_$rep.json 2> /dev/null
 done
+done
+python - <<PY
+import json
+for cfg in ("2_64", "3_96", "4_128", "3_72", "4_96", "4_64"):
+    out = []
+    for rep in (1, 2):
+        try:
+            d = json.load(open("$O/isw_%s_%d.json" % (cfg, rep))); k = d["kernels"]
+            out.append("%.0f (me %.2f tq %.3f cavlc %.3f db %.2f in %.2f)" % (d["value"], k["me"]["ms_per_launch"], k["tq"]["ms_per_launch"], k["cavlc"]["ms_per_launch"], k["deblock"]["ms_per_launch"], k["intra"]["ms_per_launch"]))
+        except Exception as ex:
+            out.append("unreadable")
+    print(cfg, " ".join(out))
+PY
