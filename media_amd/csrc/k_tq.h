@@ -190,6 +190,7 @@ __global__ __launch_bounds__(64) void k_tq(FrameParams P0)
     const int cs = P.cw >> 1;
     const bool src_al = ((P.w | (int)(uintptr_t)P.src) & 3) == 0;   // source rows are dword aligned
     const int cwv = vreg(P.cw), wv = vreg(P.w), csv = vreg(cs);
+#ifdef MI355X_AB_TQ_4MB   // (the layout of rounds 1-3: 4 macroblocks x 16 blocks per pass, four 64-byte row segments per instruction)
     unsigned long long ymask[2];
     int ybound[2];   // bit bound of the lane's macroblock, luma part (in all 16 lanes of the macroblock)
 
@@ -253,6 +254,72 @@ __global__ __launch_bounds__(64) void k_tq(FrameParams P0)
         const int y0 = __shfl(ybound[0], 16 * (m8 & 3)), y1 = __shfl(ybound[1], 16 * (m8 & 3));
         tq_chroma8(P, first, end, lane, cs, csv, cbpl, m8 < 4 ? y0 : y1, false);
     }
+#else
+    // ---- luma: two passes over the wave's 8 macroblocks, lane = (macroblock, block row of the pass, block column).  Pass p takes
+    // block rows 2 p and 2 p + 1: a load or store instruction then touches TWO picture rows of 128 contiguous bytes (8 macroblocks
+    // x 16 samples) instead of four rows of 64 - whole cache lines; the kernel is bound by the shape of its accesses ----
+    const int m8 = lane >> 3, bxl = lane & 3, by2 = (lane >> 2) & 1, mbi = first + m8;
+    bool act = mbi < end;
+    // MbInfo.type == MB_P16 and i16_mode == 0 (k_me sets i16_mode when nothing is left to code, type MB_I16 for the intra pass)
+    if (act) act = mb_to_code(*(const uint16_t*)((const uint8_t*)P.mb + (uint32_t)(mbi * 32 + 4)));
+    unsigned long long ymask[2];
+    int ybnd = 0;   // bit bound of the lane's macroblock, luma part (in all 8 lanes of the macroblock)
+    {
+        const TqConst K = tq_consts(P.qy);
+        const int my = P.mbdiv.row(act ? mbi : mb0), mx = (act ? mbi : mb0) - my * P.mbw;
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            const int byl = 2 * p + by2, blk = xy2blk(bxl, byl);
+            int nz = 0, bb = 0;
+            if (act) {
+                const int x = 16 * mx + 4 * bxl, y = 16 * my + 4 * byl;
+                uint32_t s4[4], p4[4];
+                // one 32-bit offset per access from a wave-uniform base (global_load saddr form: no 64-bit address arithmetic)
+                uint32_t po[4];
+                po[0] = (uint32_t)__mul24(y, P.cw) + (uint32_t)x;
+#pragma unroll
+                for (int r = 1; r < 4; r++) po[r] = po[r - 1] + (uint32_t)cwv;
+#pragma unroll
+                for (int r = 0; r < 4; r++) p4[r] = *(const uint32_t*)(P.rec[0] + po[r]);
+                if (src_al && x + 3 < P.w) {
+                    const uint32_t omax = (uint32_t)__mul24(P.h - 1, P.w) + (uint32_t)x;   // rows below the picture repeat its last row
+                    uint32_t o = (uint32_t)__mul24(y, P.w) + (uint32_t)x;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) { s4[r] = *(const uint32_t*)(P.src + min(o, omax)); o += (uint32_t)wv; }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+                        s4[r] = (uint32_t)src_px(P.src, P.w, P.h, x, y + r) | ((uint32_t)src_px(P.src, P.w, P.h, x + 1, y + r) << 8) |
+                                ((uint32_t)src_px(P.src, P.w, P.h, x + 2, y + r) << 16) | ((uint32_t)src_px(P.src, P.w, P.h, x + 3, y + r) << 24);
+                }
+                int d[16];
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+#pragma unroll
+                    for (int c = 0; c < 4; c++) d[4 * r + c] = (int)((s4[r] >> (8 * c)) & 255u) - (int)((p4[r] >> (8 * c)) & 255u);
+                uint32_t lvp[8];
+                nz = tq_block<false>(d, K, lvp, [](int) { return 0; });
+                bb = blk_bits_bound_packed(lvp, nz);
+                const uint32_t lo = (uint32_t)__mul24(mbi, LV_STRIDE * 2) + (uint32_t)((LV_LUMA + blk * 16) * 2);
+                *(uint4*)((uint8_t*)P.levels + lo) = make_uint4(lvp[0], lvp[1], lvp[2], lvp[3]);
+                *(uint4*)((uint8_t*)P.levels + lo + 16u) = make_uint4(lvp[4], lvp[5], lvp[6], lvp[7]);
+#pragma unroll
+                for (int r = 0; r < 4; r++) *(uint32_t*)(P.rec[0] + po[r]) = recon4(p4[r], d[4 * r], d[4 * r + 1], d[4 * r + 2], d[4 * r + 3]);
+                *((uint8_t*)P.mb + (uint32_t)(mbi * 32 + 8 + blk)) = (uint8_t)nz;   // MbInfo.tc[blk]
+            }
+            ymask[p] = __ballot(nz != 0);
+            ybnd += group_sum8_dpp(bb);
+        }
+    }
+
+    // ---- chroma of the 8 macroblocks + coded_block_pattern + I_PCM fallback (the same lanes hold the same macroblock) ----
+    {
+        // lanes of the macroblock in a pass: bit = block row of the pass * 4 + block column; an 8x8 quadrant = columns 0,1 or 2,3 of both rows
+        const unsigned t8 = (unsigned)(ymask[0] >> (8 * m8)) & 0xFFu, b8 = (unsigned)(ymask[1] >> (8 * m8)) & 0xFFu;
+        const int cbpl = ((t8 & 0x33u) ? 1 : 0) | ((t8 & 0xCCu) ? 2 : 0) | ((b8 & 0x33u) ? 4 : 0) | ((b8 & 0xCCu) ? 8 : 0);
+        tq_chroma8(P, first, end, lane, cs, csv, cbpl, ybnd, false);
+    }
+#endif
 }
 
 
