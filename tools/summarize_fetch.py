@@ -23,7 +23,7 @@ for r in csv.DictReader(open(glob.glob(src + "/stats/*/*kernel_trace.csv")[0])):
 out = {"tag": tag, "what": "tools/ubench_fetch.hip on MI355X: every kernel moves a known number of bytes once (401 MB buffers, caches flushed in "
                            "between); counters from separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes (values are KB); "
                            "ratio = counter bytes / bytes really moved", "kernels": {}}
-for k in ("rd16", "rd4_row", "rd4_tq", "rd4_win", "wr4_tq", "wr32_lv", "wr16", "flush_caches"):
+for k in ("rd16", "rd4_row", "rd4_tq", "rd4_tq8", "rd4_win", "wr4_tq", "wr4_tq8", "wr32_lv", "wr16", "flush_caches"):
     f = sum(fetch[k]) / len(fetch[k]) * 1024 if k in fetch else None
     w = sum(write[k]) / len(write[k]) * 1024 if k in write else None
     rd = known.get(k) if k.startswith("rd") else (known.get("rd4_win_requested") if k == "rd4_win" else known.get("flush_caches_read") if k == "flush_caches" else 0)

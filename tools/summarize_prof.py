@@ -46,19 +46,29 @@ print(json.dumps({k: v for k, v in out["pmc"].items() if "k_tq" in k or "k_me" i
 print(json.dumps({k: v for k, v in split.items() if "k_tq" in k or "k_me" in k or "deblock" in k}, indent=1))
 # HBM traffic of the roofline kernel (k_tq).  MI355X_MICROARCH.md: FETCH_SIZE reads half the bytes of a wide coalesced stream and
 # "other access widths are uncalibrated: calibrate on a known byte count in your own access pattern".  tools/ubench_fetch.hip did
-# (profiles/r03_ubench_fetch.json): for k_tq's loads (four 64-byte row segments per wave instruction) FETCH_SIZE / bytes = 1.0, for
-# its stores WRITE_SIZE / bytes = 1.0 - both counters are taken as they are (KB -> bytes).  The lockstep launch = the largest grid.
+# (profiles/r03b_ubench_fetch.json): WRITE_SIZE / bytes = 1.0 for every store shape of the kernel; FETCH_SIZE / bytes = 1.0 for loads that
+# touch 64-byte row segments (the chroma passes, MbInfo; the luma passes of rounds 1-3: rd4_tq) and 0.5 for loads that touch 128-byte
+# segments (the luma passes since the end of round 3: rd4_tq8).  So the luma bytes the kernel reads - 512 per coded macroblock,
+# source + prediction - are in the counter at half: traffic = WRITE_SIZE + FETCH_SIZE + 256 x coded macroblocks, the coded count from
+# the bench line of the same build (profiles/r03_bench_default.json).  The lockstep launch = the largest grid.
 tq = [(k, v) for k, v in out["pmc"].items() if k.startswith("k_tq") and not k.startswith("k_tq8") and not k.startswith("k_tq_list") and v["FETCH_SIZE_KB_raw"] and v["WRITE_SIZE_KB"]]
 if tq:
     k, v = max(tq, key=lambda kv: int(kv[0].split("grid=")[1].split()[0]))
     threads = int(k.split("grid=")[1].split()[0])
     mbs = threads // 64 * 8
-    tr_ = {"kernel": "k_tq", "lockstep_batch": mbs // 8160, "macroblocks_per_launch": mbs,
+    try:
+        coded = json.loads(open("profiles/r03_bench_default.json").read().strip().splitlines()[-1])["roofline"]["coded_fraction"] * mbs
+    except Exception:
+        coded = 0.658 * mbs
+    half_counted = int(256 * coded)
+    tr_ = {"kernel": "k_tq", "lockstep_batch": mbs // 8160, "macroblocks_per_launch": mbs, "coded_macroblocks_per_launch": round(coded, 1),
            "FETCH_SIZE_bytes": int(v["FETCH_SIZE_KB_raw"] * 1024), "WRITE_SIZE_bytes": int(v["WRITE_SIZE_KB"] * 1024),
-           "fetch_ratio_calibrated": 1.0, "write_ratio_calibrated": 1.0, "calibration": "profiles/r03_ubench_fetch.json (rd4_tq, wr4_tq, wr32_lv)",
-           "traffic_bytes_per_launch": int(v["FETCH_SIZE_KB_raw"] * 1024 + v["WRITE_SIZE_KB"] * 1024),
+           "luma_read_bytes_counted_at_half": 2 * half_counted, "correction_bytes": half_counted,
+           "fetch_ratio_calibrated": "1.0 for 64-byte segments, 0.5 for the luma passes' 128-byte segments", "write_ratio_calibrated": 1.0,
+           "calibration": "profiles/r03b_ubench_fetch.json (rd4_tq 1.0, rd4_tq8 0.5, wr4_tq / wr4_tq8 / wr32_lv 1.0)",
+           "traffic_bytes_per_launch": int(v["FETCH_SIZE_KB_raw"] * 1024 + v["WRITE_SIZE_KB"] * 1024) + half_counted,
            "note": "separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of `python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-plugin` "
-                   "(profiles/%s_summary.json); counters taken as they are: the x2 of the guide applies to >= 256-byte contiguous reads, not to this "
-                   "kernel's 64-byte segments (measured).  bench.py compares this with coded x 1952 + settled x 2 bytes of the same launch" % tag}
+                   "(profiles/%s_summary.json).  traffic = WRITE_SIZE + FETCH_SIZE + the half of the luma reads the counter leaves out (measured "
+                   "ratio 0.5 for that access shape).  bench.py compares this with coded x 1952 + settled x 2 bytes of the same launch" % tag}
     json.dump(tr_, open("profiles/%s_traffic.json" % tag, "w"), indent=1)
     print(json.dumps(tr_, indent=1))

@@ -68,6 +68,31 @@ __global__ __launch_bounds__(64) void wr4_tq(uint8_t* dst, uint32_t v)
 #pragma unroll
     for (int r = 0; r < 4; r++) *(uint32_t*)(dst + tq_offset(threadIdx.x, r)) = v + r;
 }
+// k_tq's luma accesses since the end of round 3: lane = (macroblock of 8, block row of the pass, block column); a wave = eight
+// horizontally adjacent macroblocks, two passes of block rows {0, 1} / {2, 3}: per instruction TWO 128-B segments
+__device__ __forceinline__ size_t tq8_offset(int lane, int p, int r)
+{
+    const int m = lane >> 3, bx = lane & 3, by = 2 * p + ((lane >> 2) & 1);
+    const int mb8 = blockIdx.x, mbx = (mb8 % (PITCH / 128)) * 8 + m, mby = mb8 / (PITCH / 128);
+    return (size_t)blockIdx.y * PITCH * ROWS + (size_t)(16 * mby + 4 * by + r) * PITCH + 16 * mbx + 4 * bx;
+}
+__global__ __launch_bounds__(64) void rd4_tq8(const uint8_t* __restrict__ src, uint32_t* out)
+{
+    uint32_t acc = 0;
+#pragma unroll
+    for (int p = 0; p < 2; p++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) acc ^= *(const uint32_t*)(src + tq8_offset(threadIdx.x, p, r));
+    acc ^= __shfl_xor(acc, 32);
+    if (threadIdx.x == 0) out[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = acc;
+}
+__global__ __launch_bounds__(64) void wr4_tq8(uint8_t* dst, uint32_t v)
+{
+#pragma unroll
+    for (int p = 0; p < 2; p++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) *(uint32_t*)(dst + tq8_offset(threadIdx.x, p, r)) = v + r;
+}
 // k_me's window: 56 rows x 64 B at (16 mx - 20, 16 my - 20) rounded down to a dword; one wave per macroblock, interior only.
 // Neighbouring macroblocks' windows overlap (each plane byte lies in ~12 windows): the unique bytes per plane are the plane
 // itself, so this kernel measures how much of the overlap reaches the memory-side counters, not a 1:1 ratio.
@@ -128,6 +153,8 @@ int main()
         flush(); hipLaunchKernelGGL(rd16, dim3((unsigned)(bytes / 16 / 64)), dim3(64), 0, 0, (const uint4*)a, bytes / 16, out);
         flush(); hipLaunchKernelGGL(rd4_row, dim3((unsigned)(bytes / 4 / 256)), dim3(64), 0, 0, (const uint32_t*)a, bytes / 4, out);
         flush(); hipLaunchKernelGGL(rd4_tq, dim3(mb4, NPL), dim3(64), 0, 0, (const uint8_t*)a, out);
+        flush(); hipLaunchKernelGGL(rd4_tq8, dim3(mb4 / 2, NPL), dim3(64), 0, 0, (const uint8_t*)a, out);
+        flush(); hipLaunchKernelGGL(wr4_tq8, dim3(mb4 / 2, NPL), dim3(64), 0, 0, b, 9u);
         flush(); hipLaunchKernelGGL(rd4_win, dim3(nmb, NPL), dim3(64), 0, 0, (const uint8_t*)a, out);
         flush(); hipLaunchKernelGGL(wr4_tq, dim3(mb4, NPL), dim3(64), 0, 0, b, 7u);
         flush(); hipLaunchKernelGGL(wr32_lv, dim3((unsigned)(bytes / 32 / 64)), dim3(64), 0, 0, (uint4*)b, bytes / 32, 7u);
@@ -142,7 +169,7 @@ int main()
             interior += wx0 >= 0 && wx0 + 64 <= PITCH && wy0 >= 0 && wy0 + 56 <= ROWS;
         }
     printf("{\"bytes\": {\"rd16\": %zu, \"rd4_row\": %zu, \"rd4_tq\": %zu, \"rd4_win_requested\": %zu, \"rd4_win_unique_upper\": %zu, "
-           "\"wr4_tq\": %zu, \"wr32_lv\": %zu, \"wr16\": %zu, \"flush_caches_read\": %zu, \"flush_caches_written\": %zu}, \"planes\": %d, \"plane_bytes\": %zu}\n",
-           bytes, bytes, bytes, (size_t)interior * 56 * 64 * NPL, bytes, bytes, bytes, bytes, flush_bytes, flush_bytes, (int)NPL, PLANE);
+           "\"wr4_tq\": %zu, \"wr32_lv\": %zu, \"wr16\": %zu, \"rd4_tq8\": %zu, \"wr4_tq8\": %zu, \"flush_caches_read\": %zu, \"flush_caches_written\": %zu}, \"planes\": %d, \"plane_bytes\": %zu}\n",
+           bytes, bytes, bytes, (size_t)interior * 56 * 64 * NPL, bytes, bytes, bytes, bytes, bytes, bytes, flush_bytes, flush_bytes, (int)NPL, PLANE);
     return 0;
 }
