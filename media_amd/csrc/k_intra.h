@@ -554,11 +554,11 @@ template <bool IND = false>
 __global__ __launch_bounds__(128) void k_intra_rows(IntraRowParams R)
 {
     __builtin_amdgcn_s_setprio(3);   // dependency-bound row wavefront: issue ahead of co-resident throughput kernels
-    const int lane = threadIdx.x & 63;
+    const int lane0 = threadIdx.x & 63;
     const bool chroma_wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) != 0;
     __shared__ IntraLds S;
     bool timed_out = false;
-    if (!chroma_wave) i4_lds_init(S.i4, lane);
+    if (!chroma_wave) i4_lds_init(S.i4, lane0);
     // The launch holds gridDim.y pictures at a time, not all of them: workgroup (row, y) takes pictures y, y + gridDim.y, ...  A row
     // wavefront is bound by its dependencies, not by the machine, and every resident wave holds registers the other instance's
     // kernels could run in: with all 32 pictures of a lockstep batch resident (4 352 waves of ~150 registers, three to a SIMD) neither
@@ -566,6 +566,10 @@ __global__ __launch_bounds__(128) void k_intra_rows(IntraRowParams R)
     // (Row r of a picture waits for row r - 1 of the same picture, which the workgroup dispatched just before handles: whatever part of the
     // grid is resident, the row being waited for is in it.)
     for (int pic = blockIdx.y; pic < R.npic; pic += gridDim.y) {
+    // (the lane number is made opaque per picture: otherwise every per-lane constant of BOTH waves' macroblock code is computed once
+    // in front of this loop and kept alive across it - 240 VGPRs instead of 146, two waves to a SIMD instead of three)
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
     const FrameParams P = batch_view<IND>(R.p, pic);
     unsigned long long* const handoff = R.handoff + (size_t)batch_item<IND>(R.p.itemtab, pic) * R.st_handoff;
     const int my = P.band.row0 + blockIdx.x;
@@ -679,7 +683,7 @@ __global__ __launch_bounds__(128) void k_intra_rows(IntraRowParams R)
         }
     }
     }
-    if (timed_out && lane == 0) *R.err = 2u;
+    if (timed_out && lane0 == 0) *R.err = 2u;
 }
 
 // ===========================================================================
