@@ -1,18 +1,18 @@
 #!/bin/bash
-# usage: r03_inst_sweep.sh ; the default workload with 2 / 3 / 4 instances of 32 or 24 GOPs (final build: picture-walking grids, motion-search lock)
+# usage: r03_inst_sweep.sh ; the default workload with 2 instances of 24 / 32 / 48 / 64 GOPs (final build)
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r03
 mkdir -p $O
 cd $R
 for rep in 1 2; do
-for cfg in "2 64" "3 96" "4 128" "3 72" "4 96" "4 64"; do
+for cfg in "2 48" "2 64" "2 96" "2 128"; do
   set -- $cfg
   timeout -k 10 300 python bench.py --no-plugin --no-cpu-baseline --steps 4 --instances $1 --gops-in-flight $2 > $O/isw_$1_$2_$rep.json 2> /dev/null
 done
 done
 python - <<PY
 import json
-for cfg in ("2_64", "3_96", "4_128", "3_72", "4_96", "4_64"):
+for cfg in ("2_48", "2_64", "2_96", "2_128"):
     out = []
     for rep in (1, 2):
         try:
